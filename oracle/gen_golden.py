@@ -1,0 +1,230 @@
+"""Generate tests/golden/*.npz from the REAL reference code (test infrastructure only).
+
+Runs in the build container only (needs /root/reference, which is read-only and absent on
+the GPU box).  It imports the reference's `IRSDE` (codes/utils/sde_utils.py) and
+`ConditionalUNet` (codes/config/deraining/models/modules/DenoisingUNet_arch.py) on CPU,
+feeds them the deterministic synthetic weights / inputs / injected noise from
+`oracle.irsde_oracle`, and stores the reference's outputs as small fixtures.
+
+Import recipe: stub `torchvision.utils`, load sde_utils.py by path, put
+codes/config/deraining on sys.path for `models.modules`.
+
+Usage:  python oracle/gen_golden.py [--ref /root/reference] [--only NAME]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import irsde_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load_reference(ref_root):
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.save_image = lambda *a, **k: None
+    tv.utils = tvu
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.utils", tvu)
+    spec = importlib.util.spec_from_file_location(
+        "ref_sde_utils", os.path.join(ref_root, "codes/utils/sde_utils.py"))
+    sde_utils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sde_utils)
+    sys.path.insert(0, os.path.join(ref_root, "codes/config/deraining"))
+    from models.modules.DenoisingUNet_arch import ConditionalUNet
+    return sde_utils, ConditionalUNet
+
+
+class InjectedIRSDE:
+    """Mixin factory: reference IRSDE with torch.randn_like replaced by a pre-drawn tensor
+    (the reference has no hook; we override the two methods that draw:
+    dispersion sde_utils.py:181-182 and reverse_posterior_step :219-223)."""
+
+    @staticmethod
+    def make(sde_utils):
+        class _Inj(sde_utils.IRSDE):
+            noise = None
+            cur_t = None
+
+            def dispersion(self, x, t):
+                import math
+                z = self.noise[t]
+                return self.sigmas[t] * (z * math.sqrt(self.dt)).to(self.device)
+
+            def reverse_posterior_step(self, xt, noise, t):
+                x0 = self.get_init_state_from_noise(xt, noise, t)
+                mean = self.reverse_optimum_step(xt, x0, t)
+                std = self.reverse_optimum_std(t)
+                return mean + std * self.noise[t]
+        return _Inj
+
+
+def build_ref_net(ConditionalUNet, params, nf, depth):
+    net = ConditionalUNet(in_nc=3, out_nc=3, nf=nf, depth=depth).eval()
+    sd = net.state_dict()
+    shapes = O.unet_param_shapes(3, 3, nf, depth)
+    assert set(sd.keys()) == set(shapes.keys()), (set(sd) ^ set(shapes))
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return net
+
+
+def gen_schedule(sde_utils):
+    out = {}
+    for tag, (ms, T, sched, eps) in {
+        "s10_T100": (10, 100, "cosine", 0.005),
+        "s50_T100": (50, 100, "cosine", 0.005),
+        "s50_T200": (50, 200, "cosine", 0.005),
+        "s25_T100_lin": (25, 100, "linear", 0.005),
+        "s0p1_T50_const": (0.1, 50, "constant", 0.01),
+    }.items():
+        sde = sde_utils.IRSDE(max_sigma=ms, T=T, schedule=sched, eps=eps, device="cpu")
+        out[tag + "/cfg"] = np.array([ms, T, eps], dtype=np.float64)
+        out[tag + "/sched"] = np.array(sched)
+        out[tag + "/dt"] = np.float32(sde.dt.item())
+        for n in ("thetas", "sigmas", "thetas_cumsum", "sigma_bars"):
+            out[tag + "/" + n] = getattr(sde, n).numpy()
+        std = np.zeros(T + 1, dtype=np.float32)
+        t1 = np.zeros(T + 1, dtype=np.float32)
+        t2 = np.zeros(T + 1, dtype=np.float32)
+        g = np.zeros(T + 1, dtype=np.float32)
+        sde.set_mu(torch.zeros(1))
+        for t in range(1, T + 1):
+            std[t] = sde.reverse_optimum_std(t).item()
+            # term1/term2 via reverse_optimum_step on basis inputs (mu=0)
+            t1[t] = sde.reverse_optimum_step(torch.ones(1), torch.zeros(1), t).item()
+            t2[t] = sde.reverse_optimum_step(torch.zeros(1), torch.ones(1), t).item()
+            g[t] = sde.get_init_state_from_noise(torch.ones(1), torch.zeros(1), t).item()
+        out[tag + "/post_std"] = std
+        out[tag + "/post_term1"] = t1
+        out[tag + "/post_term2"] = t2
+        out[tag + "/x0_gain"] = g
+    np.savez_compressed(os.path.join(GOLD, "schedule.npz"), **out)
+    print("schedule.npz", len(out))
+
+
+def gen_forward(sde_utils, ConditionalUNet):
+    """Single-forward goldens (nf=64, depth=4 = the deraining config) + a small net."""
+    out = {}
+    cases = {
+        # tag: (nf, depth, B, H, W, ts)
+        "nf64d4_1x64x64": (64, 4, 1, 64, 64, [1, 50, 100]),
+        "nf64d4_2x40x56": (64, 4, 2, 40, 56, [37]),      # reflect-pad path (40->48, 56->64)
+        "nf32d2_2x24x20": (32, 2, 2, 24, 20, [3, 77]),    # small net used by quick tests
+    }
+    for tag, (nf, depth, B, H, W, ts) in cases.items():
+        params = O.synth_params(seed=0, nf=nf, depth=depth)
+        net = build_ref_net(ConditionalUNet, params, nf, depth)
+        lq, xT = O.synth_inputs(1234, B, H, W)
+        out[tag + "/cfg"] = np.array([nf, depth, B, H, W], dtype=np.int64)
+        out[tag + "/ts"] = np.array(ts, dtype=np.int64)
+        for t in ts:
+            with torch.no_grad():
+                y = net(torch.from_numpy(xT), torch.from_numpy(lq), t).numpy()
+            out[tag + "/t%d" % t] = y
+            print(tag, t, float(np.abs(y).max()))
+        if tag == "nf32d2_2x24x20":
+            # training-style per-sample timesteps [B] (denoising_model.py:135)
+            tt = torch.tensor([5, 60])
+            with torch.no_grad():
+                y = net(torch.from_numpy(xT), torch.from_numpy(lq), tt).numpy()
+            out[tag + "/tvec"] = y
+    np.savez_compressed(os.path.join(GOLD, "forward.npz"), **out)
+    print("forward.npz")
+
+
+def gen_steps(sde_utils):
+    """Teacher-forced single reverse steps (elementwise part only) for the 3 samplers."""
+    Inj = InjectedIRSDE.make(sde_utils)
+    out = {}
+    rs = np.random.RandomState(99)
+    shape = (2, 3, 8, 8)
+    x = rs.standard_normal(shape).astype(np.float32)
+    mu = rs.uniform(0, 1, shape).astype(np.float32)
+    eps_hat = rs.standard_normal(shape).astype(np.float32)
+    for tag, (ms, T) in {"s10_T100": (10, 100), "s50_T200": (50, 200)}.items():
+        sde = Inj(max_sigma=ms, T=T, schedule="cosine", eps=0.005, device="cpu")
+        z = O.synth_noise(5, T, shape)
+        sde.noise = torch.from_numpy(z)
+        sde.set_mu(torch.from_numpy(mu))
+        out[tag + "/x"] = x
+        out[tag + "/mu"] = mu
+        out[tag + "/eps_hat"] = eps_hat
+        for t in (1, 2, T // 2, T):
+            xt = torch.from_numpy(x)
+            n = torch.from_numpy(eps_hat)
+            score = sde.get_score_from_noise(n, t)
+            out[tag + "/sde_t%d" % t] = sde.reverse_sde_step(xt, score, t).numpy()
+            out[tag + "/ode_t%d" % t] = sde.reverse_ode_step(xt, score, t).numpy()
+            out[tag + "/post_t%d" % t] = sde.reverse_posterior_step(xt, n, t).numpy()
+    np.savez_compressed(os.path.join(GOLD, "steps.npz"), **out)
+    print("steps.npz")
+
+
+def gen_sampler(sde_utils, ConditionalUNet, big=True):
+    """End-to-end reverse samplers with injected noise."""
+    Inj = InjectedIRSDE.make(sde_utils)
+    out = {}
+    cases = {
+        # tag: (nf, depth, B, H, W, T, modes)
+        "nf32d2_2x16x16_T20": (32, 2, 2, 16, 16, 20, ["sde", "ode", "posterior"]),
+        "nf64d4_1x32x32_T100": (64, 4, 1, 32, 32, 100, ["sde", "ode", "posterior"]),
+    }
+    if big:
+        # BASELINE.json configs[0]: the reference's own CPU-runnable case
+        cases["nf64d4_1x128x128_T100"] = (64, 4, 1, 128, 128, 100, ["sde", "posterior"])
+    for tag, (nf, depth, B, H, W, T, modes) in cases.items():
+        params = O.synth_params(seed=0, nf=nf, depth=depth)
+        net = build_ref_net(ConditionalUNet, params, nf, depth)
+        lq, xT = O.synth_inputs(1234, B, H, W)
+        z = O.synth_noise(7, T, (B, 3, H, W))
+        sde = Inj(max_sigma=10, T=T, schedule="cosine", eps=0.005, device="cpu")
+        sde.noise = torch.from_numpy(z)
+        sde.set_model(net)
+        sde.set_mu(torch.from_numpy(lq))
+        out[tag + "/cfg"] = np.array([nf, depth, B, H, W, T], dtype=np.int64)
+        for mode in modes:
+            t0 = time.time()
+            with torch.no_grad():
+                fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[mode]
+                y = fn(torch.from_numpy(xT)).numpy()
+            out[tag + "/" + mode] = y
+            out[tag + "/" + mode + "_wall_s"] = np.float64(time.time() - t0)
+            print(tag, mode, "max|x0|=%.4f" % np.abs(y).max(), "%.1fs" % (time.time() - t0))
+    np.savez_compressed(os.path.join(GOLD, "sampler.npz"), **out)
+    print("sampler.npz")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--no-big", action="store_true")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    os.makedirs(GOLD, exist_ok=True)
+    sde_utils, ConditionalUNet = load_reference(a.ref)
+    if a.only in ("", "schedule"):
+        gen_schedule(sde_utils)
+    if a.only in ("", "forward"):
+        gen_forward(sde_utils, ConditionalUNet)
+    if a.only in ("", "steps"):
+        gen_steps(sde_utils)
+    if a.only in ("", "sampler"):
+        gen_sampler(sde_utils, ConditionalUNet, big=not a.no_big)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,466 @@
+"""CPU oracle for the IR-SDE reverse sampler hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-numpy restatement of the reference algorithm
+(Algolzw/image-restoration-sde).  It is the *checker* for the HIP path; it is
+never imported by the product package (`image_restoration_sde_amd`).  Only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may use it.
+
+Parity pin: every function here is checked against golden vectors produced by
+the real reference code (imported from /root/reference on CPU) by
+`oracle/gen_golden.py`; see `tests/test_oracle_golden.py`.
+
+Each function cites the reference file:line it restates (paths relative to
+/root/reference).  The arithmetic dtype is a parameter: float32 mirrors the
+reference's dtype, float64 gives a "truth" both the reference (fp32, oneDNN
+summation order) and the HIP path (fp32, MFMA summation order) are compared to.
+"""
+import math
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# SDE schedule — codes/utils/sde_utils.py:84-152
+# --------------------------------------------------------------------------------------
+
+
+def irsde_schedule(max_sigma, T=100, schedule="cosine", eps=0.01):
+    """Restates IRSDE.__init__/_initialize (sde_utils.py:84-152) in float32 numpy.
+
+    Returns dict(max_sigma, dt, thetas, sigmas, thetas_cumsum, sigma_bars); arrays have
+    length T+1 (index 0 is never used by the samplers, sde_utils.py:81-83).
+    """
+    f32 = np.float32
+    max_sigma = max_sigma / 255 if max_sigma >= 1 else max_sigma  # :86
+    if schedule == "cosine":  # :110-121
+        timesteps = T + 2
+        steps = timesteps + 1
+        x = np.linspace(0, timesteps, steps, dtype=np.float64).astype(f32)
+        s = 0.008
+        inner = ((x / f32(timesteps)) + f32(s)) / f32(1 + s) * f32(math.pi) * f32(0.5)
+        ac = np.cos(inner.astype(f32)).astype(f32) ** 2
+        ac = (ac / ac[0]).astype(f32)
+        thetas = (f32(1) - ac[1:-1]).astype(f32)
+    elif schedule == "linear":  # :100-108
+        timesteps = T + 1
+        scale = 1000 / timesteps
+        thetas = np.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=np.float64).astype(f32)
+    elif schedule == "constant":  # :91-98
+        thetas = np.ones(T + 1, dtype=f32)
+    else:
+        raise ValueError("unknown schedule %r" % (schedule,))
+    sigmas = np.sqrt(f32(max_sigma ** 2 * 2) * thetas).astype(f32)  # :126-127
+    thetas_cumsum = (np.cumsum(thetas, dtype=f32) - thetas[0]).astype(f32)  # :142
+    dt = f32(f32(-1) / thetas_cumsum[-1]) * f32(math.log(eps))  # :143
+    dt = f32(dt)
+    sigma_bars = np.sqrt(
+        f32(max_sigma ** 2) * (f32(1) - np.exp(f32(-2) * thetas_cumsum * dt).astype(f32))
+    ).astype(f32)  # :129-130
+    return dict(max_sigma=max_sigma, T=T, dt=dt, thetas=thetas, sigmas=sigmas,
+                thetas_cumsum=thetas_cumsum, sigma_bars=sigma_bars)
+
+
+def posterior_coeffs(sch, t):
+    """(x0_gain, term1, term2, std) of reverse_posterior_step — sde_utils.py:197-223,237-239.
+
+    term1/term2/std are ratios of fp32 cancellations ((1-C^2)/(1-B^2) with B,C -> 1 at small t):
+    a 1-ulp difference between numpy's and torch's expf moves them by ~2e-4 relative, so when the
+    caller supplies the tables the reference itself produced (keys post_term1/post_term2/post_std/
+    x0_gain, e.g. from tests/golden/schedule.npz or from the product's torch-built tables, which
+    are pinned bit-exactly to the golden ones) those are used verbatim."""
+    f32 = np.float32
+    if "post_term1" in sch:
+        return (f32(sch["x0_gain"][t]), f32(sch["post_term1"][t]), f32(sch["post_term2"][t]),
+                f32(sch["post_std"][t]))
+    th, cs, dt = sch["thetas"], sch["thetas_cumsum"], sch["dt"]
+    A = np.exp(-th[t] * dt, dtype=f32)
+    B = np.exp(-cs[t] * dt, dtype=f32)
+    C = np.exp(-cs[t - 1] * dt, dtype=f32)
+    term1 = f32(A * (f32(1) - C ** 2) / (f32(1) - B ** 2))
+    term2 = f32(C * (f32(1) - A ** 2) / (f32(1) - B ** 2))
+    A2 = np.exp(f32(-2) * th[t] * dt, dtype=f32)
+    B2 = np.exp(f32(-2) * cs[t] * dt, dtype=f32)
+    C2 = np.exp(f32(-2) * cs[t - 1] * dt, dtype=f32)
+    var = f32((f32(1) - A2) * (f32(1) - C2) / (f32(1) - B2))
+    min_value = f32(f32(1e-20) * dt)
+    logv = np.log(np.maximum(var, min_value), dtype=f32)
+    std = f32(np.exp(f32(0.5) * logv, dtype=f32) * f32(sch["max_sigma"]))
+    x0_gain = np.exp(cs[t] * dt, dtype=f32)
+    return x0_gain, term1, term2, std
+
+
+# ---- one reverse step, elementwise (float32 like the reference, or float64) ----------
+
+
+def reverse_sde_step(sch, x, mu, noise, z, t, dtype=np.float32):
+    """SDE.reverse_sde_step + IRSDE.sde_reverse_drift/dispersion/get_score_from_noise —
+    sde_utils.py:44-45,175-176,181-182,184-185.  `z` is the injected N(0,1) draw that
+    replaces torch.randn_like(x)."""
+    d = dtype
+    x, mu, noise, z = (np.asarray(a, dtype=d) for a in (x, mu, noise, z))
+    theta, sigma, sbar, dt = d(sch["thetas"][t]), d(sch["sigmas"][t]), d(sch["sigma_bars"][t]), d(sch["dt"])
+    score = -noise / sbar
+    drift = (theta * (mu - x) - sigma ** 2 * score) * dt
+    disp = sigma * (z * d(math.sqrt(float(sch["dt"]))))
+    return (x - drift - disp).astype(d)
+
+
+def reverse_ode_step(sch, x, mu, noise, t, dtype=np.float32):
+    """SDE.reverse_ode_step + IRSDE.ode_reverse_drift — sde_utils.py:47-48,178-179."""
+    d = dtype
+    x, mu, noise = (np.asarray(a, dtype=d) for a in (x, mu, noise))
+    theta, sigma, sbar, dt = d(sch["thetas"][t]), d(sch["sigmas"][t]), d(sch["sigma_bars"][t]), d(sch["dt"])
+    score = -noise / sbar
+    drift = (theta * (mu - x) - d(0.5) * sigma ** 2 * score) * dt
+    return (x - drift).astype(d)
+
+
+def reverse_posterior_step(sch, x, mu, noise, z, t, dtype=np.float32):
+    """IRSDE.reverse_posterior_step — sde_utils.py:219-223 (+197-217, 237-239)."""
+    d = dtype
+    x, mu, noise, z = (np.asarray(a, dtype=d) for a in (x, mu, noise, z))
+    g, t1, t2, std = (d(v) for v in posterior_coeffs(sch, t))
+    sbar = d(sch["sigma_bars"][t])
+    x0 = (x - mu - sbar * noise) * g + mu
+    mean = t1 * (x - mu) + t2 * (x0 - mu) + mu
+    return (mean + std * z).astype(d)
+
+
+# --------------------------------------------------------------------------------------
+# ConditionalUNet — codes/config/deraining/models/modules/{DenoisingUNet_arch,module_util}.py
+# --------------------------------------------------------------------------------------
+
+
+def conv2d(x, w, b=None, stride=1, pad=0):
+    """nn.Conv2d forward (cross-correlation), NCHW / OIHW, zero padding."""
+    B, C, H, W = x.shape
+    O, C2, kh, kw = w.shape
+    assert C == C2
+    if pad:
+        x = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    win = np.lib.stride_tricks.sliding_window_view(x, (kh, kw), axis=(2, 3))
+    win = win[:, :, ::stride, ::stride]  # B,C,Ho,Wo,kh,kw
+    Ho, Wo = win.shape[2], win.shape[3]
+    a = np.ascontiguousarray(win.transpose(0, 2, 3, 1, 4, 5)).reshape(B * Ho * Wo, C * kh * kw)
+    out = a @ w.reshape(O, C * kh * kw).T
+    out = out.reshape(B, Ho, Wo, O).transpose(0, 3, 1, 2)
+    if b is not None:
+        out = out + b.reshape(1, O, 1, 1)
+    return np.ascontiguousarray(out)
+
+
+def silu(x):
+    """nn.SiLU — module_util.py:62-63."""
+    return x / (1 + np.exp(-x))
+
+
+def gelu(x):
+    """nn.GELU (erf form) — DenoisingUNet_arch.py:45."""
+    from math import erf
+    verf = np.vectorize(erf, otypes=[np.float64])
+    return (0.5 * x * (1 + verf(x.astype(np.float64) / math.sqrt(2.0)))).astype(x.dtype)
+
+
+def layer_norm_c(x, g):
+    """Channel LayerNorm (gain only) — module_util.py:70-79.  eps=1e-5 (fp32 branch)."""
+    mean = x.mean(axis=1, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=1, keepdims=True)
+    return (x - mean) / np.sqrt(var + x.dtype.type(1e-5)) * g
+
+
+def sinusoidal_pos_emb(t, dim, dtype):
+    """SinusoidalPosEmb — module_util.py:29-41.  t: array [b] of ints."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    freqs = np.exp(np.arange(half).astype(np.float32) * np.float32(-e)).astype(np.float32)
+    arg = (np.asarray(t).astype(np.float32)[:, None] * freqs[None, :]).astype(np.float32)
+    arg = arg.astype(dtype)
+    return np.concatenate([np.sin(arg), np.cos(arg)], axis=-1)
+
+
+def linear(x, w, b):
+    return x @ w.T + b
+
+
+def linear_attention(p, prefix, x, heads=4, dim_head=32):
+    """LinearAttention.forward — module_util.py:163-178."""
+    B, C, H, W = x.shape
+    N = H * W
+    qkv = conv2d(x, p[prefix + "to_qkv.weight"])
+    q, k, v = (qkv[:, i * heads * dim_head:(i + 1) * heads * dim_head].reshape(B, heads, dim_head, N)
+               for i in range(3))
+    q = np.exp(q - q.max(axis=2, keepdims=True))
+    q = q / q.sum(axis=2, keepdims=True)
+    k = np.exp(k - k.max(axis=3, keepdims=True))
+    k = k / k.sum(axis=3, keepdims=True)
+    q = q * x.dtype.type(dim_head ** -0.5)
+    v = v / x.dtype.type(N)
+    context = np.einsum("bhdn,bhen->bhde", k, v)
+    out = np.einsum("bhde,bhdn->bhen", context, q)
+    out = out.reshape(B, heads * dim_head, H, W)
+    out = conv2d(out, p[prefix + "to_out.0.weight"], p[prefix + "to_out.0.bias"])
+    return layer_norm_c(out, p[prefix + "to_out.1.g"])
+
+
+def attn_block(p, prefix, x):
+    """Residual(PreNorm(dim, LinearAttention(dim))) — module_util.py:20-26,82-90."""
+    return linear_attention(p, prefix + "fn.fn.", layer_norm_c(x, p[prefix + "fn.norm.g"])) + x
+
+
+def res_block(p, prefix, x, temb):
+    """ResBlock.forward — module_util.py:136-146 (Block :108-122)."""
+    ss = linear(silu(temb), p[prefix + "mlp.1.weight"], p[prefix + "mlp.1.bias"])  # [b, 2C]
+    C = ss.shape[1] // 2
+    scale = ss[:, :C, None, None]
+    shift = ss[:, C:, None, None]
+    h = conv2d(x, p[prefix + "block1.proj.weight"], pad=1)
+    h = silu(h * (scale + 1) + shift)
+    h = silu(conv2d(h, p[prefix + "block2.proj.weight"], pad=1))
+    if (prefix + "res_conv.weight") in p:
+        return h + conv2d(x, p[prefix + "res_conv.weight"])
+    return h + x
+
+
+def upsample_nearest2(x):
+    return x.repeat(2, axis=2).repeat(2, axis=3)
+
+
+def unet_forward(params, xt, cond, t, depth=4, dtype=np.float64, taps=None):
+    """ConditionalUNet.forward — DenoisingUNet_arch.py:85-134.
+
+    params: dict of reference state_dict names -> numpy arrays (NCHW / OIHW).
+    t: python int (sampling) or int array [B] (training-style).  `taps`: optional dict that
+    receives named intermediate activations (NCHW) for per-layer debugging.
+    """
+    p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
+    xt = np.asarray(xt, dtype=dtype)
+    cond = np.asarray(cond, dtype=dtype)
+    if np.isscalar(t):
+        t = np.array([int(t)])
+    x = np.concatenate([xt - cond, cond], axis=1)  # :90-91
+    H, W = x.shape[2:]
+    s = 2 ** depth
+    ph, pw = (s - H % s) % s, (s - W % s) % s
+    x = np.pad(x, ((0, 0), (0, 0), (0, ph), (0, pw)), mode="reflect")  # :78-83
+    x = conv2d(x, p["init_conv.weight"], pad=3)  # :96
+    x_ = x
+    nf = p["init_conv.weight"].shape[0]
+    temb = sinusoidal_pos_emb(t, nf, dtype)  # :99
+    temb = linear(temb, p["time_mlp.1.weight"], p["time_mlp.1.bias"])
+    temb = gelu(temb)
+    temb = linear(temb, p["time_mlp.3.weight"], p["time_mlp.3.bias"])
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+
+    tap("init_conv", x)
+    tap("time_emb", temb)
+    h = []
+    for i in range(depth):  # :103-111
+        x = res_block(p, "downs.%d.0." % i, x, temb)
+        tap("downs.%d.0" % i, x)
+        h.append(x)
+        x = res_block(p, "downs.%d.1." % i, x, temb)
+        tap("downs.%d.1" % i, x)
+        x = attn_block(p, "downs.%d.2." % i, x)
+        tap("downs.%d.2" % i, x)
+        h.append(x)
+        if i != depth - 1:
+            x = conv2d(x, p["downs.%d.3.weight" % i], p["downs.%d.3.bias" % i], stride=2, pad=1)
+        else:
+            x = conv2d(x, p["downs.%d.3.weight" % i], pad=1)
+        tap("downs.%d.3" % i, x)
+    x = res_block(p, "mid_block1.", x, temb)  # :113-115
+    tap("mid_block1", x)
+    x = attn_block(p, "mid_attn.", x)
+    tap("mid_attn", x)
+    x = res_block(p, "mid_block2.", x, temb)
+    tap("mid_block2", x)
+    for j in range(depth):  # :117-125
+        x = np.concatenate([x, h.pop()], axis=1)
+        x = res_block(p, "ups.%d.0." % j, x, temb)
+        tap("ups.%d.0" % j, x)
+        x = np.concatenate([x, h.pop()], axis=1)
+        x = res_block(p, "ups.%d.1." % j, x, temb)
+        tap("ups.%d.1" % j, x)
+        x = attn_block(p, "ups.%d.2." % j, x)
+        tap("ups.%d.2" % j, x)
+        if j != depth - 1:
+            x = conv2d(upsample_nearest2(x), p["ups.%d.3.1.weight" % j], p["ups.%d.3.1.bias" % j], pad=1)
+        else:
+            x = conv2d(x, p["ups.%d.3.weight" % j], pad=1)
+        tap("ups.%d.3" % j, x)
+    x = np.concatenate([x, x_], axis=1)  # :127
+    x = res_block(p, "final_res_block.", x, temb)
+    tap("final_res_block", x)
+    x = conv2d(x, p["final_conv.weight"], p["final_conv.bias"], pad=1)  # :130
+    return np.ascontiguousarray(x[..., :H, :W])  # :132
+
+
+# --------------------------------------------------------------------------------------
+# Parameter inventory + deterministic synthetic weights (shared by golden gen and tests)
+# --------------------------------------------------------------------------------------
+
+
+def unet_param_shapes(in_nc=3, out_nc=3, nf=64, depth=4):
+    """Names/shapes of ConditionalUNet's state_dict — DenoisingUNet_arch.py:19-76.
+    (151 tensors for nf=64, depth=4; checked against the reference in gen_golden.py.)"""
+    sh = {}
+    td = nf * 4
+    sh["init_conv.weight"] = (nf, in_nc * 2, 7, 7)
+    sh["time_mlp.1.weight"] = (td, nf)
+    sh["time_mlp.1.bias"] = (td,)
+    sh["time_mlp.3.weight"] = (td, td)
+    sh["time_mlp.3.bias"] = (td,)
+
+    def resblock(prefix, ci, co):
+        sh[prefix + "mlp.1.weight"] = (2 * co, td)
+        sh[prefix + "mlp.1.bias"] = (2 * co,)
+        sh[prefix + "block1.proj.weight"] = (co, ci, 3, 3)
+        sh[prefix + "block2.proj.weight"] = (co, co, 3, 3)
+        if ci != co:
+            sh[prefix + "res_conv.weight"] = (co, ci, 1, 1)
+
+    def attn(prefix, c):
+        sh[prefix + "fn.norm.g"] = (1, c, 1, 1)
+        sh[prefix + "fn.fn.to_qkv.weight"] = (384, c, 1, 1)
+        sh[prefix + "fn.fn.to_out.0.weight"] = (c, 128, 1, 1)
+        sh[prefix + "fn.fn.to_out.0.bias"] = (c,)
+        sh[prefix + "fn.fn.to_out.1.g"] = (1, c, 1, 1)
+
+    for i in range(depth):
+        di, do = nf * 2 ** i, nf * 2 ** (i + 1)
+        resblock("downs.%d.0." % i, di, di)
+        resblock("downs.%d.1." % i, di, di)
+        attn("downs.%d.2." % i, di)
+        if i != depth - 1:
+            sh["downs.%d.3.weight" % i] = (do, di, 4, 4)
+            sh["downs.%d.3.bias" % i] = (do,)
+        else:
+            sh["downs.%d.3.weight" % i] = (do, di, 3, 3)
+        j = depth - 1 - i
+        resblock("ups.%d.0." % j, do + di, do)
+        resblock("ups.%d.1." % j, do + di, do)
+        attn("ups.%d.2." % j, do)
+        if i != 0:
+            sh["ups.%d.3.1.weight" % j] = (di, do, 3, 3)
+            sh["ups.%d.3.1.bias" % j] = (di,)
+        else:
+            sh["ups.%d.3.weight" % j] = (di, do, 3, 3)
+    mid = nf * 2 ** depth
+    resblock("mid_block1.", mid, mid)
+    attn("mid_attn.", mid)
+    resblock("mid_block2.", mid, mid)
+    resblock("final_res_block.", nf * 2, nf)
+    sh["final_conv.weight"] = (out_nc, nf, 3, 3)
+    sh["final_conv.bias"] = (out_nc,)
+    return sh
+
+
+def synth_params(seed=0, in_nc=3, out_nc=3, nf=64, depth=4, gain=1.0):
+    """Deterministic synthetic weights (numpy legacy RandomState: bit-stable across
+    machines).  Conv/Linear weights & biases ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like
+    PyTorch's default init; LayerNorm gains ~ U(0.5, 1.5) so the gain path is exercised."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    shapes = unet_param_shapes(in_nc, out_nc, nf, depth)
+    for name in sorted(shapes):
+        shp = shapes[name]
+        if name.endswith(".g"):
+            a = rs.uniform(0.5, 1.5, size=shp)
+        else:
+            if name.endswith("bias"):
+                wshape = shapes[name[:-4] + "weight"]
+            else:
+                wshape = shp
+            fan_in = int(np.prod(wshape[1:]))
+            bound = gain / math.sqrt(fan_in)
+            a = rs.uniform(-bound, bound, size=shp)
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def synth_inputs(seed, B, H, W, max_sigma=10.0):
+    """LQ in [0,1], x_T = LQ + N(0,1)*max_sigma/255 (IRSDE.noise_state, sde_utils.py:360-361)."""
+    rs = np.random.RandomState(seed)
+    lq = rs.uniform(0, 1, size=(B, 3, H, W)).astype(np.float32)
+    ms = max_sigma / 255 if max_sigma >= 1 else max_sigma
+    xT = (lq + rs.standard_normal((B, 3, H, W)).astype(np.float32) * np.float32(ms)).astype(np.float32)
+    return lq, xT
+
+
+def synth_noise(seed, T, shape):
+    """Injected per-step N(0,1) draws, index [t] for t in 1..T (index 0 unused)."""
+    rs = np.random.RandomState(seed)
+    return rs.standard_normal((T + 1,) + tuple(shape)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Sampler loops — sde_utils.py:252-299
+# --------------------------------------------------------------------------------------
+
+
+def sample(params, sch, xT, mu, mode, noise=None, depth=4, dtype=np.float64, T=-1, net=None):
+    """IRSDE.reverse_sde / reverse_ode / reverse_posterior (sde_utils.py:252-299) with the
+    per-step torch.randn_like replaced by `noise[t]` (shape [T+1,B,3,H,W])."""
+    T = sch["T"] if T < 0 else T
+    x = np.asarray(xT, dtype=dtype).copy()
+    mu = np.asarray(mu, dtype=dtype)
+    fwd = net if net is not None else (lambda x_, mu_, t_: unet_forward(params, x_, mu_, t_, depth=depth, dtype=dtype))
+    for t in range(T, 0, -1):
+        eps_hat = fwd(x, mu, t)
+        if mode == "sde":
+            x = reverse_sde_step(sch, x, mu, eps_hat, noise[t], t, dtype)
+        elif mode == "ode":
+            x = reverse_ode_step(sch, x, mu, eps_hat, t, dtype)
+        elif mode == "posterior":
+            x = reverse_posterior_step(sch, x, mu, eps_hat, noise[t], t, dtype)
+        else:
+            raise ValueError(mode)
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# Philox4x32-10 + Box-Muller: restatement of the device RNG used when no noise is injected
+# (new behaviour, not in the reference, which calls torch.randn_like — sde_utils.py:182,223).
+# Spec: Salmon et al., "Parallel Random Numbers: As Easy as 1, 2, 3" (SC'11), Philox4x32-10.
+# --------------------------------------------------------------------------------------
+
+PHILOX_M0, PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
+PHILOX_W0, PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(ctr, key):
+    """ctr: uint32 array [...,4]; key: (k0,k1). Returns uint32 array [...,4]."""
+    c = [np.asarray(ctr[..., i], dtype=np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(PHILOX_M0) * c[0]
+        p1 = np.uint64(PHILOX_M1) * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c = [(hi1 ^ c[1] ^ k0) & mask, lo1, (hi0 ^ c[3] ^ k1) & mask, lo0]
+        k0 = (k0 + np.uint64(PHILOX_W0)) & mask
+        k1 = (k1 + np.uint64(PHILOX_W1)) & mask
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def device_normal(seed, t, image_index, n_elems):
+    """N(0,1) draws for one image at step t, element order (c,y,x) flattened; matches
+    `irsde_philox_normal` in csrc/elementwise.hip: counter=(e//4, t, image, 0x1D5DE),
+    key=(seed lo, seed hi); Box-Muller on (r0,r1) and (r2,r3)."""
+    nq = (n_elems + 3) // 4
+    ctr = np.zeros((nq, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(nq, dtype=np.uint32)
+    ctr[:, 1] = np.uint32(t)
+    ctr[:, 2] = np.uint32(image_index)
+    ctr[:, 3] = np.uint32(0x1D5DE)
+    r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).astype(np.float64)
+    u = ((np.floor(r / 256.0)) + 0.5) * (1.0 / 16777216.0)  # (r>>8 + 0.5) * 2^-24 in (0,1)
+    rad0 = np.sqrt(-2.0 * np.log(u[:, 0]))
+    rad1 = np.sqrt(-2.0 * np.log(u[:, 2]))
+    a0 = 2.0 * math.pi * u[:, 1]
+    a1 = 2.0 * math.pi * u[:, 3]
+    z = np.stack([rad0 * np.cos(a0), rad0 * np.sin(a0), rad1 * np.cos(a1), rad1 * np.sin(a1)], axis=1)
+    return z.reshape(-1)[:n_elems]

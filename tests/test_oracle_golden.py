@@ -1,0 +1,134 @@
+"""Pins the numpy oracle against golden vectors produced by the REAL reference
+(oracle/gen_golden.py, run in the build container against /root/reference)."""
+import numpy as np
+import pytest
+
+from oracle import irsde_oracle as O
+
+
+def _sched_from_cfg(g, tag):
+    ms, T, eps = g[tag + "/cfg"]
+    return O.irsde_schedule(float(ms) if ms < 1 else int(ms), int(T), str(g[tag + "/sched"]), float(eps))
+
+
+@pytest.mark.parametrize("tag", ["s10_T100", "s50_T100", "s50_T200", "s25_T100_lin", "s0p1_T50_const"])
+def test_schedule_tables(golden, tag):
+    g = golden.schedule
+    sch = _sched_from_cfg(g, tag)
+    # fp32 tables: numpy's cosf/cumsum differ from torch's by 1 ulp and `1 - cos^2`, `1 - exp(-x)`
+    # amplify that by cancellation at small t, hence the per-table tolerances.  (The product builds
+    # its tables with the same torch CPU ops as the reference and is checked bit-exactly elsewhere.)
+    assert abs(float(sch["dt"]) - float(g[tag + "/dt"])) <= 1e-6 * abs(float(g[tag + "/dt"]))
+    for n, rtol in (("thetas", 3e-5), ("sigmas", 2e-5), ("thetas_cumsum", 1e-5), ("sigma_bars", 5e-4)):
+        ref = g[tag + "/" + n]
+        # index 0 of the cosine theta table is ~1e-8 cancellation noise and never used (sde_utils.py:81-83)
+        np.testing.assert_allclose(sch[n][1:], ref[1:], rtol=rtol, atol=1e-9, err_msg=n)
+    T = sch["T"]
+    for t in range(1, T + 1):
+        g0, t1, t2, std = O.posterior_coeffs(sch, t)
+        np.testing.assert_allclose(g0, g[tag + "/x0_gain"][t], rtol=2e-5)
+        # (1-C^2)/(1-B^2) is a ratio of two cancellations in fp32: ill-conditioned at small t
+        np.testing.assert_allclose(t1, g[tag + "/post_term1"][t], rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(t2, g[tag + "/post_term2"][t], rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(std, g[tag + "/post_std"][t], rtol=2e-3, atol=1e-12)
+    # away from the ill-conditioned first steps the coefficients agree tightly
+    for t in range(8, T + 1):
+        g0, t1, t2, std = O.posterior_coeffs(sch, t)
+        np.testing.assert_allclose(t1, g[tag + "/post_term1"][t], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(t2, g[tag + "/post_term2"][t], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(std, g[tag + "/post_std"][t], rtol=2e-4, atol=1e-12)
+
+
+def test_schedule_anchors_baseline_md():
+    """BASELINE.md §4 known-answer anchors."""
+    s = O.irsde_schedule(10, 100, "cosine", 0.005)
+    np.testing.assert_allclose(s["dt"], 0.104093805, rtol=1e-6)
+    np.testing.assert_allclose(s["thetas"][1], 0.00169456005, rtol=1e-5)
+    np.testing.assert_allclose(s["thetas"][100], 0.999766588, rtol=1e-6)
+    np.testing.assert_allclose(s["sigmas"][100], 0.0554528832, rtol=1e-6)
+    np.testing.assert_allclose(s["thetas_cumsum"][100], 50.8994484, rtol=1e-6)
+    np.testing.assert_allclose(s["sigma_bars"][1], 0.000736524758, rtol=1e-5)
+    np.testing.assert_allclose(s["sigma_bars"][100], 0.0392151959, rtol=1e-6)
+    np.testing.assert_allclose(O.posterior_coeffs(s, 2)[3], 5.96858503e-4, rtol=1e-4)
+    np.testing.assert_allclose(O.posterior_coeffs(s, 100)[3], 1.69992093e-2, rtol=1e-5)
+    s = O.irsde_schedule(50, 200, "cosine", 0.005)
+    np.testing.assert_allclose(s["dt"], 0.052307323, rtol=1e-6)
+    np.testing.assert_allclose(s["thetas_cumsum"][200] * s["dt"], 5.298317, rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["s10_T100", "s50_T200"])
+def test_single_steps(golden, tag):
+    g = golden.steps
+    ms, T = (10, 100) if tag == "s10_T100" else (50, 200)
+    sch = O.irsde_schedule(ms, T, "cosine", 0.005)
+    gs = golden.schedule
+    sch.update({n: gs[tag + "/" + n] for n in ("thetas", "sigmas", "thetas_cumsum", "sigma_bars",
+                                               "post_term1", "post_term2", "post_std", "x0_gain")},
+               dt=gs[tag + "/dt"])
+    x, mu, eh = g[tag + "/x"], g[tag + "/mu"], g[tag + "/eps_hat"]
+    z = O.synth_noise(5, T, x.shape)
+    for t in (1, 2, T // 2, T):
+        for dtype, tol in ((np.float32, 2e-5), (np.float64, 2e-5)):
+            np.testing.assert_allclose(O.reverse_sde_step(sch, x, mu, eh, z[t], t, dtype),
+                                       g[tag + "/sde_t%d" % t], rtol=tol, atol=tol)
+            np.testing.assert_allclose(O.reverse_ode_step(sch, x, mu, eh, t, dtype),
+                                       g[tag + "/ode_t%d" % t], rtol=tol, atol=tol)
+            np.testing.assert_allclose(O.reverse_posterior_step(sch, x, mu, eh, z[t], t, dtype),
+                                       g[tag + "/post_t%d" % t], rtol=tol, atol=tol)
+
+
+def test_param_inventory_matches_reference_count():
+    assert len(O.unet_param_shapes(3, 3, 64, 4)) == 151
+    n = sum(int(np.prod(s)) for s in O.unet_param_shapes(3, 3, 64, 4).values())
+    assert n == 137147523
+
+
+@pytest.mark.parametrize("tag", ["nf32d2_2x24x20", "nf64d4_1x64x64", "nf64d4_2x40x56"])
+def test_unet_forward(golden, tag):
+    g = golden.forward
+    nf, depth, B, H, W = (int(v) for v in g[tag + "/cfg"])
+    params = O.synth_params(seed=0, nf=nf, depth=depth)
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    for t in g[tag + "/ts"]:
+        ref = g[tag + "/t%d" % t]
+        y = O.unet_forward(params, xT, lq, int(t), depth=depth, dtype=np.float64)
+        err = np.abs(y - ref).max() / np.abs(ref).max()
+        assert err < 2e-5, (tag, t, err)
+    if tag == "nf32d2_2x24x20":
+        y = O.unet_forward(params, xT, lq, np.array([5, 60]), depth=depth, dtype=np.float64)
+        ref = g[tag + "/tvec"]
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-5
+        # fp32 oracle agrees too (looser)
+        y32 = O.unet_forward(params, xT, lq, 3, depth=depth, dtype=np.float32)
+        ref = g[tag + "/t3"]
+        assert np.abs(y32 - ref).max() / np.abs(ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["sde", "ode", "posterior"])
+def test_sampler_small(golden, mode):
+    g = golden.sampler
+    tag = "nf32d2_2x16x16_T20"
+    nf, depth, B, H, W, T = (int(v) for v in g[tag + "/cfg"])
+    params = O.synth_params(seed=0, nf=nf, depth=depth)
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    z = O.synth_noise(7, T, (B, 3, H, W))
+    sch = O.irsde_schedule(10, T, "cosine", 0.005)
+    y = O.sample(params, sch, xT, lq, mode, noise=z, depth=depth, dtype=np.float64)
+    ref = g[tag + "/" + mode]
+    err = np.abs(y - ref).max() / np.abs(ref).max()
+    # the reverse drift expands perturbations ~200x: fp32 reference vs fp64 oracle
+    assert err < 1e-3, (mode, err)
+
+
+def test_philox_known_answer():
+    """Random123 known-answer vectors for philox4x32-10 (kat_vectors: zero / pi inputs)."""
+    out = O.philox4x32_10(np.zeros((1, 4), dtype=np.uint32), (0, 0))[0]
+    assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    ctr = np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], dtype=np.uint32)
+    out = O.philox4x32_10(ctr, (0xa4093822, 0x299f31d0))[0]
+    assert [hex(v) for v in out] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_device_normal_moments():
+    z = O.device_normal(1234, 7, 3, 3 * 64 * 64)
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
