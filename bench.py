@@ -1,0 +1,175 @@
+"""bench.py — images/s of the full T-step IR-SDE reverse sampler (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one batch: `IRSDE.reverse_sde` (T=100 network evaluations + state
+updates) on a synthetic batch of 16 x 3 x 256 x 256 per GPU (BASELINE.json configs[1]); weak scaling: every
+rank samples its own 16 images (global image index keyed RNG), the only collective is the final all_gather
+of the restored images (RCCL over xGMI), which is inside the timed region.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = conv_igemm on the fp32 MFMA pipe, timed live
+with hipEvents on the engine's stream during the timed steps) and `cpu_baseline` (the torch-CPU port of the
+reference timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 matrix = vector peak (guides/MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0
+
+
+def cpu_baseline(size, T, budget_s=20.0):
+    """Reference CPU path (torch CPU ops, oracle/torch_cpu_port.py) on a bounded sample: B=1 image of
+    size x size, as many reverse_sde steps as fit in ~budget_s (min 2, max 10), extrapolated to T steps."""
+    import torch
+    from oracle import irsde_oracle as O
+    from oracle import torch_cpu_port as TP
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = {k: torch.from_numpy(v) for k, v in O.synth_params(seed=0, nf=64, depth=4).items()}
+    lq, xT = O.synth_inputs(1234, 1, size, size)
+    sch = O.irsde_schedule(10, T, "cosine", 0.005)
+    z = torch.from_numpy(O.synth_noise(7, T, (1, 3, size, size)))
+    x, mu = torch.from_numpy(xT), torch.from_numpy(lq)
+    TP.reverse_sde_steps(params, sch, x, mu, z, T, 1)  # warm-up (oneDNN primitive creation)
+    n, t0 = 0, time.time()
+    while n < 10 and (n < 2 or time.time() - t0 < budget_s):
+        x = TP.reverse_sde_steps(params, sch, x, mu, z, T - n, 1)
+        n += 1
+    per_step = (time.time() - t0) / n
+    return {"value": 1.0 / (per_step * T), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "B=1 %dx%d, %d of T=%d reverse_sde steps timed (%.2f s/step), extrapolated x%d; torch %s CPU, "
+                      "%d threads" % (size, size, n, T, per_step, T, torch.__version__, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU (BASELINE config 2: 16)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--T", type=int, default=100)
+    ap.add_argument("--mode", default="sde", choices=["sde", "ode", "posterior"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="time graph replay instead of the event-instrumented loop")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import image_restoration_sde_amd as P
+    from oracle import irsde_oracle as O  # synthetic weight/input generators only (shared with the tests)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    nf, depth = 64, 4
+    params = O.synth_params(seed=0, nf=nf, depth=depth)
+    model = P.ConditionalUNet(3, 3, nf, depth=depth)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model = model.to(dev).eval()
+    sde = P.IRSDE(max_sigma=10, T=a.T, schedule="cosine", eps=0.005, device=dev)
+    sde.set_model(model)
+    sde.seed = 7
+    sde.profile = not a.no_profile
+    sde.use_graph = True
+
+    nglobal = a.batch * world
+    # every rank materialises only its shard of the synthetic global batch (same generator => same images)
+    lq, xT = O.synth_inputs(1234, a.batch, a.size, a.size)
+    rs = np.random.RandomState(1000 + rank)
+    lq = np.clip(lq + 0.01 * rs.standard_normal(lq.shape).astype(np.float32), 0, 1)
+    mu = torch.from_numpy(lq).to(dev)
+    x_T = torch.from_numpy(xT).to(dev)
+    sde.image_offset = rank * a.batch
+    sde.set_mu(mu)
+    fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[a.mode]
+
+    def one_step():
+        out = fn(x_T)
+        if world > 1:
+            parts = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(parts, out)  # the final gather: the only collective of the path
+            out = torch.cat(parts, 0)
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = one_step()
+    prof = dict(conv_ms=0.0, conv_flops=0.0, conv_launches=0.0, conv_bytes=0.0, ln_ms=0.0, attn_ms=0.0, other_ms=0.0,
+                wall_ms=0.0, net_evals=0.0)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = one_step()
+        if sde.profile:
+            torch.cuda.synchronize()
+            for k, v in sde.last_profile().items():
+                prof[k] += v
+    fence()
+    dt = time.perf_counter() - t0
+    assert out.shape[0] == nglobal and bool(torch.isfinite(out).all())
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        imgs = nglobal * a.steps
+        res = {
+            "metric": "restored images/sec at %dx%d, %d-step IR-SDE reverse sampler" % (a.size, a.size, a.T),
+            "value": imgs / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "IR-SDE deraining ConditionalUNet nf=64 depth=4, reverse_%s, batch=%d/GPU %dx%d, "
+                                   "T=%d, fp32 (BASELINE.json configs[1])" % (a.mode, a.batch, a.size, a.size, a.T),
+                       "global_batch": nglobal, "parallelism": "batch-shard x%d (no collective in the T loop; final all_gather)" % world},
+        }
+        if sde.profile and prof["conv_ms"] > 0:
+            ach = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
+            res["roofline"] = {
+                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all %d conv launches per network evaluation)"
+                          % int(round(prof["conv_launches"] / max(prof["net_evals"], 1))),
+                "avg_launch_ms": prof["conv_ms"] / max(prof["conv_launches"], 1),
+                "flops_per_launch": prof["conv_flops"] / max(prof["conv_launches"], 1),
+                "kernel_time_share": {"conv": prof["conv_ms"] / prof["wall_ms"], "layernorm": prof["ln_ms"] / prof["wall_ms"],
+                                      "attention": prof["attn_ms"] / prof["wall_ms"], "other": prof["other_ms"] / prof["wall_ms"]},
+                # north_star also asks for the HBM-roofline fraction: ideal-fusion conv bytes / wall / 8 TB/s
+                "hbm_algorithmic_GBps": prof["conv_bytes"] / (prof["wall_ms"] * 1e-3) / 1e9,
+                "hbm_frac": prof["conv_bytes"] / (prof["wall_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                "whole_path_TFLOPs": prof["conv_flops"] / (prof["wall_ms"] * 1e-3) / 1e12,
+            }
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(a.size, a.T)
+            except Exception as ex:  # the GPU number must not be lost to a host-side problem
+                res["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,16 @@
+"""image-restoration-sde_amd: the IR-SDE reverse-diffusion sampler of Algolzw/image-restoration-sde,
+rebuilt for MI355X (gfx950): hand-written HIP kernels behind a C ABI (include/irsde_hip.h,
+csrc/ -> libirsde_hip.so) with the reference's own Python interface on top:
+
+    IRSDE              codes/utils/sde_utils.py:80-361
+    ConditionalUNet    codes/config/deraining/models/modules/DenoisingUNet_arch.py:18-134
+    DenoisingModel     codes/config/deraining/models/denoising_model.py (inference surface)
+"""
+from ._lib import IrsdeError, IrsdeLibraryError, build_library  # noqa: F401
+from .denoising_model import DenoisingModel, create_model, define_G  # noqa: F401
+from .dist import gather_batch, sample_sharded, shard_bounds  # noqa: F401
+from .sde import IRSDE  # noqa: F401
+from .unet import ConditionalUNet  # noqa: F401
+
+__all__ = ["IRSDE", "ConditionalUNet", "DenoisingModel", "create_model", "define_G", "build_library",
+           "IrsdeError", "IrsdeLibraryError", "shard_bounds", "gather_batch", "sample_sharded"]

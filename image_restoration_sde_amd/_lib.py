@@ -1,0 +1,118 @@
+"""ctypes binding of libirsde_hip.so (C ABI: include/irsde_hip.h).
+
+The HIP library IS the product: there is no PyTorch / CPU fallback.  If the shared library is
+missing or fails to load, every entry point raises `IrsdeLibraryError`.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libirsde_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MODE = {"sde": 0, "ode": 1, "posterior": 2}
+COEF_STRIDE = 12
+FLAG_KEEP_ACTIVATIONS = 1
+FLAG_NAIVE_CONV = 2
+SAMPLE_GRAPH = 1
+SAMPLE_PROFILE = 2
+
+# every symbol include/irsde_hip.h declares (checked by tests/test_cabi.py)
+SYMBOLS = [
+    "irsde_last_error", "irsde_version", "irsde_create", "irsde_destroy", "irsde_num_weights",
+    "irsde_weight_name", "irsde_weight_shape", "irsde_load_weight", "irsde_finalize_weights",
+    "irsde_set_schedule", "irsde_unet_forward", "irsde_sample", "irsde_sde_step", "irsde_philox_normal",
+    "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv",
+]
+
+
+class IrsdeLibraryError(RuntimeError):
+    pass
+
+
+class IrsdeError(RuntimeError):
+    pass
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("in_nc", ctypes.c_int32), ("out_nc", ctypes.c_int32), ("nf", ctypes.c_int32),
+                ("depth", ctypes.c_int32), ("device", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into libirsde_hip.so (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    r = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise IrsdeLibraryError("building libirsde_hip.so failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+def _declare(lib):
+    c = ctypes
+    P = c.c_void_p
+    lib.irsde_last_error.restype = c.c_char_p
+    lib.irsde_last_error.argtypes = []
+    lib.irsde_version.restype = c.c_int
+    lib.irsde_create.argtypes = [c.POINTER(Config), c.POINTER(P)]
+    lib.irsde_destroy.argtypes = [P]
+    lib.irsde_destroy.restype = None
+    lib.irsde_num_weights.argtypes = [P]
+    lib.irsde_weight_name.argtypes = [P, c.c_int]
+    lib.irsde_weight_name.restype = c.c_char_p
+    lib.irsde_weight_shape.argtypes = [P, c.c_int, c.POINTER(c.c_int64), c.POINTER(c.c_int)]
+    lib.irsde_load_weight.argtypes = [P, c.c_char_p, P, c.POINTER(c.c_int64), c.c_int]
+    lib.irsde_finalize_weights.argtypes = [P]
+    lib.irsde_set_schedule.argtypes = [P, c.c_int, P]
+    lib.irsde_unet_forward.argtypes = [P, P, P, c.POINTER(c.c_int64), c.c_int, c.c_int, c.c_int, c.c_int, P, P]
+    lib.irsde_sample.argtypes = [P, c.c_int, P, P, P, c.c_uint64, c.c_uint64, c.c_int, c.c_int, c.c_int,
+                                 c.c_int, c.c_int, P, P, c.c_int]  # ..., B, H, W, T, t_stop, out, stream, flags
+    lib.irsde_sde_step.argtypes = [c.c_int, c.c_int, P, P, P, P, P, c.c_uint64, c.c_uint64, c.c_int, c.c_int,
+                                   c.c_int, c.c_int, P]
+    lib.irsde_philox_normal.argtypes = [P, c.c_int, c.c_int, c.c_int, c.c_uint64, c.c_uint64, P]
+    lib.irsde_get_profile.argtypes = [P, c.POINTER(c.c_double)]
+    lib.irsde_debug_tap.argtypes = [P, c.c_char_p, P, c.POINTER(c.c_int64)]
+    lib.irsde_work_model.argtypes = [P, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double)]
+    lib.irsde_debug_conv.argtypes = [P, c.c_int, P, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, P, c.c_int, c.c_int,
+                                     c.c_int, c.c_int, c.c_int, P, P, c.c_int, c.c_int, P, P, c.c_int, c.c_int, P]
+    for name in SYMBOLS:
+        getattr(lib, name)  # AttributeError here = the .so does not export what the header declares
+    return lib
+
+
+def lib():
+    """The loaded library; raises IrsdeLibraryError (never falls back) when it is unavailable."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise IrsdeLibraryError(
+                    "libirsde_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; "
+                    "g.build()'` or `make -C %s`. There is no CPU/PyTorch fallback for this path." % (LIB_PATH, CSRC))
+            try:
+                _lib = _declare(ctypes.CDLL(LIB_PATH))
+            except OSError as ex:
+                raise IrsdeLibraryError("failed to load %s: %s" % (LIB_PATH, ex)) from ex
+        return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().irsde_last_error()
+        raise IrsdeError("libirsde_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr(torch_stream=None):
+    """hipStream_t of torch's current stream (so calls are ordered with the caller's torch work)."""
+    import torch
+    s = torch_stream if torch_stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)

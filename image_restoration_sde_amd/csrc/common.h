@@ -1,0 +1,144 @@
+// Shared declarations for the IR-SDE gfx950 engine (internal; the public C ABI is include/irsde_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace irsde {
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define IRSDE_HIP_CHECK(expr)                                                                  \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            throw ::irsde::HipError(std::string(#expr) + " failed: " + hipGetErrorString(_e) + \
+                                    " (" __FILE__ ":" + std::to_string(__LINE__) + ")");       \
+        }                                                                                      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution, NHWC fp32, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//   out[m][n] = epilogue( sum_{ky,kx,c} in[(b, oy*stride-pad_y+ky, ox*stride-pad_x+kx), c] * w[n][ky][kx][c] )
+// with m = (b*Ho + oy)*Wo + ox.  The input may be the channel-concatenation of two tensors
+// (torch.cat([x, skip], 1) is never materialised) and may be read through a nearest x2 upsample
+// (in_shift = 1: virtual pixel (y,x) reads physical (y>>1, x>>1)).
+// Epilogue order: +bias[n] -> *(film_scale[n]+1)+film_shift[n] -> SiLU -> +res[m][n].
+// ---------------------------------------------------------------------------------------------
+struct ConvParams {
+    const float* in0 = nullptr;
+    const float* in1 = nullptr;  // second concat source or null
+    int C0 = 0, C1 = 0;          // channels looped per source (multiples of 32)
+    int pix0 = 0, pix1 = 0;      // floats between consecutive pixels of each source
+    int Hin = 0, Win = 0;        // physical input height/width (both sources)
+    int in_shift = 0;            // 1: fused nearest x2 upsample
+    const float* w = nullptr;    // [Cout][KH*KW][C0+C1]
+    int Cout = 0;
+    int KH = 1, KW = 1, stride = 1, pad_y = 0, pad_x = 0;
+    int B = 0, Ho = 0, Wo = 0;
+    float* out = nullptr;
+    int out_stride = 0;          // floats between consecutive output pixels (>= Cout)
+    const float* bias = nullptr;
+    const float* film = nullptr;  // row r: [scale(Cout) | shift(Cout)]
+    int film_bstride = 0;         // floats between rows of different batch items (0: one shared row)
+    int silu = 0;
+    const float* res = nullptr;   // [M][res_stride]
+    int res_stride = 0;
+    // split-K (small-M layers): partial sums are written to `partial` [splits][M][Cout] and the
+    // epilogue runs in conv_splitk_reduce.
+    int splits = 1;
+    float* partial = nullptr;
+};
+
+double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)
+void launch_conv(const ConvParams& p, hipStream_t s);
+void conv_global_init();  // sets the dynamic-LDS attribute of every tile configuration (call before graph capture)
+// naive direct convolution on VALU (one thread per output) — debug / cross-check path only
+void launch_conv_naive(const ConvParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Memory-bound helpers (kernels_misc.hip)
+// ---------------------------------------------------------------------------------------------
+// Channel LayerNorm over C per pixel (gain only, eps inside rsqrt), optional residual add.
+void launch_layernorm(const float* x, const float* g, const float* res, float* out, int64_t M, int C,
+                      float eps, hipStream_t s);
+
+struct AttnWorkspace {
+    float* pmax = nullptr;   // [B][nch][128]
+    float* pctx = nullptr;   // [B][4][nch][1024]
+    float* psum = nullptr;   // [B][4][nch][32]
+    float* ctx = nullptr;    // [B][4][32][32]
+    int nch = 0;             // N-chunks per image
+};
+int attn_num_chunks(int N);
+// qkv: [B][N][384] (q | k | v, 4 heads x 32 each).  out: [B][N][128].
+void launch_linear_attention(const float* qkv, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s);
+
+// xt, cond: NCHW [B][3][H][W].  x0: [B][Hp+6][Wp+6][8] (+8 floats slack), zero border of 3,
+// channels {xt-cond (3), cond (3), 0, 0}, reflect-padded right/bottom from (H,W) to (Hp,Wp).
+void launch_prep_input(const float* xt, const float* cond, float* x0, int B, int in_nc, int H, int W, int Hp, int Wp,
+                       hipStream_t s);
+
+// FiLM / time-embedding path.
+//   temb0[r][i] = sin/cos(t_r * freq[i])          (SinusoidalPosEmb)
+//   generic row-linear: out[r][o] = act_out( sum_i act_in(in[r][i]) * W[o][i] + b[o] )
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2 };
+void launch_sinusoid(const float* tvals, const float* freqs, float* out, int rows, int half, hipStream_t s);
+void launch_row_linear(const float* in, int in_stride, const float* W, const float* b, float* out, int out_stride,
+                       int rows, int in_dim, int out_dim, int act_in, int act_out, hipStream_t s);
+
+// Per-step device state (lets one captured hipGraph replay for every t).
+struct StepState {
+    int t;           // current step (T..1)
+    int t_next;      // step the next step_begin will take
+    int pad0, pad1;
+    float coef[12];  // row t of the coefficient table (see include/irsde_hip.h)
+};
+// cur.t = cur.t_next--, copy film_table[t] -> film_cur and coef_table[t] -> state.coef
+void launch_step_begin(StepState* st, const float* film_table, int film_row, float* film_cur,
+                       const float* coef_table, hipStream_t s);
+void launch_set_step(StepState* st, int t_next, hipStream_t s);
+
+// Per-call sampler arguments kept in device memory so that a captured graph stays call-invariant.
+struct SampleCtl {
+    int mode;
+    int pad;
+    const float* noise;
+    long long noise_tstride;
+    unsigned long long seed;
+    unsigned long long image_offset;
+};
+void launch_set_ctl(SampleCtl* ctl, int mode, const float* noise, long long noise_tstride, unsigned long long seed,
+                    unsigned long long image_offset, hipStream_t s);
+
+// eps_hat [B][Hp][Wp][4] (NHWC, padded) -> out [B][C][H][W] (crop)
+void launch_unpack_pred(const float* pred, float* out, int B, int C, int H, int W, int Hp, int Wp, hipStream_t s);
+// NHWC [B][H][W][C] -> NCHW (debug taps)
+void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t s);
+
+// Reverse-step update x <- f(x, mu, eps_hat, z) on NCHW state; eps_hat addressed by strides.
+struct UpdateParams {
+    float* x;            // [B][C][H][W] in/out
+    const float* mu;     // [B][C][H][W]
+    const float* pred;   // eps_hat, element (b,c,y,x) at pred[b*sb + c*sc + y*sy + x*sx]
+    int64_t sb, sc, sy, sx;
+    const float* noise;  // injected noise base [T+1][B][C][H][W] or null (=> Philox)
+    int64_t noise_tstride;
+    const StepState* st;  // device step state, or null => use t_imm / coef_imm
+    const SampleCtl* ctl; // device per-call arguments (override mode/noise/seed/image_offset) or null
+    int t_imm;
+    float coef_imm[12];
+    int mode;            // 0 sde, 1 ode, 2 posterior
+    int B, C, H, W;
+    uint64_t seed;
+    uint64_t image_offset;  // global index of image 0 of this shard (RNG invariance to sharding)
+};
+void launch_sde_update(const UpdateParams& p, hipStream_t s);
+// fills out[B][C][H][W] with the Philox N(0,1) draw for step t (test hook for the RNG)
+void launch_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint64_t image_offset, hipStream_t s);
+
+}  // namespace irsde

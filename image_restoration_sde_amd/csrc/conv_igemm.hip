@@ -1,0 +1,357 @@
+// Implicit-GEMM NHWC convolution for gfx950 on the exact-fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: D = A(32x2) * B(2x32) + C, one f32 A and one f32 B operand per lane,
+//  bit-for-bit an fmaf chain; 64 cycles per instruction per SIMD = the fp32 peak of 157 TFLOP/s).
+//
+// Replaces every nn.Conv2d of the reference score network (3x3, 1x1, 4x4 s2, 7x7 and the
+// nearest-upsample + 3x3 pair): reference call sites module_util.py:93-105 (Upsample/Downsample/
+// default_conv), :108-122 (Block), :150-161 (to_qkv / to_out), DenoisingUNet_arch.py:27,76.
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*(C0+C1).  Both operands are
+// K-contiguous in HBM (NHWC activations, [Cout][KH][KW][Cin] weights), so both LDS tiles are
+// [rows][BK] with a 16-byte pad per row (row stride 36 floats = 9 x 16-B slots, odd => the
+// 16-lane groups of ds_read_b128 hit 16 distinct slots: conflict-free).  A lane reads 4 consecutive
+// k with one ds_read_b128 and feeds 4 MFMAs; lane half h owns k = 8*sb + 4*h + {0..3}, the same
+// assignment for A and B, so the k-order inside the MFMA chain is a permutation (legal: sum over k).
+//
+// Block = 256 threads = 4 waves (one per SIMD), 2 blocks per CU; global->register->LDS staging is
+// split (loads for K-step t+1 are issued before the MFMAs of step t, written to the other LDS
+// buffer after them), one barrier per K-step of 32 channels (64 MFMAs = 4096 cycles per wave).
+#include "common.h"
+
+namespace irsde {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+struct Cfg {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    static constexpr int LDS_K = BK + 4;
+    static constexpr int TM = BM / WAVES_M / 32;
+    static constexpr int TN = BN / WAVES_N / 32;
+    static constexpr int CHUNKS = BK / 4;
+    static constexpr int ROWS = kThreads / CHUNKS;
+    static constexpr int A_PASSES = BM / ROWS;
+    static constexpr int B_PASSES = BN / ROWS;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_K * 4;
+    static_assert(BM % ROWS == 0 && BN % ROWS == 0, "tile/pass mismatch");
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+__global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvParams p, const int nblk_n,
+                                                                  const int M, const int nk_total) {
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * C::LDS_K;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    // XCD-aware block remap (bijective): each XCD (block id % 8) walks a contiguous range of tiles so
+    // that neighbouring tiles (same activation rows, other Cout slices / halo rows) share one L2.
+    int wgid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int mblk = wgid / nblk_n;
+    const int nblk = wgid - mblk * nblk_n;
+    const int m0 = mblk * BM;
+    const int n0 = nblk * BN;
+
+    // split-K range of this block
+    const int split = blockIdx.y;
+    const int nsplit = gridDim.y;
+    const int kt_begin = (int)(((long long)nk_total * split) / nsplit);
+    const int kt_end = (int)(((long long)nk_total * (split + 1)) / nsplit);
+
+    const int Ctot = p.C0 + p.C1;
+    const int steps_per_tap = Ctot / BK;
+    const int taps = p.KH * p.KW;
+    const int Hv = p.Hin << p.in_shift;
+    const int Wv = p.Win << p.in_shift;
+
+    // ---- per-thread staging coordinates (fixed for the whole K loop) ----
+    const int chunk = tid % C::CHUNKS;
+    const int row0 = tid / C::CHUNKS;
+    int a_iy0[C::A_PASSES], a_ix0[C::A_PASSES], a_pix[C::A_PASSES];
+    bool a_ok[C::A_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < C::A_PASSES; ++ps) {
+        const int m = m0 + row0 + ps * C::ROWS;
+        a_ok[ps] = m < M;
+        const int mm = a_ok[ps] ? m : 0;
+        const int ox = mm % p.Wo;
+        const int t1 = mm / p.Wo;
+        const int oy = t1 % p.Ho;
+        const int b = t1 / p.Ho;
+        a_iy0[ps] = oy * p.stride - p.pad_y;
+        a_ix0[ps] = ox * p.stride - p.pad_x;
+        a_pix[ps] = b * p.Hin * p.Win;
+    }
+    const float* wrow[C::B_PASSES];
+    bool b_ok[C::B_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < C::B_PASSES; ++ps) {
+        const int n = n0 + row0 + ps * C::ROWS;
+        b_ok[ps] = n < p.Cout;
+        wrow[ps] = p.w + (size_t)(b_ok[ps] ? n : 0) * taps * Ctot + chunk * 4;
+    }
+
+    float4 ra[C::A_PASSES], rb[C::B_PASSES];
+
+    auto load_tiles = [&](int kt) {
+        const int tap = kt / steps_per_tap;
+        const int cc = (kt - tap * steps_per_tap) * BK;
+        const int ky = tap / p.KW;
+        const int kx = tap - ky * p.KW;
+        const float* src;
+        int c, pix;
+        if (cc < p.C0) {
+            src = p.in0; c = cc; pix = p.pix0;
+        } else {
+            src = p.in1; c = cc - p.C0; pix = p.pix1;
+        }
+#pragma unroll
+        for (int ps = 0; ps < C::A_PASSES; ++ps) {
+            const int iy = a_iy0[ps] + ky;
+            const int ix = a_ix0[ps] + kx;
+            const bool ok = a_ok[ps] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+            const int py = iy >> p.in_shift, px = ix >> p.in_shift;
+            // branch-free predication: out-of-image taps read a safe address and are zeroed
+            const size_t off = ok ? (size_t)(a_pix[ps] + py * p.Win + px) * pix + c + chunk * 4 : (size_t)0;
+            const float4 v = *reinterpret_cast<const float4*>(src + off);
+            ra[ps] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const size_t wk = (size_t)tap * Ctot + cc;
+#pragma unroll
+        for (int ps = 0; ps < C::B_PASSES; ++ps) {
+            const float4 v = *reinterpret_cast<const float4*>(wrow[ps] + wk);  // row clamped to 0 if n >= Cout
+            rb[ps] = b_ok[ps] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* a = As + buf * BM * C::LDS_K;
+        float* b = Bs + buf * BN * C::LDS_K;
+#pragma unroll
+        for (int ps = 0; ps < C::A_PASSES; ++ps)
+            *reinterpret_cast<float4*>(a + (row0 + ps * C::ROWS) * C::LDS_K + chunk * 4) = ra[ps];
+#pragma unroll
+        for (int ps = 0; ps < C::B_PASSES; ++ps)
+            *reinterpret_cast<float4*>(b + (row0 + ps * C::ROWS) * C::LDS_K + chunk * 4) = rb[ps];
+    };
+
+    floatx16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt_begin < kt_end) {
+        load_tiles(kt_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tiles(kt + 1);  // HBM/L2 latency hides under this step's MFMAs
+
+        const float* a = As + buf * BM * C::LDS_K + (wm * C::TM * 32 + l31) * C::LDS_K + h * 4;
+        const float* b = Bs + buf * BN * C::LDS_K + (wn * C::TN * 32 + l31) * C::LDS_K + h * 4;
+#pragma unroll
+        for (int sb = 0; sb < BK / 8; ++sb) {
+            float4 fa[C::TM], fb[C::TN];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+                fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * C::LDS_K + sb * 8);
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+                fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * C::LDS_K + sb * 8);
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const int HW = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+        const int n = n0 + wn * C::TN * 32 + j * 32 + l31;
+        const bool n_ok = n < p.Cout;
+        float bias = 0.f, sc = 0.f, sh = 0.f;
+        if (p.splits == 1 && n_ok) {
+            if (p.bias) bias = p.bias[n];
+            if (p.film && p.film_bstride == 0) {
+                sc = p.film[n] + 1.0f;
+                sh = p.film[p.Cout + n];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = m0 + row;
+                if (m < M && n_ok) {
+                    float v = acc[i][j][r];
+                    if (p.splits > 1) {
+                        p.partial[((size_t)split * M + m) * p.Cout + n] = v;
+                    } else {
+                        v += bias;
+                        if (p.film) {
+                            if (p.film_bstride != 0) {
+                                const float* f = p.film + (size_t)(m / HW) * p.film_bstride;
+                                sc = f[n] + 1.0f;
+                                sh = f[p.Cout + n];
+                            }
+                            v = v * sc + sh;
+                        }
+                        if (p.silu) v = silu_f(v);
+                        if (p.res) v += p.res[(size_t)m * p.res_stride + n];
+                        p.out[(size_t)m * p.out_stride + n] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// split-K second stage: sum partials, run the epilogue (memory-bound, tiny layers only)
+__global__ void conv_splitk_reduce(const ConvParams p, const int M) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)M * p.Cout;
+    if (idx >= total) return;
+    const int n = (int)(idx % p.Cout);
+    const int m = (int)(idx / p.Cout);
+    float v = 0.f;
+    for (int s = 0; s < p.splits; ++s) v += p.partial[(size_t)s * total + idx];
+    if (p.bias) v += p.bias[n];
+    if (p.film) {
+        const float* f = p.film + (size_t)(p.film_bstride ? m / (p.Ho * p.Wo) : 0) * p.film_bstride;
+        v = v * (f[n] + 1.0f) + f[p.Cout + n];
+    }
+    if (p.silu) v = silu_f(v);
+    if (p.res) v += p.res[(size_t)m * p.res_stride + n];
+    p.out[(size_t)m * p.out_stride + n] = v;
+}
+
+// Debug / cross-check path: direct convolution, one thread per output element (VALU fmaf chain).
+__global__ void conv_naive_kernel(const ConvParams p, const int M) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * p.Cout) return;
+    const int n = (int)(idx % p.Cout);
+    const int m = (int)(idx / p.Cout);
+    const int ox = m % p.Wo, t1 = m / p.Wo, oy = t1 % p.Ho, b = t1 / p.Ho;
+    const int Ctot = p.C0 + p.C1;
+    const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
+    float acc = 0.f;
+    for (int ky = 0; ky < p.KH; ++ky)
+        for (int kx = 0; kx < p.KW; ++kx) {
+            const int iy = oy * p.stride - p.pad_y + ky, ix = ox * p.stride - p.pad_x + kx;
+            if ((unsigned)iy >= (unsigned)Hv || (unsigned)ix >= (unsigned)Wv) continue;
+            const size_t pixel = (size_t)b * p.Hin * p.Win + (size_t)(iy >> p.in_shift) * p.Win + (ix >> p.in_shift);
+            const float* wr = p.w + ((size_t)n * p.KH * p.KW + ky * p.KW + kx) * Ctot;
+            const float* s0 = p.in0 + pixel * p.pix0;
+            for (int c = 0; c < p.C0; ++c) acc = fmaf(s0[c], wr[c], acc);
+            if (p.C1) {
+                const float* s1 = p.in1 + pixel * p.pix1;
+                for (int c = 0; c < p.C1; ++c) acc = fmaf(s1[c], wr[p.C0 + c], acc);
+            }
+        }
+    float v = acc;
+    if (p.bias) v += p.bias[n];
+    if (p.film) {
+        const float* f = p.film + (size_t)(p.film_bstride ? b : 0) * p.film_bstride;
+        v = v * (f[n] + 1.0f) + f[p.Cout + n];
+    }
+    if (p.silu) v = silu_f(v);
+    if (p.res) v += p.res[(size_t)m * p.res_stride + n];
+    p.out[(size_t)m * p.out_stride + n] = v;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s) {
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK>;
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK>;
+    const int nblk_m = (M + BM - 1) / BM;
+    const int nblk_n = (p.Cout + BN - 1) / BN;
+    dim3 grid(nblk_m * nblk_n, p.splits, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), C::LDS_BYTES, s, p, nblk_n, M, nk_total);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+void init_cfg() {
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK>;
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+}
+
+}  // namespace
+
+void conv_global_init() {
+    init_cfg<128, 128, 2, 2, 32>();
+    init_cfg<128, 64, 2, 2, 32>();
+    init_cfg<128, 32, 4, 1, 32>();
+}
+
+double conv_flops(const ConvParams& p) {
+    return 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout * (double)(p.KH * p.KW) * (double)(p.C0 + p.C1);
+}
+
+int conv_tile_n(int Cout) { return Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32); }
+
+void launch_conv(const ConvParams& p, hipStream_t s) {
+    const int M = p.B * p.Ho * p.Wo;
+    const int Ctot = p.C0 + p.C1;
+    if (p.C0 % 32 || p.C1 % 32 || Ctot == 0)
+        throw HipError("launch_conv: channel counts must be multiples of 32 (got " + std::to_string(p.C0) + "+" +
+                       std::to_string(p.C1) + ")");
+    if (p.splits > 1 && !p.partial) throw HipError("launch_conv: split-K needs a partial buffer");
+    const int nk_total = p.KH * p.KW * (Ctot / 32);
+    if (p.Cout >= 128)
+        launch_cfg<128, 128, 2, 2, 32>(p, M, nk_total, s);
+    else if (p.Cout > 32)
+        launch_cfg<128, 64, 2, 2, 32>(p, M, nk_total, s);
+    else
+        launch_cfg<128, 32, 4, 1, 32>(p, M, nk_total, s);
+    if (p.splits > 1) {
+        const size_t total = (size_t)M * p.Cout;
+        hipLaunchKernelGGL(conv_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, M);
+        IRSDE_HIP_CHECK(hipGetLastError());
+    }
+}
+
+void launch_conv_naive(const ConvParams& p, hipStream_t s) {
+    const int M = p.B * p.Ho * p.Wo;
+    const size_t total = (size_t)M * p.Cout;
+    hipLaunchKernelGGL(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, M);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace irsde

@@ -1,0 +1,1054 @@
+// libirsde_hip.so — engine + C ABI (include/irsde_hip.h).
+//
+// Host-side structure (all C++; PyTorch never appears here):
+//   Engine      weights in kernel layout, FiLM/time table, coefficient table, plans
+//   Plan        per (B,H,W): static activation arena + the launch list of ONE network evaluation
+//               (ConditionalUNet.forward, DenoisingUNet_arch.py:85-134) built once, replayed T times
+//   sample()    the reverse loop (sde_utils.py:252-299): [step_begin, prep, net, update] per t, either
+//               eager or as one captured hipGraph replayed T times; the step index lives in device
+//               memory (StepState) so the graph is t-invariant.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/irsde_hip.h"
+#include "common.h"
+
+namespace irsde {
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool loaded = false;
+};
+
+struct ConvW {
+    float* w = nullptr;  // device [Cout][KH*KW][Cin]
+    float* bias = nullptr;
+    int Cout = 0, Cin = 0, KH = 1, KW = 1;
+};
+struct ResW {
+    ConvW b1, b2, res;
+    bool has_res = false;
+    float* mlp_w = nullptr;  // [2*Cout][time_dim]
+    float* mlp_b = nullptr;
+    int film_off = 0;
+    int Cout = 0;
+};
+struct AttnW {
+    float* g1 = nullptr;
+    ConvW qkv, out;
+    float* g2 = nullptr;
+    int C = 0;
+};
+
+enum OpKind { OP_CONV = 0, OP_LN = 1, OP_ATTN = 2, OP_OTHER = 3 };
+
+struct Op {
+    std::function<void(hipStream_t)> fn;
+    OpKind kind;
+    double flops = 0, bytes = 0;
+};
+
+struct Tensor {
+    float* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    size_t numel() const { return (size_t)B * H * W * C; }
+};
+
+struct PoolBlock {
+    float* p;
+    size_t n;
+    bool free;
+};
+
+struct Plan {
+    int B = 0, H = 0, W = 0, Hp = 0, Wp = 0;
+    bool per_sample_film = false;
+    std::vector<PoolBlock> pool;
+    std::vector<Op> net_ops;  // prep + network (one evaluation)
+    float* xin = nullptr;     // [B][in_nc][H][W]  state x / xt
+    float* cin = nullptr;     // [B][in_nc][H][W]  mu / cond
+    float* x0 = nullptr;      // prepped NHWC input
+    float* pred = nullptr;    // [B][Hp][Wp][4]
+    std::map<std::string, Tensor> taps;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    double conv_flops = 0, conv_bytes = 0;
+    uint64_t last_use = 0;
+
+    ~Plan() {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        for (auto& b : pool) (void)hipFree(b.p);
+    }
+    float* alloc(size_t n, bool reuse) {
+        if (reuse) {
+            int best = -1;
+            for (int i = 0; i < (int)pool.size(); ++i)
+                if (pool[i].free && pool[i].n >= n && (best < 0 || pool[i].n < pool[best].n)) best = i;
+            if (best >= 0 && pool[best].n <= n + n / 2 + 1024) {
+                pool[best].free = false;
+                return pool[best].p;
+            }
+        }
+        float* p = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 64) * sizeof(float)));
+        pool.push_back({p, n, false});
+        return p;
+    }
+    void release(float* p) {
+        for (auto& b : pool)
+            if (b.p == p) {
+                b.free = true;
+                return;
+            }
+    }
+};
+
+}  // namespace
+
+}  // namespace irsde
+
+using namespace irsde;
+
+struct irsde_engine {
+    irsde_config cfg{};
+    int time_dim = 0;
+    std::vector<std::string> names;  // weight inventory, reference state_dict order-independent
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    std::vector<float*> dev_allocs;
+
+    // packed weights
+    ConvW init_conv, final_conv;
+    float *tm_w1 = nullptr, *tm_b1 = nullptr, *tm_w3 = nullptr, *tm_b3 = nullptr, *freqs = nullptr;
+    std::vector<ResW> down_res;   // 2 per level
+    std::vector<AttnW> down_attn;
+    std::vector<ConvW> down_conv;
+    ResW mid1, mid2;
+    AttnW mid_attn;
+    std::vector<ResW> up_res;
+    std::vector<AttnW> up_attn;
+    std::vector<ConvW> up_conv;
+    ResW final_res;
+    std::vector<ResW*> all_res;
+    int film_row = 0;
+
+    // schedule / FiLM tables
+    int T = 0;
+    float* coef_table = nullptr;  // [(T+1)][12]
+    float* film_table = nullptr;  // [(T+1)][film_row]
+    float* film_cur = nullptr;    // [max_rows][film_row]
+    int film_cur_rows = 0;
+    StepState* step = nullptr;
+    SampleCtl* ctl = nullptr;
+
+    hipStream_t stream = nullptr;  // engine stream (graph capture needs a non-default stream)
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    std::vector<std::unique_ptr<Plan>> plans;
+    uint64_t use_counter = 0;
+    double profile[9] = {0};
+    std::vector<hipEvent_t> ev_pool;
+    std::mutex mu;
+
+    float* dmalloc(size_t n) {
+        float* p = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 16) * sizeof(float)));
+        dev_allocs.push_back(p);
+        return p;
+    }
+    float* upload(const std::vector<float>& v) {
+        float* p = dmalloc(v.size());
+        IRSDE_HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        return p;
+    }
+};
+
+namespace irsde {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Weight inventory (DenoisingUNet_arch.py:19-76; names = reference state_dict keys)
+// ---------------------------------------------------------------------------------------------
+void add_w(irsde_engine* e, const std::string& name, std::vector<int64_t> shape) {
+    e->names.push_back(name);
+    HostTensor t;
+    t.shape = std::move(shape);
+    e->host[name] = std::move(t);
+}
+void inv_resblock(irsde_engine* e, const std::string& p, int ci, int co) {
+    const int td = e->time_dim;
+    add_w(e, p + "mlp.1.weight", {2 * co, td});
+    add_w(e, p + "mlp.1.bias", {2 * co});
+    add_w(e, p + "block1.proj.weight", {co, ci, 3, 3});
+    add_w(e, p + "block2.proj.weight", {co, co, 3, 3});
+    if (ci != co) add_w(e, p + "res_conv.weight", {co, ci, 1, 1});
+}
+void inv_attn(irsde_engine* e, const std::string& p, int c) {
+    add_w(e, p + "fn.norm.g", {1, c, 1, 1});
+    add_w(e, p + "fn.fn.to_qkv.weight", {384, c, 1, 1});
+    add_w(e, p + "fn.fn.to_out.0.weight", {c, 128, 1, 1});
+    add_w(e, p + "fn.fn.to_out.0.bias", {c});
+    add_w(e, p + "fn.fn.to_out.1.g", {1, c, 1, 1});
+}
+void build_inventory(irsde_engine* e) {
+    const int nf = e->cfg.nf, depth = e->cfg.depth;
+    add_w(e, "init_conv.weight", {nf, 2 * e->cfg.in_nc, 7, 7});
+    add_w(e, "time_mlp.1.weight", {e->time_dim, nf});
+    add_w(e, "time_mlp.1.bias", {e->time_dim});
+    add_w(e, "time_mlp.3.weight", {e->time_dim, e->time_dim});
+    add_w(e, "time_mlp.3.bias", {e->time_dim});
+    for (int i = 0; i < depth; ++i) {
+        const int di = nf << i, dout = nf << (i + 1);
+        const std::string d = "downs." + std::to_string(i) + ".";
+        inv_resblock(e, d + "0.", di, di);
+        inv_resblock(e, d + "1.", di, di);
+        inv_attn(e, d + "2.", di);
+        if (i != depth - 1) {
+            add_w(e, d + "3.weight", {dout, di, 4, 4});
+            add_w(e, d + "3.bias", {dout});
+        } else {
+            add_w(e, d + "3.weight", {dout, di, 3, 3});
+        }
+        const std::string u = "ups." + std::to_string(depth - 1 - i) + ".";
+        inv_resblock(e, u + "0.", dout + di, dout);
+        inv_resblock(e, u + "1.", dout + di, dout);
+        inv_attn(e, u + "2.", dout);
+        if (i != 0) {
+            add_w(e, u + "3.1.weight", {di, dout, 3, 3});
+            add_w(e, u + "3.1.bias", {di});
+        } else {
+            add_w(e, u + "3.weight", {di, dout, 3, 3});
+        }
+    }
+    const int mid = nf << depth;
+    inv_resblock(e, "mid_block1.", mid, mid);
+    inv_attn(e, "mid_attn.", mid);
+    inv_resblock(e, "mid_block2.", mid, mid);
+    inv_resblock(e, "final_res_block.", 2 * nf, nf);
+    add_w(e, "final_conv.weight", {e->cfg.out_nc, nf, 3, 3});
+    add_w(e, "final_conv.bias", {e->cfg.out_nc});
+}
+
+const HostTensor& need(irsde_engine* e, const std::string& n) {
+    auto it = e->host.find(n);
+    if (it == e->host.end() || !it->second.loaded) throw HipError("missing weight: " + n);
+    return it->second;
+}
+
+// OIHW -> [O][KH][KW][I]
+ConvW pack_conv(irsde_engine* e, const std::string& wname, const std::string& bname) {
+    const HostTensor& t = need(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1], KH = (int)t.shape[2], KW = (int)t.shape[3];
+    std::vector<float> p((size_t)O * KH * KW * I);
+    for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i)
+            for (int ky = 0; ky < KH; ++ky)
+                for (int kx = 0; kx < KW; ++kx)
+                    p[(((size_t)o * KH + ky) * KW + kx) * I + i] = t.data[(((size_t)o * I + i) * KH + ky) * KW + kx];
+    ConvW c;
+    c.w = e->upload(p);
+    c.Cout = O; c.Cin = I; c.KH = KH; c.KW = KW;
+    if (!bname.empty()) c.bias = e->upload(need(e, bname).data);
+    return c;
+}
+
+// init 7x7 conv as a 7-tap (ky) conv over rows of 7 pixels x P channels: weight [O][7][CK], CK = roundup(7*P,32),
+// element (kx, c) at kx*P + c, zeros elsewhere (the kernel over-reads into the next pixels; zero weights).
+ConvW pack_init_conv(irsde_engine* e) {
+    const HostTensor& t = need(e, "init_conv.weight");
+    const int O = (int)t.shape[0], I = (int)t.shape[1];
+    const int P = (I + 3) & ~3;
+    const int CK = (7 * P + 31) & ~31;
+    std::vector<float> p((size_t)O * 7 * CK, 0.f);
+    for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i)
+            for (int ky = 0; ky < 7; ++ky)
+                for (int kx = 0; kx < 7; ++kx)
+                    p[((size_t)o * 7 + ky) * CK + kx * P + i] = t.data[(((size_t)o * I + i) * 7 + ky) * 7 + kx];
+    ConvW c;
+    c.w = e->upload(p);
+    c.Cout = O; c.Cin = CK; c.KH = 7; c.KW = 1;
+    return c;
+}
+
+ResW pack_res(irsde_engine* e, const std::string& p) {
+    ResW r;
+    r.b1 = pack_conv(e, p + "block1.proj.weight", "");
+    r.b2 = pack_conv(e, p + "block2.proj.weight", "");
+    r.Cout = r.b1.Cout;
+    r.has_res = e->host.count(p + "res_conv.weight") > 0;
+    if (r.has_res) r.res = pack_conv(e, p + "res_conv.weight", "");
+    r.mlp_w = e->upload(need(e, p + "mlp.1.weight").data);
+    r.mlp_b = e->upload(need(e, p + "mlp.1.bias").data);
+    return r;
+}
+AttnW pack_attn(irsde_engine* e, const std::string& p) {
+    AttnW a;
+    a.g1 = e->upload(need(e, p + "fn.norm.g").data);
+    a.qkv = pack_conv(e, p + "fn.fn.to_qkv.weight", "");
+    a.out = pack_conv(e, p + "fn.fn.to_out.0.weight", p + "fn.fn.to_out.0.bias");
+    a.g2 = e->upload(need(e, p + "fn.fn.to_out.1.g").data);
+    a.C = a.out.Cout;
+    return a;
+}
+
+void finalize(irsde_engine* e) {
+    IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+    for (auto& n : e->names)
+        if (!e->host[n].loaded) throw HipError("missing weight: " + n);
+    const int depth = e->cfg.depth;
+    e->init_conv = pack_init_conv(e);
+    e->tm_w1 = e->upload(need(e, "time_mlp.1.weight").data);
+    e->tm_b1 = e->upload(need(e, "time_mlp.1.bias").data);
+    e->tm_w3 = e->upload(need(e, "time_mlp.3.weight").data);
+    e->tm_b3 = e->upload(need(e, "time_mlp.3.bias").data);
+    {
+        // SinusoidalPosEmb frequencies (module_util.py:35-38), fp32 like the reference
+        const int half = e->cfg.nf / 2;
+        std::vector<float> f(half);
+        const double emb = std::log(10000.0) / (half - 1);
+        for (int i = 0; i < half; ++i) f[i] = expf((float)i * (float)(-emb));
+        e->freqs = e->upload(f);
+    }
+    e->down_res.reserve(2 * depth);
+    e->up_res.reserve(2 * depth);
+    for (int i = 0; i < depth; ++i) {
+        const std::string d = "downs." + std::to_string(i) + ".";
+        e->down_res.push_back(pack_res(e, d + "0."));
+        e->down_res.push_back(pack_res(e, d + "1."));
+        e->down_attn.push_back(pack_attn(e, d + "2."));
+        e->down_conv.push_back(pack_conv(e, d + "3.weight", i != depth - 1 ? d + "3.bias" : ""));
+    }
+    e->mid1 = pack_res(e, "mid_block1.");
+    e->mid_attn = pack_attn(e, "mid_attn.");
+    e->mid2 = pack_res(e, "mid_block2.");
+    for (int j = 0; j < depth; ++j) {
+        const std::string u = "ups." + std::to_string(j) + ".";
+        e->up_res.push_back(pack_res(e, u + "0."));
+        e->up_res.push_back(pack_res(e, u + "1."));
+        e->up_attn.push_back(pack_attn(e, u + "2."));
+        if (j != depth - 1)
+            e->up_conv.push_back(pack_conv(e, u + "3.1.weight", u + "3.1.bias"));
+        else
+            e->up_conv.push_back(pack_conv(e, u + "3.weight", ""));
+    }
+    e->final_res = pack_res(e, "final_res_block.");
+    e->final_conv = pack_conv(e, "final_conv.weight", "final_conv.bias");
+
+    e->all_res.clear();
+    for (auto& r : e->down_res) e->all_res.push_back(&r);
+    e->all_res.push_back(&e->mid1);
+    e->all_res.push_back(&e->mid2);
+    for (auto& r : e->up_res) e->all_res.push_back(&r);
+    e->all_res.push_back(&e->final_res);
+    int off = 0;
+    for (ResW* r : e->all_res) {
+        r->film_off = off;
+        off += 2 * r->Cout;
+    }
+    e->film_row = off;
+
+    conv_global_init();
+    IRSDE_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    IRSDE_HIP_CHECK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+    IRSDE_HIP_CHECK(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    e->step = reinterpret_cast<StepState*>(e->dmalloc(sizeof(StepState) / 4 + 4));
+    e->ctl = reinterpret_cast<SampleCtl*>(e->dmalloc(sizeof(SampleCtl) / 4 + 4));
+    IRSDE_HIP_CHECK(hipMemset(e->step, 0, sizeof(StepState)));
+    IRSDE_HIP_CHECK(hipMemset(e->ctl, 0, sizeof(SampleCtl)));
+    // free host copies
+    for (auto& kv : e->host) std::vector<float>().swap(kv.second.data);
+    e->finalized = true;
+}
+
+// FiLM rows for `rows` timesteps (device array tvals[rows]) -> dst[rows][film_row]
+void compute_film_rows(irsde_engine* e, const float* tvals, int rows, float* dst, hipStream_t s) {
+    const int nf = e->cfg.nf, td = e->time_dim;
+    float* emb = nullptr;
+    float* h1 = nullptr;
+    float* h2 = nullptr;
+    IRSDE_HIP_CHECK(hipMalloc(&emb, (size_t)rows * nf * 4));
+    IRSDE_HIP_CHECK(hipMalloc(&h1, (size_t)rows * td * 4));
+    IRSDE_HIP_CHECK(hipMalloc(&h2, (size_t)rows * td * 4));
+    launch_sinusoid(tvals, e->freqs, emb, rows, nf / 2, s);
+    launch_row_linear(emb, nf, e->tm_w1, e->tm_b1, h1, td, rows, nf, td, ACT_NONE, ACT_GELU, s);
+    launch_row_linear(h1, td, e->tm_w3, e->tm_b3, h2, td, rows, td, td, ACT_NONE, ACT_NONE, s);
+    for (ResW* r : e->all_res)
+        launch_row_linear(h2, td, r->mlp_w, r->mlp_b, dst + r->film_off, e->film_row, rows, td, 2 * r->Cout, ACT_SILU,
+                          ACT_NONE, s);
+    IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(emb);
+    (void)hipFree(h1);
+    (void)hipFree(h2);
+}
+
+void ensure_film_cur(irsde_engine* e, int rows) {
+    if (rows <= e->film_cur_rows) return;
+    e->film_cur = e->dmalloc((size_t)rows * e->film_row);
+    e->film_cur_rows = rows;
+    // plans bake the film_cur pointer: drop them
+    e->plans.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plan construction: one network evaluation as a static launch list over a static arena
+// ---------------------------------------------------------------------------------------------
+struct Builder {
+    irsde_engine* e;
+    Plan* pl;
+    bool reuse;
+    bool naive;
+    int film_bstride;
+
+    Tensor talloc(int B, int H, int W, int C) {
+        Tensor t;
+        t.B = B; t.H = H; t.W = W; t.C = C;
+        t.p = pl->alloc(t.numel(), reuse);
+        return t;
+    }
+    void tfree(const Tensor& t) {
+        if (reuse) pl->release(t.p);
+    }
+    void tap(const std::string& name, const Tensor& t) { pl->taps[name] = t; }
+
+    void push_conv(ConvParams p) {
+        const int M = p.B * p.Ho * p.Wo;
+        // split-K for under-filled grids (small batch / deep levels)
+        const int bn = p.Cout >= 128 ? 128 : (p.Cout > 32 ? 64 : 32);
+        const int blocks = ((M + 127) / 128) * ((p.Cout + bn - 1) / bn);
+        const int nk = p.KH * p.KW * ((p.C0 + p.C1) / 32);
+        int splits = 1;
+        if (!naive && blocks < 256 && nk >= 16) {
+            splits = std::min(std::min(nk / 8, (512 + blocks - 1) / blocks), 16);
+            if (splits < 2) splits = 1;
+        }
+        if (splits > 1) {
+            p.splits = splits;
+            p.partial = pl->alloc((size_t)splits * M * p.Cout, true);
+        }
+        Op op;
+        op.kind = OP_CONV;
+        op.flops = conv_flops(p);
+        const double in_bytes = 4.0 * (double)p.B * (p.Hin) * (p.Win) * (double)(p.C0 + p.C1);
+        op.bytes = in_bytes + 4.0 * (double)M * p.Cout + 4.0 * (double)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
+        pl->conv_flops += op.flops;
+        pl->conv_bytes += op.bytes;
+        const bool nv = naive;
+        op.fn = [p, nv](hipStream_t s) {
+            if (nv)
+                launch_conv_naive(p, s);
+            else
+                launch_conv(p, s);
+        };
+        pl->net_ops.push_back(std::move(op));
+        // the split-K scratch is dead once this op's reduce kernel has run (same stream): recycle it
+        if (p.partial) pl->release(p.partial);
+    }
+
+    // generic KxK conv over (in0 | in1)
+    Tensor conv(const ConvW& w, const Tensor& in0, const Tensor* in1, int stride, int pad, int in_shift,
+                const float* film, int silu, const Tensor* res, int out_stride = 0) {
+        ConvParams p;
+        p.in0 = in0.p; p.C0 = in0.C; p.pix0 = in0.C;
+        if (in1) { p.in1 = in1->p; p.C1 = in1->C; p.pix1 = in1->C; }
+        if (p.C0 + p.C1 != w.Cin) throw HipError("conv: channel mismatch");
+        p.Hin = in0.H; p.Win = in0.W; p.in_shift = in_shift;
+        p.w = w.w; p.Cout = w.Cout; p.KH = w.KH; p.KW = w.KW; p.stride = stride; p.pad_y = pad; p.pad_x = pad;
+        const int Hv = in0.H << in_shift, Wv = in0.W << in_shift;
+        p.B = in0.B;
+        p.Ho = (Hv + 2 * pad - w.KH) / stride + 1;
+        p.Wo = (Wv + 2 * pad - w.KW) / stride + 1;
+        const int ostr = out_stride ? out_stride : w.Cout;
+        Tensor out = talloc(p.B, p.Ho, p.Wo, ostr);
+        p.out = out.p; p.out_stride = ostr;
+        p.bias = w.bias;
+        p.film = film; p.film_bstride = film ? film_bstride : 0;
+        p.silu = silu;
+        if (res) { p.res = res->p; p.res_stride = res->C; }
+        push_conv(p);
+        return out;
+    }
+
+    // ResBlock.forward — module_util.py:136-146
+    Tensor resblock(const ResW& w, const Tensor& in0, const Tensor* in1) {
+        Tensor R;
+        if (w.has_res)
+            R = conv(w.res, in0, in1, 1, 0, 0, nullptr, 0, nullptr);
+        else
+            R = in0;
+        Tensor h1 = conv(w.b1, in0, in1, 1, 1, 0, e->film_cur + w.film_off, 1, nullptr);
+        Tensor out = conv(w.b2, h1, nullptr, 1, 1, 0, nullptr, 1, &R);
+        tfree(h1);
+        if (w.has_res) tfree(R);
+        return out;
+    }
+
+    // Residual(PreNorm(dim, LinearAttention(dim))) — module_util.py:20-26,82-90,150-178
+    Tensor attn(const AttnW& w, const Tensor& x) {
+        const int64_t M = (int64_t)x.B * x.H * x.W;
+        const int N = x.H * x.W;
+        Tensor xn = talloc(x.B, x.H, x.W, x.C);
+        {
+            const float *xp = x.p, *g = w.g1;
+            float* o = xn.p;
+            const int C = x.C;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(xp, g, nullptr, o, M, C, 1e-5f, s); });
+        }
+        Tensor qkv = conv(w.qkv, xn, nullptr, 1, 0, 0, nullptr, 0, nullptr);
+        tfree(xn);
+        Tensor a = talloc(x.B, x.H, x.W, 128);
+        {
+            AttnWorkspace ws;
+            ws.nch = attn_num_chunks(N);
+            ws.pmax = pl->alloc((size_t)x.B * ws.nch * 128, false);
+            ws.pctx = pl->alloc((size_t)x.B * 4 * ws.nch * 1024, false);
+            ws.psum = pl->alloc((size_t)x.B * 4 * ws.nch * 32, false);
+            ws.ctx = pl->alloc((size_t)x.B * 4 * 1024, false);
+            const float* q = qkv.p;
+            float* o = a.p;
+            const int B = x.B;
+            push_other(OP_ATTN, [=](hipStream_t s) { launch_linear_attention(q, o, B, N, ws, s); });
+        }
+        tfree(qkv);
+        Tensor o = conv(w.out, a, nullptr, 1, 0, 0, nullptr, 0, nullptr);
+        tfree(a);
+        Tensor y = talloc(x.B, x.H, x.W, x.C);
+        {
+            const float *op = o.p, *g = w.g2, *r = x.p;
+            float* yp = y.p;
+            const int C = x.C;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(op, g, r, yp, M, C, 1e-5f, s); });
+        }
+        tfree(o);
+        return y;
+    }
+
+    void push_other(OpKind k, std::function<void(hipStream_t)> fn) {
+        Op op;
+        op.kind = k;
+        op.fn = std::move(fn);
+        pl->net_ops.push_back(std::move(op));
+    }
+};
+
+Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
+    for (auto& p : e->plans)
+        if (p->B == B && p->H == H && p->W == W && p->per_sample_film == per_sample_film) {
+            p->last_use = ++e->use_counter;
+            return p.get();
+        }
+    if (e->plans.size() >= 4) {  // LRU eviction
+        size_t lru = 0;
+        for (size_t i = 1; i < e->plans.size(); ++i)
+            if (e->plans[i]->last_use < e->plans[lru]->last_use) lru = i;
+        IRSDE_HIP_CHECK(hipDeviceSynchronize());
+        e->plans.erase(e->plans.begin() + lru);
+    }
+    ensure_film_cur(e, per_sample_film ? B : 1);
+
+    const int depth = e->cfg.depth, nf = e->cfg.nf, in_nc = e->cfg.in_nc;
+    const int sdiv = 1 << depth;
+    std::unique_ptr<Plan> plan(new Plan());
+    Plan* pl = plan.get();
+    pl->B = B; pl->H = H; pl->W = W;
+    pl->Hp = (H + sdiv - 1) / sdiv * sdiv;
+    pl->Wp = (W + sdiv - 1) / sdiv * sdiv;
+    pl->per_sample_film = per_sample_film;
+    pl->last_use = ++e->use_counter;
+    // F.pad 'reflect' needs pad < dim (DenoisingUNet_arch.py:82)
+    if (pl->Hp - H >= H || pl->Wp - W >= W) throw HipError("image too small for reflect padding");
+
+    const size_t img = (size_t)B * in_nc * H * W;
+    pl->xin = pl->alloc(img, false);
+    pl->cin = pl->alloc(img, false);
+    const int P = (2 * in_nc + 3) & ~3;
+    const size_t x0n = (size_t)B * (pl->Hp + 6) * (pl->Wp + 6) * P + 64;
+    pl->x0 = pl->alloc(x0n, false);
+    IRSDE_HIP_CHECK(hipMemset(pl->x0, 0, x0n * sizeof(float)));
+
+    Builder b{e, pl, (e->cfg.flags & IRSDE_FLAG_KEEP_ACTIVATIONS) == 0, (e->cfg.flags & IRSDE_FLAG_NAIVE_CONV) != 0,
+              per_sample_film ? e->film_row : 0};
+    {
+        const float *xi = pl->xin, *ci = pl->cin;
+        float* x0 = pl->x0;
+        const int Hp = pl->Hp, Wp = pl->Wp;
+        b.push_other(OP_OTHER, [=](hipStream_t s) { launch_prep_input(xi, ci, x0, B, in_nc, H, W, Hp, Wp, s); });
+    }
+    // init_conv 7x7 (DenoisingUNet_arch.py:96) as 7 row taps over the zero-bordered input
+    Tensor x;
+    {
+        ConvParams p;
+        p.in0 = pl->x0; p.C0 = e->init_conv.Cin; p.pix0 = P;
+        p.Hin = pl->Hp + 6; p.Win = pl->Wp + 6;
+        p.w = e->init_conv.w; p.Cout = nf; p.KH = 7; p.KW = 1; p.stride = 1; p.pad_y = 0; p.pad_x = 0;
+        p.B = B; p.Ho = pl->Hp; p.Wo = pl->Wp;
+        x = b.talloc(B, pl->Hp, pl->Wp, nf);
+        p.out = x.p; p.out_stride = nf;
+        b.push_conv(p);
+        // algorithmic accounting: 7x7 x (2*in_nc) real MACs, not the padded 7 x 64
+        const double real = 2.0 * (double)B * pl->Hp * pl->Wp * nf * 49.0 * (2.0 * in_nc);
+        pl->conv_flops += real - pl->net_ops.back().flops;
+        pl->net_ops.back().flops = real;
+    }
+    b.tap("init_conv", x);
+    Tensor x_init = x;
+    std::vector<Tensor> hs;
+    for (int i = 0; i < depth; ++i) {
+        const std::string d = "downs." + std::to_string(i) + ".";
+        Tensor a = b.resblock(e->down_res[2 * i], x, nullptr);
+        if (x.p != x_init.p) b.tfree(x);
+        b.tap(d + "0", a);
+        hs.push_back(a);
+        Tensor c = b.resblock(e->down_res[2 * i + 1], a, nullptr);
+        b.tap(d + "1", c);
+        Tensor g = b.attn(e->down_attn[i], c);
+        b.tfree(c);
+        b.tap(d + "2", g);
+        hs.push_back(g);
+        if (i != depth - 1)
+            x = b.conv(e->down_conv[i], g, nullptr, 2, 1, 0, nullptr, 0, nullptr);  // Downsample 4x4 s2 p1
+        else
+            x = b.conv(e->down_conv[i], g, nullptr, 1, 1, 0, nullptr, 0, nullptr);
+        b.tap(d + "3", x);
+    }
+    {
+        Tensor a = b.resblock(e->mid1, x, nullptr);
+        b.tfree(x);
+        b.tap("mid_block1", a);
+        Tensor g = b.attn(e->mid_attn, a);
+        b.tfree(a);
+        b.tap("mid_attn", g);
+        x = b.resblock(e->mid2, g, nullptr);
+        b.tfree(g);
+        b.tap("mid_block2", x);
+    }
+    for (int j = 0; j < depth; ++j) {
+        const std::string u = "ups." + std::to_string(j) + ".";
+        Tensor s1 = hs.back(); hs.pop_back();
+        Tensor a = b.resblock(e->up_res[2 * j], x, &s1);
+        b.tfree(x); b.tfree(s1);
+        b.tap(u + "0", a);
+        Tensor s2 = hs.back(); hs.pop_back();
+        Tensor c = b.resblock(e->up_res[2 * j + 1], a, &s2);
+        b.tfree(a); b.tfree(s2);
+        b.tap(u + "1", c);
+        Tensor g = b.attn(e->up_attn[j], c);
+        b.tfree(c);
+        b.tap(u + "2", g);
+        if (j != depth - 1)
+            x = b.conv(e->up_conv[j], g, nullptr, 1, 1, 1, nullptr, 0, nullptr);  // nearest x2 fused into the 3x3
+        else
+            x = b.conv(e->up_conv[j], g, nullptr, 1, 1, 0, nullptr, 0, nullptr);
+        b.tfree(g);
+        b.tap(u + "3", x);
+    }
+    {
+        Tensor f = b.resblock(e->final_res, x, &x_init);
+        b.tfree(x); b.tfree(x_init);
+        b.tap("final_res_block", f);
+        Tensor pr = b.conv(e->final_conv, f, nullptr, 1, 1, 0, nullptr, 0, nullptr, 4);
+        b.tfree(f);
+        pl->pred = pr.p;
+    }
+    e->plans.push_back(std::move(plan));
+    return pl;
+}
+
+hipEvent_t get_event(irsde_engine* e, size_t i) {
+    while (e->ev_pool.size() <= i) {
+        hipEvent_t ev;
+        IRSDE_HIP_CHECK(hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
+    return e->ev_pool[i];
+}
+
+void run_net(Plan* pl, hipStream_t s) {
+    for (auto& op : pl->net_ops) op.fn(s);
+}
+
+UpdateParams make_update(irsde_engine* e, Plan* pl) {
+    UpdateParams u{};
+    u.x = pl->xin; u.mu = pl->cin; u.pred = pl->pred;
+    u.sb = (int64_t)pl->Hp * pl->Wp * 4; u.sc = 1; u.sy = (int64_t)pl->Wp * 4; u.sx = 4;
+    u.st = e->step; u.ctl = e->ctl;
+    u.B = pl->B; u.C = e->cfg.in_nc; u.H = pl->H; u.W = pl->W;
+    return u;
+}
+
+void one_step(irsde_engine* e, Plan* pl, hipStream_t s) {
+    launch_step_begin(e->step, e->film_table, e->film_row, e->film_cur, e->coef_table, s);
+    run_net(pl, s);
+    launch_sde_update(make_update(e, pl), s);
+}
+
+int guard(const std::function<void()>& f) {
+    try {
+        f();
+        return IRSDE_OK;
+    } catch (const HipError& ex) {
+        g_last_error = ex.what();
+        const std::string m = ex.what();
+        if (m.find("weight") != std::string::npos) return IRSDE_ERR_WEIGHT;
+        if (m.find(" failed: ") != std::string::npos) return IRSDE_ERR_HIP;
+        return IRSDE_ERR_INVALID;
+    } catch (const std::exception& ex) {
+        g_last_error = ex.what();
+        return IRSDE_ERR_INVALID;
+    }
+}
+
+}  // namespace
+}  // namespace irsde
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* irsde_last_error(void) { return g_last_error.c_str(); }
+int irsde_version(void) { return 100; }
+
+int irsde_create(const irsde_config* cfg, irsde_engine** out) {
+    return guard([&] {
+        if (!cfg || !out) throw HipError("null argument");
+        if (cfg->nf % 32 || cfg->nf < 32) throw HipError("nf must be a positive multiple of 32");
+        if (cfg->depth < 1 || cfg->depth > 6) throw HipError("depth out of range");
+        if (cfg->in_nc < 1 || cfg->in_nc > 4 || cfg->out_nc < 1 || cfg->out_nc > 4)
+            throw HipError("in_nc/out_nc must be in 1..4");
+        if (cfg->in_nc != cfg->out_nc) throw HipError("sampler needs in_nc == out_nc");
+        if ((cfg->nf << cfg->depth) > 2048) throw HipError("nf * 2^depth must be <= 2048");
+        auto* e = new irsde_engine();
+        e->cfg = *cfg;
+        e->time_dim = cfg->nf * 4;
+        build_inventory(e);
+        *out = e;
+    });
+}
+
+void irsde_destroy(irsde_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    e->plans.clear();
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    for (float* p : e->dev_allocs) (void)hipFree(p);
+    delete e;
+}
+
+int irsde_num_weights(const irsde_engine* e) { return e ? (int)e->names.size() : 0; }
+const char* irsde_weight_name(const irsde_engine* e, int i) {
+    if (!e || i < 0 || i >= (int)e->names.size()) return nullptr;
+    return e->names[i].c_str();
+}
+int irsde_weight_shape(const irsde_engine* e, int i, int64_t shape[4], int* ndim) {
+    if (!e || i < 0 || i >= (int)e->names.size()) return IRSDE_ERR_INVALID;
+    const auto& t = e->host.at(e->names[i]);
+    *ndim = (int)t.shape.size();
+    for (size_t k = 0; k < t.shape.size(); ++k) shape[k] = t.shape[k];
+    return IRSDE_OK;
+}
+
+int irsde_load_weight(irsde_engine* e, const char* name, const float* data, const int64_t* shape, int ndim) {
+    return guard([&] {
+        if (!e || !name || !data) throw HipError("null argument");
+        if (e->finalized) throw HipError("weights already finalized: create a new engine to reload weights");
+        auto it = e->host.find(name);
+        if (it == e->host.end()) throw HipError(std::string("unknown weight name: ") + name);
+        HostTensor& t = it->second;
+        size_t n = 1;
+        bool same = ndim == (int)t.shape.size();
+        for (int k = 0; k < ndim; ++k) {
+            n *= (size_t)shape[k];
+            if (same && shape[k] != t.shape[k]) same = false;
+        }
+        if (!same) throw HipError(std::string("weight shape mismatch for ") + name);
+        t.data.assign(data, data + n);
+        t.loaded = true;
+    });
+}
+
+int irsde_finalize_weights(irsde_engine* e) {
+    return guard([&] {
+        if (!e) throw HipError("null engine");
+        if (e->finalized) return;
+        finalize(e);
+    });
+}
+
+int irsde_set_schedule(irsde_engine* e, int T, const float* coef) {
+    return guard([&] {
+        if (!e || !coef || T < 1) throw HipError("bad schedule arguments");
+        if (!e->finalized) throw HipError("set_schedule: weights not finalized");
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        IRSDE_HIP_CHECK(hipDeviceSynchronize());
+        e->T = T;
+        e->coef_table = e->dmalloc((size_t)(T + 1) * IRSDE_COEF_STRIDE);
+        IRSDE_HIP_CHECK(hipMemcpy(e->coef_table, coef, (size_t)(T + 1) * IRSDE_COEF_STRIDE * 4, hipMemcpyHostToDevice));
+        e->film_table = e->dmalloc((size_t)(T + 1) * e->film_row);
+        std::vector<float> tv(T + 1);
+        for (int t = 0; t <= T; ++t) tv[t] = (float)t;
+        float* dtv = e->upload(tv);
+        compute_film_rows(e, dtv, T + 1, e->film_table, e->stream);
+    });
+}
+
+int irsde_unet_forward(irsde_engine* e, const float* xt, const float* cond, const int64_t* t_host, int nt, int B, int H,
+                       int W, float* out, void* stream) {
+    return guard([&] {
+        if (!e || !xt || !cond || !t_host || !out) throw HipError("null argument");
+        if (!e->finalized) throw HipError("unet_forward: weights not finalized");
+        if (nt != 1 && nt != B) throw HipError("unet_forward: need 1 or B timesteps");
+        if (B < 1 || H < 2 || W < 2) throw HipError("unet_forward: bad shape");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t user = reinterpret_cast<hipStream_t>(stream);
+        const bool per_sample = nt > 1;
+        Plan* pl = get_plan(e, B, H, W, per_sample);
+        hipStream_t s = e->stream;
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+        const size_t img = (size_t)B * e->cfg.in_nc * H * W * sizeof(float);
+        IRSDE_HIP_CHECK(hipMemcpyAsync(pl->xin, xt, img, hipMemcpyDeviceToDevice, s));
+        IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, cond, img, hipMemcpyDeviceToDevice, s));
+        const bool in_table = nt == 1 && e->film_table && t_host[0] >= 0 && t_host[0] <= e->T;
+        if (in_table) {
+            IRSDE_HIP_CHECK(hipMemcpyAsync(e->film_cur, e->film_table + (size_t)t_host[0] * e->film_row,
+                                           (size_t)e->film_row * 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            std::vector<float> tv(nt);
+            for (int i = 0; i < nt; ++i) tv[i] = (float)t_host[i];
+            float* dtv = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dtv, nt * sizeof(float)));
+            IRSDE_HIP_CHECK(hipMemcpy(dtv, tv.data(), nt * sizeof(float), hipMemcpyHostToDevice));
+            compute_film_rows(e, dtv, nt, e->film_cur, s);
+            (void)hipFree(dtv);
+        }
+        run_net(pl, s);
+        launch_unpack_pred(pl->pred, out, B, e->cfg.out_nc, H, W, pl->Hp, pl->Wp, s);
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+    });
+}
+
+int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, const float* noise, uint64_t seed,
+                 uint64_t image_offset, int B, int H, int W, int T, int t_stop, float* out, void* stream,
+                 int flags) {
+    return guard([&] {
+        if (!e || !xT || !mu || !out) throw HipError("null argument");
+        if (!e->finalized || !e->film_table) throw HipError("sample: weights/schedule not set");
+        if (mode < 0 || mode > 2) throw HipError("sample: bad mode");
+        if (T <= 0) T = e->T;
+        if (T > e->T) throw HipError("sample: T exceeds the schedule length");
+        if (t_stop < 0 || t_stop >= T) throw HipError("sample: t_stop must be in [0, T)");
+        const int nsteps = T - t_stop;
+        if (B < 1 || H < 2 || W < 2) throw HipError("sample: bad shape");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t user = reinterpret_cast<hipStream_t>(stream);
+        Plan* pl = get_plan(e, B, H, W, false);
+        hipStream_t s = e->stream;
+        const bool profile = (flags & IRSDE_SAMPLE_PROFILE) != 0;
+        const bool graph = (flags & IRSDE_SAMPLE_GRAPH) != 0 && !profile;
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+        const size_t img = (size_t)B * e->cfg.in_nc * H * W;
+        IRSDE_HIP_CHECK(hipMemcpyAsync(pl->xin, xT, img * 4, hipMemcpyDeviceToDevice, s));
+        IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, mu, img * 4, hipMemcpyDeviceToDevice, s));
+        launch_set_ctl(e->ctl, mode, noise, (long long)img, seed, image_offset, s);
+        launch_set_step(e->step, T, s);
+
+        if (graph) {
+            if (!pl->graph_exec) {
+                IRSDE_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                try {
+                    one_step(e, pl, s);
+                } catch (...) {
+                    hipGraph_t g = nullptr;
+                    (void)hipStreamEndCapture(s, &g);
+                    if (g) (void)hipGraphDestroy(g);
+                    throw;
+                }
+                IRSDE_HIP_CHECK(hipStreamEndCapture(s, &pl->graph));
+                IRSDE_HIP_CHECK(hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0));
+            }
+            for (int i = 0; i < nsteps; ++i) IRSDE_HIP_CHECK(hipGraphLaunch(pl->graph_exec, s));
+        } else if (!profile) {
+            for (int i = 0; i < nsteps; ++i) one_step(e, pl, s);
+        } else {
+            // eager with an event before every kernel group; interval k..k+1 belongs to group k
+            std::vector<int> kinds;
+            size_t ei = 0;
+            auto mark = [&](int kind) {
+                IRSDE_HIP_CHECK(hipEventRecord(get_event(e, ei++), s));
+                kinds.push_back(kind);
+            };
+            for (int i = 0; i < nsteps; ++i) {
+                mark(OP_OTHER);
+                launch_step_begin(e->step, e->film_table, e->film_row, e->film_cur, e->coef_table, s);
+                for (auto& op : pl->net_ops) {
+                    mark(op.kind);
+                    op.fn(s);
+                }
+                mark(OP_OTHER);
+                launch_sde_update(make_update(e, pl), s);
+            }
+            IRSDE_HIP_CHECK(hipEventRecord(get_event(e, ei++), s));
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            double ms[4] = {0, 0, 0, 0};
+            for (size_t k = 0; k < kinds.size(); ++k) {
+                float t;
+                IRSDE_HIP_CHECK(hipEventElapsedTime(&t, e->ev_pool[k], e->ev_pool[k + 1]));
+                ms[kinds[k]] += t;
+            }
+            hipEvent_t e0 = e->ev_pool[0], e1 = e->ev_pool[kinds.size()];
+            float wall;
+            IRSDE_HIP_CHECK(hipEventElapsedTime(&wall, e0, e1));
+            size_t nconv = 0;
+            for (auto& op : pl->net_ops) nconv += op.kind == OP_CONV;
+            e->profile[0] = ms[OP_CONV];
+            e->profile[1] = pl->conv_flops * nsteps;
+            e->profile[2] = (double)nconv * nsteps;
+            e->profile[3] = pl->conv_bytes * nsteps;
+            e->profile[4] = ms[OP_LN];
+            e->profile[5] = ms[OP_ATTN];
+            e->profile[6] = ms[OP_OTHER];
+            e->profile[7] = wall;
+            e->profile[8] = nsteps;
+        }
+        IRSDE_HIP_CHECK(hipMemcpyAsync(out, pl->xin, img * 4, hipMemcpyDeviceToDevice, s));
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+    });
+}
+
+int irsde_sde_step(int mode, int t, const float* coef_row, float* x, const float* mu, const float* eps_hat,
+                   const float* noise_t, uint64_t seed, uint64_t image_offset, int B, int C, int H, int W,
+                   void* stream) {
+    return guard([&] {
+        if (!coef_row || !x || !mu || !eps_hat) throw HipError("null argument");
+        if (mode < 0 || mode > 2) throw HipError("sde_step: bad mode");
+        UpdateParams u{};
+        u.x = x; u.mu = mu; u.pred = eps_hat;
+        u.sb = (int64_t)C * H * W; u.sc = (int64_t)H * W; u.sy = W; u.sx = 1;
+        // noise_t is the draw for this step: index it with tstride 0
+        u.noise = noise_t; u.noise_tstride = 0;
+        u.st = nullptr; u.ctl = nullptr; u.t_imm = t;
+        for (int i = 0; i < IRSDE_COEF_STRIDE; ++i) u.coef_imm[i] = coef_row[i];
+        u.mode = mode; u.B = B; u.C = C; u.H = H; u.W = W; u.seed = seed; u.image_offset = image_offset;
+        launch_sde_update(u, reinterpret_cast<hipStream_t>(stream));
+    });
+}
+
+int irsde_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint64_t image_offset, void* stream) {
+    return guard([&] {
+        if (!out) throw HipError("null argument");
+        launch_philox_normal(out, B, CHW, t, seed, image_offset, reinterpret_cast<hipStream_t>(stream));
+    });
+}
+
+int irsde_get_profile(const irsde_engine* e, double out[9]) {
+    if (!e || !out) return IRSDE_ERR_INVALID;
+    for (int i = 0; i < 9; ++i) out[i] = e->profile[i];
+    return IRSDE_OK;
+}
+
+int irsde_debug_tap(irsde_engine* e, const char* name, float* dst, int64_t dims[4]) {
+    return guard([&] {
+        if (!e || !name || !dims) throw HipError("null argument");
+        if (!(e->cfg.flags & IRSDE_FLAG_KEEP_ACTIVATIONS)) throw HipError("debug_tap needs IRSDE_FLAG_KEEP_ACTIVATIONS");
+        Plan* pl = nullptr;
+        for (auto& p : e->plans)
+            if (!pl || p->last_use > pl->last_use) pl = p.get();
+        if (!pl) throw HipError("debug_tap: no forward has run");
+        auto it = pl->taps.find(name);
+        if (it == pl->taps.end()) throw HipError(std::string("debug_tap: unknown tap ") + name);
+        const Tensor& t = it->second;
+        dims[0] = t.B; dims[1] = t.C; dims[2] = t.H; dims[3] = t.W;
+        if (!dst) return;
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        IRSDE_HIP_CHECK(hipDeviceSynchronize());
+        float* tmp = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&tmp, t.numel() * 4));
+        launch_nhwc_to_nchw(t.p, tmp, t.B, t.C, t.H, t.W, e->stream);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(e->stream));
+        IRSDE_HIP_CHECK(hipMemcpy(dst, tmp, t.numel() * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(tmp);
+    });
+}
+
+int irsde_work_model(irsde_engine* e, int B, int H, int W, double out[2]) {
+    return guard([&] {
+        if (!e || !out) throw HipError("null argument");
+        if (!e->finalized) throw HipError("work_model: weights not finalized");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        Plan* pl = get_plan(e, B, H, W, false);
+        out[0] = pl->conv_flops;
+        out[1] = pl->conv_bytes;
+    });
+}
+
+int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int in_shift,
+                     const float* w_oihw, int Cout, int KH, int KW, int stride, int pad, const float* bias,
+                     const float* film, int film_bstride, int silu, const float* res, float* out, int naive,
+                     int splits, void* stream) {
+    return guard([&] {
+        if (!in0 || !w_oihw || !out) throw HipError("null argument");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        conv_global_init();
+        const int Cin = C0 + C1;
+        std::vector<float> pk((size_t)Cout * KH * KW * Cin);
+        for (int o = 0; o < Cout; ++o)
+            for (int i = 0; i < Cin; ++i)
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx)
+                        pk[(((size_t)o * KH + ky) * KW + kx) * Cin + i] = w_oihw[(((size_t)o * Cin + i) * KH + ky) * KW + kx];
+        float *dw = nullptr, *db = nullptr, *dp = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&dw, pk.size() * 4));
+        IRSDE_HIP_CHECK(hipMemcpy(dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        if (bias) {
+            IRSDE_HIP_CHECK(hipMalloc(&db, Cout * 4));
+            IRSDE_HIP_CHECK(hipMemcpy(db, bias, Cout * 4, hipMemcpyHostToDevice));
+        }
+        ConvParams p;
+        p.in0 = in0; p.C0 = C0; p.pix0 = C0; p.in1 = in1; p.C1 = C1; p.pix1 = C1;
+        p.Hin = Hin; p.Win = Win; p.in_shift = in_shift;
+        p.w = dw; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad_y = pad; p.pad_x = pad;
+        p.B = B;
+        p.Ho = ((Hin << in_shift) + 2 * pad - KH) / stride + 1;
+        p.Wo = ((Win << in_shift) + 2 * pad - KW) / stride + 1;
+        p.out = out; p.out_stride = Cout; p.bias = db; p.film = film; p.film_bstride = film_bstride; p.silu = silu;
+        p.res = res; p.res_stride = Cout;
+        if (splits > 1 && !naive) {
+            p.splits = splits;
+            IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
+            p.partial = dp;
+        }
+        if (naive)
+            launch_conv_naive(p, s);
+        else
+            launch_conv(p, s);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(dw);
+        if (db) (void)hipFree(db);
+        if (dp) (void)hipFree(dp);
+    });
+}
+
+}  // extern "C"

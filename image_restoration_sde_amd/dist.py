@@ -1,0 +1,59 @@
+"""Batch sharding of the sampler over the GPUs of one node.
+
+Every image's reverse trajectory is independent (no cross-batch op in the score network), so the
+batch is split over ranks with NO collective inside the T-step loop; one all_gather of the final
+[B,3,H,W] tensors (RCCL over xGMI when the backend is "nccl", gloo in the CPU tests) reassembles the batch.
+Noise streams are keyed by the GLOBAL image index (`sde.image_offset`), so the gathered result does
+not depend on the number of ranks.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous shard [lo, hi) of `n_items` for `rank`; the first (n_items % world_size) ranks get one
+    extra item."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_batch(local, n_items, group=None):
+    """all_gather the per-rank shards (shape [n_r, ...]) back into [n_items, ...] on every rank."""
+    if not dist.is_available() or not dist.is_initialized():
+        return local
+    world = dist.get_world_size(group)
+    sizes = [shard_bounds(n_items, world, r) for r in range(world)]
+    nmax = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
+def sample_sharded(sde, mode, x_T, mu, group=None):
+    """Run `sde.reverse_<mode>` on this rank's shard of (x_T, mu) and gather the full batch.
+
+    x_T / mu are the FULL batch (identical on every rank, e.g. synthetic or broadcast inputs); each rank
+    samples images [lo, hi).  Equivalent to one single-GPU call on the full batch."""
+    n = x_T.shape[0]
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    lo, hi = shard_bounds(n, world, rank)
+    fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[mode]
+    old_off, old_noise = sde.image_offset, sde.injected_noise
+    try:
+        sde.image_offset = old_off + lo
+        if old_noise is not None:
+            sde.injected_noise = old_noise[:, lo:hi].contiguous()
+        sde.set_mu(mu[lo:hi])
+        local = fn(x_T[lo:hi]) if hi > lo else x_T[lo:hi].clone()
+    finally:
+        sde.image_offset, sde.injected_noise = old_off, old_noise
+        sde.set_mu(mu)
+    return gather_batch(local, n, group)

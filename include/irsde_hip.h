@@ -1,0 +1,150 @@
+/* irsde_hip.h — C ABI of libirsde_hip.so: the MI355X (gfx950) IR-SDE reverse-diffusion sampler.
+ *
+ * The reference (Algolzw/image-restoration-sde) is pure Python/PyTorch and has no FFI; its seam for
+ * this path is Python duck typing at two objects:
+ *   - the `sde` object  (codes/utils/sde_utils.py:80-361, class IRSDE) and
+ *   - the score model   (codes/config/deraining/models/modules/DenoisingUNet_arch.py:18-134,
+ *                        class ConditionalUNet), driven by DenoisingModel.test()
+ *                        (codes/config/deraining/models/denoising_model.py:150-160).
+ * Each entry point below names the reference interface it replaces.  All pointers are plain
+ * device (or, where stated, host) pointers to float32; no torch types cross this boundary.
+ * Image tensors are NCHW [B][C][H][W] contiguous exactly as the reference passes them; the NHWC
+ * working layout is internal.  `stream` is a hipStream_t (NULL = the legacy default stream); every
+ * call is stream-ordered with respect to it and does not synchronise the device unless stated.
+ *
+ * Return value: 0 on success, negative IRSDE_ERR_* otherwise; irsde_last_error() gives the text.
+ */
+#ifndef IRSDE_HIP_H
+#define IRSDE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct irsde_engine irsde_engine;
+
+enum {
+    IRSDE_OK = 0,
+    IRSDE_ERR_INVALID = -1, /* bad argument / unsupported shape */
+    IRSDE_ERR_HIP = -2,     /* a HIP runtime call failed */
+    IRSDE_ERR_STATE = -3,   /* call order violated (weights not finalized, schedule not set ...) */
+    IRSDE_ERR_WEIGHT = -4   /* unknown weight name / wrong shape / missing weights */
+};
+
+enum { IRSDE_MODE_SDE = 0, IRSDE_MODE_ODE = 1, IRSDE_MODE_POSTERIOR = 2 };
+
+/* engine flags (irsde_config.flags) */
+enum {
+    IRSDE_FLAG_KEEP_ACTIVATIONS = 1, /* never recycle activation buffers: enables irsde_debug_tap */
+    IRSDE_FLAG_NAIVE_CONV = 2        /* debug: run every convolution on the naive VALU kernel */
+};
+/* per-call flags (irsde_sample) */
+enum {
+    IRSDE_SAMPLE_GRAPH = 1,  /* replay one captured hipGraph per step instead of eager launches */
+    IRSDE_SAMPLE_PROFILE = 2 /* eager + hipEvent pairs around every kernel (see irsde_get_profile) */
+};
+
+/* ConditionalUNet(in_nc, out_nc, nf, depth) — DenoisingUNet_arch.py:19-20 (upscale is unused there). */
+typedef struct irsde_config {
+    int32_t in_nc;
+    int32_t out_nc;
+    int32_t nf;
+    int32_t depth;
+    int32_t device; /* HIP device ordinal */
+    int32_t flags;  /* IRSDE_FLAG_* */
+} irsde_config;
+
+/* Row layout of the per-step coefficient table passed to irsde_set_schedule (floats per row). */
+#define IRSDE_COEF_STRIDE 12
+/*  [0] thetas[t]  [1] sigmas[t]  [2] sigma_bars[t]  [3] dt  [4] sqrt(dt)
+ *  [5] exp(thetas_cumsum[t]*dt)                      (get_init_state_from_noise, sde_utils.py:237-239)
+ *  [6] posterior term1  [7] posterior term2          (reverse_optimum_step,      sde_utils.py:197-205)
+ *  [8] posterior std                                 (reverse_optimum_std,       sde_utils.py:207-217)
+ *  [9..11] reserved (0)                                                                        */
+
+const char* irsde_last_error(void);
+int irsde_version(void);
+
+/* Replaces ConditionalUNet.__init__ (DenoisingUNet_arch.py:19-76).  Host-only; no GPU work. */
+int irsde_create(const irsde_config* cfg, irsde_engine** out);
+void irsde_destroy(irsde_engine* e);
+
+/* Weight inventory = the reference state_dict (151 tensors for nf=64, depth=4). */
+int irsde_num_weights(const irsde_engine* e);
+const char* irsde_weight_name(const irsde_engine* e, int index);
+int irsde_weight_shape(const irsde_engine* e, int index, int64_t shape[4], int* ndim);
+
+/* Replaces load_state_dict / BaseModel.load_network (deraining/models/base_model.py:92-105):
+ * `data` is a HOST pointer to the tensor in the reference's own layout (OIHW conv weights,
+ * [out][in] linear weights, (1,C,1,1) LayerNorm gains).  Repacked to the kernel layout
+ * ([Cout][KH][KW][Cin]) and uploaded by irsde_finalize_weights. */
+int irsde_load_weight(irsde_engine* e, const char* name, const float* data, const int64_t* shape, int ndim);
+int irsde_finalize_weights(irsde_engine* e);
+
+/* Replaces IRSDE._initialize's device tables (sde_utils.py:145-148).  `coef` is a HOST table of
+ * (T+1) rows x IRSDE_COEF_STRIDE floats (row 0 unused).  Also builds the [T+1] x sum(2*Cout) FiLM
+ * table: time_mlp (DenoisingUNet_arch.py:42-47) and every ResBlock.mlp (module_util.py:127-141)
+ * evaluated for t = 0..T.  Needs finalized weights.  Synchronises the device. */
+int irsde_set_schedule(irsde_engine* e, int T, const float* coef);
+
+/* Replaces ConditionalUNet.forward(xt, cond, time) (DenoisingUNet_arch.py:85-134).
+ * xt, cond, out: device NCHW [B][in_nc|out_nc][H][W].  t_host: HOST array of nt timesteps,
+ * nt == 1 (python int / tensor([t]): shared by the batch) or nt == B (training-style [B] tensor,
+ * denoising_model.py:135).  Any H, W >= 2 (reflect pad to a multiple of 2^depth, :78-83). */
+int irsde_unet_forward(irsde_engine* e, const float* xt, const float* cond, const int64_t* t_host, int nt, int B,
+                       int H, int W, float* out, void* stream);
+
+/* Replaces IRSDE.reverse_sde / reverse_ode / reverse_posterior (sde_utils.py:252-299) with the score
+ * network evaluated by this engine: for t = T..1: eps = net(x, mu, t); x = step(x, mu, eps, z_t).
+ *   xT, mu, out : device NCHW [B][C][H][W]; xT is not modified (the reference clones it, :254).
+ *   noise       : device [T_sched+1][B][C][H][W] injected N(0,1) draws indexed by t (parity runs), or
+ *                 NULL => Philox4x32-10 keyed by (seed, image_offset + b, t, element).
+ *   T           : first step (<= the T given to irsde_set_schedule; <= 0 means that T), like the
+ *                 reference's `T` argument; t_stop: last step NOT taken (0 = run down to t = 1); running
+ *                 T..t_stop+1 and then t_stop..1 equals one T..1 call (used for save_states dumps).
+ *   flags       : IRSDE_SAMPLE_* */
+int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, const float* noise, uint64_t seed,
+                 uint64_t image_offset, int B, int H, int W, int T, int t_stop, float* out, void* stream,
+                 int flags);
+
+/* One reverse step with an externally computed eps_hat (NCHW, e.g. from a foreign nn.Module):
+ * replaces SDE.reverse_sde_step / reverse_ode_step / IRSDE.reverse_posterior_step
+ * (sde_utils.py:44-48, 219-223).  x is updated in place.  `coef_row` is a HOST row (IRSDE_COEF_STRIDE
+ * floats).  noise_t: device [B][C][H][W] or NULL (Philox).  No engine state is needed (e may be NULL). */
+int irsde_sde_step(int mode, int t, const float* coef_row, float* x, const float* mu, const float* eps_hat,
+                   const float* noise_t, uint64_t seed, uint64_t image_offset, int B, int C, int H, int W,
+                   void* stream);
+
+/* The device RNG on its own: out[B][CHW] = the N(0,1) draws irsde_sample would use at step t. */
+int irsde_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint64_t image_offset, void* stream);
+
+/* Timing of the last IRSDE_SAMPLE_PROFILE call (hipEvents on the engine's own stream).
+ * out[0] conv kernel ms (sum)      out[1] conv algorithmic FLOPs (sum)  out[2] conv launches
+ * out[3] conv algorithmic bytes    out[4] layernorm ms                   out[5] attention ms
+ * out[6] other kernels ms          out[7] wall ms of the whole call      out[8] network evaluations */
+int irsde_get_profile(const irsde_engine* e, double out[9]);
+
+/* Debug (IRSDE_FLAG_KEEP_ACTIVATIONS): copy a named intermediate activation of the last forward to
+ * HOST memory as NCHW.  Names follow the reference module paths ("downs.0.0", "mid_attn", ...).
+ * dims receives {B, C, H, W}; pass dst == NULL to query dims only. */
+int irsde_debug_tap(irsde_engine* e, const char* name, float* dst, int64_t dims[4]);
+
+/* Algorithmic work of one network evaluation at (B,H,W): flops[0] = conv FLOPs, flops[1] = ideal-fusion
+ * conv bytes (inputs + outputs + weights once). */
+int irsde_work_model(irsde_engine* e, int B, int H, int W, double out[2]);
+
+/* Kernel-level test hook: one implicit-GEMM convolution (csrc/conv_igemm.hip) on NHWC device tensors.
+ * in0/in1: [B][Hin][Win][C0|C1] (channel concat, in1 may be NULL); w_oihw/bias: HOST, reference layout;
+ * film: device [rows][2*Cout] or NULL; res/out: device [B][Ho][Wo][Cout].  naive != 0 runs the VALU
+ * cross-check kernel; splits > 1 forces split-K.  Synchronises `stream`. */
+int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int in_shift,
+                     const float* w_oihw, int Cout, int KH, int KW, int stride, int pad, const float* bias,
+                     const float* film, int film_bstride, int silu, const float* res, float* out, int naive,
+                     int splits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRSDE_HIP_H */

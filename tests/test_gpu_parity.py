@@ -1,0 +1,394 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI of
+libirsde_hip.so; the numpy oracle and the committed golden vectors (generated from the real reference)
+are the checkers.  /root/reference is never read here.
+
+Tolerances (floating point path, fp32 arithmetic on both sides):
+  single convolution vs float64 oracle conv ........ 2e-5 relative to max|ref|
+  one UNet evaluation vs reference golden .......... 1e-4 relative to max|ref|  (~200 fp32 layers)
+  one reverse step (elementwise) vs golden ......... 2e-6 abs / 1e-5 rel
+  full sampler vs reference golden ................. 2e-3 relative to max|ref|  (reverse drift expands
+      perturbations ~200x; the reference's own fp32-vs-fp64 gap is of the same size)
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import image_restoration_sde_amd as P
+from image_restoration_sde_amd import _lib
+from oracle import irsde_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def relerr(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def make_model(nf, depth, flags=0, seed=0):
+    m = P.ConditionalUNet(3, 3, nf, depth=depth)
+    params = O.synth_params(seed=seed, nf=nf, depth=depth)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m.engine_flags = flags
+    return m.to(DEV).eval(), params
+
+
+_MODELS = {}
+
+
+def model(nf, depth, flags=0):
+    key = (nf, depth, flags)
+    if key not in _MODELS:
+        _MODELS[key] = make_model(nf, depth, flags)
+    return _MODELS[key]
+
+
+def test_native_library_is_loaded():
+    """The HIP extension (in-tree .so) is what runs; there is no eager/PyTorch fallback."""
+    assert torch.cuda.is_available()
+    L = _lib.lib()
+    assert L.irsde_version() == 100
+    maps = open("/proc/self/maps").read()
+    assert "libirsde_hip.so" in maps
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel level: implicit-GEMM convolution (every shape class the network uses)
+# ---------------------------------------------------------------------------------------------
+def run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=0, splits=1, film_bstride=0):
+    """x0/x1/res: numpy NCHW.  Returns numpy NCHW."""
+    L = _lib.lib()
+    to_nhwc = lambda a: torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 3, 1))).to(DEV)
+    d0 = to_nhwc(x0)
+    d1 = to_nhwc(x1) if x1 is not None else None
+    B, C0, Hin, Win = x0.shape
+    C1 = x1.shape[1] if x1 is not None else 0
+    Cout, _, KH, KW = w.shape
+    Ho = ((Hin << in_shift) + 2 * pad - KH) // stride + 1
+    Wo = ((Win << in_shift) + 2 * pad - KW) // stride + 1
+    out = torch.full((B, Ho, Wo, Cout), float("nan"), device=DEV)
+    dres = to_nhwc(res) if res is not None else None
+    dfilm = torch.from_numpy(film).to(DEV) if film is not None else None
+    wc = np.ascontiguousarray(w, dtype=np.float32)
+    bc = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    torch.cuda.synchronize()
+    _lib.check(L.irsde_debug_conv(p(d0), C0, p(d1), C1, B, Hin, Win, in_shift, wc.ctypes.data_as(ctypes.c_void_p), Cout,
+                                  KH, KW, stride, pad, bc.ctypes.data_as(ctypes.c_void_p) if bc is not None else None,
+                                  p(dfilm), film_bstride, silu, p(dres), p(out), naive, splits, None))
+    return out.cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def oracle_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, film_bstride=0):
+    x = x0 if x1 is None else np.concatenate([x0, x1], axis=1)
+    x = x.astype(np.float64)
+    if in_shift:
+        x = O.upsample_nearest2(x)
+    y = O.conv2d(x, w.astype(np.float64), None if bias is None else bias.astype(np.float64), stride=stride, pad=pad)
+    if film is not None:
+        Cout = w.shape[0]
+        f = film.astype(np.float64)
+        if film_bstride:
+            sc, sh = f[:, :Cout, None, None], f[:, Cout:, None, None]
+        else:
+            sc, sh = f[0, :Cout].reshape(1, -1, 1, 1), f[0, Cout:].reshape(1, -1, 1, 1)
+        y = y * (sc + 1) + sh
+    if silu:
+        y = O.silu(y)
+    if res is not None:
+        y = y + res
+    return y
+
+
+CONV_CASES = {
+    # name: (B, C0, C1, H, W, Cout, K, stride, pad, in_shift, bias, film, silu, res)
+    "3x3_64_64_film_silu": (2, 64, 0, 24, 20, 64, 3, 1, 1, 0, False, True, True, False),
+    "3x3_64_64_silu_res": (2, 64, 0, 24, 20, 64, 3, 1, 1, 0, False, False, True, True),
+    "3x3_concat_192_128": (1, 128, 64, 16, 16, 128, 3, 1, 1, 0, False, True, True, False),
+    "1x1_concat_res_conv": (1, 128, 64, 16, 16, 128, 1, 1, 0, 0, False, False, False, False),
+    "1x1_qkv_384": (2, 64, 0, 12, 12, 384, 1, 1, 0, 0, False, False, False, False),
+    "1x1_to_out_bias": (2, 128, 0, 12, 12, 256, 1, 1, 0, 0, True, False, False, False),
+    "4x4_s2_down": (2, 64, 0, 16, 24, 128, 4, 2, 1, 0, True, False, False, False),
+    "3x3_upsample_fused": (2, 128, 0, 8, 12, 64, 3, 1, 1, 1, True, False, False, False),
+    "3x3_final_cout3": (2, 64, 0, 24, 20, 3, 3, 1, 1, 0, True, False, False, False),
+    "3x3_m_tail_odd": (1, 32, 0, 7, 9, 96, 3, 1, 1, 0, False, False, True, False),
+    "3x3_deep_k_1536": (1, 1024, 512, 4, 4, 256, 3, 1, 1, 0, False, True, True, False),
+}
+
+
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv_kernel(name):
+    B, C0, C1, H, W, Cout, K, stride, pad, in_shift, has_bias, has_film, silu, has_res = CONV_CASES[name]
+    rs = np.random.RandomState(hash(name) % 2 ** 31)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, K, K)) / np.sqrt((C0 + C1) * K * K)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32) if has_bias else None
+    film = (0.3 * rs.standard_normal((1, 2 * Cout))).astype(np.float32) if has_film else None
+    Ho = ((H << in_shift) + 2 * pad - K) // stride + 1
+    Wo = ((W << in_shift) + 2 * pad - K) // stride + 1
+    res = rs.standard_normal((B, Cout, Ho, Wo)).astype(np.float32) if has_res else None
+    ref = oracle_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res)
+    got = run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert relerr(got, ref) < 2e-5, name
+    # the VALU cross-check kernel and the forced split-K path agree with the oracle too
+    assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=1), ref) < 2e-5
+    assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, splits=3), ref) < 2e-5
+
+
+def test_conv_per_sample_film():
+    rs = np.random.RandomState(5)
+    x0 = rs.standard_normal((3, 32, 10, 10)).astype(np.float32)
+    w = (rs.standard_normal((64, 32, 3, 3)) / 17).astype(np.float32)
+    film = (0.3 * rs.standard_normal((3, 128))).astype(np.float32)
+    ref = oracle_conv(x0, None, w, None, 1, 1, 0, film, 1, None, film_bstride=128)
+    got = run_conv(x0, None, w, None, 1, 1, 0, film, 1, None, film_bstride=128)
+    assert relerr(got, ref) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# network level
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["nf32d2_2x24x20", "nf64d4_1x64x64", "nf64d4_2x40x56"])
+def test_unet_forward_vs_reference_golden(golden, tag):
+    g = golden.forward
+    nf, depth, B, H, W = (int(v) for v in g[tag + "/cfg"])
+    m, _ = model(nf, depth)
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    for t in g[tag + "/ts"]:
+        y = m(x, c, int(t)).cpu().numpy()
+        assert relerr(y, g[tag + "/t%d" % t]) < 1e-4, (tag, int(t))
+    # tensor-valued time (tensor([t]) on device, DenoisingUNet_arch.py:87-88)
+    t0 = int(g[tag + "/ts"][0])
+    y = m(x, c, torch.tensor([t0], device=DEV)).cpu().numpy()
+    assert relerr(y, g[tag + "/t%d" % t0]) < 1e-4
+    if tag == "nf32d2_2x24x20":  # training-style [B] timesteps
+        y = m(x, c, torch.tensor([5, 60])).cpu().numpy()
+        assert relerr(y, g[tag + "/tvec"]) < 1e-4
+
+
+def test_unet_layers_vs_oracle():
+    """Per-layer parity against the float64 oracle (every tap point of the network)."""
+    nf, depth, B, H, W = 32, 2, 2, 24, 20
+    m, params = make_model(nf, depth, flags=_lib.FLAG_KEEP_ACTIVATIONS)
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    taps = {}
+    ref = O.unet_forward(params, xT, lq, 7, depth=depth, dtype=np.float64, taps=taps)
+    y = m(torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV), 7).cpu().numpy()
+    worst = {}
+    for name, want in taps.items():
+        if name == "time_emb":
+            continue
+        got = m.debug_tap(name).numpy()
+        assert got.shape == want.shape, name
+        worst[name] = relerr(got, want)
+    bad = {k: v for k, v in worst.items() if not v < 5e-5}
+    assert not bad, bad
+    assert relerr(y, ref) < 5e-5
+
+
+def test_unet_mfma_vs_naive_full_resolution():
+    """Size-independent cross-check at a BASELINE-sized input (B=4, 256x256, nf=64): the MFMA
+    implicit-GEMM path and the VALU direct-convolution path compute the same network."""
+    B, H, W = 4, 256, 256
+    m, _ = model(64, 4)
+    mn, _ = make_model(64, 4, flags=_lib.FLAG_NAIVE_CONV)
+    lq, xT = O.synth_inputs(99, B, H, W)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    a = m(x, c, 42).cpu().numpy()
+    b = mn(x, c, 42).cpu().numpy()
+    assert np.isfinite(a).all()
+    assert relerr(a, b) < 5e-5
+    # batch independence (no cross-batch op): image 2 alone == image 2 in the batch
+    a2 = m(x[2:3], c[2:3], 42).cpu().numpy()
+    assert relerr(a2, a[2:3]) < 5e-5
+    del mn
+
+
+# ---------------------------------------------------------------------------------------------
+# sampler level
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["s10_T100", "s50_T200"])
+def test_reverse_step_kernel_vs_reference_golden(golden, tag):
+    g = golden.steps
+    ms, T = (10, 100) if tag == "s10_T100" else (50, 200)
+    sde = P.IRSDE(ms, T, "cosine", 0.005, device=DEV)
+    x, mu, eh = (torch.from_numpy(g[tag + "/" + k]).to(DEV) for k in ("x", "mu", "eps_hat"))
+    z = torch.from_numpy(O.synth_noise(5, T, tuple(x.shape))).to(DEV)
+    L = _lib.lib()
+    B, C, H, W = x.shape
+    for t in (1, 2, T // 2, T):
+        for mode, key in (("sde", "sde"), ("ode", "ode"), ("posterior", "post")):
+            xx = x.clone()
+            row = sde._coef[t].contiguous()
+            _lib.check(L.irsde_sde_step(_lib.MODE[mode], t, ctypes.c_void_p(row.data_ptr()),
+                                        ctypes.c_void_p(xx.data_ptr()), ctypes.c_void_p(mu.data_ptr()),
+                                        ctypes.c_void_p(eh.data_ptr()), ctypes.c_void_p(z[t].data_ptr()), 0, 0,
+                                        B, C, H, W, None))
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(xx.cpu().numpy(), g[tag + "/%s_t%d" % (key, t)], rtol=1e-5, atol=2e-6)
+
+
+def _sample(m, mode, T, lq, xT, z, graph, sde=None):
+    sde = sde or P.IRSDE(10, T, "cosine", 0.005, device=DEV)
+    sde.set_model(m)
+    sde.use_graph = graph
+    sde.injected_noise = torch.from_numpy(z).to(DEV) if z is not None else None
+    sde.set_mu(torch.from_numpy(lq).to(DEV))
+    x_in = torch.from_numpy(xT).to(DEV)
+    keep = x_in.clone()
+    fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[mode]
+    out = fn(x_in)
+    assert torch.equal(x_in, keep)  # the input state is not modified (reference clones it)
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("tag,modes", [("nf32d2_2x16x16_T20", ["sde", "ode", "posterior"]),
+                                       ("nf64d4_1x32x32_T100", ["sde", "ode", "posterior"]),
+                                       ("nf64d4_1x128x128_T100", ["sde", "posterior"])])
+def test_sampler_vs_reference_golden(golden, tag, modes):
+    """End-to-end reverse samplers with injected noise vs the REAL reference's outputs
+    (last case = BASELINE.json configs[0]: 1x3x128x128, T=100)."""
+    g = golden.sampler
+    nf, depth, B, H, W, T = (int(v) for v in g[tag + "/cfg"])
+    m, _ = model(nf, depth)
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    z = O.synth_noise(7, T, (B, 3, H, W))
+    for mode in modes:
+        ref = g[tag + "/" + mode]
+        eager = _sample(m, mode, T, lq, xT, z, graph=False)
+        assert np.isfinite(eager).all()
+        assert relerr(eager, ref) < 2e-3, (tag, mode)
+        graph = _sample(m, mode, T, lq, xT, z, graph=True)
+        assert np.array_equal(eager, graph), "hipGraph replay must be bit-identical to eager launches"
+
+
+def test_sampler_vs_oracle_small():
+    """Same sampler vs the float64 oracle loop (tighter 'truth' than the fp32 reference)."""
+    nf, depth, B, H, W, T = 32, 2, 2, 16, 16, 20
+    m, params = model(nf, depth)
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    z = O.synth_noise(7, T, (B, 3, H, W))
+    sde = P.IRSDE(10, T, "cosine", 0.005, device=DEV)
+    c = sde._coef.numpy()
+    sch = dict(T=T, max_sigma=sde.max_sigma, dt=np.float32(float(sde.dt)), thetas=c[:, 0], sigmas=c[:, 1],
+               sigma_bars=c[:, 2], x0_gain=c[:, 5], post_term1=c[:, 6], post_term2=c[:, 7], post_std=c[:, 8],
+               thetas_cumsum=sde._cpu["thetas_cumsum"].numpy())
+    for mode in ("sde", "ode", "posterior"):
+        want = O.sample(params, sch, xT, lq, mode, noise=z, depth=depth, dtype=np.float64)
+        got = _sample(m, mode, T, lq, xT, z, graph=True)
+        assert relerr(got, want) < 1e-3, mode
+
+
+def test_partial_T_and_segments():
+    """reverse_*(xt, T=k) starts at step k (sde_utils.py:253-256); T..s then s..1 equals T..1."""
+    nf, depth, B, H, W, T = 32, 2, 1, 16, 16, 20
+    m, _ = model(nf, depth)
+    lq, xT = O.synth_inputs(3, B, H, W)
+    z = O.synth_noise(7, T, (B, 3, H, W))
+    sde = P.IRSDE(10, T, "cosine", 0.005, device=DEV)
+    full = _sample(m, "posterior", T, lq, xT, z, True, sde)
+    L = _lib.lib()
+    eng = m.engine()
+    x = torch.from_numpy(xT).to(DEV)
+    mu = torch.from_numpy(lq).to(DEV)
+    zz = torch.from_numpy(z).to(DEV)
+    mid = torch.empty_like(x)
+    out = torch.empty_like(x)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(L.irsde_sample(eng.h, 2, p(x), p(mu), p(zz), 0, 0, B, H, W, T, 7, p(mid), None, 1))
+    _lib.check(L.irsde_sample(eng.h, 2, p(mid), p(mu), p(zz), 0, 0, B, H, W, 7, 0, p(out), None, 1))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), full)
+
+
+def test_foreign_model_path_matches_engine_path():
+    """A score model that is NOT our ConditionalUNet is called per step like the reference does, with
+    the fused HIP update kernel in between; with our UNet wrapped as an opaque callable both paths agree."""
+    nf, depth, B, H, W, T = 32, 2, 2, 16, 16, 12
+    m, _ = model(nf, depth)
+    lq, xT = O.synth_inputs(5, B, H, W)
+    z = O.synth_noise(7, T, (B, 3, H, W))
+    a = _sample(m, "sde", T, lq, xT, z, True)
+
+    class Opaque(torch.nn.Module):
+        def forward(self, x, mu, t, **kw):
+            return m(x, mu, t)
+    b = _sample(Opaque(), "sde", T, lq, xT, z, True)
+    assert relerr(b, a) < 1e-6
+
+
+def test_philox_rng_vs_oracle_and_sharding_invariance():
+    L = _lib.lib()
+    B, CHW, t, seed = 3, 3 * 17 * 13, 9, 0x1234567890ABCDEF
+    out = torch.empty(B, CHW, device=DEV)
+    _lib.check(L.irsde_philox_normal(ctypes.c_void_p(out.data_ptr()), B, CHW, t, seed, 5, None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for b in range(B):
+        want = O.device_normal(seed, t, 5 + b, CHW)
+        np.testing.assert_allclose(got[b], want, rtol=0, atol=2e-5)
+    # image 6 drawn as "image 1 of a shard starting at 5" == "image 0 of a shard starting at 6"
+    out2 = torch.empty(1, CHW, device=DEV)
+    _lib.check(L.irsde_philox_normal(ctypes.c_void_p(out2.data_ptr()), 1, CHW, t, seed, 6, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy()[0], got[1])
+    assert abs(got.mean()) < 0.05 and abs(got.std() - 1) < 0.05
+
+
+def test_sampler_philox_is_shard_invariant():
+    """Without injected noise the sampler draws Philox noise keyed by the global image index:
+    sampling images [0,4) at once == sampling [0,2) and [2,4) as two shards."""
+    nf, depth, B, H, W, T = 32, 2, 4, 16, 16, 10
+    m, _ = model(nf, depth)
+    lq, xT = O.synth_inputs(11, B, H, W)
+    sde = P.IRSDE(10, T, "cosine", 0.005, device=DEV)
+    sde.seed = 77
+    full = _sample(m, "sde", T, lq, xT, None, True, sde)
+    parts = []
+    for lo in (0, 2):
+        sde.image_offset = lo
+        parts.append(_sample(m, "sde", T, lq[lo:lo + 2], xT[lo:lo + 2], None, True, sde))
+    sde.image_offset = 0
+    assert relerr(np.concatenate(parts), full) < 1e-5
+    other = P.IRSDE(10, T, "cosine", 0.005, device=DEV)
+    other.seed = 78
+    assert relerr(_sample(m, "sde", T, lq, xT, None, True, other), full) > 1e-3  # the seed matters
+
+
+def test_denoising_model_boundary(tmp_path):
+    """DenoisingModel.feed_data/test/get_current_visuals (deraining/models/denoising_model.py:121-171)
+    driven exactly like deraining/test.py:104-112, loading a reference-format checkpoint."""
+    nf, depth, H, W, T = 32, 2, 24, 20, 8
+    params = O.synth_params(seed=0, nf=nf, depth=depth)
+    ckpt = tmp_path / "G.pth"
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in params.items()}, ckpt)
+    opt = {"model": "denoising", "is_train": False, "gpu_ids": [0], "dist": False,
+           "network_G": {"which_model_G": "ConditionalUNet", "setting": {"in_nc": 3, "out_nc": 3, "nf": nf, "depth": depth}},
+           "path": {"pretrain_model_G": str(ckpt), "strict_load": True}}
+    mdl = P.create_model(opt)
+    sde = P.IRSDE(max_sigma=10, T=T, schedule="cosine", eps=0.005, device=mdl.device)
+    sde.set_model(mdl.model)
+    lq, xT = O.synth_inputs(21, 1, H, W)
+    z = O.synth_noise(7, T, (1, 3, H, W))
+    sde.injected_noise = torch.from_numpy(z).to(mdl.device)
+    mdl.feed_data(torch.from_numpy(xT), torch.from_numpy(lq), torch.from_numpy(lq))  # CPU tensors, like test.py
+    sch = None
+    for mode in ("posterior", "sde"):
+        mdl.test(sde, mode=mode, save_states=False)
+        vis = mdl.get_current_visuals()
+        assert set(vis) == {"Input", "Output", "GT"} and vis["Output"].shape == (3, H, W)
+        c = sde._coef.numpy()
+        sch = dict(T=T, max_sigma=sde.max_sigma, dt=np.float32(float(sde.dt)), thetas=c[:, 0], sigmas=c[:, 1],
+                   sigma_bars=c[:, 2], x0_gain=c[:, 5], post_term1=c[:, 6], post_term2=c[:, 7], post_std=c[:, 8])
+        want = O.sample(params, sch, xT, lq, mode, noise=z, depth=depth, dtype=np.float64)
+        assert relerr(vis["Output"].numpy()[None], want) < 1e-3
+    # save_states dumps PNGs every T//100 (>=1) steps like sde_utils.py:260-264 and gives the same result
+    out_a = sde.reverse_sde(mdl.state)
+    out_b = sde.reverse_sde(mdl.state, save_states=True, save_dir=str(tmp_path / "sde_state"))
+    assert torch.equal(out_a, out_b)
+    assert len(list((tmp_path / "sde_state").glob("state_*.png"))) == T

@@ -1,0 +1,136 @@
+"""Host-side logic of the product package (no GPU): schedule/coefficient tables bit-identical to the
+reference's, reference-compatible state_dict, loud failure without a GPU, sharding arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+import image_restoration_sde_amd as P
+from oracle import irsde_oracle as O
+
+CFGS = {"s10_T100": (10, 100, "cosine", 0.005), "s50_T100": (50, 100, "cosine", 0.005),
+        "s50_T200": (50, 200, "cosine", 0.005), "s25_T100_lin": (25, 100, "linear", 0.005),
+        "s0p1_T50_const": (0.1, 50, "constant", 0.01)}
+
+
+@pytest.mark.parametrize("tag", list(CFGS))
+def test_schedule_bit_identical_to_reference(golden, tag):
+    ms, T, sched, eps = CFGS[tag]
+    g = golden.schedule
+    sde = P.IRSDE(ms, T, sched, eps, device="cpu")
+    assert float(sde.dt) == float(g[tag + "/dt"])
+    for n in ("thetas", "sigmas", "thetas_cumsum", "sigma_bars"):
+        assert np.array_equal(getattr(sde, n).numpy(), g[tag + "/" + n]), n
+    c = sde._coef.numpy()
+    assert c.shape == (T + 1, 12)
+    assert np.array_equal(c[1:, 5], g[tag + "/x0_gain"][1:])
+    assert np.array_equal(c[1:, 6], g[tag + "/post_term1"][1:])
+    assert np.array_equal(c[1:, 7], g[tag + "/post_term2"][1:])
+    assert np.array_equal(c[1:, 8], g[tag + "/post_std"][1:])
+    assert np.array_equal(c[:, 0], g[tag + "/thetas"]) and np.array_equal(c[:, 2], g[tag + "/sigma_bars"])
+
+
+def test_irsde_surface_matches_reference_names():
+    sde = P.IRSDE(10, 100, "cosine", 0.005, device="cpu")
+    for name in ["set_mu", "set_model", "noise_state", "reverse_sde", "reverse_ode", "reverse_posterior",
+                 "generate_random_states", "noise_fn", "score_fn", "get_score_from_noise", "reverse_sde_step_mean",
+                 "reverse_optimum_step", "reverse_optimum_std", "weights", "mu_bar", "sigma_bar", "forward",
+                 "drift", "dispersion", "sde_reverse_drift", "ode_reverse_drift", "get_init_state_from_noise",
+                 "reverse_posterior_step", "get_real_noise", "get_real_score", "optimal_reverse"]:
+        assert callable(getattr(sde, name)), name
+    for attr in ["T", "dt", "max_sigma", "thetas", "sigmas", "thetas_cumsum", "sigma_bars", "mu", "model"]:
+        assert hasattr(sde, attr)
+    assert abs(sde.max_sigma - 10 / 255) < 1e-12
+    assert P.IRSDE(0.5, 10).max_sigma == 0.5  # sde_utils.py:86
+    with pytest.raises(ValueError):
+        P.IRSDE(10, 10, schedule="quadratic")
+
+
+def test_training_helpers_match_oracle_formulas(golden):
+    """The helper formulas reproduce the reference's single-step goldens (elementwise torch algebra)."""
+    g = golden.steps
+    sde = P.IRSDE(10, 100, "cosine", 0.005, device="cpu")
+    x, mu, eh = (torch.from_numpy(g["s10_T100/" + k]) for k in ("x", "mu", "eps_hat"))
+    sde.set_mu(mu)
+    for t in (1, 2, 50, 100):
+        score = sde.get_score_from_noise(eh, t)
+        np.testing.assert_allclose(sde.reverse_ode_step(x, score, t).numpy(), g["s10_T100/ode_t%d" % t], rtol=1e-6,
+                                   atol=1e-6)
+        x0 = sde.get_init_state_from_noise(x, eh, t)
+        mean = sde.reverse_optimum_step(x, x0, t)
+        z = torch.from_numpy(O.synth_noise(5, 100, x.shape)[t])
+        np.testing.assert_allclose((mean + sde.reverse_optimum_std(t) * z).numpy(), g["s10_T100/post_t%d" % t],
+                                   rtol=1e-6, atol=1e-6)
+
+
+def test_unet_state_dict_is_reference_compatible():
+    m = P.ConditionalUNet(in_nc=3, out_nc=3, nf=64, depth=4)
+    sd = m.state_dict()
+    shapes = O.unet_param_shapes(3, 3, 64, 4)
+    assert set(sd) == set(shapes) and len(sd) == 151
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    assert sum(v.numel() for v in sd.values()) == 137147523
+    # loads a reference-style checkpoint (with DataParallel "module." prefixes) through DenoisingModel's loader
+    params = O.synth_params(seed=0, nf=32, depth=2)
+    m2 = P.ConditionalUNet(3, 3, 32, depth=2)
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    assert np.array_equal(m2.state_dict()["ups.0.3.1.bias"].numpy(), params["ups.0.3.1.bias"])
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a GPU instead of computing on the CPU."""
+    m = P.ConditionalUNet(3, 3, 32, depth=2)
+    x = torch.zeros(1, 3, 16, 16)
+    with pytest.raises(P.IrsdeError):
+        m(x, x, 5)
+    sde = P.IRSDE(10, 10, "cosine", 0.005, device="cpu")
+    sde.set_model(m)
+    sde.set_mu(x)
+    for fn in (sde.reverse_sde, sde.reverse_ode, sde.reverse_posterior):
+        with pytest.raises(P.IrsdeError):
+            fn(x)
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from image_restoration_sde_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.IrsdeLibraryError):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under the product package may import or execute it."""
+    import os
+    import re
+    root = os.path.dirname(P.__file__)
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle[./]irsde_oracle|#include\s+\".*oracle", re.M)
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert not pat.search(open(os.path.join(dp, f)).read()), f
+
+
+def test_shard_bounds():
+    for n in (1, 7, 8, 16, 17):
+        for w in (1, 2, 4, 8):
+            cover = []
+            for r in range(w):
+                lo, hi = P.shard_bounds(n, w, r)
+                assert 0 <= lo <= hi <= n
+                cover += list(range(lo, hi))
+            assert cover == list(range(n))
+    assert P.shard_bounds(16, 8, 3) == (6, 8)
+    with pytest.raises(ValueError):
+        P.shard_bounds(4, 2, 2)
+
+
+def test_create_model_boundary_without_gpu():
+    opt = {"model": "denoising", "is_train": False, "gpu_ids": [0], "dist": False,
+           "network_G": {"which_model_G": "ConditionalUNet", "setting": {"in_nc": 3, "out_nc": 3, "nf": 32, "depth": 2}},
+           "path": {"pretrain_model_G": None, "strict_load": True}}
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    with pytest.raises(Exception):
+        P.create_model(opt)  # .to('cuda') fails loudly on a CPU-only box; no silent CPU model
+    assert P.define_G(opt).__class__.__name__ == "ConditionalUNet"

@@ -132,3 +132,34 @@ def test_philox_known_answer():
 def test_device_normal_moments():
     z = O.device_normal(1234, 7, 3, 3 * 64 * 64)
     assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+
+
+@pytest.mark.parametrize("tag", ["nf32d2_2x24x20", "nf64d4_2x40x56"])
+def test_torch_cpu_port_matches_reference(golden, tag):
+    """oracle/torch_cpu_port.py (the cpu_baseline 'port') reproduces the real reference's outputs."""
+    import torch
+    from oracle import torch_cpu_port as TP
+    g = golden.forward
+    nf, depth, B, H, W = (int(v) for v in g[tag + "/cfg"])
+    params = {k: torch.from_numpy(v) for k, v in O.synth_params(seed=0, nf=nf, depth=depth).items()}
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    for t in g[tag + "/ts"]:
+        with torch.no_grad():
+            y = TP.unet_forward(params, torch.from_numpy(xT), torch.from_numpy(lq), int(t), depth).numpy()
+        ref = g[tag + "/t%d" % t]
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def test_torch_cpu_port_sampler_steps(golden):
+    import torch
+    from oracle import torch_cpu_port as TP
+    g = golden.sampler
+    tag = "nf32d2_2x16x16_T20"
+    nf, depth, B, H, W, T = (int(v) for v in g[tag + "/cfg"])
+    params = {k: torch.from_numpy(v) for k, v in O.synth_params(seed=0, nf=nf, depth=depth).items()}
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    z = torch.from_numpy(O.synth_noise(7, T, (B, 3, H, W)))
+    sch = O.irsde_schedule(10, T, "cosine", 0.005)
+    y = TP.reverse_sde_steps(params, sch, torch.from_numpy(xT), torch.from_numpy(lq), z, T, T, depth).numpy()
+    ref = g[tag + "/sde"]
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-3
