@@ -748,6 +748,8 @@ void irsde_destroy(irsde_engine* e) {
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     for (float* p : e->dev_allocs) (void)hipFree(p);
+    if (e->coef_table) (void)hipFree(e->coef_table);
+    if (e->film_table) (void)hipFree(e->film_table);
     delete e;
 }
 
@@ -797,14 +799,28 @@ int irsde_set_schedule(irsde_engine* e, int T, const float* coef) {
         if (!e->finalized) throw HipError("set_schedule: weights not finalized");
         IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
         IRSDE_HIP_CHECK(hipDeviceSynchronize());
+        std::lock_guard<std::mutex> lk(e->mu);
+        // captured graphs bake the table pointers into their kernel nodes: drop them with the old tables
+        for (auto& pl : e->plans) {
+            if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
+            if (pl->graph) (void)hipGraphDestroy(pl->graph);
+            pl->graph_exec = nullptr;
+            pl->graph = nullptr;
+        }
+        if (e->coef_table) (void)hipFree(e->coef_table);
+        if (e->film_table) (void)hipFree(e->film_table);
+        e->coef_table = e->film_table = nullptr;
         e->T = T;
-        e->coef_table = e->dmalloc((size_t)(T + 1) * IRSDE_COEF_STRIDE);
+        IRSDE_HIP_CHECK(hipMalloc(&e->coef_table, (size_t)(T + 1) * IRSDE_COEF_STRIDE * 4));
         IRSDE_HIP_CHECK(hipMemcpy(e->coef_table, coef, (size_t)(T + 1) * IRSDE_COEF_STRIDE * 4, hipMemcpyHostToDevice));
-        e->film_table = e->dmalloc((size_t)(T + 1) * e->film_row);
+        IRSDE_HIP_CHECK(hipMalloc(&e->film_table, (size_t)(T + 1) * e->film_row * 4));
         std::vector<float> tv(T + 1);
         for (int t = 0; t <= T; ++t) tv[t] = (float)t;
-        float* dtv = e->upload(tv);
+        float* dtv = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&dtv, (T + 1) * sizeof(float)));
+        IRSDE_HIP_CHECK(hipMemcpy(dtv, tv.data(), (T + 1) * sizeof(float), hipMemcpyHostToDevice));
         compute_film_rows(e, dtv, T + 1, e->film_table, e->stream);
+        (void)hipFree(dtv);
     });
 }
 

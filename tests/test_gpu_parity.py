@@ -306,6 +306,20 @@ def test_partial_T_and_segments():
     assert np.array_equal(out.cpu().numpy(), full)
 
 
+def test_schedule_change_invalidates_captured_graphs():
+    """A graph captured under one schedule must not be replayed after IRSDE(T', ...) re-sets the tables."""
+    nf, depth, B, H, W = 32, 2, 1, 16, 16
+    m, _ = make_model(nf, depth)
+    lq, xT = O.synth_inputs(5, B, H, W)
+    outs = {}
+    for T in (8, 5, 8):
+        z = O.synth_noise(7, 8, (B, 3, H, W))
+        outs.setdefault(T, []).append(_sample(m, "posterior", T, lq, xT, z, True))
+    assert np.array_equal(outs[8][0], outs[8][1])
+    eager = _sample(m, "posterior", 5, lq, xT, O.synth_noise(7, 8, (B, 3, H, W)), False)
+    assert np.array_equal(outs[5][0], eager)
+
+
 def test_foreign_model_path_matches_engine_path():
     """A score model that is NOT our ConditionalUNet is called per step like the reference does, with
     the fused HIP update kernel in between; with our UNet wrapped as an opaque callable both paths agree."""
