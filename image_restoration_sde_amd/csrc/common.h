@@ -56,7 +56,9 @@ struct ConvParams {
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)
 void launch_conv(const ConvParams& p, hipStream_t s);
-void conv_global_init();  // sets the dynamic-LDS attribute of every tile configuration (call before graph capture)
+void conv_global_init();
+void conv_set_variant(int v);  // tuning experiments (irsde_bench_conv)
+void launch_fill_random(float* p, size_t n, unsigned seed, float scale, hipStream_t s);  // sets the dynamic-LDS attribute of every tile configuration (call before graph capture)
 // naive direct convolution on VALU (one thread per output) — debug / cross-check path only
 void launch_conv_naive(const ConvParams& p, hipStream_t s);
 

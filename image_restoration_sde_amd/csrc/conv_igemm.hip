@@ -13,9 +13,14 @@
 // k with one ds_read_b128 and feeds 4 MFMAs; lane half h owns k = 8*sb + 4*h + {0..3}, the same
 // assignment for A and B, so the k-order inside the MFMA chain is a permutation (legal: sum over k).
 //
-// Block = 256 threads = 4 waves (one per SIMD), 2 blocks per CU; global->register->LDS staging is
-// split (loads for K-step t+1 are issued before the MFMAs of step t, written to the other LDS
-// buffer after them), one barrier per K-step of 32 channels (64 MFMAs = 4096 cycles per wave).
+// K loop: taps outer / 32-channel chunks inner.  The per-row pixel offset of a tap is computed once
+// per tap (not per K-step); a K-step then costs one 64-bit mad + one load per staged row.
+// global->register->LDS staging is split: the loads of K-step t+1 are issued before the MFMAs of
+// step t and written to the other LDS buffer after them; one barrier per K-step.
+//
+// Epilogue: the accumulator tile is transposed through LDS (the A/B buffers are dead by then) so
+// that every lane handles 4 consecutive output channels: bias / FiLM / residual / output move as
+// 16-byte accesses, 512 contiguous bytes per output pixel row of a 128-wide tile.
 #include "common.h"
 
 namespace irsde {
@@ -24,27 +29,29 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int kThreads = 256;
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
 struct Cfg {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    static constexpr int NT = 64 * WAVES_M * WAVES_N;
     static constexpr int LDS_K = BK + 4;
     static constexpr int TM = BM / WAVES_M / 32;
     static constexpr int TN = BN / WAVES_N / 32;
     static constexpr int CHUNKS = BK / 4;
-    static constexpr int ROWS = kThreads / CHUNKS;
+    static constexpr int ROWS = NT / CHUNKS;
     static constexpr int A_PASSES = BM / ROWS;
-    static constexpr int B_PASSES = BN / ROWS;
-    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_K * 4;
-    static_assert(BM % ROWS == 0 && BN % ROWS == 0, "tile/pass mismatch");
+    static constexpr int B_PASSES = (BN + ROWS - 1) / ROWS;
+    static constexpr int LDS_C = BN + 4;  // epilogue tile row stride (floats): 16-B aligned, odd number of slots
+    static constexpr int MAIN_BYTES = 2 * (BM + BN) * LDS_K * 4;
+    static constexpr int EPI_BYTES = BM * LDS_C * 4;
+    static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+    static_assert(BM % ROWS == 0, "tile/pass mismatch");
+    static_assert(BN % ROWS == 0 || BN < ROWS, "tile/pass mismatch");
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvParams p, const int nblk_n,
-                                                                  const int M, const int nk_total) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void conv_igemm_kernel(
+    const ConvParams p, const int nblk_n, const int M, const int nk_total) {
     using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -87,17 +94,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvParam
     const int chunk = tid % C::CHUNKS;
     const int row0 = tid / C::CHUNKS;
     int a_iy0[C::A_PASSES], a_ix0[C::A_PASSES], a_pix[C::A_PASSES];
-    bool a_ok[C::A_PASSES];
 #pragma unroll
     for (int ps = 0; ps < C::A_PASSES; ++ps) {
         const int m = m0 + row0 + ps * C::ROWS;
-        a_ok[ps] = m < M;
-        const int mm = a_ok[ps] ? m : 0;
+        const bool ok = m < M;
+        const int mm = ok ? m : 0;
         const int ox = mm % p.Wo;
         const int t1 = mm / p.Wo;
         const int oy = t1 % p.Ho;
         const int b = t1 / p.Ho;
-        a_iy0[ps] = oy * p.stride - p.pad_y;
+        // rows beyond M get an iy far outside the image: every tap is then "out of range" => zeros
+        a_iy0[ps] = ok ? oy * p.stride - p.pad_y : -(1 << 28);
         a_ix0[ps] = ox * p.stride - p.pad_x;
         a_pix[ps] = b * p.Hin * p.Win;
     }
@@ -105,18 +112,42 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvParam
     bool b_ok[C::B_PASSES];
 #pragma unroll
     for (int ps = 0; ps < C::B_PASSES; ++ps) {
-        const int n = n0 + row0 + ps * C::ROWS;
-        b_ok[ps] = n < p.Cout;
+        const int r = row0 + ps * C::ROWS;
+        const int n = n0 + r;
+        b_ok[ps] = n < p.Cout && r < BN;
         wrow[ps] = p.w + (size_t)(b_ok[ps] ? n : 0) * taps * Ctot + chunk * 4;
     }
 
-    float4 ra[C::A_PASSES], rb[C::B_PASSES];
+    // ---- K-loop state: (tap, channel offset); per-tap pixel offsets of the staged rows ----
+    int tap = kt_begin / steps_per_tap;
+    int cc = (kt_begin - tap * steps_per_tap) * BK;
+    int ky = tap / p.KW;
+    int kx = tap - ky * p.KW;
+    int a_poff[C::A_PASSES];  // pixel index into the source tensors for the current tap, or -1
+    auto set_tap = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < C::A_PASSES; ++ps) {
+            const int iy = a_iy0[ps] + ky;
+            const int ix = a_ix0[ps] + kx;
+            const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+            a_poff[ps] = ok ? a_pix[ps] + (iy >> p.in_shift) * p.Win + (ix >> p.in_shift) : -1;
+        }
+    };
+    auto advance = [&]() {
+        cc += BK;
+        if (cc >= Ctot) {
+            cc = 0;
+            ++tap;
+            if (++kx == p.KW) {
+                kx = 0;
+                ++ky;
+            }
+            set_tap();
+        }
+    };
 
-    auto load_tiles = [&](int kt) {
-        const int tap = kt / steps_per_tap;
-        const int cc = (kt - tap * steps_per_tap) * BK;
-        const int ky = tap / p.KW;
-        const int kx = tap - ky * p.KW;
+    float4 ra[C::A_PASSES], rb[C::B_PASSES];
+    auto load_tiles = [&]() {
         const float* src;
         int c, pix;
         if (cc < p.C0) {
@@ -124,21 +155,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvParam
         } else {
             src = p.in1; c = cc - p.C0; pix = p.pix1;
         }
+        src += c + chunk * 4;
 #pragma unroll
         for (int ps = 0; ps < C::A_PASSES; ++ps) {
-            const int iy = a_iy0[ps] + ky;
-            const int ix = a_ix0[ps] + kx;
-            const bool ok = a_ok[ps] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-            const int py = iy >> p.in_shift, px = ix >> p.in_shift;
-            // branch-free predication: out-of-image taps read a safe address and are zeroed
-            const size_t off = ok ? (size_t)(a_pix[ps] + py * p.Win + px) * pix + c + chunk * 4 : (size_t)0;
-            const float4 v = *reinterpret_cast<const float4*>(src + off);
+            const bool ok = a_poff[ps] >= 0;
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(ok ? a_poff[ps] : 0) * pix);
             ra[ps] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const size_t wk = (size_t)tap * Ctot + cc;
 #pragma unroll
         for (int ps = 0; ps < C::B_PASSES; ++ps) {
-            const float4 v = *reinterpret_cast<const float4*>(wrow[ps] + wk);  // row clamped to 0 if n >= Cout
+            const float4 v = *reinterpret_cast<const float4*>(wrow[ps] + wk);
             rb[ps] = b_ok[ps] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -150,7 +177,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvParam
             *reinterpret_cast<float4*>(a + (row0 + ps * C::ROWS) * C::LDS_K + chunk * 4) = ra[ps];
 #pragma unroll
         for (int ps = 0; ps < C::B_PASSES; ++ps)
-            *reinterpret_cast<float4*>(b + (row0 + ps * C::ROWS) * C::LDS_K + chunk * 4) = rb[ps];
+            if (C::B_PASSES * C::ROWS == BN || row0 + ps * C::ROWS < BN)
+                *reinterpret_cast<float4*>(b + (row0 + ps * C::ROWS) * C::LDS_K + chunk * 4) = rb[ps];
     };
 
     floatx16 acc[C::TM][C::TN];
@@ -162,7 +190,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvParam
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (kt_begin < kt_end) {
-        load_tiles(kt_begin);
+        set_tap();
+        load_tiles();
         store_tiles(0);
     }
     __syncthreads();
@@ -170,8 +199,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvParam
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int buf = (kt - kt_begin) & 1;
         const bool more = kt + 1 < kt_end;
-        if (more) load_tiles(kt + 1);  // HBM/L2 latency hides under this step's MFMAs
-
+        if (more) {
+            advance();
+            load_tiles();  // HBM/L2 latency hides under this step's MFMAs
+        }
         const float* a = As + buf * BM * C::LDS_K + (wm * C::TM * 32 + l31) * C::LDS_K + h * 4;
         const float* b = Bs + buf * BN * C::LDS_K + (wn * C::TN * 32 + l31) * C::LDS_K + h * 4;
 #pragma unroll
@@ -197,45 +228,90 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvParam
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    const int HW = p.Ho * p.Wo;
+    // ---- epilogue: transpose the accumulators through LDS (A/B buffers are dead after the last barrier) ----
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cs = smem;
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j) {
-        const int n = n0 + wn * C::TN * 32 + j * 32 + l31;
-        const bool n_ok = n < p.Cout;
-        float bias = 0.f, sc = 0.f, sh = 0.f;
-        if (p.splits == 1 && n_ok) {
-            if (p.bias) bias = p.bias[n];
-            if (p.film && p.film_bstride == 0) {
-                sc = p.film[n] + 1.0f;
-                sh = p.film[p.Cout + n];
-            }
-        }
+    for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-        for (int i = 0; i < C::TM; ++i) {
+        for (int j = 0; j < C::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int m = m0 + row;
-                if (m < M && n_ok) {
-                    float v = acc[i][j][r];
-                    if (p.splits > 1) {
-                        p.partial[((size_t)split * M + m) * p.Cout + n] = v;
-                    } else {
-                        v += bias;
-                        if (p.film) {
-                            if (p.film_bstride != 0) {
-                                const float* f = p.film + (size_t)(m / HW) * p.film_bstride;
-                                sc = f[n] + 1.0f;
-                                sh = f[p.Cout + n];
-                            }
-                            v = v * sc + sh;
-                        }
-                        if (p.silu) v = silu_f(v);
-                        if (p.res) v += p.res[(size_t)m * p.res_stride + n];
-                        p.out[(size_t)m * p.out_stride + n] = v;
+                Cs[row * C::LDS_C + wn * C::TN * 32 + j * 32 + l31] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    constexpr int NV = BN / 4;         // float4 columns of the tile
+    constexpr int RSTEP = C::NT / NV;  // rows covered per sweep
+    const int c4 = tid % NV;
+    const int n = n0 + c4 * 4;
+    const int HW = p.Ho * p.Wo;
+    const bool vec_ok = (n + 3 < p.Cout) && ((p.out_stride & 3) == 0);
+    if (n < p.Cout) {
+        float bias[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.splits == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.Cout) {
+                    if (p.bias) bias[e] = p.bias[n + e];
+                    if (p.film && p.film_bstride == 0) {
+                        sc[e] = p.film[n + e] + 1.0f;
+                        sh[e] = p.film[p.Cout + n + e];
                     }
                 }
+        }
+        for (int row = tid / NV; row < BM; row += RSTEP) {
+            const int m = m0 + row;
+            if (m >= M) break;
+            const float4 cv = *reinterpret_cast<const float4*>(Cs + row * C::LDS_C + c4 * 4);
+            float v[4] = {cv.x, cv.y, cv.z, cv.w};
+            if (p.splits > 1) {
+                float* dst = p.partial + ((size_t)split * M + m) * p.Cout + n;
+                if (n + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    *reinterpret_cast<float4*>(dst) = cv;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Cout) dst[e] = v[e];
+                }
+                continue;
+            }
+            if (p.film && p.film_bstride != 0) {
+                const float* f = p.film + (size_t)(m / HW) * p.film_bstride;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.Cout) {
+                        sc[e] = f[n + e] + 1.0f;
+                        sh[e] = f[p.Cout + n + e];
+                    }
+            }
+            float rr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.res) {
+                const float* rp = p.res + (size_t)m * p.res_stride + n;
+                if (n + 3 < p.Cout && (p.res_stride & 3) == 0) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(rp);
+                    rr[0] = t4.x; rr[1] = t4.y; rr[2] = t4.z; rr[3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Cout) rr[e] = rp[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e] + bias[e];
+                if (p.film) t = t * sc[e] + sh[e];
+                if (p.silu) t = silu_f(t);
+                v[e] = t + rr[e];
+            }
+            float* dst = p.out + (size_t)m * p.out_stride + n;
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.Cout) dst[e] = v[e];
             }
         }
     }
@@ -294,37 +370,40 @@ __global__ void conv_naive_kernel(const ConvParams p, const int M) {
     p.out[(size_t)m * p.out_stride + n] = v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
-void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MINW>
+void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds_override = 0) {
     using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK>;
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK>;
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK, MINW>;
     const int nblk_m = (M + BM - 1) / BM;
     const int nblk_n = (p.Cout + BN - 1) / BN;
     dim3 grid(nblk_m * nblk_n, p.splits, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(kThreads), C::LDS_BYTES, s, p, nblk_n, M, nk_total);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds_override ? lds_override : C::LDS_BYTES, s, p, nblk_n, M, nk_total);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MINW>
 void init_cfg() {
-    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK>;
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK, MINW>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
+
+int g_variant = 0;  // tuning experiments only (irsde_bench_conv)
 
 }  // namespace
 
+void conv_set_variant(int v) { g_variant = v; }
+
 void conv_global_init() {
-    init_cfg<128, 128, 2, 2, 32>();
-    init_cfg<128, 64, 2, 2, 32>();
-    init_cfg<128, 32, 4, 1, 32>();
+    init_cfg<128, 128, 2, 2, 32, 2>();
+    init_cfg<128, 64, 2, 2, 32, 2>();
+    init_cfg<128, 32, 4, 1, 32, 2>();
+    init_cfg<256, 128, 4, 2, 32, 2>();
 }
 
 double conv_flops(const ConvParams& p) {
     return 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout * (double)(p.KH * p.KW) * (double)(p.C0 + p.C1);
 }
-
-int conv_tile_n(int Cout) { return Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32); }
 
 void launch_conv(const ConvParams& p, hipStream_t s) {
     const int M = p.B * p.Ho * p.Wo;
@@ -334,12 +413,18 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
                        std::to_string(p.C1) + ")");
     if (p.splits > 1 && !p.partial) throw HipError("launch_conv: split-K needs a partial buffer");
     const int nk_total = p.KH * p.KW * (Ctot / 32);
-    if (p.Cout >= 128)
-        launch_cfg<128, 128, 2, 2, 32>(p, M, nk_total, s);
-    else if (p.Cout > 32)
-        launch_cfg<128, 64, 2, 2, 32>(p, M, nk_total, s);
-    else
-        launch_cfg<128, 32, 4, 1, 32>(p, M, nk_total, s);
+    if (p.Cout >= 128) {
+        if (g_variant == 3)
+            launch_cfg<256, 128, 4, 2, 32, 2>(p, M, nk_total, s);
+        else if (g_variant == 5)
+            launch_cfg<128, 128, 2, 2, 32, 2>(p, M, nk_total, s, 120 * 1024);  // diagnostic: force 1 block/CU
+        else
+            launch_cfg<128, 128, 2, 2, 32, 2>(p, M, nk_total, s);
+    } else if (p.Cout > 32) {
+        launch_cfg<128, 64, 2, 2, 32, 2>(p, M, nk_total, s);
+    } else {
+        launch_cfg<128, 32, 4, 1, 32, 2>(p, M, nk_total, s);
+    }
     if (p.splits > 1) {
         const size_t total = (size_t)M * p.Cout;
         hipLaunchKernelGGL(conv_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, M);

@@ -58,6 +58,7 @@ struct Op {
     std::function<void(hipStream_t)> fn;
     OpKind kind;
     double flops = 0, bytes = 0;
+    std::string desc;
 };
 
 struct Tensor {
@@ -445,6 +446,12 @@ struct Builder {
         op.bytes = in_bytes + 4.0 * (double)M * p.Cout + 4.0 * (double)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
         pl->conv_flops += op.flops;
         pl->conv_bytes += op.bytes;
+        {
+            char buf[256];
+            snprintf(buf, sizeof buf, "conv M=%d Cout=%d Cin=%d k=%dx%d s=%d up=%d splits=%d blocks=%d flops=%.4g", M, p.Cout,
+                     p.C0 + p.C1, p.KH, p.KW, p.stride, p.in_shift, splits, blocks, op.flops);
+            op.desc = buf;
+        }
         const bool nv = naive;
         op.fn = [p, nv](hipStream_t s) {
             if (nv)
@@ -538,6 +545,7 @@ struct Builder {
     void push_other(OpKind k, std::function<void(hipStream_t)> fn) {
         Op op;
         op.kind = k;
+        op.desc = k == OP_LN ? "layernorm" : (k == OP_ATTN ? "linear_attention" : "other");
         op.fn = std::move(fn);
         pl->net_ops.push_back(std::move(op));
     }
@@ -1008,6 +1016,20 @@ int irsde_debug_tap(irsde_engine* e, const char* name, float* dst, int64_t dims[
     });
 }
 
+int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buflen) {
+    return guard([&] {
+        if (!e || !buf || buflen < 1) throw HipError("null argument");
+        if (!e->finalized) throw HipError("plan_describe: weights not finalized");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        Plan* pl = get_plan(e, B, H, W, false);
+        std::string out;
+        for (auto& op : pl->net_ops) out += op.desc + "\n";
+        strncpy(buf, out.c_str(), buflen - 1);
+        buf[buflen - 1] = 0;
+    });
+}
+
 int irsde_work_model(irsde_engine* e, int B, int H, int W, double out[2]) {
     return guard([&] {
         if (!e || !out) throw HipError("null argument");
@@ -1064,6 +1086,53 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
         (void)hipFree(dw);
         if (db) (void)hipFree(db);
         if (dp) (void)hipFree(dp);
+    });
+}
+
+int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
+                     double* ms_out) {
+    return guard([&] {
+        if (!ms_out || iters < 1) throw HipError("bad argument");
+        conv_global_init();
+        hipStream_t s = nullptr;
+        IRSDE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        ConvParams p;
+        const int pad = K / 2 - (stride == 2 ? 1 : 0) + (K == 4 ? 0 : 0);
+        p.B = B; p.Hin = H; p.Win = W; p.in_shift = up; p.C0 = Cin; p.pix0 = Cin;
+        p.Cout = Cout; p.KH = K; p.KW = K; p.stride = stride; p.pad_y = p.pad_x = (K == 4 ? 1 : K / 2);
+        (void)pad;
+        p.Ho = ((H << up) + 2 * p.pad_y - K) / stride + 1;
+        p.Wo = ((W << up) + 2 * p.pad_x - K) / stride + 1;
+        const size_t nin = (size_t)B * H * W * Cin, nw = (size_t)Cout * K * K * Cin, nout = (size_t)B * p.Ho * p.Wo * Cout;
+        float *din = nullptr, *dw = nullptr, *dout = nullptr, *dres = nullptr, *dfilm = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&din, nin * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dw, nw * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dout, nout * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dres, nout * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dfilm, (size_t)2 * Cout * 4));
+        launch_fill_random(din, nin, 1, 1.0f, s);
+        launch_fill_random(dw, nw, 2, 1.0f / sqrtf((float)(K * K * Cin)), s);
+        launch_fill_random(dres, nout, 3, 1.0f, s);
+        launch_fill_random(dfilm, (size_t)2 * Cout, 4, 0.3f, s);
+        p.in0 = din; p.w = dw; p.out = dout; p.out_stride = Cout;
+        if (epi == 1) { p.film = dfilm; p.silu = 1; }
+        if (epi == 2) { p.silu = 1; p.res = dres; p.res_stride = Cout; }
+        conv_set_variant(variant);
+        hipEvent_t e0, e1;
+        IRSDE_HIP_CHECK(hipEventCreate(&e0));
+        IRSDE_HIP_CHECK(hipEventCreate(&e1));
+        for (int i = 0; i < 2; ++i) launch_conv(p, s);
+        IRSDE_HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) launch_conv(p, s);
+        IRSDE_HIP_CHECK(hipEventRecord(e1, s));
+        IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0;
+        IRSDE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        conv_set_variant(0);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
+        (void)hipStreamDestroy(s);
     });
 }
 

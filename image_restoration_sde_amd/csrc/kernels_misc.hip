@@ -443,6 +443,15 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restr
     out[idx] = in[(((size_t)b * H + y) * W + x) * C + c];
 }
 
+__global__ void fill_random_kernel(float* p, const size_t n, const unsigned seed, const float scale) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    float z[4];
+    philox_normal4((uint32_t)q, (uint32_t)(q >> 32), seed, 0x5EEDULL, z);
+    for (int k = 0; k < 4; ++k)
+        if (q * 4 + k < n) p[q * 4 + k] = z[k] * scale;
+}
+
 __global__ void philox_normal_kernel(float* out, const int CHW, const int t, const uint64_t seed,
                                      const uint64_t image_offset) {
     const int b = blockIdx.y;
@@ -558,6 +567,12 @@ void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W
     const size_t total = (size_t)B * C * H * W;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, B, C, H,
                        W);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_fill_random(float* p, size_t n, unsigned seed, float scale, hipStream_t s) {
+    const size_t quads = (n + 3) / 4;
+    hipLaunchKernelGGL(fill_random_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, p, n, seed, scale);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

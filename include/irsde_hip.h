@@ -135,6 +135,9 @@ int irsde_debug_tap(irsde_engine* e, const char* name, float* dst, int64_t dims[
  * conv bytes (inputs + outputs + weights once). */
 int irsde_work_model(irsde_engine* e, int B, int H, int W, double out[2]);
 
+/* Text description (one line per launch group) of the network-evaluation plan at (B,H,W): debugging/analysis. */
+int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buflen);
+
 /* Kernel-level test hook: one implicit-GEMM convolution (csrc/conv_igemm.hip) on NHWC device tensors.
  * in0/in1: [B][Hin][Win][C0|C1] (channel concat, in1 may be NULL); w_oihw/bias: HOST, reference layout;
  * film: device [rows][2*Cout] or NULL; res/out: device [B][Ho][Wo][Cout].  naive != 0 runs the VALU
@@ -143,6 +146,11 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
                      const float* w_oihw, int Cout, int KH, int KW, int stride, int pad, const float* bias,
                      const float* film, int film_bstride, int silu, const float* res, float* out, int naive,
                      int splits, void* stream);
+
+/* Kernel tuning hook: average ms of one KxK convolution (pad K/2, or 4x4 s2 p1) on random NHWC data.
+ * variant selects an experimental tile configuration (0 = production); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
+int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
+                     double* ms_out);
 
 #ifdef __cplusplus
 }
