@@ -146,39 +146,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         }
     };
 
-    float4 ra[C::A_PASSES], rb[C::B_PASSES];
-    auto load_tiles = [&]() {
+    // ---- staging pieces: A rows (A_PASSES) then B rows (B_PASSES), one 16-byte load/store each ----
+    constexpr int NP = C::A_PASSES + C::B_PASSES;
+    float4 rs[NP];
+    const float* cur_src = nullptr;  // source pointer (+channel +chunk) of the K-step being staged
+    int cur_pix = 0;
+    size_t cur_wk = 0;
+    auto stage_setup = [&]() {
         const float* src;
-        int c, pix;
+        int c;
         if (cc < p.C0) {
-            src = p.in0; c = cc; pix = p.pix0;
+            src = p.in0; c = cc; cur_pix = p.pix0;
         } else {
-            src = p.in1; c = cc - p.C0; pix = p.pix1;
+            src = p.in1; c = cc - p.C0; cur_pix = p.pix1;
         }
-        src += c + chunk * 4;
-#pragma unroll
-        for (int ps = 0; ps < C::A_PASSES; ++ps) {
-            const bool ok = a_poff[ps] >= 0;
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(ok ? a_poff[ps] : 0) * pix);
-            ra[ps] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const size_t wk = (size_t)tap * Ctot + cc;
-#pragma unroll
-        for (int ps = 0; ps < C::B_PASSES; ++ps) {
-            const float4 v = *reinterpret_cast<const float4*>(wrow[ps] + wk);
-            rb[ps] = b_ok[ps] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        cur_src = src + c + chunk * 4;
+        cur_wk = (size_t)tap * Ctot + cc;
+    };
+    auto load_piece = [&](int q) {
+        if (q < C::A_PASSES) {
+            const bool ok = a_poff[q] >= 0;  // branch-free: out-of-image taps read pixel 0 and are zeroed
+            const float4 v = *reinterpret_cast<const float4*>(cur_src + (size_t)(ok ? a_poff[q] : 0) * cur_pix);
+            rs[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const int ps = q - C::A_PASSES;
+            const float4 v = *reinterpret_cast<const float4*>(wrow[ps] + cur_wk);
+            rs[q] = b_ok[ps] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_tiles = [&](int buf) {
-        float* a = As + buf * BM * C::LDS_K;
-        float* b = Bs + buf * BN * C::LDS_K;
-#pragma unroll
-        for (int ps = 0; ps < C::A_PASSES; ++ps)
-            *reinterpret_cast<float4*>(a + (row0 + ps * C::ROWS) * C::LDS_K + chunk * 4) = ra[ps];
-#pragma unroll
-        for (int ps = 0; ps < C::B_PASSES; ++ps)
+    auto store_piece = [&](int q, int buf) {
+        if (q < C::A_PASSES) {
+            *reinterpret_cast<float4*>(As + buf * BM * C::LDS_K + (row0 + q * C::ROWS) * C::LDS_K + chunk * 4) = rs[q];
+        } else {
+            const int ps = q - C::A_PASSES;
             if (C::B_PASSES * C::ROWS == BN || row0 + ps * C::ROWS < BN)
-                *reinterpret_cast<float4*>(b + (row0 + ps * C::ROWS) * C::LDS_K + chunk * 4) = rb[ps];
+                *reinterpret_cast<float4*>(Bs + buf * BN * C::LDS_K + (row0 + ps * C::ROWS) * C::LDS_K + chunk * 4) =
+                    rs[q];
+        }
     };
 
     floatx16 acc[C::TM][C::TN];
@@ -191,40 +195,67 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
 
     if (kt_begin < kt_end) {
         set_tap();
-        load_tiles();
-        store_tiles(0);
+        stage_setup();
+#pragma unroll
+        for (int q = 0; q < NP; ++q) load_piece(q);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) store_piece(q, 0);
     }
     __syncthreads();
 
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < kt_end;
-        if (more) {
-            advance();
-            load_tiles();  // HBM/L2 latency hides under this step's MFMAs
-        }
+    // One K-step = NG groups of 4 chained MFMAs (one accumulator tile x 8 k).  All LDS fragments of the
+    // step are read up front into distinct registers (no LDS wait inside the MFMA stream); the staging
+    // of the next K-step rides in the MFMA shadows: one global load per group in the first half of the
+    // step, one LDS write per group in the second half (counted vmcnt waits), order pinned with
+    // sched_barrier so the compiler cannot re-serialise it.  Only lgkmcnt(0)+barrier remain at the end.
+    constexpr int NSB = BK / 8;
+    constexpr int NG = C::TM * C::TN * NSB;
+    constexpr int HALF = NG / 2;
+    constexpr int PPG = (NP + HALF - 1) / HALF;  // staging pieces per group
+    static_assert(NG >= 2 && NG % 2 == 0, "group count");
+
+    auto k_step = [&](const int buf, const bool more) {
+        float4 fa[NSB][C::TM], fb[NSB][C::TN];
         const float* a = As + buf * BM * C::LDS_K + (wm * C::TM * 32 + l31) * C::LDS_K + h * 4;
         const float* b = Bs + buf * BN * C::LDS_K + (wn * C::TN * 32 + l31) * C::LDS_K + h * 4;
 #pragma unroll
-        for (int sb = 0; sb < BK / 8; ++sb) {
-            float4 fa[C::TM], fb[C::TN];
+        for (int sb = 0; sb < NSB; ++sb) {
 #pragma unroll
             for (int i = 0; i < C::TM; ++i)
-                fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * C::LDS_K + sb * 8);
+                fa[sb][i] = *reinterpret_cast<const float4*>(a + i * 32 * C::LDS_K + sb * 8);
 #pragma unroll
             for (int j = 0; j < C::TN; ++j)
-                fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * C::LDS_K + sb * 8);
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
+                fb[sb][j] = *reinterpret_cast<const float4*>(b + j * 32 * C::LDS_K + sb * 8);
         }
-        if (more) store_tiles(buf ^ 1);
+        if (more) {
+            advance();
+            stage_setup();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int sb = g / (C::TM * C::TN);
+            const int i = (g % (C::TM * C::TN)) / C::TN;
+            const int j = g % C::TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].x, fb[sb][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].y, fb[sb][j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].z, fb[sb][j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].w, fb[sb][j].w, acc[i][j], 0, 0, 0);
+            if (more) {
+                if (g < HALF) {
+#pragma unroll
+                    for (int q = g * PPG; q < (g + 1) * PPG && q < NP; ++q) load_piece(q);
+                } else {
+#pragma unroll
+                    for (int q = (g - HALF) * PPG; q < (g - HALF + 1) * PPG && q < NP; ++q) store_piece(q, buf ^ 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        k_step((kt - kt_begin) & 1, kt + 1 < kt_end);
         __syncthreads();
     }
 
