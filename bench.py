@@ -24,13 +24,25 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 matrix = vector peak (guides/MI355X_MIC
 PEAK_HBM_GBPS = 8000.0
 
 
+def host_cores():
+    """CPU cores this process may actually use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(size, T, budget_s=20.0):
     """Reference CPU path (torch CPU ops, oracle/torch_cpu_port.py) on a bounded sample: B=1 image of
     size x size, as many reverse_sde steps as fit in ~budget_s (min 2, max 10), extrapolated to T steps."""
     import torch
     from oracle import irsde_oracle as O
     from oracle import torch_cpu_port as TP
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     params = {k: torch.from_numpy(v) for k, v in O.synth_params(seed=0, nf=64, depth=4).items()}
     lq, xT = O.synth_inputs(1234, 1, size, size)
@@ -45,7 +57,8 @@ def cpu_baseline(size, T, budget_s=20.0):
     per_step = (time.time() - t0) / n
     return {"value": 1.0 / (per_step * T), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "B=1 %dx%d, %d of T=%d reverse_sde steps timed (%.2f s/step), extrapolated x%d; torch %s CPU, "
-                      "%d threads" % (size, size, n, T, per_step, T, torch.__version__, cores)}
+                      "%d threads (affinity/cgroup quota; host has %d logical CPUs)" % (size, size, n, T, per_step, T,
+                                                                                       torch.__version__, cores, os.cpu_count() or 0)}
 
 
 def main():

@@ -52,6 +52,7 @@ struct ConvParams {
     // epilogue runs in conv_splitk_reduce.
     int splits = 1;
     float* partial = nullptr;
+    const float* zeros = nullptr;  // >= 16 zero bytes (source of out-of-image taps for LDS-DMA staging)
 };
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)

@@ -29,10 +29,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int DMA = 0>
 struct Cfg {
     static constexpr int NT = 64 * WAVES_M * WAVES_N;
-    static constexpr int LDS_K = BK + 4;
+    // register staging: rows padded by 16 B (conflict-free b128 reads); LDS-DMA staging: dense 128-B rows,
+    // 16-B chunks XOR-swizzled by ((row >> 1) & 7) on the SOURCE side (the DMA destination is lane-linear)
+    static constexpr int LDS_K = DMA ? BK : BK + 4;
     static constexpr int TM = BM / WAVES_M / 32;
     static constexpr int TN = BN / WAVES_N / 32;
     static constexpr int CHUNKS = BK / 4;
@@ -49,10 +51,14 @@ struct Cfg {
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MIN_WAVES_PER_SIMD>
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MIN_WAVES_PER_SIMD, int SCHED = 0, int DMA = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void conv_igemm_kernel(
     const ConvParams p, const int nblk_n, const int M, const int nk_total) {
-    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK>;
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK, DMA>;
+    static_assert(!DMA || BK == 32, "LDS-DMA staging assumes 128-byte rows");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * BM * C::LDS_K;
@@ -64,6 +70,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     const int wn = wave % WAVES_N;
     const int l31 = lane & 31;
     const int h = lane >> 5;
+
+    // Two blocks share a CU (one wave of each per SIMD).  Running identical code they phase-lock: they
+    // share the MFMA pipe evenly, so both leave the MFMA phase together and both sit in the staging /
+    // barrier gap together, idling the pipe (measured: 18 % idle).  Breaking the symmetry with a static
+    // priority by hardware wave slot (HW_REG_HW_ID.WAVE_ID parity: co-resident waves of one SIMD hold
+    // different slots) lets one block run its MFMA phase at full rate while the other fills its gaps.
+    if (SCHED & 2) {
+        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID[3:0] = wave slot
+        if (hwid & 1) __builtin_amdgcn_s_setprio(2);
+    }
+    if (SCHED & 8 && !(SCHED & 4)) {  // experiment: initial half-period phase offset for odd wave slots
+        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        if (hwid & 1)
+            for (int i = 0; i < 40; ++i) __builtin_amdgcn_s_sleep(1);
+    }
 
     // XCD-aware block remap (bijective): each XCD (block id % 8) walks a contiguous range of tiles so
     // that neighbouring tiles (same activation rows, other Cout slices / halo rows) share one L2.
@@ -93,6 +114,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     // ---- per-thread staging coordinates (fixed for the whole K loop) ----
     const int chunk = tid % C::CHUNKS;
     const int row0 = tid / C::CHUNKS;
+    // logical 16-B chunk of the K slice this lane fetches (DMA: inverse of the read-side swizzle)
+    const int cchunk = DMA ? (chunk ^ ((row0 >> 1) & 7)) : chunk;
     int a_iy0[C::A_PASSES], a_ix0[C::A_PASSES], a_pix[C::A_PASSES];
 #pragma unroll
     for (int ps = 0; ps < C::A_PASSES; ++ps) {
@@ -115,7 +138,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         const int r = row0 + ps * C::ROWS;
         const int n = n0 + r;
         b_ok[ps] = n < p.Cout && r < BN;
-        wrow[ps] = p.w + (size_t)(b_ok[ps] ? n : 0) * taps * Ctot + chunk * 4;
+        wrow[ps] = p.w + (size_t)(b_ok[ps] ? n : 0) * taps * Ctot + cchunk * 4;
     }
 
     // ---- K-loop state: (tap, channel offset); per-tap pixel offsets of the staged rows ----
@@ -160,8 +183,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         } else {
             src = p.in1; c = cc - p.C0; cur_pix = p.pix1;
         }
-        cur_src = src + c + chunk * 4;
+        cur_src = src + c + cchunk * 4;
         cur_wk = (size_t)tap * Ctot + cc;
+    };
+    // LDS-DMA: one global_load_lds_dwordx4 per piece writes 64 lanes x 16 B = 8 rows x 128 B straight into the
+    // LDS tile (destination = wave-uniform base + lane*16); out-of-image taps / rows read a zero page.
+    auto dma_piece = [&](int q, int buf) {
+        if (q < C::A_PASSES) {
+            const bool ok = a_poff[q] >= 0;
+            const float* g = ok ? cur_src + (size_t)a_poff[q] * cur_pix : p.zeros;
+            float* dst = As + buf * BM * C::LDS_K + (q * C::ROWS + wave * (64 / C::CHUNKS)) * C::LDS_K;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
+        } else {
+            const int ps = q - C::A_PASSES;
+            if (C::B_PASSES * C::ROWS == BN || ps * C::ROWS + wave * (64 / C::CHUNKS) < BN) {
+                const float* g = b_ok[ps] ? wrow[ps] + cur_wk : p.zeros;
+                float* dst = Bs + buf * BN * C::LDS_K + (ps * C::ROWS + wave * (64 / C::CHUNKS)) * C::LDS_K;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
+            }
+        }
     };
     auto load_piece = [&](int q) {
         if (q < C::A_PASSES) {
@@ -196,10 +236,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     if (kt_begin < kt_end) {
         set_tap();
         stage_setup();
+        if (DMA) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) load_piece(q);
+            for (int q = 0; q < NP; ++q) dma_piece(q, 0);
+        } else {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) store_piece(q, 0);
+            for (int q = 0; q < NP; ++q) load_piece(q);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) store_piece(q, 0);
+        }
     }
     __syncthreads();
 
@@ -254,9 +299,107 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         }
     };
 
+    // SCHED 0: lumped schedule — next-tile loads issued first, then the MFMAs (the compiler streams the
+    // fragment reads between them), then the LDS writes.  The other block on the CU covers the gaps.
+    constexpr int ABL = (SCHED >> 4) & 7;  // ablation experiments only (results are wrong when ABL != 0)
+    // float offset of the 16-B fragment chunk (k = 8*sb + 4*h .. +3) inside a tile row
+    const int rsw = (l31 >> 1) & 7;
+    auto koff = [&](int sb) { return DMA ? (((sb * 2 + h) ^ rsw) * 4) : (sb * 8 + h * 4); };
+    auto k_step_lumped = [&](const int buf, const bool more) {
+        if (more) {
+            advance();
+            stage_setup();
+            if (DMA) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) dma_piece(q, buf ^ 1);  // lands during this step's MFMAs
+            } else if (ABL != 1 && ABL != 2 && ABL != 3) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) load_piece(q);
+            }
+        }
+        const float* a = As + buf * BM * C::LDS_K + (wm * C::TM * 32 + l31) * C::LDS_K;
+        const float* b = Bs + buf * BN * C::LDS_K + (wn * C::TN * 32 + l31) * C::LDS_K;
+        if (SCHED & 128) __builtin_amdgcn_s_setprio(1);
+        if (SCHED & 4) {
+            // all fragments of the step in distinct registers: no LDS wait inside the MFMA stream
+            float4 fa[NSB][C::TM], fb[NSB][C::TN];
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) {
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+                    fa[sb][i] = *reinterpret_cast<const float4*>(a + i * 32 * C::LDS_K + koff(sb));
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+                    fb[sb][j] = *reinterpret_cast<const float4*>(b + j * 32 * C::LDS_K + koff(sb));
+            }
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) {
+                if (SCHED & 8) {
+                    // rotate accumulators: consecutive MFMAs are independent (a dependent 32x32x2 chain from one
+                    // wave issues at ~72 instead of 64 cycles)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < C::TN; ++j) {
+                                const float av = e == 0 ? fa[sb][i].x : e == 1 ? fa[sb][i].y : e == 2 ? fa[sb][i].z : fa[sb][i].w;
+                                const float bv = e == 0 ? fb[sb][j].x : e == 1 ? fb[sb][j].y : e == 2 ? fb[sb][j].z : fb[sb][j].w;
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                            }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].x, fb[sb][j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].y, fb[sb][j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].z, fb[sb][j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].w, fb[sb][j].w, acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+        } else {
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+            float4 fa[C::TM], fb[C::TN];
+            if (ABL == 4) {
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) fa[i] = make_float4(lane * 0.001f, 0.5f, 0.25f, 0.125f);
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) fb[j] = make_float4(0.3f, lane * 0.002f, 0.1f, 0.7f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+                    fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * C::LDS_K + koff(sb));
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+                    fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * C::LDS_K + koff(sb));
+            }
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        }  // SCHED & 4
+        if (SCHED & 128) __builtin_amdgcn_s_setprio(0);
+        if (more && !DMA && ABL != 2 && ABL != 3) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) store_piece(q, buf ^ 1);
+        }
+    };
+
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        k_step((kt - kt_begin) & 1, kt + 1 < kt_end);
-        __syncthreads();
+        if (SCHED & 1)
+            k_step((kt - kt_begin) & 1, kt + 1 < kt_end);
+        else
+            k_step_lumped((kt - kt_begin) & 1, kt + 1 < kt_end);
+        if (ABL != 3) __syncthreads();
     }
 
     // ---- epilogue: transpose the accumulators through LDS (A/B buffers are dead after the last barrier) ----
@@ -401,10 +544,11 @@ __global__ void conv_naive_kernel(const ConvParams p, const int M) {
     p.out[(size_t)m * p.out_stride + n] = v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MINW>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MINW, int SCHED = 0, int DMA = 0>
 void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds_override = 0) {
-    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK>;
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK, MINW>;
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK, DMA>;
+    if (DMA && !p.zeros) throw HipError("launch_conv: DMA staging needs ConvParams::zeros");
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK, MINW, SCHED, DMA>;
     const int nblk_m = (M + BM - 1) / BM;
     const int nblk_n = (p.Cout + BN - 1) / BN;
     dim3 grid(nblk_m * nblk_n, p.splits, 1);
@@ -412,10 +556,10 @@ void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MINW>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MINW, int SCHED = 0, int DMA = 0>
 void init_cfg() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK, MINW>),
+        reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK, MINW, SCHED, DMA>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
@@ -430,6 +574,20 @@ void conv_global_init() {
     init_cfg<128, 64, 2, 2, 32, 2>();
     init_cfg<128, 32, 4, 1, 32, 2>();
     init_cfg<256, 128, 4, 2, 32, 2>();
+    init_cfg<128, 128, 2, 2, 32, 2, 1>();
+    init_cfg<128, 128, 2, 2, 32, 2, 2>();
+    init_cfg<128, 128, 2, 2, 32, 2, 3>();
+    init_cfg<128, 128, 2, 2, 32, 2, 128>();
+    init_cfg<128, 128, 2, 2, 32, 2, 0, 1>();
+    init_cfg<256, 128, 4, 2, 32, 2, 0, 1>();
+    init_cfg<128, 128, 2, 2, 32, 2, 4>();
+    init_cfg<128, 128, 2, 2, 32, 2, 8>();
+    init_cfg<128, 128, 2, 2, 32, 2, 10>();
+    init_cfg<128, 128, 2, 2, 32, 2, 12>();
+    init_cfg<128, 128, 2, 2, 32, 2, 16>();
+    init_cfg<128, 128, 2, 2, 32, 2, 32>();
+    init_cfg<128, 128, 2, 2, 32, 2, 48>();
+    init_cfg<128, 128, 2, 2, 32, 2, 64>();
 }
 
 double conv_flops(const ConvParams& p) {
@@ -447,6 +605,34 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.Cout >= 128) {
         if (g_variant == 3)
             launch_cfg<256, 128, 4, 2, 32, 2>(p, M, nk_total, s);
+        else if (g_variant == 1)
+            launch_cfg<128, 128, 2, 2, 32, 2, 1>(p, M, nk_total, s);
+        else if (g_variant == 6)
+            launch_cfg<128, 128, 2, 2, 32, 2, 2>(p, M, nk_total, s);
+        else if (g_variant == 7)
+            launch_cfg<128, 128, 2, 2, 32, 2, 3>(p, M, nk_total, s);
+        else if (g_variant == 40)
+            launch_cfg<128, 128, 2, 2, 32, 2, 128>(p, M, nk_total, s);
+        else if (g_variant == 30)
+            launch_cfg<128, 128, 2, 2, 32, 2, 0, 1>(p, M, nk_total, s);
+        else if (g_variant == 31)
+            launch_cfg<256, 128, 4, 2, 32, 2, 0, 1>(p, M, nk_total, s);
+        else if (g_variant == 20)
+            launch_cfg<128, 128, 2, 2, 32, 2, 8>(p, M, nk_total, s);
+        else if (g_variant == 21)
+            launch_cfg<128, 128, 2, 2, 32, 2, 10>(p, M, nk_total, s);
+        else if (g_variant == 8)
+            launch_cfg<128, 128, 2, 2, 32, 2, 4>(p, M, nk_total, s);
+        else if (g_variant == 9)
+            launch_cfg<128, 128, 2, 2, 32, 2, 12>(p, M, nk_total, s);
+        else if (g_variant == 11)
+            launch_cfg<128, 128, 2, 2, 32, 2, 16>(p, M, nk_total, s);
+        else if (g_variant == 12)
+            launch_cfg<128, 128, 2, 2, 32, 2, 32>(p, M, nk_total, s);
+        else if (g_variant == 13)
+            launch_cfg<128, 128, 2, 2, 32, 2, 48>(p, M, nk_total, s);
+        else if (g_variant == 14)
+            launch_cfg<128, 128, 2, 2, 32, 2, 64>(p, M, nk_total, s);
         else if (g_variant == 5)
             launch_cfg<128, 128, 2, 2, 32, 2>(p, M, nk_total, s, 120 * 1024);  // diagnostic: force 1 block/CU
         else

@@ -155,6 +155,7 @@ struct irsde_engine {
     StepState* step = nullptr;
     SampleCtl* ctl = nullptr;
 
+    float* zeros = nullptr;        // zero page for LDS-DMA staging of out-of-image taps
     hipStream_t stream = nullptr;  // engine stream (graph capture needs a non-default stream)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::vector<std::unique_ptr<Plan>> plans;
@@ -362,6 +363,8 @@ void finalize(irsde_engine* e) {
     e->film_row = off;
 
     conv_global_init();
+    e->zeros = e->dmalloc(256);
+    IRSDE_HIP_CHECK(hipMemset(e->zeros, 0, 1024));
     IRSDE_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     IRSDE_HIP_CHECK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     IRSDE_HIP_CHECK(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
@@ -439,6 +442,7 @@ struct Builder {
             p.splits = splits;
             p.partial = pl->alloc((size_t)splits * M * p.Cout, true);
         }
+        p.zeros = e->zeros;
         Op op;
         op.kind = OP_CONV;
         op.flops = conv_flops(p);
@@ -1073,17 +1077,25 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
         p.Wo = ((Win << in_shift) + 2 * pad - KW) / stride + 1;
         p.out = out; p.out_stride = Cout; p.bias = db; p.film = film; p.film_bstride = film_bstride; p.silu = silu;
         p.res = res; p.res_stride = Cout;
-        if (splits > 1 && !naive) {
+        float* dz = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&dz, 1024));
+        IRSDE_HIP_CHECK(hipMemset(dz, 0, 1024));
+        p.zeros = dz;
+        if (splits > 1 && naive != 1) {
             p.splits = splits;
             IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
             p.partial = dp;
         }
-        if (naive)
+        if (naive == 1) {
             launch_conv_naive(p, s);
-        else
+        } else {
+            conv_set_variant(naive >= 100 ? naive - 100 : 0);  // test hook for experimental tile variants
             launch_conv(p, s);
+            conv_set_variant(0);
+        }
         IRSDE_HIP_CHECK(hipStreamSynchronize(s));
         (void)hipFree(dw);
+        (void)hipFree(dz);
         if (db) (void)hipFree(db);
         if (dp) (void)hipFree(dp);
     });
@@ -1109,7 +1121,10 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         IRSDE_HIP_CHECK(hipMalloc(&dw, nw * 4));
         IRSDE_HIP_CHECK(hipMalloc(&dout, nout * 4));
         IRSDE_HIP_CHECK(hipMalloc(&dres, nout * 4));
-        IRSDE_HIP_CHECK(hipMalloc(&dfilm, (size_t)2 * Cout * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dfilm, (size_t)2 * Cout * 4 + 1024));
+        float* dz = dfilm + 2 * Cout;
+        IRSDE_HIP_CHECK(hipMemset(dz, 0, 1024));
+        p.zeros = dz;
         launch_fill_random(din, nin, 1, 1.0f, s);
         launch_fill_random(dw, nw, 2, 1.0f / sqrtf((float)(K * K * Cin)), s);
         launch_fill_random(dres, nout, 3, 1.0f, s);

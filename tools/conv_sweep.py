@@ -21,6 +21,8 @@ cases = [
     ("down 4x4s2 256->512", 16, 64, 64, 256, 512, 4, 2, 0, 0),
     ("1x1 1536->1024", 16, 32, 32, 1536, 1024, 1, 1, 0, 0),
 ]
+flt = sys.argv[2] if len(sys.argv) > 2 else ""
+cases = [c for c in cases if flt in c[0]]
 print("%-24s" % "case" + "".join("%14s" % ("v%d TF/s" % v) for v in variants))
 for name, B, H, W, Cin, Cout, K, stride, up, epi in cases:
     Ho = ((H << up) + 2 * (1 if K == 4 else K // 2) - K) // stride + 1
