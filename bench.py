@@ -160,9 +160,18 @@ def main():
         }
         if sde.profile and prof["conv_ms"] > 0:
             ach = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
+            traffic = None  # HBM bytes per conv launch from the PMC passes (cannot be collected live here)
+            try:
+                if a.batch == 16 and a.size == 256:
+                    pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc_hbm.json"))
+                    traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"]
+            except (OSError, IndexError, KeyError, ValueError):
+                traffic = None
             res["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
+                "traffic_unit": "bytes per conv launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes, profiles/*_bench_pmc_hbm.txt)",
+                "algorithmic_bytes_per_launch": prof["conv_bytes"] / max(prof["conv_launches"], 1),
                 "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all %d conv launches per network evaluation)"
                           % int(round(prof["conv_launches"] / max(prof["net_evals"], 1))),
                 "avg_launch_ms": prof["conv_ms"] / max(prof["conv_launches"], 1),
