@@ -43,13 +43,26 @@ struct Cfg {
     static constexpr int B_PASSES = (BN + ROWS - 1) / ROWS;
     static constexpr int LDS_C = BN + 4;  // epilogue tile row stride (floats): 16-B aligned, odd number of slots
     static constexpr int MAIN_BYTES = 2 * (BM + BN) * LDS_K * 4;
-    static constexpr int EPI_BYTES = BM * LDS_C * 4;
+    static constexpr int EPI_ROWS = BM > 128 ? 128 : BM;  // the epilogue transposes EPI_ROWS tile rows per pass
+    static constexpr int EPI_BYTES = EPI_ROWS * LDS_C * 4;
+    static_assert((BM / WAVES_M) <= EPI_ROWS && EPI_ROWS % (BM / WAVES_M) == 0, "wave rows must tile an epilogue pass");
     static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
     static_assert(BM % ROWS == 0, "tile/pass mismatch");
     static_assert(BN % ROWS == 0 || BN < ROWS, "tile/pass mismatch");
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+// MFMA with the accumulator pinned to the AGPR half of the register file (experiment: keeps the 16-register
+// C/D traffic off the arch-VGPR ports that LDS stores / VMEM address reads use).
+template <bool AGPR>
+__device__ __forceinline__ void mfma32(floatx16& acc, float a, float b) {
+    if (AGPR) {
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -380,10 +393,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
             for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    mfma32<(SCHED & 256) != 0>(acc[i][j], fa[i].x, fb[j].x);
+                    mfma32<(SCHED & 256) != 0>(acc[i][j], fa[i].y, fb[j].y);
+                    mfma32<(SCHED & 256) != 0>(acc[i][j], fa[i].z, fb[j].z);
+                    mfma32<(SCHED & 256) != 0>(acc[i][j], fa[i].w, fb[j].w);
                 }
         }
         }  // SCHED & 4
@@ -405,38 +418,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     // ---- epilogue: transpose the accumulators through LDS (A/B buffers are dead after the last barrier) ----
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cs = smem;
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                Cs[row * C::LDS_C + wn * C::TN * 32 + j * 32 + l31] = acc[i][j][r];
-            }
-    __syncthreads();
-
-    constexpr int NV = BN / 4;         // float4 columns of the tile
-    constexpr int RSTEP = C::NT / NV;  // rows covered per sweep
+    constexpr int NV = BN / 4;            // float4 columns of the tile
+    constexpr int RSTEP = C::NT / NV;     // rows covered per sweep
     const int c4 = tid % NV;
     const int n = n0 + c4 * 4;
     const int HW = p.Ho * p.Wo;
     const bool vec_ok = (n + 3 < p.Cout) && ((p.out_stride & 3) == 0);
-    if (n < p.Cout) {
-        float bias[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.splits == 1) {
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.splits == 1 && n < p.Cout) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < p.Cout) {
-                    if (p.bias) bias[e] = p.bias[n + e];
-                    if (p.film && p.film_bstride == 0) {
-                        sc[e] = p.film[n + e] + 1.0f;
-                        sh[e] = p.film[p.Cout + n + e];
-                    }
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) {
+                if (p.bias) bias[e] = p.bias[n + e];
+                if (p.film && p.film_bstride == 0) {
+                    sc[e] = p.film[n + e] + 1.0f;
+                    sh[e] = p.film[p.Cout + n + e];
                 }
+            }
+    }
+    constexpr int WAVE_ROWS = C::TM * 32;
+#pragma unroll 1
+    for (int pass = 0; pass < BM / C::EPI_ROWS; ++pass) {
+        if (pass > 0) __syncthreads();  // previous pass fully stored before Cs is overwritten
+        if ((wm * WAVE_ROWS) / C::EPI_ROWS == pass) {
+            const int rbase = wm * WAVE_ROWS - pass * C::EPI_ROWS;
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        Cs[row * C::LDS_C + wn * C::TN * 32 + j * 32 + l31] = acc[i][j][r];
+                    }
         }
-        for (int row = tid / NV; row < BM; row += RSTEP) {
-            const int m = m0 + row;
+        __syncthreads();
+        if (n < p.Cout) {
+        for (int row = tid / NV; row < C::EPI_ROWS; row += RSTEP) {
+            const int m = m0 + pass * C::EPI_ROWS + row;
             if (m >= M) break;
             const float4 cv = *reinterpret_cast<const float4*>(Cs + row * C::LDS_C + c4 * 4);
             float v[4] = {cv.x, cv.y, cv.z, cv.w};
@@ -487,6 +506,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
                 for (int e = 0; e < 4; ++e)
                     if (n + e < p.Cout) dst[e] = v[e];
             }
+        }
         }
     }
 }
@@ -577,7 +597,9 @@ void conv_global_init() {
     init_cfg<128, 128, 2, 2, 32, 2, 1>();
     init_cfg<128, 128, 2, 2, 32, 2, 2>();
     init_cfg<128, 128, 2, 2, 32, 2, 3>();
+    init_cfg<256, 256, 2, 4, 32, 2>();
     init_cfg<128, 128, 2, 2, 32, 2, 128>();
+    init_cfg<128, 128, 2, 2, 32, 2, 256>();
     init_cfg<128, 128, 2, 2, 32, 2, 0, 1>();
     init_cfg<256, 128, 4, 2, 32, 2, 0, 1>();
     init_cfg<128, 128, 2, 2, 32, 2, 4>();
@@ -592,6 +614,14 @@ void conv_global_init() {
 
 double conv_flops(const ConvParams& p) {
     return 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout * (double)(p.KH * p.KW) * (double)(p.C0 + p.C1);
+}
+
+// 256x256 tiles (8 waves, 128x64 per wave) halve the staging instructions per MFMA (+5..8 % on deep layers) but
+// need Cout % 256 == 0 and a tile count that fills the 256 CUs without a ragged last round.
+bool conv_use_tile256(int M, int Cout, int splits) {
+    if (splits != 1 || Cout % 256) return false;
+    const long long nb = (long long)((M + 255) / 256) * (Cout / 256);
+    return nb % 256 == 0 || nb >= 1024;
 }
 
 void launch_conv(const ConvParams& p, hipStream_t s) {
@@ -611,6 +641,10 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
             launch_cfg<128, 128, 2, 2, 32, 2, 2>(p, M, nk_total, s);
         else if (g_variant == 7)
             launch_cfg<128, 128, 2, 2, 32, 2, 3>(p, M, nk_total, s);
+        else if (g_variant == 50)
+            launch_cfg<256, 256, 2, 4, 32, 2>(p, M, nk_total, s);
+        else if (g_variant == 41)
+            launch_cfg<128, 128, 2, 2, 32, 2, 256>(p, M, nk_total, s);
         else if (g_variant == 40)
             launch_cfg<128, 128, 2, 2, 32, 2, 128>(p, M, nk_total, s);
         else if (g_variant == 30)
@@ -635,6 +669,8 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
             launch_cfg<128, 128, 2, 2, 32, 2, 64>(p, M, nk_total, s);
         else if (g_variant == 5)
             launch_cfg<128, 128, 2, 2, 32, 2>(p, M, nk_total, s, 120 * 1024);  // diagnostic: force 1 block/CU
+        else if (g_variant == 0 && conv_use_tile256(M, p.Cout, p.splits))
+            launch_cfg<256, 256, 2, 4, 32, 2>(p, M, nk_total, s);
         else
             launch_cfg<128, 128, 2, 2, 32, 2>(p, M, nk_total, s);
     } else if (p.Cout > 32) {
