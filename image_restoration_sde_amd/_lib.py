@@ -16,6 +16,7 @@ MODE = {"sde": 0, "ode": 1, "posterior": 2}
 COEF_STRIDE = 12
 FLAG_KEEP_ACTIVATIONS = 1
 FLAG_NAIVE_CONV = 2
+FLAG_NO_WINOGRAD = 4
 SAMPLE_GRAPH = 1
 SAMPLE_PROFILE = 2
 

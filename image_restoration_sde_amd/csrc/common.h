@@ -53,7 +53,32 @@ struct ConvParams {
     int splits = 1;
     float* partial = nullptr;
     const float* zeros = nullptr;  // >= 16 zero bytes (source of out-of-image taps for LDS-DMA staging)
+    // batched launch (Winograd: 16 independent GEMMs): blockIdx.z = k offsets the three tensors (floats)
+    int nz = 1;
+    long long z_in = 0, z_w = 0, z_out = 0;
 };
+
+// Winograd F(2x2,3x3) transforms (wino.hip).  Tiles: T = B * TH * TW with TH = Ho/2, TW = Wo/2.
+struct WinoParams {
+    const float* in0 = nullptr;
+    const float* in1 = nullptr;
+    int C0 = 0, C1 = 0, Hin = 0, Win = 0, in_shift = 0;
+    int B = 0, TH = 0, TW = 0, T = 0;
+    float* V = nullptr;         // [16][T][C0+C1]
+    const float* M = nullptr;   // [16][T][Cout]
+    int Cout = 0;
+    float* out = nullptr;
+    int out_stride = 0;
+    const float* bias = nullptr;
+    const float* film = nullptr;
+    int film_bstride = 0;
+    int silu = 0;
+    const float* res = nullptr;
+    int res_stride = 0;
+};
+void launch_wino_input(const WinoParams& p, hipStream_t s);
+void launch_wino_output(const WinoParams& p, hipStream_t s);
+void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U);  // host
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)
 void launch_conv(const ConvParams& p, hipStream_t s);

@@ -69,9 +69,16 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MIN_WAVES_PER_SIMD, int SCHED = 0, int DMA = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void conv_igemm_kernel(
-    const ConvParams p, const int nblk_n, const int M, const int nk_total) {
+    const ConvParams pin, const int nblk_n, const int M, const int nk_total) {
     using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK, DMA>;
     static_assert(!DMA || BK == 32, "LDS-DMA staging assumes 128-byte rows");
+    ConvParams p = pin;  // batched launch: component blockIdx.z works on its own slice of in0 / w / out
+    if (pin.nz > 1) {
+        const long long z = blockIdx.z;
+        p.in0 = pin.in0 + z * pin.z_in;
+        p.w = pin.w + z * pin.z_w;
+        p.out = pin.out + z * pin.z_out;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * BM * C::LDS_K;
@@ -571,7 +578,7 @@ void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds
     auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK, MINW, SCHED, DMA>;
     const int nblk_m = (M + BM - 1) / BM;
     const int nblk_n = (p.Cout + BN - 1) / BN;
-    dim3 grid(nblk_m * nblk_n, p.splits, 1);
+    dim3 grid(nblk_m * nblk_n, p.splits, p.nz);
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds_override ? lds_override : C::LDS_BYTES, s, p, nblk_n, M, nk_total);
     IRSDE_HIP_CHECK(hipGetLastError());
 }

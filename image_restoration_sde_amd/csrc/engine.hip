@@ -25,6 +25,7 @@ namespace irsde {
 namespace {
 
 thread_local std::string g_last_error;
+constexpr int kWinoMinC = 256;  // Winograd only where the transforms' extra HBM traffic is small next to the GEMM
 
 struct HostTensor {
     std::vector<int64_t> shape;
@@ -36,6 +37,7 @@ struct ConvW {
     float* w = nullptr;  // device [Cout][KH*KW][Cin]
     float* bias = nullptr;
     int Cout = 0, Cin = 0, KH = 1, KW = 1;
+    float* wino_u = nullptr;  // device [16][Cout][Cin] = G g G^T (wide 3x3 layers only)
 };
 struct ResW {
     ConvW b1, b2, res;
@@ -52,14 +54,42 @@ struct AttnW {
     int C = 0;
 };
 
-enum OpKind { OP_CONV = 0, OP_LN = 1, OP_ATTN = 2, OP_OTHER = 3 };
+enum OpKind { OP_CONV = 0, OP_LN = 1, OP_ATTN = 2, OP_OTHER = 3, OP_WINO = 4, OP_NKINDS = 5 };
 
 struct Op {
     std::function<void(hipStream_t)> fn;
     OpKind kind;
-    double flops = 0, bytes = 0;
+    double flops = 0, bytes = 0;  // algorithmic (direct-convolution) work attributed to this launch group
+    double exec_flops = 0;        // multiply-adds actually issued to the MFMA pipe (differs for Winograd)
     std::string desc;
 };
+
+// Winograd F(2x2,3x3) launch triple derived from the direct-form parameters of a 3x3 stride-1 pad-1 convolution
+struct WinoPlan {
+    WinoParams in, out;
+    ConvParams gemm;
+};
+inline WinoPlan make_wino(const ConvParams& d, const float* U, float* V, float* Mb) {
+    WinoPlan w;
+    const int Ctot = d.C0 + d.C1;
+    const int TH = d.Ho / 2, TW = d.Wo / 2, T = d.B * TH * TW;
+    w.in.in0 = d.in0; w.in.in1 = d.in1; w.in.C0 = d.C0; w.in.C1 = d.C1; w.in.Hin = d.Hin; w.in.Win = d.Win;
+    w.in.in_shift = d.in_shift; w.in.B = d.B; w.in.TH = TH; w.in.TW = TW; w.in.T = T; w.in.V = V;
+    w.out = w.in;
+    w.out.M = Mb; w.out.Cout = d.Cout; w.out.out = d.out; w.out.out_stride = d.out_stride; w.out.bias = d.bias;
+    w.out.film = d.film; w.out.film_bstride = d.film_bstride; w.out.silu = d.silu; w.out.res = d.res;
+    w.out.res_stride = d.res_stride;
+    ConvParams& g = w.gemm;
+    g.in0 = V; g.C0 = Ctot; g.pix0 = Ctot; g.Hin = 1; g.Win = T; g.w = U; g.Cout = d.Cout;
+    g.KH = g.KW = 1; g.stride = 1; g.pad_y = g.pad_x = 0; g.B = 1; g.Ho = 1; g.Wo = T;
+    g.out = Mb; g.out_stride = d.Cout; g.zeros = d.zeros;
+    g.nz = 16; g.z_in = (long long)T * Ctot; g.z_w = (long long)d.Cout * Ctot; g.z_out = (long long)T * d.Cout;
+    return w;
+}
+inline bool wino_shape_ok(const ConvParams& d) {
+    return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.Ho % 2 == 0 && d.Wo % 2 == 0 &&
+           (d.C0 + d.C1) % 32 == 0 && d.Cout % 4 == 0 && d.out_stride % 4 == 0 && (!d.res || d.res_stride % 4 == 0);
+}
 
 struct Tensor {
     float* p = nullptr;
@@ -85,7 +115,7 @@ struct Plan {
     std::map<std::string, Tensor> taps;
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
-    double conv_flops = 0, conv_bytes = 0;
+    double conv_flops = 0, conv_bytes = 0, conv_exec_flops = 0;
     uint64_t last_use = 0;
 
     ~Plan() {
@@ -160,7 +190,7 @@ struct irsde_engine {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::vector<std::unique_ptr<Plan>> plans;
     uint64_t use_counter = 0;
-    double profile[9] = {0};
+    double profile[12] = {0};
     std::vector<hipEvent_t> ev_pool;
     std::mutex mu;
 
@@ -263,6 +293,11 @@ ConvW pack_conv(irsde_engine* e, const std::string& wname, const std::string& bn
     c.w = e->upload(p);
     c.Cout = O; c.Cin = I; c.KH = KH; c.KW = KW;
     if (!bname.empty()) c.bias = e->upload(need(e, bname).data);
+    if (KH == 3 && KW == 3 && I >= kWinoMinC && O >= kWinoMinC && I % 32 == 0 && !(e->cfg.flags & IRSDE_FLAG_NO_WINOGRAD)) {
+        std::vector<float> U((size_t)16 * O * I);
+        wino_transform_weights(p.data(), O, I, U.data());
+        c.wino_u = e->upload(U);
+    }
     return c;
 }
 
@@ -448,7 +483,9 @@ struct Builder {
         op.flops = conv_flops(p);
         const double in_bytes = 4.0 * (double)p.B * (p.Hin) * (p.Win) * (double)(p.C0 + p.C1);
         op.bytes = in_bytes + 4.0 * (double)M * p.Cout + 4.0 * (double)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
+        op.exec_flops = op.flops;
         pl->conv_flops += op.flops;
+        pl->conv_exec_flops += op.exec_flops;
         pl->conv_bytes += op.bytes;
         {
             char buf[256];
@@ -488,8 +525,60 @@ struct Builder {
         p.film = film; p.film_bstride = film ? film_bstride : 0;
         p.silu = silu;
         if (res) { p.res = res->p; p.res_stride = res->C; }
+        if (w.wino_u && !naive && wino_shape_ok(p) && push_wino(p, w.wino_u)) return out;
         push_conv(p);
         return out;
+    }
+
+    // Winograd F(2x2,3x3): input transform -> 16 batched GEMMs on the MFMA kernel -> output transform + epilogue
+    bool push_wino(const ConvParams& d, const float* U) {
+        const int Ctot = d.C0 + d.C1;
+        const long long T = (long long)d.B * (d.Ho / 2) * (d.Wo / 2);
+        const long long gemm_blocks = 16 * ((T + 127) / 128) * ((d.Cout + 127) / 128);
+        if (gemm_blocks < 256 || T * Ctot * 16 > (1ll << 31) * 4) return false;  // tiny layers: direct conv + split-K
+        ConvParams dd = d;
+        dd.zeros = e->zeros;
+        float* V = pl->alloc((size_t)16 * T * Ctot, true);
+        float* Mb = pl->alloc((size_t)16 * T * d.Cout, true);
+        const WinoPlan wp = make_wino(dd, U, V, Mb);
+        const double direct = conv_flops(d);
+        {
+            Op op;
+            op.kind = OP_WINO;
+            op.desc = "wino_input T=" + std::to_string(T) + " C=" + std::to_string(Ctot);
+            const WinoParams ip = wp.in;
+            op.fn = [ip](hipStream_t s) { launch_wino_input(ip, s); };
+            pl->net_ops.push_back(std::move(op));
+        }
+        {
+            Op op;
+            op.kind = OP_CONV;
+            op.flops = direct;
+            op.exec_flops = 16.0 * 2.0 * (double)T * Ctot * d.Cout;
+            const double in_bytes = 4.0 * (double)d.B * d.Hin * d.Win * Ctot;
+            op.bytes = in_bytes + 4.0 * (double)d.B * d.Ho * d.Wo * d.Cout + 4.0 * 9.0 * (double)d.Cout * Ctot;
+            pl->conv_flops += op.flops;
+            pl->conv_exec_flops += op.exec_flops;
+            pl->conv_bytes += op.bytes;
+            char buf[256];
+            snprintf(buf, sizeof buf, "conv(winograd gemm x16) T=%lld Cout=%d Cin=%d flops=%.4g exec=%.4g", T, d.Cout, Ctot,
+                     op.flops, op.exec_flops);
+            op.desc = buf;
+            const ConvParams g = wp.gemm;
+            op.fn = [g](hipStream_t s) { launch_conv(g, s); };
+            pl->net_ops.push_back(std::move(op));
+        }
+        {
+            Op op;
+            op.kind = OP_WINO;
+            op.desc = "wino_output T=" + std::to_string(T) + " Cout=" + std::to_string(d.Cout);
+            const WinoParams oparm = wp.out;
+            op.fn = [oparm](hipStream_t s) { launch_wino_output(oparm, s); };
+            pl->net_ops.push_back(std::move(op));
+        }
+        pl->release(V);
+        pl->release(Mb);
+        return true;
     }
 
     // ResBlock.forward — module_util.py:136-146
@@ -612,7 +701,7 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
         // algorithmic accounting: 7x7 x (2*in_nc) real MACs, not the padded 7 x 64
         const double real = 2.0 * (double)B * pl->Hp * pl->Wp * nf * 49.0 * (2.0 * in_nc);
         pl->conv_flops += real - pl->net_ops.back().flops;
-        pl->net_ops.back().flops = real;
+        pl->net_ops.back().flops = real;  // (exec_flops keeps the padded 7 x 64 K that is actually issued)
     }
     b.tap("init_conv", x);
     Tensor x_init = x;
@@ -938,7 +1027,7 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
             }
             IRSDE_HIP_CHECK(hipEventRecord(get_event(e, ei++), s));
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
-            double ms[4] = {0, 0, 0, 0};
+            double ms[OP_NKINDS] = {0, 0, 0, 0, 0};
             for (size_t k = 0; k < kinds.size(); ++k) {
                 float t;
                 IRSDE_HIP_CHECK(hipEventElapsedTime(&t, e->ev_pool[k], e->ev_pool[k + 1]));
@@ -958,6 +1047,9 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
             e->profile[6] = ms[OP_OTHER];
             e->profile[7] = wall;
             e->profile[8] = nsteps;
+            e->profile[9] = ms[OP_WINO];
+            e->profile[10] = pl->conv_exec_flops * nsteps;
+            e->profile[11] = 0;
         }
         IRSDE_HIP_CHECK(hipMemcpyAsync(out, pl->xin, img * 4, hipMemcpyDeviceToDevice, s));
         IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
@@ -990,9 +1082,9 @@ int irsde_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint64
     });
 }
 
-int irsde_get_profile(const irsde_engine* e, double out[9]) {
+int irsde_get_profile(const irsde_engine* e, double out[12]) {
     if (!e || !out) return IRSDE_ERR_INVALID;
-    for (int i = 0; i < 9; ++i) out[i] = e->profile[i];
+    for (int i = 0; i < 12; ++i) out[i] = e->profile[i];
     return IRSDE_OK;
 }
 
@@ -1081,12 +1173,28 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
         IRSDE_HIP_CHECK(hipMalloc(&dz, 1024));
         IRSDE_HIP_CHECK(hipMemset(dz, 0, 1024));
         p.zeros = dz;
-        if (splits > 1 && naive != 1) {
+        if (splits > 1 && naive != 1 && naive != 2) {
             p.splits = splits;
             IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
             p.partial = dp;
         }
-        if (naive == 1) {
+        if (naive == 2) {
+            if (!wino_shape_ok(p)) throw HipError("debug_conv: shape not eligible for Winograd");
+            std::vector<float> U((size_t)16 * Cout * Cin);
+            wino_transform_weights(pk.data(), Cout, Cin, U.data());
+            const long long T = (long long)B * (p.Ho / 2) * (p.Wo / 2);
+            float *dU = nullptr, *dV = nullptr, *dM = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dU, U.size() * 4));
+            IRSDE_HIP_CHECK(hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+            IRSDE_HIP_CHECK(hipMalloc(&dV, (size_t)16 * T * Cin * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)16 * T * Cout * 4));
+            const WinoPlan wp = make_wino(p, dU, dV, dM);
+            launch_wino_input(wp.in, s);
+            launch_conv(wp.gemm, s);
+            launch_wino_output(wp.out, s);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(dU); (void)hipFree(dV); (void)hipFree(dM);
+        } else if (naive == 1) {
             launch_conv_naive(p, s);
         } else {
             conv_set_variant(naive >= 100 ? naive - 100 : 0);  // test hook for experimental tile variants

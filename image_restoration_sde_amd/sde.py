@@ -215,10 +215,10 @@ class IRSDE:
     def last_profile(self):
         """Per-kernel-class timing of the last `profile=True` sampling call (irsde_get_profile)."""
         m = _unwrap(self.model)
-        out = (ctypes.c_double * 9)()
+        out = (ctypes.c_double * 12)()
         _lib.check(_lib.lib().irsde_get_profile(m.engine().h, out))
         keys = ["conv_ms", "conv_flops", "conv_launches", "conv_bytes", "ln_ms", "attn_ms", "other_ms", "wall_ms",
-                "net_evals"]
+                "net_evals", "wino_ms", "conv_exec_flops", "reserved"]
         return dict(zip(keys, list(out)))
 
     # ---- model plumbing (sde_utils.py:184-194) ------------------------------------------------

@@ -38,7 +38,8 @@ enum { IRSDE_MODE_SDE = 0, IRSDE_MODE_ODE = 1, IRSDE_MODE_POSTERIOR = 2 };
 /* engine flags (irsde_config.flags) */
 enum {
     IRSDE_FLAG_KEEP_ACTIVATIONS = 1, /* never recycle activation buffers: enables irsde_debug_tap */
-    IRSDE_FLAG_NAIVE_CONV = 2        /* debug: run every convolution on the naive VALU kernel */
+    IRSDE_FLAG_NAIVE_CONV = 2,       /* debug: run every convolution on the naive VALU kernel */
+    IRSDE_FLAG_NO_WINOGRAD = 4       /* run the wide 3x3 layers as direct implicit GEMMs instead of Winograd F(2x2,3x3) */
 };
 /* per-call flags (irsde_sample) */
 enum {
@@ -123,8 +124,10 @@ int irsde_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint64
 /* Timing of the last IRSDE_SAMPLE_PROFILE call (hipEvents on the engine's own stream).
  * out[0] conv kernel ms (sum)      out[1] conv algorithmic FLOPs (sum)  out[2] conv launches
  * out[3] conv algorithmic bytes    out[4] layernorm ms                   out[5] attention ms
- * out[6] other kernels ms          out[7] wall ms of the whole call      out[8] network evaluations */
-int irsde_get_profile(const irsde_engine* e, double out[9]);
+ * out[6] other kernels ms          out[7] wall ms of the whole call      out[8] network evaluations
+ * out[9] Winograd transform kernels ms   out[10] FLOPs actually issued by the conv kernels (Winograd layers
+ * issue 2.25x fewer than the algorithmic direct-convolution count in out[1])   out[11] reserved */
+int irsde_get_profile(const irsde_engine* e, double out[12]);
 
 /* Debug (IRSDE_FLAG_KEEP_ACTIVATIONS): copy a named intermediate activation of the last forward to
  * HOST memory as NCHW.  Names follow the reference module paths ("downs.0.0", "mid_attn", ...).
@@ -141,7 +144,8 @@ int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buf
 /* Kernel-level test hook: one implicit-GEMM convolution (csrc/conv_igemm.hip) on NHWC device tensors.
  * in0/in1: [B][Hin][Win][C0|C1] (channel concat, in1 may be NULL); w_oihw/bias: HOST, reference layout;
  * film: device [rows][2*Cout] or NULL; res/out: device [B][Ho][Wo][Cout].  naive != 0 runs the VALU
- * cross-check kernel; splits > 1 forces split-K.  Synchronises `stream`. */
+ * cross-check kernel, naive == 2 the Winograd F(2x2,3x3) path (3x3 s1 p1 only), naive >= 100 an experimental
+ * tile variant; splits > 1 forces split-K.  Synchronises `stream`. */
 int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int in_shift,
                      const float* w_oihw, int Cout, int KH, int KW, int stride, int pad, const float* bias,
                      const float* film, int film_bstride, int silu, const float* res, float* out, int naive,

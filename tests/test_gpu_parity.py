@@ -115,6 +115,8 @@ CONV_CASES = {
     "3x3_final_cout3": (2, 64, 0, 24, 20, 3, 3, 1, 1, 0, True, False, False, False),
     "3x3_m_tail_odd": (1, 32, 0, 7, 9, 96, 3, 1, 1, 0, False, False, True, False),
     "3x3_deep_k_1536": (1, 1024, 512, 4, 4, 256, 3, 1, 1, 0, False, True, True, False),
+    "3x3_wino_res_bias": (2, 256, 0, 12, 20, 256, 3, 1, 1, 0, True, False, True, True),
+    "3x3_wino_upsample": (1, 256, 0, 6, 10, 256, 3, 1, 1, 1, True, False, False, False),
 }
 
 
@@ -137,6 +139,9 @@ def test_conv_kernel(name):
     # the VALU cross-check kernel and the forced split-K path agree with the oracle too
     assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=1), ref) < 2e-5
     assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, splits=3), ref) < 2e-5
+    if K == 3 and stride == 1 and pad == 1 and Cout % 4 == 0 and Ho % 2 == 0 and Wo % 2 == 0:
+        # Winograd F(2x2,3x3) path (input transform -> 16 batched MFMA GEMMs -> output transform + epilogue)
+        assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=2), ref) < 2e-5
 
 
 def test_conv_per_sample_film():
@@ -189,6 +194,23 @@ def test_unet_layers_vs_oracle():
     bad = {k: v for k, v in worst.items() if not v < 5e-5}
     assert not bad, bad
     assert relerr(y, ref) < 5e-5
+
+
+def test_winograd_vs_direct_network():
+    """The Winograd layers (Cin, Cout >= 256) and the direct implicit-GEMM layers compute the same network."""
+    B, H, W = 2, 64, 64
+    m, _ = model(64, 4)
+    md, _ = make_model(64, 4, flags=_lib.FLAG_NO_WINOGRAD)
+    lq, xT = O.synth_inputs(7, B, H, W)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    a = m(x, c, 33).cpu().numpy()
+    b = md(x, c, 33).cpu().numpy()
+    assert relerr(a, b) < 2e-5
+    import ctypes as _c
+    buf = _c.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, B, H, W, buf, len(buf)))
+    assert b"winograd" in buf.value  # the production plan really takes the Winograd path at this size
+    del md
 
 
 def test_unet_mfma_vs_naive_full_resolution():
