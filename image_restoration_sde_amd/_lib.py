@@ -25,7 +25,7 @@ SYMBOLS = [
     "irsde_last_error", "irsde_version", "irsde_create", "irsde_destroy", "irsde_num_weights",
     "irsde_weight_name", "irsde_weight_shape", "irsde_load_weight", "irsde_finalize_weights",
     "irsde_set_schedule", "irsde_unet_forward", "irsde_sample", "irsde_sde_step", "irsde_philox_normal",
-    "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv", "irsde_plan_describe", "irsde_bench_conv",
+    "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv", "irsde_plan_describe", "irsde_bench_conv", "irsde_op_profile",
 ]
 
 
@@ -86,6 +86,7 @@ def _declare(lib):
     lib.irsde_debug_conv.argtypes = [P, c.c_int, P, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, P, c.c_int, c.c_int,
                                      c.c_int, c.c_int, c.c_int, P, P, c.c_int, c.c_int, P, P, c.c_int, c.c_int, P]
     lib.irsde_plan_describe.argtypes = [P, c.c_int, c.c_int, c.c_int, c.c_char_p, c.c_int]
+    lib.irsde_op_profile.argtypes = [P, c.c_char_p, c.c_int]
     lib.irsde_bench_conv.argtypes = [c.c_int] * 11 + [c.POINTER(c.c_double)]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError here = the .so does not export what the header declares

@@ -625,8 +625,9 @@ double conv_flops(const ConvParams& p) {
 
 // 256x256 tiles (8 waves, 128x64 per wave) halve the staging instructions per MFMA (+5..8 % on deep layers) but
 // need Cout % 256 == 0 and a tile count that fills the 256 CUs without a ragged last round.
-bool conv_use_tile256(int M, int Cout, int splits) {
-    if (splits != 1 || Cout % 256) return false;
+bool conv_use_tile256(int M, int Cout, int splits, int nk_total) {
+    static const int min_nk = getenv("IRSDE_T256_MIN_NK") ? atoi(getenv("IRSDE_T256_MIN_NK")) : 0;
+    if (splits != 1 || Cout % 256 || nk_total < min_nk) return false;
     const long long nb = (long long)((M + 255) / 256) * (Cout / 256);
     return nb % 256 == 0 || nb >= 1024;
 }
@@ -676,7 +677,7 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
             launch_cfg<128, 128, 2, 2, 32, 2, 64>(p, M, nk_total, s);
         else if (g_variant == 5)
             launch_cfg<128, 128, 2, 2, 32, 2>(p, M, nk_total, s, 120 * 1024);  // diagnostic: force 1 block/CU
-        else if (g_variant == 0 && conv_use_tile256(M, p.Cout, p.splits))
+        else if (g_variant == 0 && conv_use_tile256(M, p.Cout, p.splits, nk_total))
             launch_cfg<256, 256, 2, 4, 32, 2>(p, M, nk_total, s);
         else
             launch_cfg<128, 128, 2, 2, 32, 2>(p, M, nk_total, s);

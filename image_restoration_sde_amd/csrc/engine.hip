@@ -25,7 +25,13 @@ namespace irsde {
 namespace {
 
 thread_local std::string g_last_error;
-constexpr int kWinoMinC = 256;  // Winograd only where the transforms' extra HBM traffic is small next to the GEMM
+// Winograd only where the transforms' extra HBM traffic (4x input + 4x output) is small next to the GEMM.
+// IRSDE_WINO_MINC overrides the channel threshold (tuning experiments).
+static int wino_min_c() {
+    const char* v = getenv("IRSDE_WINO_MINC");
+    return v ? atoi(v) : 256;
+}
+#define kWinoMinC wino_min_c()
 
 struct HostTensor {
     std::vector<int64_t> shape;
@@ -191,6 +197,9 @@ struct irsde_engine {
     std::vector<std::unique_ptr<Plan>> plans;
     uint64_t use_counter = 0;
     double profile[12] = {0};
+    std::vector<double> op_ms;          // per launch group of the last profiled plan (summed over steps)
+    std::vector<std::string> op_desc;
+    int op_steps = 0;
     std::vector<hipEvent_t> ev_pool;
     std::mutex mu;
 
@@ -1028,10 +1037,17 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
             IRSDE_HIP_CHECK(hipEventRecord(get_event(e, ei++), s));
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             double ms[OP_NKINDS] = {0, 0, 0, 0, 0};
+            const size_t per_step = pl->net_ops.size() + 2;
+            e->op_ms.assign(pl->net_ops.size(), 0.0);
+            e->op_desc.clear();
+            for (auto& op : pl->net_ops) e->op_desc.push_back(op.desc);
+            e->op_steps = nsteps;
             for (size_t k = 0; k < kinds.size(); ++k) {
                 float t;
                 IRSDE_HIP_CHECK(hipEventElapsedTime(&t, e->ev_pool[k], e->ev_pool[k + 1]));
                 ms[kinds[k]] += t;
+                const size_t in_step = k % per_step;
+                if (in_step >= 1 && in_step <= pl->net_ops.size()) e->op_ms[in_step - 1] += t;
             }
             hipEvent_t e0 = e->ev_pool[0], e1 = e->ev_pool[kinds.size()];
             float wall;
@@ -1109,6 +1125,20 @@ int irsde_debug_tap(irsde_engine* e, const char* name, float* dst, int64_t dims[
         IRSDE_HIP_CHECK(hipStreamSynchronize(e->stream));
         IRSDE_HIP_CHECK(hipMemcpy(dst, tmp, t.numel() * 4, hipMemcpyDeviceToHost));
         (void)hipFree(tmp);
+    });
+}
+
+int irsde_op_profile(irsde_engine* e, char* buf, int buflen) {
+    return guard([&] {
+        if (!e || !buf || buflen < 1) throw HipError("null argument");
+        std::string out;
+        char line[512];
+        for (size_t i = 0; i < e->op_ms.size(); ++i) {
+            snprintf(line, sizeof line, "%9.4f ms  %s\n", e->op_ms[i] / std::max(e->op_steps, 1), e->op_desc[i].c_str());
+            out += line;
+        }
+        strncpy(buf, out.c_str(), buflen - 1);
+        buf[buflen - 1] = 0;
     });
 }
 

@@ -138,6 +138,9 @@ int irsde_debug_tap(irsde_engine* e, const char* name, float* dst, int64_t dims[
  * conv bytes (inputs + outputs + weights once). */
 int irsde_work_model(irsde_engine* e, int B, int H, int W, double out[2]);
 
+/* Per-launch-group average ms of the last IRSDE_SAMPLE_PROFILE call, one text line per group. */
+int irsde_op_profile(irsde_engine* e, char* buf, int buflen);
+
 /* Text description (one line per launch group) of the network-evaluation plan at (B,H,W): debugging/analysis. */
 int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buflen);
 

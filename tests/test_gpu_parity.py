@@ -198,7 +198,7 @@ def test_unet_layers_vs_oracle():
 
 def test_winograd_vs_direct_network():
     """The Winograd layers (Cin, Cout >= 256) and the direct implicit-GEMM layers compute the same network."""
-    B, H, W = 2, 64, 64
+    B, H, W = 4, 128, 128
     m, _ = model(64, 4)
     md, _ = make_model(64, 4, flags=_lib.FLAG_NO_WINOGRAD)
     lq, xT = O.synth_inputs(7, B, H, W)
@@ -207,7 +207,7 @@ def test_winograd_vs_direct_network():
     b = md(x, c, 33).cpu().numpy()
     assert relerr(a, b) < 2e-5
     import ctypes as _c
-    buf = _c.create_string_buffer(1 << 16)
+    buf = _c.create_string_buffer(1 << 18)
     _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, B, H, W, buf, len(buf)))
     assert b"winograd" in buf.value  # the production plan really takes the Winograd path at this size
     del md
