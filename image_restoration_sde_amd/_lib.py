@@ -17,6 +17,7 @@ COEF_STRIDE = 12
 FLAG_KEEP_ACTIVATIONS = 1
 FLAG_NAIVE_CONV = 2
 FLAG_NO_WINOGRAD = 4
+FLAG_NO_WINOGRAD_F43 = 8
 SAMPLE_GRAPH = 1
 SAMPLE_PROFILE = 2
 

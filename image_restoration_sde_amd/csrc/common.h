@@ -59,14 +59,15 @@ struct ConvParams {
     long long z_in = 0, z_w = 0, z_out = 0;
 };
 
-// Winograd F(2x2,3x3) transforms (wino.hip).  Tiles: T = B * TH * TW with TH = Ho/2, TW = Wo/2.
+// Winograd F(m x m,3x3) transforms (wino.hip).  Tiles: T = B * TH * TW with TH = Ho/m, TW = Wo/m.
 struct WinoParams {
     const float* in0 = nullptr;
     const float* in1 = nullptr;
     int C0 = 0, C1 = 0, Hin = 0, Win = 0, in_shift = 0;
     int B = 0, TH = 0, TW = 0, T = 0;
-    float* V = nullptr;         // [16][T][C0+C1]
-    const float* M = nullptr;   // [16][T][Cout]
+    int tile = 2;               // output tile edge m of F(m x m, 3x3): 2 or 4; components = (m+2)^2
+    float* V = nullptr;         // [(m+2)^2][T][C0+C1]
+    const float* M = nullptr;   // [(m+2)^2][T][Cout]
     int Cout = 0;
     float* out = nullptr;
     int out_stride = 0;
@@ -79,7 +80,7 @@ struct WinoParams {
 };
 void launch_wino_input(const WinoParams& p, hipStream_t s);
 void launch_wino_output(const WinoParams& p, hipStream_t s);
-void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U);  // host
+void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U, int tile);  // host
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)
 void launch_conv(const ConvParams& p, hipStream_t s);

@@ -25,13 +25,13 @@ namespace irsde {
 namespace {
 
 thread_local std::string g_last_error;
-// Winograd only where the transforms' extra HBM traffic (4x input + 4x output) is small next to the GEMM.
-// IRSDE_WINO_MINC overrides the channel threshold (tuning experiments).
-static int wino_min_c() {
-    const char* v = getenv("IRSDE_WINO_MINC");
-    return v ? atoi(v) : 256;
+// Winograd only where the transforms' extra HBM traffic is small next to the GEMM: F(2x2) moves 4x the input and
+// 4x the output through HBM and pays from 256 channels, F(4x4) 2.25x and pays from 128 (measured, profiles/).
+// IRSDE_WINO2_MINC / IRSDE_WINO4_MINC override the thresholds (tuning experiments).
+static int wino_min_c(int tile) {
+    const char* v = getenv(tile == 4 ? "IRSDE_WINO4_MINC" : "IRSDE_WINO2_MINC");
+    return v ? atoi(v) : (tile == 4 ? 128 : 256);
 }
-#define kWinoMinC wino_min_c()
 
 struct HostTensor {
     std::vector<int64_t> shape;
@@ -43,7 +43,8 @@ struct ConvW {
     float* w = nullptr;  // device [Cout][KH*KW][Cin]
     float* bias = nullptr;
     int Cout = 0, Cin = 0, KH = 1, KW = 1;
-    float* wino_u = nullptr;  // device [16][Cout][Cin] = G g G^T (wide 3x3 layers only)
+    float* wino_u2 = nullptr;  // device [16][Cout][Cin] = G g G^T of F(2x2,3x3)  (3x3 layers with Cin,Cout >= 256)
+    float* wino_u4 = nullptr;  // device [36][Cout][Cin]              F(4x4,3x3)  (3x3 layers with Cin,Cout >= 128)
 };
 struct ResW {
     ConvW b1, b2, res;
@@ -75,10 +76,12 @@ struct WinoPlan {
     WinoParams in, out;
     ConvParams gemm;
 };
-inline WinoPlan make_wino(const ConvParams& d, const float* U, float* V, float* Mb) {
+inline WinoPlan make_wino(const ConvParams& d, const float* U, float* V, float* Mb, int tile) {
     WinoPlan w;
     const int Ctot = d.C0 + d.C1;
-    const int TH = d.Ho / 2, TW = d.Wo / 2, T = d.B * TH * TW;
+    const int TH = d.Ho / tile, TW = d.Wo / tile, T = d.B * TH * TW;
+    const int ncomp = (tile + 2) * (tile + 2);
+    w.in.tile = tile;
     w.in.in0 = d.in0; w.in.in1 = d.in1; w.in.C0 = d.C0; w.in.C1 = d.C1; w.in.Hin = d.Hin; w.in.Win = d.Win;
     w.in.in_shift = d.in_shift; w.in.B = d.B; w.in.TH = TH; w.in.TW = TW; w.in.T = T; w.in.V = V;
     w.out = w.in;
@@ -89,11 +92,11 @@ inline WinoPlan make_wino(const ConvParams& d, const float* U, float* V, float* 
     g.in0 = V; g.C0 = Ctot; g.pix0 = Ctot; g.Hin = 1; g.Win = T; g.w = U; g.Cout = d.Cout;
     g.KH = g.KW = 1; g.stride = 1; g.pad_y = g.pad_x = 0; g.B = 1; g.Ho = 1; g.Wo = T;
     g.out = Mb; g.out_stride = d.Cout; g.zeros = d.zeros;
-    g.nz = 16; g.z_in = (long long)T * Ctot; g.z_w = (long long)d.Cout * Ctot; g.z_out = (long long)T * d.Cout;
+    g.nz = ncomp; g.z_in = (long long)T * Ctot; g.z_w = (long long)d.Cout * Ctot; g.z_out = (long long)T * d.Cout;
     return w;
 }
-inline bool wino_shape_ok(const ConvParams& d) {
-    return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.Ho % 2 == 0 && d.Wo % 2 == 0 &&
+inline bool wino_shape_ok(const ConvParams& d, int tile) {
+    return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.Ho % tile == 0 && d.Wo % tile == 0 &&
            (d.C0 + d.C1) % 32 == 0 && d.Cout % 4 == 0 && d.out_stride % 4 == 0 && (!d.res || d.res_stride % 4 == 0);
 }
 
@@ -302,10 +305,14 @@ ConvW pack_conv(irsde_engine* e, const std::string& wname, const std::string& bn
     c.w = e->upload(p);
     c.Cout = O; c.Cin = I; c.KH = KH; c.KW = KW;
     if (!bname.empty()) c.bias = e->upload(need(e, bname).data);
-    if (KH == 3 && KW == 3 && I >= kWinoMinC && O >= kWinoMinC && I % 32 == 0 && !(e->cfg.flags & IRSDE_FLAG_NO_WINOGRAD)) {
-        std::vector<float> U((size_t)16 * O * I);
-        wino_transform_weights(p.data(), O, I, U.data());
-        c.wino_u = e->upload(U);
+    if (KH == 3 && KW == 3 && I % 32 == 0 && !(e->cfg.flags & IRSDE_FLAG_NO_WINOGRAD)) {
+        for (int tile : {2, 4}) {
+            if (tile == 4 && (e->cfg.flags & IRSDE_FLAG_NO_WINOGRAD_F43)) continue;
+            if (I < wino_min_c(tile) || O < wino_min_c(tile)) continue;
+            std::vector<float> U((size_t)(tile + 2) * (tile + 2) * O * I);
+            wino_transform_weights(p.data(), O, I, U.data(), tile);
+            (tile == 4 ? c.wino_u4 : c.wino_u2) = e->upload(U);
+        }
     }
     return c;
 }
@@ -534,22 +541,26 @@ struct Builder {
         p.film = film; p.film_bstride = film ? film_bstride : 0;
         p.silu = silu;
         if (res) { p.res = res->p; p.res_stride = res->C; }
-        if (w.wino_u && !naive && wino_shape_ok(p) && push_wino(p, w.wino_u)) return out;
+        if (!naive) {  // prefer F(4x4,3x3), then F(2x2,3x3), then the direct implicit GEMM
+            if (w.wino_u4 && wino_shape_ok(p, 4) && push_wino(p, w.wino_u4, 4)) return out;
+            if (w.wino_u2 && wino_shape_ok(p, 2) && push_wino(p, w.wino_u2, 2)) return out;
+        }
         push_conv(p);
         return out;
     }
 
     // Winograd F(2x2,3x3): input transform -> 16 batched GEMMs on the MFMA kernel -> output transform + epilogue
-    bool push_wino(const ConvParams& d, const float* U) {
+    bool push_wino(const ConvParams& d, const float* U, int tile) {
         const int Ctot = d.C0 + d.C1;
-        const long long T = (long long)d.B * (d.Ho / 2) * (d.Wo / 2);
-        const long long gemm_blocks = 16 * ((T + 127) / 128) * ((d.Cout + 127) / 128);
-        if (gemm_blocks < 256 || T * Ctot * 16 > (1ll << 31) * 4) return false;  // tiny layers: direct conv + split-K
+        const int ncomp = (tile + 2) * (tile + 2);
+        const long long T = (long long)d.B * (d.Ho / tile) * (d.Wo / tile);
+        const long long gemm_blocks = ncomp * ((T + 127) / 128) * ((d.Cout + 127) / 128);
+        if (gemm_blocks < 256) return false;  // tiny layers: direct conv + split-K
         ConvParams dd = d;
         dd.zeros = e->zeros;
-        float* V = pl->alloc((size_t)16 * T * Ctot, true);
-        float* Mb = pl->alloc((size_t)16 * T * d.Cout, true);
-        const WinoPlan wp = make_wino(dd, U, V, Mb);
+        float* V = pl->alloc((size_t)ncomp * T * Ctot, true);
+        float* Mb = pl->alloc((size_t)ncomp * T * d.Cout, true);
+        const WinoPlan wp = make_wino(dd, U, V, Mb, tile);
         const double direct = conv_flops(d);
         {
             Op op;
@@ -563,15 +574,15 @@ struct Builder {
             Op op;
             op.kind = OP_CONV;
             op.flops = direct;
-            op.exec_flops = 16.0 * 2.0 * (double)T * Ctot * d.Cout;
+            op.exec_flops = ncomp * 2.0 * (double)T * Ctot * d.Cout;
             const double in_bytes = 4.0 * (double)d.B * d.Hin * d.Win * Ctot;
             op.bytes = in_bytes + 4.0 * (double)d.B * d.Ho * d.Wo * d.Cout + 4.0 * 9.0 * (double)d.Cout * Ctot;
             pl->conv_flops += op.flops;
             pl->conv_exec_flops += op.exec_flops;
             pl->conv_bytes += op.bytes;
             char buf[256];
-            snprintf(buf, sizeof buf, "conv(winograd gemm x16) T=%lld Cout=%d Cin=%d flops=%.4g exec=%.4g", T, d.Cout, Ctot,
-                     op.flops, op.exec_flops);
+            snprintf(buf, sizeof buf, "conv(winograd F%d gemm x%d) T=%lld Cout=%d Cin=%d flops=%.4g exec=%.4g", tile, ncomp, T,
+                     d.Cout, Ctot, op.flops, op.exec_flops);
             op.desc = buf;
             const ConvParams g = wp.gemm;
             op.fn = [g](hipStream_t s) { launch_conv(g, s); };
@@ -1203,22 +1214,23 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
         IRSDE_HIP_CHECK(hipMalloc(&dz, 1024));
         IRSDE_HIP_CHECK(hipMemset(dz, 0, 1024));
         p.zeros = dz;
-        if (splits > 1 && naive != 1 && naive != 2) {
+        if (splits > 1 && naive != 1 && naive != 2 && naive != 3) {
             p.splits = splits;
             IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
             p.partial = dp;
         }
-        if (naive == 2) {
-            if (!wino_shape_ok(p)) throw HipError("debug_conv: shape not eligible for Winograd");
-            std::vector<float> U((size_t)16 * Cout * Cin);
-            wino_transform_weights(pk.data(), Cout, Cin, U.data());
-            const long long T = (long long)B * (p.Ho / 2) * (p.Wo / 2);
+        if (naive == 2 || naive == 3) {
+            const int tile = naive == 3 ? 4 : 2, ncomp = (tile + 2) * (tile + 2);
+            if (!wino_shape_ok(p, tile)) throw HipError("debug_conv: shape not eligible for Winograd");
+            std::vector<float> U((size_t)ncomp * Cout * Cin);
+            wino_transform_weights(pk.data(), Cout, Cin, U.data(), tile);
+            const long long T = (long long)B * (p.Ho / tile) * (p.Wo / tile);
             float *dU = nullptr, *dV = nullptr, *dM = nullptr;
             IRSDE_HIP_CHECK(hipMalloc(&dU, U.size() * 4));
             IRSDE_HIP_CHECK(hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice));
-            IRSDE_HIP_CHECK(hipMalloc(&dV, (size_t)16 * T * Cin * 4));
-            IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)16 * T * Cout * 4));
-            const WinoPlan wp = make_wino(p, dU, dV, dM);
+            IRSDE_HIP_CHECK(hipMalloc(&dV, (size_t)ncomp * T * Cin * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)ncomp * T * Cout * 4));
+            const WinoPlan wp = make_wino(p, dU, dV, dM, tile);
             launch_wino_input(wp.in, s);
             launch_conv(wp.gemm, s);
             launch_wino_output(wp.out, s);

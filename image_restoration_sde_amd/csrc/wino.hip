@@ -1,23 +1,66 @@
-// Winograd F(2x2, 3x3) for the wide 3x3 stride-1 convolutions (Cin, Cout >= 256) of the score network.
+// Winograd F(m x m, 3x3), m = 2 (default) or 4 (opt-in), for the wide 3x3 stride-1 convolutions of the score network.
 //   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A         (Lavin & Gray, "Fast Algorithms for Convolutional Neural
-//                                                        Networks", CVPR 2016; 2.25x fewer multiplies, fp32 throughout)
+//                                                        Networks", CVPR 2016; fp32 throughout)
+//   m = 2: 16 products per 4 outputs  (2.25x fewer multiplies than direct), V/M tensors 4x    the input/output size
+//   m = 4: 36 products per 16 outputs (4x    fewer multiplies),             V/M tensors 2.25x the input/output size,
+//          ~15-30x the rounding error of the direct kernel (1e-5 instead of 5e-7 relative per layer)
 // Three launches per convolution:
-//   wino_input_kernel   V[k][tile][c]  = (B^T d B)_k   of every 4x4 input patch (stride 2), both concat sources and
-//                                         the fused nearest-x2 upsample are gathered here           (HBM bound)
-//   conv_igemm_kernel   M[k][tile][n]  = sum_c V[k][tile][c] * U[k][n][c], 16 independent GEMMs (blockIdx.z = k) on the
-//                                         fp32 MFMA pipe — the same kernel as the direct path, run as a 1x1 conv
-//   wino_output_kernel  y = A^T M A (2x2 pixels per tile) + bias / FiLM / SiLU / residual            (HBM bound)
+//   wino_input_kernel   V[k][tile][c]  = (B^T d B)_k   of every (m+2)x(m+2) input patch (stride m); both concat sources
+//                                         and the fused nearest-x2 upsample are gathered here          (HBM bound)
+//   conv_igemm_kernel   M[k][tile][n]  = sum_c V[k][tile][c] * U[k][n][c], (m+2)^2 independent GEMMs (blockIdx.z = k) on
+//                                         the fp32 MFMA pipe — the same kernel as the direct path, run as a 1x1 conv
+//   wino_output_kernel  y = A^T M A (m x m pixels per tile) + bias / FiLM / SiLU / residual            (HBM bound)
 // U = G g G^T is computed once at weight-load time (engine.hip).
 #include "common.h"
 
 namespace irsde {
 namespace {
 
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 __device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }
 
+// one application of B^T (input side) / A^T (output side) along one axis
+template <int TILE>
+__device__ __forceinline__ void bt_apply(const float4* d, float4* t);
+template <>
+__device__ __forceinline__ void bt_apply<2>(const float4* d, float4* t) {  // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    t[0] = d[0] - d[2];
+    t[1] = d[1] + d[2];
+    t[2] = d[2] - d[1];
+    t[3] = d[1] - d[3];
+}
+template <>
+__device__ __forceinline__ void bt_apply<4>(const float4* d, float4* t) {
+    // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+    t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+    t[1] = (d[3] + d[4]) - 4.0f * (d[1] + d[2]);
+    t[2] = 4.0f * (d[1] - d[2]) + (d[4] - d[3]);
+    t[3] = 2.0f * (d[3] - d[1]) + (d[4] - d[2]);
+    t[4] = 2.0f * (d[1] - d[3]) + (d[4] - d[2]);
+    t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+}
+template <int TILE>
+__device__ __forceinline__ void at_apply(const float4* m, float4* y);
+template <>
+__device__ __forceinline__ void at_apply<2>(const float4* m, float4* y) {  // A^T = [1 1 1 0; 0 1 -1 -1]
+    y[0] = m[0] + m[1] + m[2];
+    y[1] = m[1] - m[2] - m[3];
+}
+template <>
+__device__ __forceinline__ void at_apply<4>(const float4* m, float4* y) {
+    // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+    const float4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = m[0] + s12 + s34;
+    y[1] = d12 + 2.0f * d34;
+    y[2] = s12 + 4.0f * s34;
+    y[3] = d12 + 8.0f * d34 + m[5];
+}
+
+template <int TILE>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
+    constexpr int A = TILE + 2;
     const int C4 = (p.C0 + p.C1) >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)p.T * C4;
@@ -37,41 +80,47 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
         src = p.in1 + (c - p.C0); pix = p.C1;
     }
     const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
-    float4 d[4][4];
+    float4 w[A][A];  // after the row pass: w[r][s] = (B^T d)[r][s]
+    {
+        float4 d[A][A];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int iy = 2 * ty - 1 + r;
+        for (int r = 0; r < A; ++r) {
+            const int iy = TILE * ty - 1 + r;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ix = 2 * tx - 1 + s;
-            const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-            const size_t pixel = (size_t)b * p.Hin * p.Win + (size_t)((ok ? iy : 0) >> p.in_shift) * p.Win + ((ok ? ix : 0) >> p.in_shift);
-            const float4 v = *reinterpret_cast<const float4*>(src + pixel * pix);
-            d[r][s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < A; ++s) {
+                const int ix = TILE * tx - 1 + s;
+                const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                const size_t pixel = (size_t)b * p.Hin * p.Win + (size_t)((ok ? iy : 0) >> p.in_shift) * p.Win +
+                                     ((ok ? ix : 0) >> p.in_shift);
+                const float4 v = *reinterpret_cast<const float4*>(src + pixel * pix);
+                d[r][s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
-    }
-    // B^T d  (rows), then (.) B (columns);  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-    float4 w[4][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        w[0][s] = f4sub(d[0][s], d[2][s]);
-        w[1][s] = f4add(d[1][s], d[2][s]);
-        w[2][s] = f4sub(d[2][s], d[1][s]);
-        w[3][s] = f4sub(d[1][s], d[3][s]);
+        for (int s = 0; s < A; ++s) {
+            float4 col[A], tc[A];
+#pragma unroll
+            for (int r = 0; r < A; ++r) col[r] = d[r][s];
+            bt_apply<TILE>(col, tc);
+#pragma unroll
+            for (int r = 0; r < A; ++r) w[r][s] = tc[r];
+        }
     }
     const size_t Ctot = (size_t)(p.C0 + p.C1);
     float* vp = p.V + (size_t)t * Ctot + c;
     const size_t kstride = (size_t)p.T * Ctot;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        *reinterpret_cast<float4*>(vp + (size_t)(r * 4 + 0) * kstride) = f4sub(w[r][0], w[r][2]);
-        *reinterpret_cast<float4*>(vp + (size_t)(r * 4 + 1) * kstride) = f4add(w[r][1], w[r][2]);
-        *reinterpret_cast<float4*>(vp + (size_t)(r * 4 + 2) * kstride) = f4sub(w[r][2], w[r][1]);
-        *reinterpret_cast<float4*>(vp + (size_t)(r * 4 + 3) * kstride) = f4sub(w[r][1], w[r][3]);
+    for (int r = 0; r < A; ++r) {
+        float4 o[A];
+        bt_apply<TILE>(w[r], o);
+#pragma unroll
+        for (int s = 0; s < A; ++s) *reinterpret_cast<float4*>(vp + (size_t)(r * A + s) * kstride) = o[s];
     }
 }
 
+template <int TILE>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
+    constexpr int A = TILE + 2;
     const int N4 = p.Cout >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)p.T * N4;
@@ -85,23 +134,22 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
     const int n = ng * 4;
     const float* mp = p.M + (size_t)t * p.Cout + n;
     const size_t kstride = (size_t)p.T * p.Cout;
-    float4 m[4][4];
+    float4 u[TILE][A];  // u = A^T m (row pass)
+    {
+        float4 m[A][A];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < A; ++r)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) m[r][s] = *reinterpret_cast<const float4*>(mp + (size_t)(r * 4 + s) * kstride);
-    // A^T m (rows), then (.) A;  A^T = [1 1 1 0; 0 1 -1 -1]
-    float4 u[2][4];
+            for (int s = 0; s < A; ++s) m[r][s] = *reinterpret_cast<const float4*>(mp + (size_t)(r * A + s) * kstride);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        u[0][s] = f4add(f4add(m[0][s], m[1][s]), m[2][s]);
-        u[1][s] = f4sub(f4sub(m[1][s], m[2][s]), m[3][s]);
-    }
-    float4 y[2][2];
+        for (int s = 0; s < A; ++s) {
+            float4 col[A], yc[TILE];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        y[i][0] = f4add(f4add(u[i][0], u[i][1]), u[i][2]);
-        y[i][1] = f4sub(f4sub(u[i][1], u[i][2]), u[i][3]);
+            for (int r = 0; r < A; ++r) col[r] = m[r][s];
+            at_apply<TILE>(col, yc);
+#pragma unroll
+            for (int i = 0; i < TILE; ++i) u[i][s] = yc[i];
+        }
     }
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bias;
     if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
@@ -111,13 +159,15 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
         sc = make_float4(s4.x + 1.0f, s4.y + 1.0f, s4.z + 1.0f, s4.w + 1.0f);
         sh = *reinterpret_cast<const float4*>(f + p.Cout + n);
     }
-    const int Ho = 2 * p.TH, Wo = 2 * p.TW;
+    const int Ho = TILE * p.TH, Wo = TILE * p.TW;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TILE; ++i) {
+        float4 y[TILE];
+        at_apply<TILE>(u[i], y);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const size_t pixel = ((size_t)b * Ho + 2 * ty + i) * Wo + 2 * tx + j;
-            float v[4] = {y[i][j].x + bias.x, y[i][j].y + bias.y, y[i][j].z + bias.z, y[i][j].w + bias.w};
+        for (int j = 0; j < TILE; ++j) {
+            const size_t pixel = ((size_t)b * Ho + TILE * ty + i) * Wo + TILE * tx + j;
+            float v[4] = {y[j].x + bias.x, y[j].y + bias.y, y[j].z + bias.z, y[j].w + bias.w};
             if (p.film) {
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
             }
@@ -130,38 +180,52 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
             }
             *reinterpret_cast<float4*>(p.out + pixel * p.out_stride + n) = make_float4(v[0], v[1], v[2], v[3]);
         }
+    }
 }
 
 }  // namespace
 
 void launch_wino_input(const WinoParams& p, hipStream_t s) {
     const long long total = (long long)p.T * ((p.C0 + p.C1) >> 2);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (p.tile == 4)
+        hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, s, p);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
 void launch_wino_output(const WinoParams& p, hipStream_t s) {
     const long long total = (long long)p.T * (p.Cout >> 2);
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (p.tile == 4)
+        hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, s, p);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-// U[k][n][c] = (G g G^T)_k with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1];  g given as [Cout][3][3][Cin] (packed layout)
-void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U) {
-    static const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+// U[k][n][c] = (G g G^T)_k;  g given as [Cout][3][3][Cin] (packed layout); tile = 2 or 4 (host, at weight load)
+void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U, int tile) {
+    static const float G2[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    static const float G4[6][3] = {{1.f / 4, 0.f, 0.f},          {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                                   {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    const int A = tile + 2;
+    const float(*G)[3] = tile == 4 ? G4 : G2;
     const size_t kstride = (size_t)Cout * Cin;
     for (int n = 0; n < Cout; ++n)
         for (int c = 0; c < Cin; ++c) {
-            float g[3][3];
+            double g[3][3];
             for (int ky = 0; ky < 3; ++ky)
                 for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w_packed[(((size_t)n * 3 + ky) * 3 + kx) * Cin + c];
-            float tmp[4][3];
-            for (int r = 0; r < 4; ++r)
-                for (int kx = 0; kx < 3; ++kx) tmp[r][kx] = G[r][0] * g[0][kx] + G[r][1] * g[1][kx] + G[r][2] * g[2][kx];
-            for (int r = 0; r < 4; ++r)
-                for (int s = 0; s < 4; ++s)
-                    U[(size_t)(r * 4 + s) * kstride + (size_t)n * Cin + c] =
-                        tmp[r][0] * G[s][0] + tmp[r][1] * G[s][1] + tmp[r][2] * G[s][2];
+            double tmp[6][3];
+            for (int r = 0; r < A; ++r)
+                for (int kx = 0; kx < 3; ++kx)
+                    tmp[r][kx] = (double)G[r][0] * g[0][kx] + (double)G[r][1] * g[1][kx] + (double)G[r][2] * g[2][kx];
+            for (int r = 0; r < A; ++r)
+                for (int s = 0; s < A; ++s)
+                    U[(size_t)(r * A + s) * kstride + (size_t)n * Cin + c] =
+                        (float)(tmp[r][0] * G[s][0] + tmp[r][1] * G[s][1] + tmp[r][2] * G[s][2]);
         }
 }
 

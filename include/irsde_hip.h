@@ -39,7 +39,9 @@ enum { IRSDE_MODE_SDE = 0, IRSDE_MODE_ODE = 1, IRSDE_MODE_POSTERIOR = 2 };
 enum {
     IRSDE_FLAG_KEEP_ACTIVATIONS = 1, /* never recycle activation buffers: enables irsde_debug_tap */
     IRSDE_FLAG_NAIVE_CONV = 2,       /* debug: run every convolution on the naive VALU kernel */
-    IRSDE_FLAG_NO_WINOGRAD = 4       /* run the wide 3x3 layers as direct implicit GEMMs instead of Winograd F(2x2,3x3) */
+    IRSDE_FLAG_NO_WINOGRAD = 4,      /* run every 3x3 layer as a direct implicit GEMM (no Winograd) */
+    IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
+                                        channels up where H, W are multiples of 4 */
 };
 /* per-call flags (irsde_sample) */
 enum {
@@ -147,7 +149,7 @@ int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buf
 /* Kernel-level test hook: one implicit-GEMM convolution (csrc/conv_igemm.hip) on NHWC device tensors.
  * in0/in1: [B][Hin][Win][C0|C1] (channel concat, in1 may be NULL); w_oihw/bias: HOST, reference layout;
  * film: device [rows][2*Cout] or NULL; res/out: device [B][Ho][Wo][Cout].  naive != 0 runs the VALU
- * cross-check kernel, naive == 2 the Winograd F(2x2,3x3) path (3x3 s1 p1 only), naive >= 100 an experimental
+ * cross-check kernel, naive == 2 / 3 the Winograd F(2x2,3x3) / F(4x4,3x3) path (3x3 s1 p1 only), naive >= 100 an experimental
  * tile variant; splits > 1 forces split-K.  Synchronises `stream`. */
 int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int in_shift,
                      const float* w_oihw, int Cout, int KH, int KW, int stride, int pad, const float* bias,
