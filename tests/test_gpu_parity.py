@@ -218,6 +218,14 @@ def test_winograd_vs_direct_network():
     buf = _c.create_string_buffer(1 << 18)
     _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, B, H, W, buf, len(buf)))
     assert b"winograd F4" in buf.value  # the production plan really takes the Winograd path at this size
+    # a Rain100H-like odd size (reflect-padded to 176x160): the deepest level is 22x20 -> F(4x4) does not tile it and the
+    # plan falls back to F(2x2,3x3) there
+    B, H, W = 8, 170, 150
+    lq, xT = O.synth_inputs(8, B, H, W)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    assert relerr(m(x, c, 61).cpu().numpy(), md(x, c, 61).cpu().numpy()) < 2e-5
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, B, H, W, buf, len(buf)))
+    assert b"winograd F2" in buf.value and b"winograd F4" in buf.value
     del md
 
 
