@@ -206,6 +206,56 @@ def gen_sampler(sde_utils, ConditionalUNet, big=True):
     print("sampler.npz")
 
 
+def gen_nafnet(sde_utils):
+    """ConditionalNAFNet (Refusion) forward + sampler goldens from the real reference."""
+    from models.modules.DenoisingNAFNet_arch import ConditionalNAFNet
+    Inj = InjectedIRSDE.make(sde_utils)
+    out = {}
+    cases = {
+        # tag: (cfg, B, H, W, ts)
+        "refusion_1x64x64": (dict(width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1]), 1, 64, 64, [1, 60]),
+        "refusion_2x40x56": (dict(width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1]), 2, 40, 56, [37]),
+        "w32_e12_2x24x20": (dict(width=32, enc_blk_nums=[1, 2], middle_blk_num=1, dec_blk_nums=[1, 1]), 2, 24, 20, [3, 77]),
+    }
+    nets = {}
+    for tag, (cfg, B, H, W, ts) in cases.items():
+        params = O.naf_synth_params(seed=0, img_channel=3, width=cfg["width"], middle_blk_num=cfg["middle_blk_num"],
+                                    enc_blk_nums=tuple(cfg["enc_blk_nums"]), dec_blk_nums=tuple(cfg["dec_blk_nums"]))
+        net = ConditionalNAFNet(img_channel=3, **cfg).eval()
+        sd = net.state_dict()
+        assert set(sd) == set(params), set(sd) ^ set(params)
+        for k in sd:
+            assert tuple(sd[k].shape) == params[k].shape, (k, sd[k].shape, params[k].shape)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        nets[tag] = (net, cfg)
+        lq, xT = O.synth_inputs(1234, B, H, W, max_sigma=50)
+        out[tag + "/shape"] = np.array([B, H, W], dtype=np.int64)
+        out[tag + "/ts"] = np.array(ts, dtype=np.int64)
+        for t in ts:
+            with torch.no_grad():
+                y = net(torch.from_numpy(xT), torch.from_numpy(lq), t).numpy()
+            out[tag + "/t%d" % t] = y
+            print(tag, t, float(np.abs(y).max()))
+    # samplers (refusion.yml: max_sigma 50, T 100, cosine, eps 0.005; deraining test.py default mode posterior)
+    for tag, (B, H, W, T) in {"w32_e12_2x24x20": (2, 24, 20, 20), "refusion_1x64x64": (1, 32, 32, 100)}.items():
+        net, cfg = nets[tag]
+        lq, xT = O.synth_inputs(1234, B, H, W, max_sigma=50)
+        z = O.synth_noise(7, T, (B, 3, H, W))
+        sde = Inj(max_sigma=50, T=T, schedule="cosine", eps=0.005, device="cpu")
+        sde.noise = torch.from_numpy(z)
+        sde.set_model(net)
+        sde.set_mu(torch.from_numpy(lq))
+        key = "%s/sampler_%dx%dx%d_T%d" % (tag, B, H, W, T)
+        for mode in ("sde", "posterior"):
+            with torch.no_grad():
+                fn = {"sde": sde.reverse_sde, "posterior": sde.reverse_posterior}[mode]
+                y = fn(torch.from_numpy(xT)).numpy()
+            out[key + "/" + mode] = y
+            print(key, mode, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(GOLD, "nafnet.npz"), **out)
+    print("nafnet.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -224,6 +274,8 @@ def main():
         gen_steps(sde_utils)
     if a.only in ("", "sampler"):
         gen_sampler(sde_utils, ConditionalUNet, big=not a.no_big)
+    if a.only in ("", "nafnet"):
+        gen_nafnet(sde_utils)
 
 
 if __name__ == "__main__":

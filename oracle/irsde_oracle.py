@@ -464,3 +464,170 @@ def device_normal(seed, t, image_index, n_elems):
     a1 = 2.0 * math.pi * u[:, 3]
     z = np.stack([rad0 * np.cos(a0), rad0 * np.sin(a0), rad1 * np.cos(a1), rad1 * np.sin(a1)], axis=1)
     return z.reshape(-1)[:n_elems]
+
+
+# --------------------------------------------------------------------------------------
+# ConditionalNAFNet (Refusion) — codes/config/deraining/models/modules/DenoisingNAFNet_arch.py
+# --------------------------------------------------------------------------------------
+
+
+def naf_param_shapes(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28), dec_blk_nums=(1, 1, 1, 1)):
+    """Names/shapes of ConditionalNAFNet's state_dict — DenoisingNAFNet_arch.py:85-147 (NAFBlock :15-49)."""
+    sh = {}
+    td = width * 4
+    sh["time_mlp.1.weight"] = (td * 2, width)
+    sh["time_mlp.1.bias"] = (td * 2,)
+    sh["time_mlp.3.weight"] = (td, td)
+    sh["time_mlp.3.bias"] = (td,)
+    sh["intro.weight"] = (width, img_channel * 2, 3, 3)
+    sh["intro.bias"] = (width,)
+    sh["ending.weight"] = (img_channel, width, 3, 3)
+    sh["ending.bias"] = (img_channel,)
+
+    def block(p, c):
+        sh[p + "mlp.1.weight"] = (4 * c, td // 2)
+        sh[p + "mlp.1.bias"] = (4 * c,)
+        sh[p + "conv1.weight"] = (2 * c, c, 1, 1)
+        sh[p + "conv1.bias"] = (2 * c,)
+        sh[p + "conv2.weight"] = (2 * c, 1, 3, 3)
+        sh[p + "conv2.bias"] = (2 * c,)
+        sh[p + "conv3.weight"] = (c, c, 1, 1)
+        sh[p + "conv3.bias"] = (c,)
+        sh[p + "sca.1.weight"] = (c, c, 1, 1)
+        sh[p + "sca.1.bias"] = (c,)
+        sh[p + "conv4.weight"] = (2 * c, c, 1, 1)
+        sh[p + "conv4.bias"] = (2 * c,)
+        sh[p + "conv5.weight"] = (c, c, 1, 1)
+        sh[p + "conv5.bias"] = (c,)
+        sh[p + "norm1.g"] = (1, c, 1, 1)
+        sh[p + "norm2.g"] = (1, c, 1, 1)
+        sh[p + "beta"] = (1, c, 1, 1)
+        sh[p + "gamma"] = (1, c, 1, 1)
+
+    chan = width
+    for i, num in enumerate(enc_blk_nums):
+        for j in range(num):
+            block("encoders.%d.%d." % (i, j), chan)
+        sh["downs.%d.weight" % i] = (2 * chan, chan, 2, 2)
+        sh["downs.%d.bias" % i] = (2 * chan,)
+        chan *= 2
+    for j in range(middle_blk_num):
+        block("middle_blks.%d." % j, chan)
+    for i, num in enumerate(dec_blk_nums):
+        sh["ups.%d.0.weight" % i] = (chan * 2, chan, 1, 1)
+        chan //= 2
+        for j in range(num):
+            block("decoders.%d.%d." % (i, j), chan)
+    return sh
+
+
+def naf_synth_params(seed=0, **cfg):
+    """Deterministic synthetic NAFNet weights.  beta/gamma (zero-initialised in the reference, which would make every
+    block the identity) ~ U(-0.5, 0.5); LayerNorm gains ~ U(0.5, 1.5); conv/linear ~ U(+-1/sqrt(fan_in))."""
+    rs = np.random.RandomState(seed)
+    shapes = naf_param_shapes(**cfg)
+    out = {}
+    for name in sorted(shapes):
+        shp = shapes[name]
+        if name.endswith(".g"):
+            a = rs.uniform(0.5, 1.5, size=shp)
+        elif name.endswith("beta") or name.endswith("gamma"):
+            a = rs.uniform(-0.5, 0.5, size=shp)
+        else:
+            wshape = shapes[name[:-4] + "weight"] if name.endswith("bias") else shp
+            bound = 1.0 / math.sqrt(int(np.prod(wshape[1:])))
+            a = rs.uniform(-bound, bound, size=shp)
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def _dwconv3x3(x, w, b):
+    """Depthwise 3x3, pad 1 (nn.Conv2d(groups=C)) — DenoisingNAFNet_arch.py:24-25."""
+    B, C, H, W = x.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    out = np.zeros_like(x)
+    for ky in range(3):
+        for kx in range(3):
+            out += xp[:, :, ky:ky + H, kx:kx + W] * w[:, 0, ky, kx].reshape(1, C, 1, 1)
+    return out + b.reshape(1, C, 1, 1)
+
+
+def _simple_gate(x):
+    c = x.shape[1] // 2
+    return x[:, :c] * x[:, c:]
+
+
+def naf_block(p, pre, x, temb):
+    """NAFBlock.forward — DenoisingNAFNet_arch.py:56-82."""
+    half = temb.shape[1] // 2
+    tt = linear(temb[:, :half] * temb[:, half:], p[pre + "mlp.1.weight"], p[pre + "mlp.1.bias"])[:, :, None, None]
+    c = x.shape[1]
+    shift_att, scale_att, shift_ffn, scale_ffn = (tt[:, i * c:(i + 1) * c] for i in range(4))
+    inp = x
+    x = layer_norm_c(inp, p[pre + "norm1.g"])
+    x = x * (scale_att + 1) + shift_att
+    x = conv2d(x, p[pre + "conv1.weight"], p[pre + "conv1.bias"])
+    x = _dwconv3x3(x, p[pre + "conv2.weight"], p[pre + "conv2.bias"])
+    x = _simple_gate(x)
+    pooled = x.mean(axis=(2, 3), keepdims=True)
+    x = x * conv2d(pooled, p[pre + "sca.1.weight"], p[pre + "sca.1.bias"])
+    x = conv2d(x, p[pre + "conv3.weight"], p[pre + "conv3.bias"])
+    y = inp + x * p[pre + "beta"]
+    x = layer_norm_c(y, p[pre + "norm2.g"])
+    x = x * (scale_ffn + 1) + shift_ffn
+    x = conv2d(x, p[pre + "conv4.weight"], p[pre + "conv4.bias"])
+    x = _simple_gate(x)
+    x = conv2d(x, p[pre + "conv5.weight"], p[pre + "conv5.bias"])
+    return y + x * p[pre + "gamma"]
+
+
+def _pixel_shuffle2(x):
+    B, C, H, W = x.shape
+    x = x.reshape(B, C // 4, 2, 2, H, W).transpose(0, 1, 4, 2, 5, 3)
+    return np.ascontiguousarray(x.reshape(B, C // 4, 2 * H, 2 * W))
+
+
+def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_num=1, dec_blk_nums=(1, 1, 1, 1),
+                   dtype=np.float64, taps=None):
+    """ConditionalNAFNet.forward — DenoisingNAFNet_arch.py:149-187."""
+    p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
+    xt = np.asarray(xt, dtype=dtype)
+    cond = np.asarray(cond, dtype=dtype)
+    if np.isscalar(t):
+        t = np.array([int(t)])
+    x = np.concatenate([xt - cond, cond], axis=1)
+    width = p["intro.weight"].shape[0]
+    temb = sinusoidal_pos_emb(t, width, dtype)
+    temb = linear(temb, p["time_mlp.1.weight"], p["time_mlp.1.bias"])
+    h2 = temb.shape[1] // 2
+    temb = linear(temb[:, :h2] * temb[:, h2:], p["time_mlp.3.weight"], p["time_mlp.3.bias"])
+    B, C, H, W = x.shape
+    ps = 2 ** len(enc_blk_nums)
+    x = np.pad(x, ((0, 0), (0, 0), (0, (ps - H % ps) % ps), (0, (ps - W % ps) % ps)))  # zero pad (:189-194)
+    x = conv2d(x, p["intro.weight"], p["intro.bias"], pad=1)
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+
+    tap("intro", x)
+    encs = []
+    for i, num in enumerate(enc_blk_nums):
+        for j in range(num):
+            x = naf_block(p, "encoders.%d.%d." % (i, j), x, temb)
+        tap("encoders.%d" % i, x)
+        encs.append(x)
+        x = conv2d(x, p["downs.%d.weight" % i], p["downs.%d.bias" % i], stride=2, pad=0)
+        tap("downs.%d" % i, x)
+    for j in range(middle_blk_num):
+        x = naf_block(p, "middle_blks.%d." % j, x, temb)
+    tap("middle", x)
+    for i, num in enumerate(dec_blk_nums):
+        x = _pixel_shuffle2(conv2d(x, p["ups.%d.0.weight" % i]))
+        x = x + encs[len(encs) - 1 - i]
+        tap("ups.%d" % i, x)
+        for j in range(num):
+            x = naf_block(p, "decoders.%d.%d." % (i, j), x, temb)
+        tap("decoders.%d" % i, x)
+    x = conv2d(x, p["ending.weight"], p["ending.bias"], pad=1)
+    return np.ascontiguousarray(x[..., :H, :W])

@@ -163,3 +163,22 @@ def test_torch_cpu_port_sampler_steps(golden):
     y = TP.reverse_sde_steps(params, sch, torch.from_numpy(xT), torch.from_numpy(lq), z, T, T, depth).numpy()
     ref = g[tag + "/sde"]
     assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-3
+
+
+NAF_CFGS = {"refusion": dict(width=64, enc_blk_nums=(1, 1, 1, 28), middle_blk_num=1, dec_blk_nums=(1, 1, 1, 1)),
+            "w32_e12": dict(width=32, enc_blk_nums=(1, 2), middle_blk_num=1, dec_blk_nums=(1, 1))}
+
+
+@pytest.mark.parametrize("tag", ["w32_e12_2x24x20", "refusion_2x40x56"])
+def test_nafnet_forward(golden, tag):
+    """ConditionalNAFNet (Refusion) oracle vs the real reference (zero-pad path included)."""
+    g = golden.nafnet
+    cfg = NAF_CFGS["refusion" if tag.startswith("refusion") else "w32_e12"]
+    B, H, W = (int(v) for v in g[tag + "/shape"])
+    params = O.naf_synth_params(seed=0, img_channel=3, **cfg)
+    assert len(O.naf_param_shapes(3, **NAF_CFGS["refusion"])) == 668
+    lq, xT = O.synth_inputs(1234, B, H, W, max_sigma=50)
+    for t in g[tag + "/ts"]:
+        y = O.nafnet_forward(params, xT, lq, int(t), cfg["enc_blk_nums"], cfg["middle_blk_num"], cfg["dec_blk_nums"])
+        ref = g[tag + "/t%d" % t]
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-5, (tag, t)
