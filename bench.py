@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--mode", default="sde", choices=["sde", "ode", "posterior"])
+    ap.add_argument("--model", default="unet", choices=["unet", "nafnet"],
+                    help="unet: IR-SDE ConditionalUNet (BASELINE configs[1]); nafnet: Refusion ConditionalNAFNet (configs[3])")
+    ap.add_argument("--max-sigma", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="time graph replay instead of the event-instrumented loop")
     a = ap.parse_args()
@@ -91,12 +94,19 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    nf, depth = 64, 4
-    params = O.synth_params(seed=0, nf=nf, depth=depth)
-    model = P.ConditionalUNet(3, 3, nf, depth=depth)
+    if a.model == "nafnet":  # refusion.yml network_G
+        ncfg = dict(width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+        params = O.naf_synth_params(seed=0, img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28),
+                                    dec_blk_nums=(1, 1, 1, 1))
+        model = P.ConditionalNAFNet(img_channel=3, **ncfg)
+    else:
+        nf, depth = 64, 4
+        params = O.synth_params(seed=0, nf=nf, depth=depth)
+        model = P.ConditionalUNet(3, 3, nf, depth=depth)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(dev).eval()
-    sde = P.IRSDE(max_sigma=10, T=a.T, schedule="cosine", eps=0.005, device=dev)
+    max_sigma = a.max_sigma if a.max_sigma is not None else (50 if a.model == "nafnet" else 10)
+    sde = P.IRSDE(max_sigma=max_sigma, T=a.T, schedule="cosine", eps=0.005, device=dev)
     sde.set_model(model)
     sde.seed = 7
     sde.profile = not a.no_profile
@@ -154,8 +164,10 @@ def main():
             "value": imgs / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "IR-SDE deraining ConditionalUNet nf=64 depth=4, reverse_%s, batch=%d/GPU %dx%d, "
-                                   "T=%d, fp32 (BASELINE.json configs[1])" % (a.mode, a.batch, a.size, a.size, a.T),
+            "config": {"workload": ("Refusion ConditionalNAFNet width=64 enc[1,1,1,28], reverse_%s, batch=%d/GPU %dx%d, T=%d, fp32 "
+                                    "(BASELINE.json configs[3] network)" if a.model == "nafnet" else
+                                    "IR-SDE deraining ConditionalUNet nf=64 depth=4, reverse_%s, batch=%d/GPU %dx%d, "
+                                    "T=%d, fp32 (BASELINE.json configs[1])") % (a.mode, a.batch, a.size, a.size, a.T),
                        "global_batch": nglobal, "parallelism": "batch-shard x%d (no collective in the T loop; final all_gather)" % world},
         }
         if sde.profile and prof["conv_ms"] > 0:
@@ -191,7 +203,7 @@ def main():
                 "hbm_frac": prof["conv_bytes"] / (prof["wall_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                 "whole_path_TFLOPs": prof["conv_flops"] / (prof["wall_ms"] * 1e-3) / 1e12,
             }
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and a.model == "unet":
             try:
                 res["cpu_baseline"] = cpu_baseline(a.size, a.T)
             except Exception as ex:  # the GPU number must not be lost to a host-side problem

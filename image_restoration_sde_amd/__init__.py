@@ -4,6 +4,7 @@ csrc/ -> libirsde_hip.so) with the reference's own Python interface on top:
 
     IRSDE              codes/utils/sde_utils.py:80-361
     ConditionalUNet    codes/config/deraining/models/modules/DenoisingUNet_arch.py:18-134
+    ConditionalNAFNet  codes/config/deraining/models/modules/DenoisingNAFNet_arch.py:85-187 (Refusion)
     DenoisingModel     codes/config/deraining/models/denoising_model.py (inference surface)
 """
 from ._lib import IrsdeError, IrsdeLibraryError, build_library  # noqa: F401
@@ -11,6 +12,7 @@ from .denoising_model import DenoisingModel, create_model, define_G  # noqa: F40
 from .dist import gather_batch, sample_sharded, shard_bounds  # noqa: F401
 from .sde import IRSDE  # noqa: F401
 from .unet import ConditionalUNet  # noqa: F401
+from .nafnet import ConditionalNAFNet  # noqa: F401
 
-__all__ = ["IRSDE", "ConditionalUNet", "DenoisingModel", "create_model", "define_G", "build_library",
+__all__ = ["IRSDE", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
            "IrsdeError", "IrsdeLibraryError", "shard_bounds", "gather_batch", "sample_sharded"]

@@ -23,7 +23,7 @@ SAMPLE_PROFILE = 2
 
 # every symbol include/irsde_hip.h declares (checked by tests/test_cabi.py)
 SYMBOLS = [
-    "irsde_last_error", "irsde_version", "irsde_create", "irsde_destroy", "irsde_num_weights",
+    "irsde_last_error", "irsde_version", "irsde_create", "irsde_create_nafnet", "irsde_destroy", "irsde_num_weights",
     "irsde_weight_name", "irsde_weight_shape", "irsde_load_weight", "irsde_finalize_weights",
     "irsde_set_schedule", "irsde_unet_forward", "irsde_sample", "irsde_sde_step", "irsde_philox_normal",
     "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv", "irsde_plan_describe", "irsde_bench_conv", "irsde_op_profile",
@@ -41,6 +41,12 @@ class IrsdeError(RuntimeError):
 class Config(ctypes.Structure):
     _fields_ = [("in_nc", ctypes.c_int32), ("out_nc", ctypes.c_int32), ("nf", ctypes.c_int32),
                 ("depth", ctypes.c_int32), ("device", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class NafConfig(ctypes.Structure):
+    _fields_ = [("img_channel", ctypes.c_int32), ("width", ctypes.c_int32), ("middle_blk_num", ctypes.c_int32),
+                ("n_enc", ctypes.c_int32), ("enc_blk_nums", ctypes.c_int32 * 8), ("n_dec", ctypes.c_int32),
+                ("dec_blk_nums", ctypes.c_int32 * 8), ("device", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 _lib = None
@@ -66,6 +72,7 @@ def _declare(lib):
     lib.irsde_last_error.argtypes = []
     lib.irsde_version.restype = c.c_int
     lib.irsde_create.argtypes = [c.POINTER(Config), c.POINTER(P)]
+    lib.irsde_create_nafnet.argtypes = [c.POINTER(NafConfig), c.POINTER(P)]
     lib.irsde_destroy.argtypes = [P]
     lib.irsde_destroy.restype = None
     lib.irsde_num_weights.argtypes = [P]

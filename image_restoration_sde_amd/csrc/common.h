@@ -54,6 +54,13 @@ struct ConvParams {
     int splits = 1;
     float* partial = nullptr;
     const float* zeros = nullptr;  // >= 16 zero bytes (source of out-of-image taps for LDS-DMA staging)
+    // --- NAFNet (Refusion) fusions -------------------------------------------------------------------------
+    const float* ch_scale = nullptr;  // [Cout]: v *= ch_scale[n] after the activation, before +res  (beta / gamma)
+    const float* in_scale = nullptr;  // [B][C0]: input element (b, k) is multiplied by in_scale[b][k] while staged (SCA)
+    int gate = 0;      // SimpleGate epilogue: weight rows are interleaved (2j <- j, 2j+1 <- j + Cout/2); writes the Cout/2
+                       // products out[m][j] = v[2j] * v[2j+1]  (out_stride counts the gated width)
+    int shuffle = 0;   // PixelShuffle(2) epilogue: weight rows ordered n' = (dy*2+dx)*Cout/4 + co; writes (and adds res at)
+                       // out[b][2y+dy][2x+dx][co]  (out/res tensors are [B][2Ho][2Wo][Cout/4])
     // batched launch (Winograd: 16 independent GEMMs): blockIdx.z = k offsets the three tensors (floats)
     int nz = 1;
     long long z_in = 0, z_w = 0, z_out = 0;
@@ -96,6 +103,19 @@ void launch_conv_naive(const ConvParams& p, hipStream_t s);
 // Channel LayerNorm over C per pixel (gain only, eps inside rsqrt), optional residual add.
 void launch_layernorm(const float* x, const float* g, const float* res, float* out, int64_t M, int C,
                       float eps, hipStream_t s);
+// NAFNet: y = LN(x) * g * (scale + 1) + shift with per-channel FiLM rows (row stride film_bstride per batch item, 0 = shared)
+void launch_layernorm_film(const float* x, const float* g, const float* scale, const float* shift, int film_bstride,
+                           int64_t pixels_per_image, float* out, int64_t M, int C, float eps, hipStream_t s);
+// NAFNet: depthwise 3x3 (pad 1, bias) over u [B][H][W][2c] fused with SimpleGate -> out [B][H][W][c], plus per-tile
+// channel sums partial[b][tile][c] (deterministic two-stage global average pool).  w: [9][2c], bias: [2c].
+int dwgate_tiles(int HW);
+void launch_dwconv_gate(const float* u, const float* w, const float* bias, float* out, float* partial, int B, int H, int W,
+                        int c, hipStream_t s);
+// NAFNet SCA: s[b][o] = bias[o] + sum_k W[o][k] * mean_hw(gated)[b][k]
+void launch_sca(const float* partial, int ntiles, const float* W, const float* bias, float* s_out, int B, int c, int HW,
+                hipStream_t s);
+// out[r][j] = in[r][j] * in[r][j + h]  (SimpleGate on time-embedding rows)
+void launch_row_gate(const float* in, float* out, int rows, int h, hipStream_t s);
 
 struct AttnWorkspace {
     float* pmax = nullptr;   // [B][nch][128]
@@ -111,7 +131,7 @@ void launch_linear_attention(const float* qkv, float* out, int B, int N, const A
 // xt, cond: NCHW [B][3][H][W].  x0: [B][Hp+6][Wp+6][8] (+8 floats slack), zero border of 3,
 // channels {xt-cond (3), cond (3), 0, 0}, reflect-padded right/bottom from (H,W) to (Hp,Wp).
 void launch_prep_input(const float* xt, const float* cond, float* x0, int B, int in_nc, int H, int W, int Hp, int Wp,
-                       hipStream_t s);
+                       hipStream_t s, int reflect = 1);
 
 // FiLM / time-embedding path.
 //   temb0[r][i] = sin/cos(t_r * freq[i])          (SinusoidalPosEmb)

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     const int row0 = tid / C::CHUNKS;
     // logical 16-B chunk of the K slice this lane fetches (DMA: inverse of the read-side swizzle)
     const int cchunk = DMA ? (chunk ^ ((row0 >> 1) & 7)) : chunk;
-    int a_iy0[C::A_PASSES], a_ix0[C::A_PASSES], a_pix[C::A_PASSES];
+    int a_iy0[C::A_PASSES], a_ix0[C::A_PASSES], a_pix[C::A_PASSES], a_b[C::A_PASSES];
 #pragma unroll
     for (int ps = 0; ps < C::A_PASSES; ++ps) {
         const int m = m0 + row0 + ps * C::ROWS;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         a_iy0[ps] = ok ? oy * p.stride - p.pad_y : -(1 << 28);
         a_ix0[ps] = ox * p.stride - p.pad_x;
         a_pix[ps] = b * p.Hin * p.Win;
+        a_b[ps] = b;
     }
     const float* wrow[C::B_PASSES];
     bool b_ok[C::B_PASSES];
@@ -226,7 +227,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     auto load_piece = [&](int q) {
         if (q < C::A_PASSES) {
             const bool ok = a_poff[q] >= 0;  // branch-free: out-of-image taps read pixel 0 and are zeroed
-            const float4 v = *reinterpret_cast<const float4*>(cur_src + (size_t)(ok ? a_poff[q] : 0) * cur_pix);
+            float4 v = *reinterpret_cast<const float4*>(cur_src + (size_t)(ok ? a_poff[q] : 0) * cur_pix);
+            if (p.in_scale) {  // per-(batch, input channel) scale applied while staging (NAFNet SCA), single source
+                const float4 sc4 = *reinterpret_cast<const float4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + cchunk * 4);
+                v.x *= sc4.x; v.y *= sc4.y; v.z *= sc4.z; v.w *= sc4.w;
+            }
             rs[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
             const int ps = q - C::A_PASSES;
@@ -486,26 +491,48 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
                         sh[e] = f[p.Cout + n + e];
                     }
             }
-            float rr[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.res) {
-                const float* rp = p.res + (size_t)m * p.res_stride + n;
-                if (n + 3 < p.Cout && (p.res_stride & 3) == 0) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(rp);
-                    rr[0] = t4.x; rr[1] = t4.y; rr[2] = t4.z; rr[3] = t4.w;
-                } else {
+            // output addressing: plain [m][n], gated [m][n/2], or pixel-shuffled [b][2y+dy][2x+dx][co]
+            size_t opix = (size_t)m;
+            int ocol = n;
+            if (p.shuffle) {
+                const int Cq = p.Cout >> 2;
+                const int q = n / Cq;
+                const int ox = m % p.Wo, t1 = m / p.Wo, oy = t1 % p.Ho, ob = t1 / p.Ho;
+                opix = ((size_t)ob * 2 * p.Ho + 2 * oy + (q >> 1)) * (2 * p.Wo) + 2 * ox + (q & 1);
+                ocol = n - q * Cq;
+            } else if (p.gate) {
+                ocol = n >> 1;
+            }
+            float cs[4] = {1.f, 1.f, 1.f, 1.f};
+            if (p.ch_scale) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.Cout) rr[e] = rp[e];
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.Cout) cs[e] = p.ch_scale[n + e];
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float t = v[e] + bias[e];
                 if (p.film) t = t * sc[e] + sh[e];
                 if (p.silu) t = silu_f(t);
-                v[e] = t + rr[e];
+                v[e] = t * cs[e];
             }
-            float* dst = p.out + (size_t)m * p.out_stride + n;
+            if (p.gate) {  // SimpleGate: pairs are adjacent by construction of the packed weights
+                float* dst = p.out + opix * p.out_stride + ocol;
+                *reinterpret_cast<float2*>(dst) = make_float2(v[0] * v[1], v[2] * v[3]);
+                continue;
+            }
+            if (p.res) {
+                const float* rp = p.res + opix * p.res_stride + ocol;
+                if (n + 3 < p.Cout && (p.res_stride & 3) == 0) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(rp);
+                    v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Cout) v[e] += rp[e];
+                }
+            }
+            float* dst = p.out + opix * p.out_stride + ocol;
             if (vec_ok) {
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -533,6 +560,7 @@ __global__ void conv_splitk_reduce(const ConvParams p, const int M) {
         v = v * (f[n] + 1.0f) + f[p.Cout + n];
     }
     if (p.silu) v = silu_f(v);
+    if (p.ch_scale) v *= p.ch_scale[n];
     if (p.res) v += p.res[(size_t)m * p.res_stride + n];
     p.out[(size_t)m * p.out_stride + n] = v;
 }

@@ -61,6 +61,18 @@ struct AttnW {
     int C = 0;
 };
 
+// NAFBlock weights (DenoisingNAFNet_arch.py:15-49) in kernel layout
+struct NafBlockW {
+    int c = 0;
+    float *g1 = nullptr, *g2 = nullptr;          // norm1.g / norm2.g
+    ConvW conv1, conv3, conv4, conv5;            // 1x1: c->2c, c->c, c->2c (rows interleaved for the gate), c->c
+    float *dw_w = nullptr, *dw_b = nullptr;      // conv2 depthwise 3x3: [9][2c], [2c]
+    float *sca_w = nullptr, *sca_b = nullptr;    // sca.1: [c][c], [c]
+    float *beta = nullptr, *gamma = nullptr;
+    float *mlp_w = nullptr, *mlp_b = nullptr;    // mlp.1: Linear(time_dim/2, 4c)
+    int film_off = 0;                            // [shift_att | scale_att | shift_ffn | scale_ffn]
+};
+
 enum OpKind { OP_CONV = 0, OP_LN = 1, OP_ATTN = 2, OP_OTHER = 3, OP_WINO = 4, OP_NKINDS = 5 };
 
 struct Op {
@@ -185,6 +197,16 @@ struct irsde_engine {
     std::vector<ResW*> all_res;
     int film_row = 0;
 
+    // ConditionalNAFNet (arch == 1)
+    int arch = 0;
+    std::vector<int> naf_enc_nums, naf_dec_nums;
+    int naf_mid_num = 0;
+    std::vector<std::vector<NafBlockW>> naf_enc, naf_dec;
+    std::vector<NafBlockW> naf_mid;
+    std::vector<ConvW> naf_downs, naf_ups;
+    ConvW naf_intro, naf_ending;
+    std::vector<NafBlockW*> naf_all;
+
     // schedule / FiLM tables
     int T = 0;
     float* coef_table = nullptr;  // [(T+1)][12]
@@ -225,6 +247,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // Weight inventory (DenoisingUNet_arch.py:19-76; names = reference state_dict keys)
 // ---------------------------------------------------------------------------------------------
+void finalize_common(irsde_engine* e);
 void add_w(irsde_engine* e, const std::string& name, std::vector<int64_t> shape) {
     e->names.push_back(name);
     HostTensor t;
@@ -357,10 +380,184 @@ AttnW pack_attn(irsde_engine* e, const std::string& p) {
     return a;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ConditionalNAFNet (Refusion): inventory, packing — DenoisingNAFNet_arch.py:85-147
+// ---------------------------------------------------------------------------------------------
+void inv_nafblock(irsde_engine* e, const std::string& p, int c) {
+    const int td = e->time_dim;
+    add_w(e, p + "mlp.1.weight", {4 * c, td / 2});
+    add_w(e, p + "mlp.1.bias", {4 * c});
+    add_w(e, p + "conv1.weight", {2 * c, c, 1, 1});
+    add_w(e, p + "conv1.bias", {2 * c});
+    add_w(e, p + "conv2.weight", {2 * c, 1, 3, 3});
+    add_w(e, p + "conv2.bias", {2 * c});
+    add_w(e, p + "conv3.weight", {c, c, 1, 1});
+    add_w(e, p + "conv3.bias", {c});
+    add_w(e, p + "sca.1.weight", {c, c, 1, 1});
+    add_w(e, p + "sca.1.bias", {c});
+    add_w(e, p + "conv4.weight", {2 * c, c, 1, 1});
+    add_w(e, p + "conv4.bias", {2 * c});
+    add_w(e, p + "conv5.weight", {c, c, 1, 1});
+    add_w(e, p + "conv5.bias", {c});
+    add_w(e, p + "norm1.g", {1, c, 1, 1});
+    add_w(e, p + "norm2.g", {1, c, 1, 1});
+    add_w(e, p + "beta", {1, c, 1, 1});
+    add_w(e, p + "gamma", {1, c, 1, 1});
+}
+void build_inventory_naf(irsde_engine* e) {
+    const int width = e->cfg.nf, ic = e->cfg.in_nc, td = e->time_dim;
+    add_w(e, "time_mlp.1.weight", {td * 2, width});
+    add_w(e, "time_mlp.1.bias", {td * 2});
+    add_w(e, "time_mlp.3.weight", {td, td});
+    add_w(e, "time_mlp.3.bias", {td});
+    add_w(e, "intro.weight", {width, 2 * ic, 3, 3});
+    add_w(e, "intro.bias", {width});
+    add_w(e, "ending.weight", {ic, width, 3, 3});
+    add_w(e, "ending.bias", {ic});
+    int chan = width;
+    for (size_t i = 0; i < e->naf_enc_nums.size(); ++i) {
+        for (int j = 0; j < e->naf_enc_nums[i]; ++j)
+            inv_nafblock(e, "encoders." + std::to_string(i) + "." + std::to_string(j) + ".", chan);
+        add_w(e, "downs." + std::to_string(i) + ".weight", {2 * chan, chan, 2, 2});
+        add_w(e, "downs." + std::to_string(i) + ".bias", {2 * chan});
+        chan *= 2;
+    }
+    for (int j = 0; j < e->naf_mid_num; ++j) inv_nafblock(e, "middle_blks." + std::to_string(j) + ".", chan);
+    for (size_t i = 0; i < e->naf_dec_nums.size(); ++i) {
+        add_w(e, "ups." + std::to_string(i) + ".0.weight", {chan * 2, chan, 1, 1});
+        chan /= 2;
+        for (int j = 0; j < e->naf_dec_nums[i]; ++j)
+            inv_nafblock(e, "decoders." + std::to_string(i) + "." + std::to_string(j) + ".", chan);
+    }
+}
+
+// 1x1 / KxK conv with an output-row permutation: packed row n' = original row perm[n']
+ConvW pack_conv_perm(irsde_engine* e, const std::string& wname, const std::string& bname, const std::vector<int>& perm) {
+    const HostTensor& t = need(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1], KH = (int)t.shape[2], KW = (int)t.shape[3];
+    std::vector<float> p((size_t)O * KH * KW * I);
+    for (int o = 0; o < O; ++o) {
+        const int so = perm.empty() ? o : perm[o];
+        for (int i = 0; i < I; ++i)
+            for (int ky = 0; ky < KH; ++ky)
+                for (int kx = 0; kx < KW; ++kx)
+                    p[(((size_t)o * KH + ky) * KW + kx) * I + i] = t.data[(((size_t)so * I + i) * KH + ky) * KW + kx];
+    }
+    ConvW c;
+    c.w = e->upload(p);
+    c.Cout = O; c.Cin = I; c.KH = KH; c.KW = KW;
+    if (!bname.empty()) {
+        const HostTensor& b = need(e, bname);
+        std::vector<float> pb(O);
+        for (int o = 0; o < O; ++o) pb[o] = b.data[perm.empty() ? o : perm[o]];
+        c.bias = e->upload(pb);
+    }
+    return c;
+}
+
+NafBlockW pack_nafblock(irsde_engine* e, const std::string& p, int c) {
+    NafBlockW b;
+    b.c = c;
+    b.g1 = e->upload(need(e, p + "norm1.g").data);
+    b.g2 = e->upload(need(e, p + "norm2.g").data);
+    b.conv1 = pack_conv_perm(e, p + "conv1.weight", p + "conv1.bias", {});
+    b.conv3 = pack_conv_perm(e, p + "conv3.weight", p + "conv3.bias", {});
+    std::vector<int> gate_perm(2 * c);  // SimpleGate pairs (j, j + c) made adjacent: 2j <- j, 2j+1 <- j + c
+    for (int j = 0; j < c; ++j) {
+        gate_perm[2 * j] = j;
+        gate_perm[2 * j + 1] = j + c;
+    }
+    b.conv4 = pack_conv_perm(e, p + "conv4.weight", p + "conv4.bias", gate_perm);
+    b.conv5 = pack_conv_perm(e, p + "conv5.weight", p + "conv5.bias", {});
+    {
+        const HostTensor& t = need(e, p + "conv2.weight");  // [2c][1][3][3] -> [9][2c]
+        std::vector<float> w((size_t)9 * 2 * c);
+        for (int ch = 0; ch < 2 * c; ++ch)
+            for (int k = 0; k < 9; ++k) w[(size_t)k * 2 * c + ch] = t.data[(size_t)ch * 9 + k];
+        b.dw_w = e->upload(w);
+        b.dw_b = e->upload(need(e, p + "conv2.bias").data);
+    }
+    b.sca_w = e->upload(need(e, p + "sca.1.weight").data);
+    b.sca_b = e->upload(need(e, p + "sca.1.bias").data);
+    b.beta = e->upload(need(e, p + "beta").data);
+    b.gamma = e->upload(need(e, p + "gamma").data);
+    b.mlp_w = e->upload(need(e, p + "mlp.1.weight").data);
+    b.mlp_b = e->upload(need(e, p + "mlp.1.bias").data);
+    return b;
+}
+
+void finalize_naf(irsde_engine* e) {
+    const int width = e->cfg.nf, ic = e->cfg.in_nc;
+    e->tm_w1 = e->upload(need(e, "time_mlp.1.weight").data);
+    e->tm_b1 = e->upload(need(e, "time_mlp.1.bias").data);
+    e->tm_w3 = e->upload(need(e, "time_mlp.3.weight").data);
+    e->tm_b3 = e->upload(need(e, "time_mlp.3.bias").data);
+    {
+        const int half = width / 2;
+        std::vector<float> f(half);
+        const double emb = std::log(10000.0) / (half - 1);
+        for (int i = 0; i < half; ++i) f[i] = expf((float)i * (float)(-emb));
+        e->freqs = e->upload(f);
+    }
+    {   // intro 3x3 (2*ic -> width, bias) as a 3-tap (ky) conv over rows of 3 pixels x P channels (+ zero K padding)
+        const HostTensor& t = need(e, "intro.weight");
+        const int O = (int)t.shape[0], I = (int)t.shape[1];
+        const int P = (I + 3) & ~3;
+        const int CK = (3 * P + 31) & ~31;
+        std::vector<float> p((size_t)O * 3 * CK, 0.f);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx)
+                        p[((size_t)o * 3 + ky) * CK + kx * P + i] = t.data[(((size_t)o * I + i) * 3 + ky) * 3 + kx];
+        e->naf_intro.w = e->upload(p);
+        e->naf_intro.Cout = O; e->naf_intro.Cin = CK; e->naf_intro.KH = 3; e->naf_intro.KW = 1;
+        e->naf_intro.bias = e->upload(need(e, "intro.bias").data);
+    }
+    e->naf_ending = pack_conv_perm(e, "ending.weight", "ending.bias", {});
+    (void)ic;
+    int chan = width;
+    e->naf_enc.resize(e->naf_enc_nums.size());
+    for (size_t i = 0; i < e->naf_enc_nums.size(); ++i) {
+        for (int j = 0; j < e->naf_enc_nums[i]; ++j)
+            e->naf_enc[i].push_back(pack_nafblock(e, "encoders." + std::to_string(i) + "." + std::to_string(j) + ".", chan));
+        e->naf_downs.push_back(pack_conv_perm(e, "downs." + std::to_string(i) + ".weight", "downs." + std::to_string(i) + ".bias", {}));
+        chan *= 2;
+    }
+    for (int j = 0; j < e->naf_mid_num; ++j) e->naf_mid.push_back(pack_nafblock(e, "middle_blks." + std::to_string(j) + ".", chan));
+    e->naf_dec.resize(e->naf_dec_nums.size());
+    for (size_t i = 0; i < e->naf_dec_nums.size(); ++i) {
+        // ups.i.0: 1x1 chan -> 2 chan, then PixelShuffle(2): row n' = q * Cq + co  <-  co * 4 + q
+        const int Cq = chan / 2;
+        std::vector<int> perm(2 * chan);
+        for (int q = 0; q < 4; ++q)
+            for (int co = 0; co < Cq; ++co) perm[q * Cq + co] = co * 4 + q;
+        e->naf_ups.push_back(pack_conv_perm(e, "ups." + std::to_string(i) + ".0.weight", "", perm));
+        chan /= 2;
+        for (int j = 0; j < e->naf_dec_nums[i]; ++j)
+            e->naf_dec[i].push_back(pack_nafblock(e, "decoders." + std::to_string(i) + "." + std::to_string(j) + ".", chan));
+    }
+    e->naf_all.clear();
+    for (auto& v : e->naf_enc) for (auto& b : v) e->naf_all.push_back(&b);
+    for (auto& b : e->naf_mid) e->naf_all.push_back(&b);
+    for (auto& v : e->naf_dec) for (auto& b : v) e->naf_all.push_back(&b);
+    int off = 0;
+    for (NafBlockW* b : e->naf_all) {
+        b->film_off = off;
+        off += 4 * b->c;
+    }
+    e->film_row = off;
+}
+
 void finalize(irsde_engine* e) {
     IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
     for (auto& n : e->names)
         if (!e->host[n].loaded) throw HipError("missing weight: " + n);
+    if (e->arch == 1) {
+        finalize_naf(e);
+        finalize_common(e);
+        return;
+    }
     const int depth = e->cfg.depth;
     e->init_conv = pack_init_conv(e);
     e->tm_w1 = e->upload(need(e, "time_mlp.1.weight").data);
@@ -412,7 +609,10 @@ void finalize(irsde_engine* e) {
         off += 2 * r->Cout;
     }
     e->film_row = off;
+    finalize_common(e);
+}
 
+void finalize_common(irsde_engine* e) {
     conv_global_init();
     e->zeros = e->dmalloc(256);
     IRSDE_HIP_CHECK(hipMemset(e->zeros, 0, 1024));
@@ -438,11 +638,29 @@ void compute_film_rows(irsde_engine* e, const float* tvals, int rows, float* dst
     IRSDE_HIP_CHECK(hipMalloc(&h1, (size_t)rows * td * 4));
     IRSDE_HIP_CHECK(hipMalloc(&h2, (size_t)rows * td * 4));
     launch_sinusoid(tvals, e->freqs, emb, rows, nf / 2, s);
+    if (e->arch == 1) {
+        // time_mlp: Linear(width, 2*td) -> SimpleGate -> Linear(td, td); block mlp: SimpleGate -> Linear(td/2, 4c)
+        // (DenoisingNAFNet_arch.py:93-98, 18-20)
+        float *w1 = nullptr, *g1 = nullptr, *g2 = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&w1, (size_t)rows * 2 * td * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&g1, (size_t)rows * td * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&g2, (size_t)rows * (td / 2) * 4));
+        launch_row_linear(emb, nf, e->tm_w1, e->tm_b1, w1, 2 * td, rows, nf, 2 * td, ACT_NONE, ACT_NONE, s);
+        launch_row_gate(w1, g1, rows, td, s);
+        launch_row_linear(g1, td, e->tm_w3, e->tm_b3, h2, td, rows, td, td, ACT_NONE, ACT_NONE, s);
+        launch_row_gate(h2, g2, rows, td / 2, s);
+        for (NafBlockW* b : e->naf_all)
+            launch_row_linear(g2, td / 2, b->mlp_w, b->mlp_b, dst + b->film_off, e->film_row, rows, td / 2, 4 * b->c,
+                              ACT_NONE, ACT_NONE, s);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(w1); (void)hipFree(g1); (void)hipFree(g2);
+    } else {
     launch_row_linear(emb, nf, e->tm_w1, e->tm_b1, h1, td, rows, nf, td, ACT_NONE, ACT_GELU, s);
     launch_row_linear(h1, td, e->tm_w3, e->tm_b3, h2, td, rows, td, td, ACT_NONE, ACT_NONE, s);
     for (ResW* r : e->all_res)
         launch_row_linear(h2, td, r->mlp_w, r->mlp_b, dst + r->film_off, e->film_row, rows, td, 2 * r->Cout, ACT_SILU,
                           ACT_NONE, s);
+    }
     IRSDE_HIP_CHECK(hipStreamSynchronize(s));
     (void)hipFree(emb);
     (void)hipFree(h1);
@@ -485,7 +703,7 @@ struct Builder {
         const int blocks = ((M + 127) / 128) * ((p.Cout + bn - 1) / bn);
         const int nk = p.KH * p.KW * ((p.C0 + p.C1) / 32);
         int splits = 1;
-        if (!naive && blocks < 256 && nk >= 16) {
+        if (!naive && blocks < 256 && nk >= 16 && !p.gate && !p.shuffle) {
             splits = std::min(std::min(nk / 8, (512 + blocks - 1) / blocks), 16);
             if (splits < 2) splits = 1;
         }
@@ -601,6 +819,91 @@ struct Builder {
         return true;
     }
 
+    struct ConvOpts {
+        int stride = 1, pad = 0;
+        const Tensor* res = nullptr;
+        const float* ch_scale = nullptr;
+        const float* in_scale = nullptr;
+        int gate = 0, shuffle = 0, out_stride = 0;
+    };
+    // 1x1 / KxK conv with the NAFNet fusions (bias from the ConvW; no FiLM / SiLU in NAFNet convs)
+    Tensor conv_naf(const ConvW& w, const Tensor& in, const ConvOpts& o) {
+        ConvParams p;
+        p.in0 = in.p; p.C0 = in.C; p.pix0 = in.C;
+        if (in.C != w.Cin) throw HipError("conv_naf: channel mismatch");
+        p.Hin = in.H; p.Win = in.W;
+        p.w = w.w; p.Cout = w.Cout; p.KH = w.KH; p.KW = w.KW; p.stride = o.stride; p.pad_y = o.pad; p.pad_x = o.pad;
+        p.B = in.B;
+        p.Ho = (in.H + 2 * o.pad - w.KH) / o.stride + 1;
+        p.Wo = (in.W + 2 * o.pad - w.KW) / o.stride + 1;
+        Tensor out;
+        if (o.shuffle)
+            out = talloc(p.B, 2 * p.Ho, 2 * p.Wo, w.Cout / 4);
+        else if (o.gate)
+            out = talloc(p.B, p.Ho, p.Wo, w.Cout / 2);
+        else
+            out = talloc(p.B, p.Ho, p.Wo, o.out_stride ? o.out_stride : w.Cout);
+        p.out = out.p; p.out_stride = out.C;
+        p.bias = w.bias;
+        p.ch_scale = o.ch_scale; p.in_scale = o.in_scale; p.gate = o.gate; p.shuffle = o.shuffle;
+        if (o.res) { p.res = o.res->p; p.res_stride = o.res->C; }
+        push_conv(p);
+        return out;
+    }
+
+    // NAFBlock.forward — DenoisingNAFNet_arch.py:56-82
+    Tensor nafblock(const NafBlockW& w, const Tensor& x) {
+        const int64_t M = (int64_t)x.B * x.H * x.W;
+        const int64_t ppi = (int64_t)x.H * x.W;
+        const int c = w.c;
+        const float* film = e->film_cur + w.film_off;  // [shift_att | scale_att | shift_ffn | scale_ffn]
+        const int fb = film_bstride;
+        Tensor t1 = talloc(x.B, x.H, x.W, c);
+        {
+            const float *xp = x.p, *g = w.g1;
+            float* o = t1.p;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm_film(xp, g, film + c, film, fb, ppi, o, M, c, 1e-5f, s); });
+        }
+        Tensor u = conv_naf(w.conv1, t1, ConvOpts());
+        tfree(t1);
+        Tensor gt = talloc(x.B, x.H, x.W, c);
+        const int nt = dwgate_tiles(x.H * x.W);
+        float* partial = pl->alloc((size_t)x.B * nt * c, true);
+        float* sca = pl->alloc((size_t)x.B * c, true);
+        {
+            const float *up = u.p, *dw = w.dw_w, *db = w.dw_b, *sw = w.sca_w, *sb = w.sca_b;
+            float* gp = gt.p;
+            const int B = x.B, H = x.H, W = x.W;
+            push_other(OP_OTHER, [=](hipStream_t s) {
+                launch_dwconv_gate(up, dw, db, gp, partial, B, H, W, c, s);
+                launch_sca(partial, nt, sw, sb, sca, B, c, H * W, s);
+            });
+        }
+        tfree(u);
+        ConvOpts o3;
+        o3.in_scale = sca; o3.ch_scale = w.beta; o3.res = &x;
+        Tensor y = conv_naf(w.conv3, gt, o3);
+        tfree(gt);
+        pl->release(partial);
+        pl->release(sca);
+        Tensor t2 = talloc(x.B, x.H, x.W, c);
+        {
+            const float *yp = y.p, *g = w.g2;
+            float* o = t2.p;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm_film(yp, g, film + 3 * c, film + 2 * c, fb, ppi, o, M, c, 1e-5f, s); });
+        }
+        ConvOpts o4;
+        o4.gate = 1;
+        Tensor v = conv_naf(w.conv4, t2, o4);
+        tfree(t2);
+        ConvOpts o5;
+        o5.ch_scale = w.gamma; o5.res = &y;
+        Tensor out = conv_naf(w.conv5, v, o5);
+        tfree(v);
+        tfree(y);
+        return out;
+    }
+
     // ResBlock.forward — module_util.py:136-146
     Tensor resblock(const ResW& w, const Tensor& in0, const Tensor* in1) {
         Tensor R;
@@ -664,6 +967,68 @@ struct Builder {
     }
 };
 
+// ConditionalNAFNet.forward — DenoisingNAFNet_arch.py:149-187
+void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
+    const int B = pl->B;
+    Tensor x;
+    {   // intro 3x3 (+bias) as 3 row taps over the zero-bordered NHWC input (border 3: first tap row/col = +2)
+        ConvParams p;
+        p.in0 = pl->x0; p.C0 = e->naf_intro.Cin; p.pix0 = P;
+        p.Hin = pl->Hp + 6; p.Win = pl->Wp + 6;
+        p.w = e->naf_intro.w; p.Cout = e->naf_intro.Cout; p.KH = 3; p.KW = 1; p.stride = 1; p.pad_y = -2; p.pad_x = -2;
+        p.B = B; p.Ho = pl->Hp; p.Wo = pl->Wp;
+        p.bias = e->naf_intro.bias;
+        x = b.talloc(B, pl->Hp, pl->Wp, p.Cout);
+        p.out = x.p; p.out_stride = p.Cout;
+        b.push_conv(p);
+        const double real = 2.0 * (double)B * pl->Hp * pl->Wp * p.Cout * 9.0 * (2.0 * e->cfg.in_nc);
+        pl->conv_flops += real - pl->net_ops.back().flops;
+        pl->net_ops.back().flops = real;
+    }
+    b.tap("intro", x);
+    std::vector<Tensor> encs;
+    for (size_t i = 0; i < e->naf_enc.size(); ++i) {
+        for (auto& blk : e->naf_enc[i]) {
+            Tensor y = b.nafblock(blk, x);
+            b.tfree(x);
+            x = y;
+        }
+        b.tap("encoders." + std::to_string(i), x);
+        encs.push_back(x);
+        Builder::ConvOpts od;
+        od.stride = 2;
+        x = b.conv_naf(e->naf_downs[i], x, od);  // Conv2d(chan, 2 chan, 2, 2)
+        b.tap("downs." + std::to_string(i), x);
+    }
+    for (auto& blk : e->naf_mid) {
+        Tensor y = b.nafblock(blk, x);
+        b.tfree(x);
+        x = y;
+    }
+    b.tap("middle", x);
+    for (size_t i = 0; i < e->naf_dec.size(); ++i) {
+        Tensor skip = encs[encs.size() - 1 - i];
+        Builder::ConvOpts ou;
+        ou.shuffle = 1; ou.res = &skip;  // Conv2d(chan, 2 chan, 1) -> PixelShuffle(2) -> + enc_skip
+        Tensor y = b.conv_naf(e->naf_ups[i], x, ou);
+        b.tfree(x);
+        b.tfree(skip);
+        x = y;
+        b.tap("ups." + std::to_string(i), x);
+        for (auto& blk : e->naf_dec[i]) {
+            Tensor z = b.nafblock(blk, x);
+            b.tfree(x);
+            x = z;
+        }
+        b.tap("decoders." + std::to_string(i), x);
+    }
+    Builder::ConvOpts oe;
+    oe.pad = 1; oe.out_stride = 4;
+    Tensor pr = b.conv_naf(e->naf_ending, x, oe);
+    b.tfree(x);
+    pl->pred = pr.p;
+}
+
 Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
     for (auto& p : e->plans)
         if (p->B == B && p->H == H && p->W == W && p->per_sample_film == per_sample_film) {
@@ -689,7 +1054,7 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
     pl->per_sample_film = per_sample_film;
     pl->last_use = ++e->use_counter;
     // F.pad 'reflect' needs pad < dim (DenoisingUNet_arch.py:82)
-    if (pl->Hp - H >= H || pl->Wp - W >= W) throw HipError("image too small for reflect padding");
+    if (e->arch != 1 && (pl->Hp - H >= H || pl->Wp - W >= W)) throw HipError("image too small for reflect padding");
 
     const size_t img = (size_t)B * in_nc * H * W;
     pl->xin = pl->alloc(img, false);
@@ -705,7 +1070,13 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
         const float *xi = pl->xin, *ci = pl->cin;
         float* x0 = pl->x0;
         const int Hp = pl->Hp, Wp = pl->Wp;
-        b.push_other(OP_OTHER, [=](hipStream_t s) { launch_prep_input(xi, ci, x0, B, in_nc, H, W, Hp, Wp, s); });
+        const int reflect = e->arch == 1 ? 0 : 1;  // NAFNet zero-pads (DenoisingNAFNet_arch.py:189-194)
+        b.push_other(OP_OTHER, [=](hipStream_t s) { launch_prep_input(xi, ci, x0, B, in_nc, H, W, Hp, Wp, s, reflect); });
+    }
+    if (e->arch == 1) {
+        build_naf_plan(e, pl, b, P);
+        e->plans.push_back(std::move(plan));
+        return pl;
     }
     // init_conv 7x7 (DenoisingUNet_arch.py:96) as 7 row taps over the zero-bordered input
     Tensor x;
@@ -855,6 +1226,32 @@ int irsde_create(const irsde_config* cfg, irsde_engine** out) {
         e->cfg = *cfg;
         e->time_dim = cfg->nf * 4;
         build_inventory(e);
+        *out = e;
+    });
+}
+
+int irsde_create_nafnet(const irsde_nafnet_config* cfg, irsde_engine** out) {
+    return guard([&] {
+        if (!cfg || !out) throw HipError("null argument");
+        if (cfg->width % 32 || cfg->width < 32) throw HipError("width must be a positive multiple of 32");
+        if (cfg->img_channel < 1 || cfg->img_channel > 4) throw HipError("img_channel must be in 1..4");
+        if (cfg->n_enc < 1 || cfg->n_enc > 6 || cfg->n_dec != cfg->n_enc) throw HipError("need 1..6 encoder stages and as many decoder stages");
+        if ((cfg->width << cfg->n_enc) > 2048) throw HipError("width * 2^stages must be <= 2048");
+        auto* e = new irsde_engine();
+        e->arch = 1;
+        e->cfg.in_nc = e->cfg.out_nc = cfg->img_channel;
+        e->cfg.nf = cfg->width;
+        e->cfg.depth = cfg->n_enc;  // pad multiple 2^stages (padder_size, DenoisingNAFNet_arch.py:147)
+        e->cfg.device = cfg->device;
+        e->cfg.flags = cfg->flags;
+        e->time_dim = cfg->width * 4;
+        for (int i = 0; i < cfg->n_enc; ++i) {
+            if (cfg->enc_blk_nums[i] < 0 || cfg->dec_blk_nums[i] < 0) throw HipError("negative block count");
+            e->naf_enc_nums.push_back(cfg->enc_blk_nums[i]);
+            e->naf_dec_nums.push_back(cfg->dec_blk_nums[i]);
+        }
+        e->naf_mid_num = cfg->middle_blk_num;
+        build_inventory_naf(e);
         *out = e;
     });
 }

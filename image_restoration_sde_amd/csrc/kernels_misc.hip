@@ -26,7 +26,10 @@ constexpr int kLnMaxVec = 8;  // float4 vectors per lane -> C <= 2048
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ res, float* __restrict__ out,
-                                                        const long long M, const int C, const int L, const float eps) {
+                                                        const long long M, const int C, const int L, const float eps,
+                                                        const float* __restrict__ fscale = nullptr,
+                                                        const float* __restrict__ fshift = nullptr,
+                                                        const int film_bstride = 0, const long long ppi = 1) {
     const int lane = threadIdx.x & 63;
     const int ppw = 64 / L;
     const int li = lane % L;
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             float4* op = reinterpret_cast<float4*>(out + pix * C);
             const float4* gp = reinterpret_cast<const float4*>(g);
             const float4* rp = res ? reinterpret_cast<const float4*>(res + pix * C) : nullptr;
+            const size_t frow = fscale ? (size_t)(film_bstride ? pix / ppi : 0) * film_bstride : 0;
 #pragma unroll
             for (int k = 0; k < kLnMaxVec; ++k) {
                 const int vi = li + k * L;
@@ -76,6 +80,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                     o.y = (v[k].y - mean) * rstd * gg.y;
                     o.z = (v[k].z - mean) * rstd * gg.z;
                     o.w = (v[k].w - mean) * rstd * gg.w;
+                    if (fscale) {  // NAFNet: x * (scale + 1) + shift  (DenoisingNAFNet_arch.py:64,75)
+                        const float4 s4 = reinterpret_cast<const float4*>(fscale + frow)[vi];
+                        const float4 h4 = reinterpret_cast<const float4*>(fshift + frow)[vi];
+                        o.x = o.x * (s4.x + 1.0f) + h4.x; o.y = o.y * (s4.y + 1.0f) + h4.y;
+                        o.z = o.z * (s4.z + 1.0f) + h4.z; o.w = o.w * (s4.w + 1.0f) + h4.w;
+                    }
                     if (rp) {
                         const float4 r = rp[vi];
                         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 __global__ void prep_input_kernel(const float* __restrict__ xt, const float* __restrict__ cond, float* __restrict__ x0,
                                   const int B, const int in_nc, const int P, const int H, const int W, const int Hp,
-                                  const int Wp) {
+                                  const int Wp, const int reflect) {
     const int Hb = Hp + 6, Wb = Wp + 6;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)B * Hb * Wb;
@@ -258,7 +268,8 @@ __global__ void prep_input_kernel(const float* __restrict__ xt, const float* __r
     const int b = (int)(t1 / Hb);
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int y = yb - 3, x = xb - 3;
-    if (y >= 0 && y < Hp && x >= 0 && x < Wp) {
+    // UNet: F.pad(..., 'reflect') to a multiple of 2^depth; NAFNet: zero pad (DenoisingNAFNet_arch.py:189-194)
+    if (y >= 0 && y < Hp && x >= 0 && x < Wp && (reflect || (y < H && x < W))) {
         const int sy = y < H ? y : 2 * (H - 1) - y;  // F.pad(..., 'reflect') on the right/bottom
         const int sx = x < W ? x : 2 * (W - 1) - x;
         for (int c = 0; c < in_nc; ++c) {
@@ -443,6 +454,104 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restr
     out[idx] = in[(((size_t)b * H + y) * W + x) * C + c];
 }
 
+// ---------------------------------------------------------------------------------------------
+// NAFNet (Refusion) — DenoisingNAFNet_arch.py:15-82
+// depthwise 3x3 (+bias) -> SimpleGate, with per-tile channel sums for the SCA global average pool.
+// Block = one tile of kDwTile pixels of one image; thread = (pixel lane, 4-channel group).
+// ---------------------------------------------------------------------------------------------
+constexpr int kDwTile = 64;
+
+__global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          float* __restrict__ partial, const int H, const int W,
+                                                          const int c, const int ntiles) {
+    __shared__ float4 red[256];
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int HW = H * W;
+    const int G = c >> 2;                        // float4 groups of gated channels
+    const int gpp = G < 256 ? G : 256;           // groups handled per pass
+    const int PP = 256 / gpp;                    // pixels in flight per pass
+    const int C2 = 2 * c;
+    for (int gc = 0; gc < G; gc += gpp) {
+        const int g = gc + (int)(threadIdx.x % gpp);
+        const int pl = threadIdx.x / gpp;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < G && pl < PP) {
+            const int ch = g * 4;
+            const float4 b1 = *reinterpret_cast<const float4*>(bias + ch);
+            const float4 b2 = *reinterpret_cast<const float4*>(bias + c + ch);
+            for (int pi = pl; pi < kDwTile; pi += PP) {
+                const int pix = tile * kDwTile + pi;
+                if (pix >= HW) break;
+                const int y = pix / W, x = pix - y * W;
+                float4 a1 = b1, a2 = b2;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int iy = y + ky - 1;
+                    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ix = x + kx - 1;
+                        if ((unsigned)ix >= (unsigned)W) continue;
+                        const float* up = u + ((size_t)b * HW + (size_t)iy * W + ix) * C2 + ch;
+                        const float4 v1 = *reinterpret_cast<const float4*>(up);
+                        const float4 v2 = *reinterpret_cast<const float4*>(up + c);
+                        const float4 w1 = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C2 + ch);
+                        const float4 w2 = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C2 + c + ch);
+                        a1.x = fmaf(v1.x, w1.x, a1.x); a1.y = fmaf(v1.y, w1.y, a1.y);
+                        a1.z = fmaf(v1.z, w1.z, a1.z); a1.w = fmaf(v1.w, w1.w, a1.w);
+                        a2.x = fmaf(v2.x, w2.x, a2.x); a2.y = fmaf(v2.y, w2.y, a2.y);
+                        a2.z = fmaf(v2.z, w2.z, a2.z); a2.w = fmaf(v2.w, w2.w, a2.w);
+                    }
+                }
+                const float4 o = make_float4(a1.x * a2.x, a1.y * a2.y, a1.z * a2.z, a1.w * a2.w);
+                *reinterpret_cast<float4*>(out + ((size_t)b * HW + pix) * c + ch) = o;
+                sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+            }
+        }
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        if (pl == 0 && g < G) {  // fixed-order reduction over the PP pixel lanes: deterministic
+            float4 t = red[threadIdx.x];
+            for (int q = 1; q < PP; ++q) {
+                const float4 r = red[threadIdx.x + q * gpp];
+                t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+            }
+            *reinterpret_cast<float4*>(partial + ((size_t)b * ntiles + tile) * c + g * 4) = t;
+        }
+        __syncthreads();
+    }
+}
+
+// s[b][o] = bias[o] + sum_k W[o][k] * mean[b][k]   (AdaptiveAvgPool2d(1) -> 1x1 conv, DenoisingNAFNet_arch.py:29-33)
+__global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ partial, const int ntiles,
+                                                  const float* __restrict__ W, const float* __restrict__ bias,
+                                                  float* __restrict__ s_out, const int c, const float inv_hw) {
+    extern __shared__ float mean[];
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < c; k += blockDim.x) {
+        float t = 0.f;
+        for (int q = 0; q < ntiles; ++q) t += partial[((size_t)b * ntiles + q) * c + k];
+        mean[k] = t * inv_hw;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = wave; o < c; o += 4) {
+        const float* wr = W + (size_t)o * c;
+        float t = 0.f;
+        for (int k = lane; k < c; k += 64) t = fmaf(wr[k], mean[k], t);
+        t = wave_xor_sum(t, 64);
+        if (lane == 0) s_out[(size_t)b * c + o] = t + bias[o];
+    }
+}
+
+__global__ void row_gate_kernel(const float* __restrict__ in, float* __restrict__ out, const int rows, const int h) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * h) return;
+    const int r = idx / h, j = idx - r * h;
+    out[idx] = in[(size_t)r * 2 * h + j] * in[(size_t)r * 2 * h + h + j];
+}
+
 __global__ void fill_random_kernel(float* p, const size_t n, const unsigned seed, const float scale) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q * 4 >= n) return;
@@ -480,7 +589,46 @@ void launch_layernorm(const float* x, const float* g, const float* res, float* o
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, g, res, out, (long long)M, C, L,
-                       eps);
+                       eps, (const float*)nullptr, (const float*)nullptr, 0, (long long)1);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_layernorm_film(const float* x, const float* g, const float* scale, const float* shift, int film_bstride,
+                           int64_t pixels_per_image, float* out, int64_t M, int C, float eps, hipStream_t s) {
+    if (C % 4 || C > 4 * 64 * kLnMaxVec) throw HipError("layernorm: unsupported channel count " + std::to_string(C));
+    int L = 1;
+    while (L * 2 <= 64 && L * 2 <= C / 4) L *= 2;
+    if ((C / 4 + L - 1) / L > kLnMaxVec) throw HipError("layernorm: channel count too large");
+    const int ppw = 64 / L;
+    const int64_t waves = (M + ppw - 1) / ppw;
+    int64_t blocks = (waves + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, g, (const float*)nullptr, out,
+                       (long long)M, C, L, eps, scale, shift, film_bstride, (long long)pixels_per_image);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+int dwgate_tiles(int HW) { return (HW + kDwTile - 1) / kDwTile; }
+
+void launch_dwconv_gate(const float* u, const float* w, const float* bias, float* out, float* partial, int B, int H, int W,
+                        int c, hipStream_t s) {
+    if (c % 4) throw HipError("dwconv_gate: channel count must be a multiple of 4");
+    const int nt = dwgate_tiles(H * W);
+    hipLaunchKernelGGL(dwconv_gate_kernel, dim3(nt, B), dim3(256), 0, s, u, w, bias, out, partial, H, W, c, nt);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_sca(const float* partial, int ntiles, const float* W, const float* bias, float* s_out, int B, int c, int HW,
+                hipStream_t s) {
+    hipLaunchKernelGGL(sca_kernel, dim3(B), dim3(256), c * sizeof(float), s, partial, ntiles, W, bias, s_out, c,
+                       1.0f / (float)HW);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_row_gate(const float* in, float* out, int rows, int h, hipStream_t s) {
+    const int total = rows * h;
+    hipLaunchKernelGGL(row_gate_kernel, dim3((total + 255) / 256), dim3(256), 0, s, in, out, rows, h);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
@@ -510,12 +658,12 @@ void launch_linear_attention(const float* qkv, float* out, int B, int N, const A
 }
 
 void launch_prep_input(const float* xt, const float* cond, float* x0, int B, int in_nc, int H, int W, int Hp, int Wp,
-                       hipStream_t s) {
+                       hipStream_t s, int reflect) {
     const int P = (2 * in_nc + 3) & ~3;
     if (P > 8) throw HipError("prep_input: in_nc > 4 unsupported");
     const size_t total = (size_t)B * (Hp + 6) * (Wp + 6);
     hipLaunchKernelGGL(prep_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xt, cond, x0, B,
-                       in_nc, P, H, W, Hp, Wp);
+                       in_nc, P, H, W, Hp, Wp, reflect);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

@@ -14,13 +14,16 @@ from collections import OrderedDict
 
 import torch
 
-from . import unet as _modules
+from . import unet as _unet
+from . import nafnet as _nafnet
 
 
 def define_G(opt):
     """networks.define_G (deraining/models/networks.py:10-15): class looked up by name."""
     opt_net = opt["network_G"]
-    return getattr(_modules, opt_net["which_model_G"])(**opt_net["setting"])
+    name = opt_net["which_model_G"]
+    cls = getattr(_nafnet, name, None) or getattr(_unet, name)
+    return cls(**opt_net["setting"])
 
 
 def create_model(opt):

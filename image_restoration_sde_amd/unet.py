@@ -69,10 +69,8 @@ class _Engine:
 
     def __init__(self, module, device_index, flags=0):
         L = _lib.lib()
-        cfg = _lib.Config(module.in_nc, module.out_nc, module.nf, module.depth, device_index, flags)
-        h = ctypes.c_void_p()
-        _lib.check(L.irsde_create(ctypes.byref(cfg), ctypes.byref(h)))
-        self.h = h
+        self.h = module._create_handle(L, device_index, flags)
+        h = self.h
         self.schedule_key = None
         sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in module.state_dict().items()}
         n = L.irsde_num_weights(h)
@@ -124,6 +122,12 @@ class ConditionalUNet(nn.Module):
         self.engine_flags = 0
 
     # ---- engine management -------------------------------------------------------------------
+    def _create_handle(self, L, device_index, flags):
+        cfg = _lib.Config(self.in_nc, self.out_nc, self.nf, self.depth, device_index, flags)
+        h = ctypes.c_void_p()
+        _lib.check(L.irsde_create(ctypes.byref(cfg), ctypes.byref(h)))
+        return h
+
     def _param_key(self, device):
         return (device.index if device.index is not None else torch.cuda.current_device(),
                 self.engine_flags, tuple((p.data_ptr(), p._version) for p in self.parameters()))

@@ -59,6 +59,21 @@ typedef struct irsde_config {
     int32_t flags;  /* IRSDE_FLAG_* */
 } irsde_config;
 
+/* ConditionalNAFNet(img_channel, width, middle_blk_num, enc_blk_nums, dec_blk_nums) — the Refusion score network,
+ * codes/config/deraining/models/modules/DenoisingNAFNet_arch.py:85-147 (refusion.yml: width 64, enc [1,1,1,28],
+ * middle 1, dec [1,1,1,1]).  Everything after creation (weights, schedule, forward, sample) uses the same entry points. */
+typedef struct irsde_nafnet_config {
+    int32_t img_channel;
+    int32_t width;
+    int32_t middle_blk_num;
+    int32_t n_enc;
+    int32_t enc_blk_nums[8];
+    int32_t n_dec;
+    int32_t dec_blk_nums[8];
+    int32_t device;
+    int32_t flags;
+} irsde_nafnet_config;
+
 /* Row layout of the per-step coefficient table passed to irsde_set_schedule (floats per row). */
 #define IRSDE_COEF_STRIDE 12
 /*  [0] thetas[t]  [1] sigmas[t]  [2] sigma_bars[t]  [3] dt  [4] sqrt(dt)
@@ -72,6 +87,8 @@ int irsde_version(void);
 
 /* Replaces ConditionalUNet.__init__ (DenoisingUNet_arch.py:19-76).  Host-only; no GPU work. */
 int irsde_create(const irsde_config* cfg, irsde_engine** out);
+/* Replaces ConditionalNAFNet.__init__ (DenoisingNAFNet_arch.py:87-147).  Host-only. */
+int irsde_create_nafnet(const irsde_nafnet_config* cfg, irsde_engine** out);
 void irsde_destroy(irsde_engine* e);
 
 /* Weight inventory = the reference state_dict (151 tensors for nf=64, depth=4). */

@@ -444,3 +444,76 @@ def test_denoising_model_boundary(tmp_path):
     out_b = sde.reverse_sde(mdl.state, save_states=True, save_dir=str(tmp_path / "sde_state"))
     assert torch.equal(out_a, out_b)
     assert len(list((tmp_path / "sde_state").glob("state_*.png"))) == T
+
+
+# ---------------------------------------------------------------------------------------------
+# ConditionalNAFNet (Refusion) — SURVEY.md §8(f) N1
+# ---------------------------------------------------------------------------------------------
+NAF_CFGS = {"refusion": dict(width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1]),
+            "w32_e12": dict(width=32, enc_blk_nums=[1, 2], middle_blk_num=1, dec_blk_nums=[1, 1])}
+_NAF = {}
+
+
+def naf_model(name, flags=0):
+    if (name, flags) not in _NAF:
+        cfg = NAF_CFGS[name]
+        params = O.naf_synth_params(seed=0, img_channel=3, width=cfg["width"], middle_blk_num=cfg["middle_blk_num"],
+                                    enc_blk_nums=tuple(cfg["enc_blk_nums"]), dec_blk_nums=tuple(cfg["dec_blk_nums"]))
+        m = P.ConditionalNAFNet(img_channel=3, **cfg)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        m.engine_flags = flags
+        _NAF[name, flags] = (m.to(DEV).eval(), params)
+    return _NAF[name, flags]
+
+
+@pytest.mark.parametrize("tag", ["w32_e12_2x24x20", "refusion_1x64x64", "refusion_2x40x56"])
+def test_nafnet_forward_vs_reference_golden(golden, tag):
+    g = golden.nafnet
+    m, _ = naf_model("refusion" if tag.startswith("refusion") else "w32_e12")
+    B, H, W = (int(v) for v in g[tag + "/shape"])
+    lq, xT = O.synth_inputs(1234, B, H, W, max_sigma=50)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    for t in g[tag + "/ts"]:
+        y = m(x, c, int(t)).cpu().numpy()
+        assert relerr(y, g[tag + "/t%d" % t]) < 1e-4, (tag, int(t))
+
+
+def test_nafnet_layers_vs_oracle():
+    cfg = NAF_CFGS["w32_e12"]
+    m, params = naf_model("w32_e12", flags=_lib.FLAG_KEEP_ACTIVATIONS)
+    B, H, W = 2, 24, 20
+    lq, xT = O.synth_inputs(1234, B, H, W, max_sigma=50)
+    taps = {}
+    ref = O.nafnet_forward(params, xT, lq, 7, tuple(cfg["enc_blk_nums"]), cfg["middle_blk_num"], tuple(cfg["dec_blk_nums"]),
+                           dtype=np.float64, taps=taps)
+    y = m(torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV), 7).cpu().numpy()
+    bad = {}
+    for name, want in taps.items():
+        got = m.debug_tap(name).numpy()
+        assert got.shape == want.shape, name
+        e = relerr(got, want)
+        if not e < 5e-5:
+            bad[name] = e
+    assert not bad, bad
+    assert relerr(y, ref) < 5e-5
+    # training-style per-sample timesteps
+    y2 = m(torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV), torch.tensor([5, 60])).cpu().numpy()
+    r2 = O.nafnet_forward(params, xT, lq, np.array([5, 60]), tuple(cfg["enc_blk_nums"]), cfg["middle_blk_num"],
+                          tuple(cfg["dec_blk_nums"]), dtype=np.float64)
+    assert relerr(y2, r2) < 5e-5
+
+
+@pytest.mark.parametrize("tag,key,T", [("w32_e12_2x24x20", "sampler_2x24x20_T20", 20), ("refusion_1x64x64", "sampler_1x32x32_T100", 100)])
+def test_nafnet_sampler_vs_reference_golden(golden, tag, key, T):
+    """Refusion sampler (refusion.yml: max_sigma 50, cosine, eps 0.005) with injected noise vs the real reference."""
+    g = golden.nafnet
+    m, _ = naf_model("refusion" if tag.startswith("refusion") else "w32_e12")
+    ref_sde = g["%s/%s/sde" % (tag, key)]
+    B, _, H, W = ref_sde.shape
+    lq, xT = O.synth_inputs(1234, B, H, W, max_sigma=50)
+    z = O.synth_noise(7, T, (B, 3, H, W))
+    sde = P.IRSDE(50, T, "cosine", 0.005, device=DEV)
+    for mode in ("sde", "posterior"):
+        got = _sample(m, mode, T, lq, xT, z, graph=True, sde=sde)
+        assert relerr(got, g["%s/%s/%s" % (tag, key, mode)]) < 2e-3, (tag, mode)
+        assert np.array_equal(got, _sample(m, mode, T, lq, xT, z, graph=False, sde=sde))
