@@ -112,8 +112,8 @@ int dwgate_tiles(int HW);
 void launch_dwconv_gate(const float* u, const float* w, const float* bias, float* out, float* partial, int B, int H, int W,
                         int c, hipStream_t s);
 // NAFNet SCA: s[b][o] = bias[o] + sum_k W[o][k] * mean_hw(gated)[b][k]
-void launch_sca(const float* partial, int ntiles, const float* W, const float* bias, float* s_out, int B, int c, int HW,
-                hipStream_t s);
+void launch_sca(const float* partial, int ntiles, const float* W, const float* bias, float* mean, float* s_out, int B,
+                int c, int HW, hipStream_t s);  // mean: scratch [B][c]
 // out[r][j] = in[r][j] * in[r][j + h]  (SimpleGate on time-embedding rows)
 void launch_row_gate(const float* in, float* out, int rows, int h, hipStream_t s);
 

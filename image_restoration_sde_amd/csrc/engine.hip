@@ -870,13 +870,14 @@ struct Builder {
         const int nt = dwgate_tiles(x.H * x.W);
         float* partial = pl->alloc((size_t)x.B * nt * c, true);
         float* sca = pl->alloc((size_t)x.B * c, true);
+        float* mean = pl->alloc((size_t)x.B * c, true);
         {
             const float *up = u.p, *dw = w.dw_w, *db = w.dw_b, *sw = w.sca_w, *sb = w.sca_b;
             float* gp = gt.p;
             const int B = x.B, H = x.H, W = x.W;
             push_other(OP_OTHER, [=](hipStream_t s) {
                 launch_dwconv_gate(up, dw, db, gp, partial, B, H, W, c, s);
-                launch_sca(partial, nt, sw, sb, sca, B, c, H * W, s);
+                launch_sca(partial, nt, sw, sb, mean, sca, B, c, H * W, s);
             });
         }
         tfree(u);
@@ -886,6 +887,7 @@ struct Builder {
         tfree(gt);
         pl->release(partial);
         pl->release(sca);
+        pl->release(mean);
         Tensor t2 = talloc(x.B, x.H, x.W, c);
         {
             const float *yp = y.p, *g = w.g2;

@@ -461,6 +461,8 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restr
 // ---------------------------------------------------------------------------------------------
 constexpr int kDwTile = 64;
 
+// Thread = (4-channel group g, pixel lane): the 2 x 9 depthwise weights of its channels live in registers; the lane walks
+// a run of CONSECUTIVE pixels keeping a 3x3 (x 2 halves) register window, so each new pixel costs 6 float4 loads.
 __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restrict__ u, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           float* __restrict__ partial, const int H, const int W,
@@ -470,7 +472,8 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restric
     const int HW = H * W;
     const int G = c >> 2;                        // float4 groups of gated channels
     const int gpp = G < 256 ? G : 256;           // groups handled per pass
-    const int PP = 256 / gpp;                    // pixels in flight per pass
+    const int PP = 256 / gpp;                    // pixel lanes per pass
+    const int run = (kDwTile + PP - 1) / PP;     // consecutive pixels per lane
     const int C2 = 2 * c;
     for (int gc = 0; gc < G; gc += gpp) {
         const int g = gc + (int)(threadIdx.x % gpp);
@@ -480,30 +483,52 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restric
             const int ch = g * 4;
             const float4 b1 = *reinterpret_cast<const float4*>(bias + ch);
             const float4 b2 = *reinterpret_cast<const float4*>(bias + c + ch);
-            for (int pi = pl; pi < kDwTile; pi += PP) {
-                const int pix = tile * kDwTile + pi;
-                if (pix >= HW) break;
+            float4 w1[9], w2[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                w1[k] = *reinterpret_cast<const float4*>(w + k * C2 + ch);
+                w2[k] = *reinterpret_cast<const float4*>(w + k * C2 + c + ch);
+            }
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* ub = u + (size_t)b * HW * C2 + ch;
+            auto ld = [&](int iy, int ix, int half) -> float4 {
+                if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return zero;
+                return *reinterpret_cast<const float4*>(ub + ((size_t)iy * W + ix) * C2 + half * c);
+            };
+            float4 win1[3][3], win2[3][3];  // [ky][kx] window of the two gate halves
+            int wy = -2, wx = -2;           // pixel the window is centred on
+            const int p0 = tile * kDwTile + pl * run;
+            for (int pi = 0; pi < run; ++pi) {
+                const int pix = p0 + pi;
+                if (pix >= HW || pix >= (tile + 1) * kDwTile) break;
                 const int y = pix / W, x = pix - y * W;
+                if (y == wy && x == wx + 1) {  // slide right: reuse two columns
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        win1[ky][0] = win1[ky][1]; win1[ky][1] = win1[ky][2]; win1[ky][2] = ld(y + ky - 1, x + 1, 0);
+                        win2[ky][0] = win2[ky][1]; win2[ky][1] = win2[ky][2]; win2[ky][2] = ld(y + ky - 1, x + 1, 1);
+                    }
+                } else {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            win1[ky][kx] = ld(y + ky - 1, x + kx - 1, 0);
+                            win2[ky][kx] = ld(y + ky - 1, x + kx - 1, 1);
+                        }
+                }
+                wy = y; wx = x;
                 float4 a1 = b1, a2 = b2;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int iy = y + ky - 1;
-                    if ((unsigned)iy >= (unsigned)H) continue;
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int ix = x + kx - 1;
-                        if ((unsigned)ix >= (unsigned)W) continue;
-                        const float* up = u + ((size_t)b * HW + (size_t)iy * W + ix) * C2 + ch;
-                        const float4 v1 = *reinterpret_cast<const float4*>(up);
-                        const float4 v2 = *reinterpret_cast<const float4*>(up + c);
-                        const float4 w1 = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C2 + ch);
-                        const float4 w2 = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C2 + c + ch);
-                        a1.x = fmaf(v1.x, w1.x, a1.x); a1.y = fmaf(v1.y, w1.y, a1.y);
-                        a1.z = fmaf(v1.z, w1.z, a1.z); a1.w = fmaf(v1.w, w1.w, a1.w);
-                        a2.x = fmaf(v2.x, w2.x, a2.x); a2.y = fmaf(v2.y, w2.y, a2.y);
-                        a2.z = fmaf(v2.z, w2.z, a2.z); a2.w = fmaf(v2.w, w2.w, a2.w);
+                        const float4 v1 = win1[ky][kx], v2 = win2[ky][kx], q1 = w1[ky * 3 + kx], q2 = w2[ky * 3 + kx];
+                        a1.x = fmaf(v1.x, q1.x, a1.x); a1.y = fmaf(v1.y, q1.y, a1.y);
+                        a1.z = fmaf(v1.z, q1.z, a1.z); a1.w = fmaf(v1.w, q1.w, a1.w);
+                        a2.x = fmaf(v2.x, q2.x, a2.x); a2.y = fmaf(v2.y, q2.y, a2.y);
+                        a2.z = fmaf(v2.z, q2.z, a2.z); a2.w = fmaf(v2.w, q2.w, a2.w);
                     }
-                }
                 const float4 o = make_float4(a1.x * a2.x, a1.y * a2.y, a1.z * a2.z, a1.w * a2.w);
                 *reinterpret_cast<float4*>(out + ((size_t)b * HW + pix) * c + ch) = o;
                 sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
@@ -511,7 +536,7 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restric
         }
         red[threadIdx.x] = sum;
         __syncthreads();
-        if (pl == 0 && g < G) {  // fixed-order reduction over the PP pixel lanes: deterministic
+        if (pl == 0 && g < G) {  // fixed-order reduction over the pixel lanes: deterministic
             float4 t = red[threadIdx.x];
             for (int q = 1; q < PP; ++q) {
                 const float4 r = red[threadIdx.x + q * gpp];
@@ -523,26 +548,34 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restric
     }
 }
 
-// s[b][o] = bias[o] + sum_k W[o][k] * mean[b][k]   (AdaptiveAvgPool2d(1) -> 1x1 conv, DenoisingNAFNet_arch.py:29-33)
-__global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ partial, const int ntiles,
-                                                  const float* __restrict__ W, const float* __restrict__ bias,
-                                                  float* __restrict__ s_out, const int c, const float inv_hw) {
-    extern __shared__ float mean[];
-    const int b = blockIdx.x;
-    for (int k = threadIdx.x; k < c; k += blockDim.x) {
-        float t = 0.f;
-        for (int q = 0; q < ntiles; ++q) t += partial[((size_t)b * ntiles + q) * c + k];
-        mean[k] = t * inv_hw;
-    }
+// mean[b][k] = sum_tiles partial / HW  (second stage of the deterministic global average pool)
+__global__ __launch_bounds__(256) void sca_mean_kernel(const float* __restrict__ partial, const int ntiles,
+                                                       float* __restrict__ mean, const int c, const float inv_hw) {
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int tl = threadIdx.x >> 6;
+    float t = 0.f;
+    if (k < c)
+        for (int q = tl; q < ntiles; q += 4) t += partial[((size_t)b * ntiles + q) * c + k];
+    red[threadIdx.x] = t;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = wave; o < c; o += 4) {
-        const float* wr = W + (size_t)o * c;
-        float t = 0.f;
-        for (int k = lane; k < c; k += 64) t = fmaf(wr[k], mean[k], t);
-        t = wave_xor_sum(t, 64);
-        if (lane == 0) s_out[(size_t)b * c + o] = t + bias[o];
-    }
+    if (tl == 0 && k < c) mean[(size_t)b * c + k] = ((red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192])) * inv_hw;
+}
+
+// s[b][o] = bias[o] + sum_k W[o][k] * mean[b][k]   (AdaptiveAvgPool2d(1) -> 1x1 conv, DenoisingNAFNet_arch.py:29-33)
+__global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ mean, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, float* __restrict__ s_out, const int c) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= c) return;
+    const float* wr = W + (size_t)o * c;
+    const float* mb = mean + (size_t)b * c;
+    float t = 0.f;
+    for (int k = lane; k < c; k += 64) t = fmaf(wr[k], mb[k], t);
+    t = wave_xor_sum(t, 64);
+    if (lane == 0) s_out[(size_t)b * c + o] = t + bias[o];
 }
 
 __global__ void row_gate_kernel(const float* __restrict__ in, float* __restrict__ out, const int rows, const int h) {
@@ -619,10 +652,10 @@ void launch_dwconv_gate(const float* u, const float* w, const float* bias, float
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-void launch_sca(const float* partial, int ntiles, const float* W, const float* bias, float* s_out, int B, int c, int HW,
-                hipStream_t s) {
-    hipLaunchKernelGGL(sca_kernel, dim3(B), dim3(256), c * sizeof(float), s, partial, ntiles, W, bias, s_out, c,
-                       1.0f / (float)HW);
+void launch_sca(const float* partial, int ntiles, const float* W, const float* bias, float* mean, float* s_out, int B,
+                int c, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(sca_mean_kernel, dim3((c + 63) / 64, B), dim3(256), 0, s, partial, ntiles, mean, c, 1.0f / (float)HW);
+    hipLaunchKernelGGL(sca_kernel, dim3((c + 3) / 4, B), dim3(256), 0, s, mean, W, bias, s_out, c);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

@@ -9,8 +9,14 @@ from oracle import irsde_oracle as O
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-m = P.ConditionalUNet(3, 3, 64, depth=4)
-m.load_state_dict({k: torch.from_numpy(v) for k, v in O.synth_params(seed=0).items()})
+arch = sys.argv[4] if len(sys.argv) > 4 else "unet"
+if arch == "nafnet":
+    m = P.ConditionalNAFNet(3, width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in O.naf_synth_params(seed=0, img_channel=3, width=64, middle_blk_num=1,
+                       enc_blk_nums=(1, 1, 1, 28), dec_blk_nums=(1, 1, 1, 1)).items()})
+else:
+    m = P.ConditionalUNet(3, 3, 64, depth=4)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in O.synth_params(seed=0).items()})
 m.engine_flags = flags
 m = m.to("cuda:0").eval()
 lq, xT = O.synth_inputs(1, B, S, S)
