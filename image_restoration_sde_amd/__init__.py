@@ -5,6 +5,8 @@ csrc/ -> libirsde_hip.so) with the reference's own Python interface on top:
     IRSDE              codes/utils/sde_utils.py:80-361
     ConditionalUNet    codes/config/deraining/models/modules/DenoisingUNet_arch.py:18-134
     ConditionalNAFNet  codes/config/deraining/models/modules/DenoisingNAFNet_arch.py:85-187 (Refusion)
+    DenoisingSDE, denoising_sde.ConditionalUNet
+                       codes/utils/sde_utils.py:373-593, codes/config/denoising-sde/models/modules/DenoisingUNet_arch.py
     DenoisingModel     codes/config/deraining/models/denoising_model.py (inference surface)
 """
 from ._lib import IrsdeError, IrsdeLibraryError, build_library  # noqa: F401
@@ -13,6 +15,8 @@ from .dist import gather_batch, sample_sharded, shard_bounds  # noqa: F401
 from .sde import IRSDE  # noqa: F401
 from .unet import ConditionalUNet  # noqa: F401
 from .nafnet import ConditionalNAFNet  # noqa: F401
+from . import denoising_sde  # noqa: F401
+from .denoising_sde import DenoisingSDE  # noqa: F401
 
-__all__ = ["IRSDE", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
+__all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
            "IrsdeError", "IrsdeLibraryError", "shard_bounds", "gather_batch", "sample_sharded"]

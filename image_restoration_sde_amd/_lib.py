@@ -12,12 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libirsde_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-MODE = {"sde": 0, "ode": 1, "posterior": 2}
+MODE = {"sde": 0, "ode": 1, "posterior": 2, "dsde_sde": 3, "dsde_ode": 4}
 COEF_STRIDE = 12
 FLAG_KEEP_ACTIVATIONS = 1
 FLAG_NAIVE_CONV = 2
 FLAG_NO_WINOGRAD = 4
 FLAG_NO_WINOGRAD_F43 = 8
+FLAG_UNCOND_FULLATTN = 16
 SAMPLE_GRAPH = 1
 SAMPLE_PROFILE = 2
 

@@ -128,7 +128,10 @@ int attn_num_chunks(int N);
 // qkv: [B][N][384] (q | k | v, 4 heads x 32 each).  out: [B][N][128].
 void launch_linear_attention(const float* qkv, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s);
 
-// xt, cond: NCHW [B][3][H][W].  x0: [B][Hp+6][Wp+6][8] (+8 floats slack), zero border of 3,
+// Full softmax attention over N tokens (denoising-sde bottleneck): qkv [B][N][384] -> out [B][N][128].
+void launch_full_attention(const float* qkv, float* out, int B, int N, hipStream_t s);
+
+// xt, cond: NCHW [B][3][H][W] (cond may be null: unconditional variant, channels = xt only).  x0: [B][Hp+6][Wp+6][8] (+8 floats slack), zero border of 3,
 // channels {xt-cond (3), cond (3), 0, 0}, reflect-padded right/bottom from (H,W) to (Hp,Wp).
 void launch_prep_input(const float* xt, const float* cond, float* x0, int B, int in_nc, int H, int W, int Hp, int Wp,
                        hipStream_t s, int reflect = 1);
@@ -182,7 +185,7 @@ struct UpdateParams {
     const SampleCtl* ctl; // device per-call arguments (override mode/noise/seed/image_offset) or null
     int t_imm;
     float coef_imm[12];
-    int mode;            // 0 sde, 1 ode, 2 posterior
+    int mode;            // IRSDE: 0 sde, 1 ode, 2 posterior; DenoisingSDE: 3 sde, 4 ode
     int B, C, H, W;
     uint64_t seed;
     uint64_t image_offset;  // global index of image 0 of this shard (RNG invariance to sharding)

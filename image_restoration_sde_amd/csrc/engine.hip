@@ -271,7 +271,8 @@ void inv_attn(irsde_engine* e, const std::string& p, int c) {
 }
 void build_inventory(irsde_engine* e) {
     const int nf = e->cfg.nf, depth = e->cfg.depth;
-    add_w(e, "init_conv.weight", {nf, 2 * e->cfg.in_nc, 7, 7});
+    const bool uncond = (e->cfg.flags & IRSDE_FLAG_UNCOND_FULLATTN) != 0;  // denoising-sde variant
+    add_w(e, "init_conv.weight", {nf, (uncond ? 1 : 2) * e->cfg.in_nc, 7, 7});
     add_w(e, "time_mlp.1.weight", {e->time_dim, nf});
     add_w(e, "time_mlp.1.bias", {e->time_dim});
     add_w(e, "time_mlp.3.weight", {e->time_dim, e->time_dim});
@@ -301,7 +302,14 @@ void build_inventory(irsde_engine* e) {
     }
     const int mid = nf << depth;
     inv_resblock(e, "mid_block1.", mid, mid);
-    inv_attn(e, "mid_attn.", mid);
+    if (uncond) {  // full Attention: to_out is a bare Conv2d, no LayerNorm (module_util.py:182-191)
+        add_w(e, "mid_attn.fn.norm.g", {1, mid, 1, 1});
+        add_w(e, "mid_attn.fn.fn.to_qkv.weight", {384, mid, 1, 1});
+        add_w(e, "mid_attn.fn.fn.to_out.weight", {mid, 128, 1, 1});
+        add_w(e, "mid_attn.fn.fn.to_out.bias", {mid});
+    } else {
+        inv_attn(e, "mid_attn.", mid);
+    }
     inv_resblock(e, "mid_block2.", mid, mid);
     inv_resblock(e, "final_res_block.", 2 * nf, nf);
     add_w(e, "final_conv.weight", {e->cfg.out_nc, nf, 3, 3});
@@ -582,7 +590,16 @@ void finalize(irsde_engine* e) {
         e->down_conv.push_back(pack_conv(e, d + "3.weight", i != depth - 1 ? d + "3.bias" : ""));
     }
     e->mid1 = pack_res(e, "mid_block1.");
-    e->mid_attn = pack_attn(e, "mid_attn.");
+    if (e->cfg.flags & IRSDE_FLAG_UNCOND_FULLATTN) {
+        AttnW a;
+        a.g1 = e->upload(need(e, "mid_attn.fn.norm.g").data);
+        a.qkv = pack_conv(e, "mid_attn.fn.fn.to_qkv.weight", "");
+        a.out = pack_conv(e, "mid_attn.fn.fn.to_out.weight", "mid_attn.fn.fn.to_out.bias");
+        a.C = a.out.Cout;
+        e->mid_attn = a;  // g2 == nullptr marks the full-attention block
+    } else {
+        e->mid_attn = pack_attn(e, "mid_attn.");
+    }
     e->mid2 = pack_res(e, "mid_block2.");
     for (int j = 0; j < depth; ++j) {
         const std::string u = "ups." + std::to_string(j) + ".";
@@ -934,6 +951,17 @@ struct Builder {
         Tensor qkv = conv(w.qkv, xn, nullptr, 1, 0, 0, nullptr, 0, nullptr);
         tfree(xn);
         Tensor a = talloc(x.B, x.H, x.W, 128);
+        if (!w.g2) {
+            // Residual(PreNorm(dim, Attention(dim))): full softmax attention, to_out without LayerNorm, + x
+            const float* q = qkv.p;
+            float* o = a.p;
+            const int B = x.B;
+            push_other(OP_ATTN, [=](hipStream_t s) { launch_full_attention(q, o, B, N, s); });
+            tfree(qkv);
+            Tensor y = conv(w.out, a, nullptr, 1, 0, 0, nullptr, 0, &x);
+            tfree(a);
+            return y;
+        }
         {
             AttnWorkspace ws;
             ws.nch = attn_num_chunks(N);
@@ -1061,7 +1089,8 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
     const size_t img = (size_t)B * in_nc * H * W;
     pl->xin = pl->alloc(img, false);
     pl->cin = pl->alloc(img, false);
-    const int P = (2 * in_nc + 3) & ~3;
+    const bool uncond = e->arch == 0 && (e->cfg.flags & IRSDE_FLAG_UNCOND_FULLATTN) != 0;
+    const int P = ((uncond ? 1 : 2) * in_nc + 3) & ~3;
     const size_t x0n = (size_t)B * (pl->Hp + 6) * (pl->Wp + 6) * P + 64;
     pl->x0 = pl->alloc(x0n, false);
     IRSDE_HIP_CHECK(hipMemset(pl->x0, 0, x0n * sizeof(float)));
@@ -1069,7 +1098,7 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
     Builder b{e, pl, (e->cfg.flags & IRSDE_FLAG_KEEP_ACTIVATIONS) == 0, (e->cfg.flags & IRSDE_FLAG_NAIVE_CONV) != 0,
               per_sample_film ? e->film_row : 0};
     {
-        const float *xi = pl->xin, *ci = pl->cin;
+        const float *xi = pl->xin, *ci = uncond ? nullptr : pl->cin;
         float* x0 = pl->x0;
         const int Hp = pl->Hp, Wp = pl->Wp;
         const int reflect = e->arch == 1 ? 0 : 1;  // NAFNet zero-pads (DenoisingNAFNet_arch.py:189-194)
@@ -1092,7 +1121,7 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
         p.out = x.p; p.out_stride = nf;
         b.push_conv(p);
         // algorithmic accounting: 7x7 x (2*in_nc) real MACs, not the padded 7 x 64
-        const double real = 2.0 * (double)B * pl->Hp * pl->Wp * nf * 49.0 * (2.0 * in_nc);
+        const double real = 2.0 * (double)B * pl->Hp * pl->Wp * nf * 49.0 * ((uncond ? 1.0 : 2.0) * in_nc);
         pl->conv_flops += real - pl->net_ops.back().flops;
         pl->net_ops.back().flops = real;  // (exec_flops keeps the padded 7 x 64 K that is actually issued)
     }
@@ -1347,7 +1376,8 @@ int irsde_set_schedule(irsde_engine* e, int T, const float* coef) {
 int irsde_unet_forward(irsde_engine* e, const float* xt, const float* cond, const int64_t* t_host, int nt, int B, int H,
                        int W, float* out, void* stream) {
     return guard([&] {
-        if (!e || !xt || !cond || !t_host || !out) throw HipError("null argument");
+        const bool uncond_e = e && e->arch == 0 && (e->cfg.flags & IRSDE_FLAG_UNCOND_FULLATTN);
+        if (!e || !xt || (!cond && !uncond_e) || !t_host || !out) throw HipError("null argument");
         if (!e->finalized) throw HipError("unet_forward: weights not finalized");
         if (nt != 1 && nt != B) throw HipError("unet_forward: need 1 or B timesteps");
         if (B < 1 || H < 2 || W < 2) throw HipError("unet_forward: bad shape");
@@ -1361,7 +1391,7 @@ int irsde_unet_forward(irsde_engine* e, const float* xt, const float* cond, cons
         IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
         const size_t img = (size_t)B * e->cfg.in_nc * H * W * sizeof(float);
         IRSDE_HIP_CHECK(hipMemcpyAsync(pl->xin, xt, img, hipMemcpyDeviceToDevice, s));
-        IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, cond, img, hipMemcpyDeviceToDevice, s));
+        if (cond) IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, cond, img, hipMemcpyDeviceToDevice, s));
         const bool in_table = nt == 1 && e->film_table && t_host[0] >= 0 && t_host[0] <= e->T;
         if (in_table) {
             IRSDE_HIP_CHECK(hipMemcpyAsync(e->film_cur, e->film_table + (size_t)t_host[0] * e->film_row,
@@ -1386,9 +1416,12 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
                  uint64_t image_offset, int B, int H, int W, int T, int t_stop, float* out, void* stream,
                  int flags) {
     return guard([&] {
-        if (!e || !xT || !mu || !out) throw HipError("null argument");
+        if (!e || !xT || !out) throw HipError("null argument");
         if (!e->finalized || !e->film_table) throw HipError("sample: weights/schedule not set");
-        if (mode < 0 || mode > 2) throw HipError("sample: bad mode");
+        if (mode < 0 || mode > 4) throw HipError("sample: bad mode");
+        const bool uncond_e = e->arch == 0 && (e->cfg.flags & IRSDE_FLAG_UNCOND_FULLATTN);
+        if ((mode >= 3) != uncond_e) throw HipError("sample: DenoisingSDE modes (3,4) go with the unconditional network and vice versa");
+        if (!mu && !uncond_e) throw HipError("null argument");
         if (T <= 0) T = e->T;
         if (T > e->T) throw HipError("sample: T exceeds the schedule length");
         if (t_stop < 0 || t_stop >= T) throw HipError("sample: t_stop must be in [0, T)");
@@ -1405,7 +1438,7 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
         IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
         const size_t img = (size_t)B * e->cfg.in_nc * H * W;
         IRSDE_HIP_CHECK(hipMemcpyAsync(pl->xin, xT, img * 4, hipMemcpyDeviceToDevice, s));
-        IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, mu, img * 4, hipMemcpyDeviceToDevice, s));
+        if (mu) IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, mu, img * 4, hipMemcpyDeviceToDevice, s));
         launch_set_ctl(e->ctl, mode, noise, (long long)img, seed, image_offset, s);
         launch_set_step(e->step, T, s);
 
@@ -1487,8 +1520,9 @@ int irsde_sde_step(int mode, int t, const float* coef_row, float* x, const float
                    const float* noise_t, uint64_t seed, uint64_t image_offset, int B, int C, int H, int W,
                    void* stream) {
     return guard([&] {
-        if (!coef_row || !x || !mu || !eps_hat) throw HipError("null argument");
-        if (mode < 0 || mode > 2) throw HipError("sde_step: bad mode");
+        if (!coef_row || !x || !eps_hat || (!mu && mode < 3)) throw HipError("null argument");
+        if (!mu) mu = x;  // DenoisingSDE has no mu term; the kernel still reads the pointer
+        if (mode < 0 || mode > 4) throw HipError("sde_step: bad mode");
         UpdateParams u{};
         u.x = x; u.mu = mu; u.pred = eps_hat;
         u.sb = (int64_t)C * H * W; u.sc = (int64_t)H * W; u.sy = W; u.sx = 1;

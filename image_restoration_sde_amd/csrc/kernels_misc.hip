@@ -253,6 +253,92 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Full softmax attention (denoising-sde bottleneck) — module_util.py:182-204.  qkv: [B][N][384], out: [B][N][128].
+// One wave = one 32-query tile of one (batch, head); flash-style loop over 32-key tiles on the fp32 MFMA pipe:
+//   S^T = K Q^T   (A = K rows, B = Q^T; 16 x v_mfma_f32_32x32x2_f32)   -> lane (q = lane&31, half h) holds 16 of the 32 scores
+//   online softmax over the keys of this query: 16 registers + one cross-half shuffle
+//   O^T += V^T P^T (A = V rows straight from HBM, B = the lane's own P registers — the swapped product needs no transposition)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void full_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, const int N,
+                                                        const float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh >> 2, head = bh & 3;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= N) return;  // wave-uniform
+    const float* base = qkv + (size_t)b * N * kQkv + head * kDh;
+    const int q = q0 + l31;
+    float qreg[16];
+    {
+        const float4* qp = reinterpret_cast<const float4*>(base + (size_t)(q < N ? q : q0) * kQkv + 16 * h);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 t4 = qp[v];
+            qreg[4 * v + 0] = t4.x * scale; qreg[4 * v + 1] = t4.y * scale;
+            qreg[4 * v + 2] = t4.z * scale; qreg[4 * v + 3] = t4.w * scale;
+        }
+    }
+    float m = -INFINITY, l = 0.f;
+    floatx16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 32) {
+        const int j = j0 + l31;
+        float kreg[16];
+        {
+            const float4* kp = reinterpret_cast<const float4*>(base + (size_t)(j < N ? j : 0) * kQkv + kHid + 16 * h);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 t4 = kp[v];
+                kreg[4 * v + 0] = t4.x; kreg[4 * v + 1] = t4.y; kreg[4 * v + 2] = t4.z; kreg[4 * v + 3] = t4.w;
+            }
+        }
+        float vreg[16];  // V[j0 + jj_h(s)][d = l31], jj_h(s) = (s&3) + 8(s>>2) + 4h  (the C-layout row of register s)
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int jj = j0 + (s2 & 3) + 8 * (s2 >> 2) + 4 * h;
+            vreg[s2] = jj < N ? base[(size_t)jj * kQkv + 2 * kHid + l31] : 0.f;
+        }
+        floatx16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s2], qreg[s2], st, 0, 0, 0);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (jj >= N) st[r] = -INFINITY;
+            tmax = fmaxf(tmax, st[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(m, tmax);
+        const float alpha = expf(m - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = expf(st[r] - mnew);
+            psum += st[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
+        m = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[s2], st[s2], o, 0, 0, 0);
+    }
+    if (q < N) {
+        const float il = 1.0f / l;
+        float* op = out + ((size_t)b * N + q) * kHid + head * kDh;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)  // registers 4g..4g+3 are d = 8g + 4h + {0..3}
+            *reinterpret_cast<float4*>(op + 8 * g4 + 4 * h) =
+                make_float4(o[4 * g4] * il, o[4 * g4 + 1] * il, o[4 * g4 + 2] * il, o[4 * g4 + 3] * il);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Input prep: x0[b][y][x][0..P) over the physically zero-bordered (3 px) image, NCHW -> NHWC.
 // ---------------------------------------------------------------------------------------------
 __global__ void prep_input_kernel(const float* __restrict__ xt, const float* __restrict__ cond, float* __restrict__ x0,
@@ -274,9 +360,13 @@ __global__ void prep_input_kernel(const float* __restrict__ xt, const float* __r
         const int sx = x < W ? x : 2 * (W - 1) - x;
         for (int c = 0; c < in_nc; ++c) {
             const size_t o = (((size_t)b * in_nc + c) * H + sy) * W + sx;
-            const float cv = cond[o];
-            v[c] = xt[o] - cv;
-            v[in_nc + c] = cv;
+            if (cond) {
+                const float cv = cond[o];
+                v[c] = xt[o] - cv;
+                v[in_nc + c] = cv;
+            } else {
+                v[c] = xt[o];  // denoising-sde variant: no condition input
+            }
         }
     }
     float* op = x0 + idx * P;
@@ -391,7 +481,7 @@ __global__ __launch_bounds__(256) void sde_update_kernel(const UpdateParams p) {
         seed = p.ctl->seed; image_offset = p.ctl->image_offset;
     }
     float z[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool need_z = mode != 1;
+    const bool need_z = mode != 1 && mode != 4;
     if (need_z && !noise) philox_normal4((uint32_t)quad, (uint32_t)t, (uint32_t)(image_offset + b), seed, z);
     for (int k = 0; k < 4; ++k) {
         const int e = quad * 4 + k;
@@ -402,7 +492,18 @@ __global__ __launch_bounds__(256) void sde_update_kernel(const UpdateParams p) {
         const float x = p.x[si], mu = p.mu[si];
         if (need_z && noise) z[k] = noise[(size_t)t * noise_tstride + si];
         float xn;
-        if (mode == 2) {
+        if (mode >= 3) {
+            // DenoisingSDE (sde_utils.py:448-457, 44-48): mode 3 reverse_sde, mode 4 reverse_ode; cf[9] = exp(-2 Theta_t dt)
+            const float score = -eps_hat / sbar;
+            if (mode == 3) {
+                const float drift = -0.5f * (sigma * sigma) * (1.0f + cf[9]) * score * dt;
+                const float disp = sigma * (z[k] * sqdt);
+                xn = x - drift - disp;
+            } else {
+                const float drift = -0.5f * (sigma * sigma) * cf[9] * score * dt;
+                xn = x - drift;
+            }
+        } else if (mode == 2) {
             // sde_utils.py:237-239, 197-205, 219-223
             const float x0 = (x - mu - sbar * eps_hat) * gain + mu;
             const float mean = t1 * (x - mu) + t2 * (x0 - mu) + mu;
@@ -690,9 +791,16 @@ void launch_linear_attention(const float* qkv, float* out, int B, int N, const A
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
+void launch_full_attention(const float* qkv, float* out, int B, int N, hipStream_t s) {
+    const int qtiles = (N + 31) / 32;
+    hipLaunchKernelGGL(full_attn_kernel, dim3((qtiles + 3) / 4, B * kHeads), dim3(256), 0, s, qkv, out, N,
+                       1.0f / sqrtf((float)kDh));
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
 void launch_prep_input(const float* xt, const float* cond, float* x0, int B, int in_nc, int H, int W, int Hp, int Wp,
                        hipStream_t s, int reflect) {
-    const int P = (2 * in_nc + 3) & ~3;
+    const int P = ((cond ? 2 : 1) * in_nc + 3) & ~3;
     if (P > 8) throw HipError("prep_input: in_nc > 4 unsupported");
     const size_t total = (size_t)B * (Hp + 6) * (Wp + 6);
     hipLaunchKernelGGL(prep_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xt, cond, x0, B,

@@ -33,13 +33,18 @@ enum {
     IRSDE_ERR_WEIGHT = -4   /* unknown weight name / wrong shape / missing weights */
 };
 
-enum { IRSDE_MODE_SDE = 0, IRSDE_MODE_ODE = 1, IRSDE_MODE_POSTERIOR = 2 };
+enum { IRSDE_MODE_SDE = 0, IRSDE_MODE_ODE = 1, IRSDE_MODE_POSTERIOR = 2,
+       /* DenoisingSDE.reverse_sde / reverse_ode (sde_utils.py:488-528): no mu term; coef[9] = exp(-2*thetas_cumsum[t]*dt) */
+       IRSDE_MODE_DSDE_SDE = 3, IRSDE_MODE_DSDE_ODE = 4 };
 
 /* engine flags (irsde_config.flags) */
 enum {
     IRSDE_FLAG_KEEP_ACTIVATIONS = 1, /* never recycle activation buffers: enables irsde_debug_tap */
     IRSDE_FLAG_NAIVE_CONV = 2,       /* debug: run every convolution on the naive VALU kernel */
     IRSDE_FLAG_NO_WINOGRAD = 4,      /* run every 3x3 layer as a direct implicit GEMM (no Winograd) */
+    IRSDE_FLAG_UNCOND_FULLATTN = 16, /* the denoising-sde variant of ConditionalUNet (codes/config/denoising-sde/models/modules/
+                                        DenoisingUNet_arch.py:20-130): forward(x, time) without a condition input (init_conv takes
+                                        in_nc channels) and full softmax Attention at the bottleneck (module_util.py:182-204) */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };
@@ -80,7 +85,7 @@ typedef struct irsde_nafnet_config {
  *  [5] exp(thetas_cumsum[t]*dt)                      (get_init_state_from_noise, sde_utils.py:237-239)
  *  [6] posterior term1  [7] posterior term2          (reverse_optimum_step,      sde_utils.py:197-205)
  *  [8] posterior std                                 (reverse_optimum_std,       sde_utils.py:207-217)
- *  [9..11] reserved (0)                                                                        */
+ *  [9] exp(-2*thetas_cumsum[t]*dt)  (DenoisingSDE drifts, sde_utils.py:448-454)   [10..11] reserved (0)   */
 
 const char* irsde_last_error(void);
 int irsde_version(void);

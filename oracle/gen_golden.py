@@ -256,6 +256,69 @@ def gen_nafnet(sde_utils):
     print("nafnet.npz")
 
 
+def gen_dsde(sde_utils, ref_root):
+    """denoising-sde variant: DenoisingSDE + unconditional UNet (full attention at mid) from the real reference."""
+    import importlib
+    # the denoising-sde task dir has its own models.modules (same package name): load it under a private name
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(ref_root, "codes/config/denoising-sde"))
+    arch = importlib.import_module("models.modules.DenoisingUNet_arch")
+    assert "denoising-sde" in arch.__file__, arch.__file__
+    Net = arch.ConditionalUNet
+    out = {}
+    cases = {"nf32d2_2x24x20": (32, 2, 2, 24, 20, [3, 77]), "nf64d4_1x64x64": (64, 4, 1, 64, 64, [50]),
+             "nf64d4_2x88x80": (64, 4, 2, 88, 80, [20])}   # 88x80 -> 96x80 padded; bottleneck 12x10 = 120 tokens (not a multiple of 32)
+    nets = {}
+    for tag, (nf, depth, B, H, W, ts) in cases.items():
+        params = O.uncond_synth_params(seed=0, nf=nf, depth=depth)
+        net = Net(in_nc=3, out_nc=3, nf=nf, depth=depth).eval()
+        sd = net.state_dict()
+        assert set(sd) == set(params), set(sd) ^ set(params)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        nets[tag] = net
+        lq, xT = O.synth_inputs(1234, B, H, W, max_sigma=25)
+        out[tag + "/cfg"] = np.array([nf, depth, B, H, W], dtype=np.int64)
+        out[tag + "/ts"] = np.array(ts, dtype=np.int64)
+        for t in ts:
+            with torch.no_grad():
+                y = net(torch.from_numpy(xT), t).numpy()
+            out[tag + "/t%d" % t] = y
+            print(tag, t, float(np.abs(y).max()))
+    # DenoisingSDE(max_sigma=75, T=100) as in denoising-sde/options/test/ir-sde.yml
+    sde = sde_utils.DenoisingSDE(max_sigma=75, T=100, device="cpu")
+    out["sde/dt"] = np.float32(sde.dt.item())
+    for n in ("thetas", "sigmas", "thetas_cumsum", "sigma_bars"):
+        out["sde/" + n] = getattr(sde, n).numpy()
+    out["sde/opt_t"] = np.array([int(sde.get_optimal_timestep(s)) for s in (15, 25, 50)], dtype=np.int64)
+
+    class Inj(sde_utils.DenoisingSDE):
+        noise = None
+
+        def dispersion(self, x, t):
+            import math
+            return self.sigmas[t] * (self.noise[t] * math.sqrt(self.dt)).to(self.device)
+    for tag, (B, H, W) in {"nf32d2_2x24x20": (2, 16, 16), "nf64d4_1x64x64": (1, 32, 32)}.items():
+        net = nets[tag]
+        isde = Inj(max_sigma=75, T=100, device="cpu")
+        lq, _ = O.synth_inputs(1234, B, H, W)
+        rs = np.random.RandomState(5)
+        noisy = (lq + rs.standard_normal(lq.shape).astype(np.float32) * np.float32(25 / 255)).astype(np.float32)
+        z = O.synth_noise(7, 100, (B, 3, H, W))
+        isde.noise = torch.from_numpy(z)
+        isde.set_model(net)
+        Topt = int(isde.get_optimal_timestep(25))
+        key = "%s/sampler_%dx%dx%d" % (tag, B, H, W)
+        out[key + "/T"] = np.int64(Topt)
+        out[key + "/noisy"] = noisy
+        with torch.no_grad():
+            out[key + "/ode"] = isde.reverse_ode(torch.from_numpy(noisy), T=Topt).numpy()
+            out[key + "/sde"] = isde.reverse_sde(torch.from_numpy(noisy), T=Topt).numpy()
+        print(key, Topt, float(np.abs(out[key + "/ode"]).max()), float(np.abs(out[key + "/sde"]).max()))
+    np.savez_compressed(os.path.join(GOLD, "dsde.npz"), **out)
+    print("dsde.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -276,6 +339,8 @@ def main():
         gen_sampler(sde_utils, ConditionalUNet, big=not a.no_big)
     if a.only in ("", "nafnet"):
         gen_nafnet(sde_utils)
+    if a.only in ("", "dsde"):
+        gen_dsde(sde_utils, a.ref)
 
 
 if __name__ == "__main__":

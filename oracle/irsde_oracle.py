@@ -631,3 +631,143 @@ def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_n
         tap("decoders.%d" % i, x)
     x = conv2d(x, p["ending.weight"], p["ending.bias"], pad=1)
     return np.ascontiguousarray(x[..., :H, :W])
+
+
+# --------------------------------------------------------------------------------------
+# denoising-sde variant: DenoisingSDE + unconditional UNet with full attention at the bottleneck
+#   codes/utils/sde_utils.py:373-593, codes/config/denoising-sde/models/modules/DenoisingUNet_arch.py,
+#   module_util.py:182-204 (Attention)
+# --------------------------------------------------------------------------------------
+
+
+def dsde_schedule(max_sigma, T, schedule="cosine"):
+    """DenoisingSDE.__init__/_initialize (sde_utils.py:377-426): eps fixed at 0.04, `max_sigma > 1` (not >=) rescales."""
+    ms = max_sigma / 255 if max_sigma > 1 else max_sigma
+    sch = irsde_schedule(ms if ms < 1 else ms, T, schedule if schedule == "cosine" else "linear", eps=0.04)
+    sch["max_sigma"] = ms
+    # irsde_schedule divides by 255 when max_sigma >= 1; ms is already < 1 for every real config
+    return sch
+
+
+def dsde_reverse_step(sch, x, noise, z, t, ode, dtype=np.float32):
+    """SDE.reverse_sde_step / reverse_ode_step with DenoisingSDE's drifts (sde_utils.py:44-48, 448-457)."""
+    d = dtype
+    x, noise = np.asarray(x, dtype=d), np.asarray(noise, dtype=d)
+    sigma, sbar, dt = d(sch["sigmas"][t]), d(sch["sigma_bars"][t]), d(sch["dt"])
+    A = d(np.exp(np.float32(-2) * sch["thetas_cumsum"][t] * sch["dt"], dtype=np.float32))
+    score = -noise / sbar
+    if ode:
+        return (x - d(-0.5) * sigma ** 2 * A * score * dt).astype(d)
+    drift = d(-0.5) * sigma ** 2 * (1 + A) * score * dt
+    disp = sigma * (np.asarray(z, dtype=d) * d(math.sqrt(float(sch["dt"]))))
+    return (x - drift - disp).astype(d)
+
+
+def dsde_optimal_timestep(sch, sigma, eps=1e-6):
+    """DenoisingSDE.get_optimal_timestep (sde_utils.py:547-551)."""
+    sigma = sigma / 255 if sigma > 1 else sigma
+    hat = -1 / (2 * float(sch["dt"])) * math.log(1 - sigma ** 2 / sch["max_sigma"] ** 2 + eps)
+    return int(np.argmin(np.abs(sch["thetas_cumsum"] - np.float32(hat))))
+
+
+def uncond_unet_param_shapes(in_nc=3, out_nc=3, nf=64, depth=4):
+    """state_dict of the denoising-sde ConditionalUNet: init_conv takes in_nc channels, mid_attn is full Attention
+    (to_out is a bare Conv2d: no LayerNorm) — denoising-sde/.../DenoisingUNet_arch.py:26,71."""
+    sh = unet_param_shapes(in_nc, out_nc, nf, depth)
+    sh["init_conv.weight"] = (nf, in_nc, 7, 7)
+    mid = nf * 2 ** depth
+    for k in ("mid_attn.fn.fn.to_out.0.weight", "mid_attn.fn.fn.to_out.0.bias", "mid_attn.fn.fn.to_out.1.g"):
+        del sh[k]
+    sh["mid_attn.fn.fn.to_out.weight"] = (mid, 128, 1, 1)
+    sh["mid_attn.fn.fn.to_out.bias"] = (mid,)
+    return sh
+
+
+def uncond_synth_params(seed=0, in_nc=3, out_nc=3, nf=64, depth=4):
+    rs = np.random.RandomState(seed)
+    shapes = uncond_unet_param_shapes(in_nc, out_nc, nf, depth)
+    out = {}
+    for name in sorted(shapes):
+        shp = shapes[name]
+        if name.endswith(".g"):
+            a = rs.uniform(0.5, 1.5, size=shp)
+        else:
+            wshape = shapes[name[:-4] + "weight"] if name.endswith("bias") else shp
+            bound = 1.0 / math.sqrt(int(np.prod(wshape[1:])))
+            a = rs.uniform(-bound, bound, size=shp)
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def full_attention(p, prefix, x, heads=4, dim_head=32):
+    """Attention.forward — module_util.py:193-204."""
+    B, C, H, W = x.shape
+    N = H * W
+    qkv = conv2d(x, p[prefix + "to_qkv.weight"])
+    q, k, v = (qkv[:, i * heads * dim_head:(i + 1) * heads * dim_head].reshape(B, heads, dim_head, N) for i in range(3))
+    q = q * x.dtype.type(dim_head ** -0.5)
+    sim = np.einsum("bhdi,bhdj->bhij", q, k)
+    sim = sim - sim.max(axis=-1, keepdims=True)
+    attn = np.exp(sim)
+    attn = attn / attn.sum(axis=-1, keepdims=True)
+    out = np.einsum("bhij,bhdj->bhid", attn, v)  # b h N d
+    out = out.transpose(0, 1, 3, 2).reshape(B, heads * dim_head, H, W)
+    return conv2d(out, p[prefix + "to_out.weight"], p[prefix + "to_out.bias"])
+
+
+def uncond_unet_forward(params, x, t, depth=4, dtype=np.float64, taps=None):
+    """denoising-sde ConditionalUNet.forward(x, time) — denoising-sde/.../DenoisingUNet_arch.py:84-130."""
+    p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
+    x = np.asarray(x, dtype=dtype)
+    if np.isscalar(t):
+        t = np.array([int(t)])
+    H, W = x.shape[2:]
+    s = 2 ** depth
+    x = np.pad(x, ((0, 0), (0, 0), (0, (s - H % s) % s), (0, (s - W % s) % s)), mode="reflect")
+    x = conv2d(x, p["init_conv.weight"], pad=3)
+    x_ = x
+    nf = p["init_conv.weight"].shape[0]
+    temb = sinusoidal_pos_emb(t, nf, dtype)
+    temb = linear(gelu(linear(temb, p["time_mlp.1.weight"], p["time_mlp.1.bias"])), p["time_mlp.3.weight"], p["time_mlp.3.bias"])
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+
+    h = []
+    for i in range(depth):
+        x = res_block(p, "downs.%d.0." % i, x, temb)
+        h.append(x)
+        x = res_block(p, "downs.%d.1." % i, x, temb)
+        x = attn_block(p, "downs.%d.2." % i, x)
+        h.append(x)
+        if i != depth - 1:
+            x = conv2d(x, p["downs.%d.3.weight" % i], p["downs.%d.3.bias" % i], stride=2, pad=1)
+        else:
+            x = conv2d(x, p["downs.%d.3.weight" % i], pad=1)
+    x = res_block(p, "mid_block1.", x, temb)
+    tap("mid_block1", x)
+    x = full_attention(p, "mid_attn.fn.fn.", layer_norm_c(x, p["mid_attn.fn.norm.g"])) + x
+    tap("mid_attn", x)
+    x = res_block(p, "mid_block2.", x, temb)
+    for j in range(depth):
+        x = res_block(p, "ups.%d.0." % j, np.concatenate([x, h.pop()], axis=1), temb)
+        x = res_block(p, "ups.%d.1." % j, np.concatenate([x, h.pop()], axis=1), temb)
+        x = attn_block(p, "ups.%d.2." % j, x)
+        if j != depth - 1:
+            x = conv2d(upsample_nearest2(x), p["ups.%d.3.1.weight" % j], p["ups.%d.3.1.bias" % j], pad=1)
+        else:
+            x = conv2d(x, p["ups.%d.3.weight" % j], pad=1)
+    x = res_block(p, "final_res_block.", np.concatenate([x, x_], axis=1), temb)
+    x = conv2d(x, p["final_conv.weight"], p["final_conv.bias"], pad=1)
+    return np.ascontiguousarray(x[..., :H, :W])
+
+
+def dsde_sample(params, sch, xT, ode, noise=None, depth=4, dtype=np.float64, T=-1):
+    """DenoisingSDE.reverse_sde / reverse_ode (sde_utils.py:488-528) with injected noise."""
+    T = sch["T"] if T < 0 else T
+    x = np.asarray(xT, dtype=dtype).copy()
+    for t in range(T, 0, -1):
+        eps_hat = uncond_unet_forward(params, x, t, depth=depth, dtype=dtype)
+        x = dsde_reverse_step(sch, x, eps_hat, None if ode else noise[t], t, ode, dtype)
+    return x

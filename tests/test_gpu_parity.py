@@ -517,3 +517,70 @@ def test_nafnet_sampler_vs_reference_golden(golden, tag, key, T):
         got = _sample(m, mode, T, lq, xT, z, graph=True, sde=sde)
         assert relerr(got, g["%s/%s/%s" % (tag, key, mode)]) < 2e-3, (tag, mode)
         assert np.array_equal(got, _sample(m, mode, T, lq, xT, z, graph=False, sde=sde))
+
+
+# ---------------------------------------------------------------------------------------------
+# denoising-sde variant: DenoisingSDE + unconditional UNet with full attention — SURVEY.md §8(f) N2
+# ---------------------------------------------------------------------------------------------
+_DSDE = {}
+
+
+def dsde_model(nf, depth, flags=0):
+    if (nf, depth, flags) not in _DSDE:
+        params = O.uncond_synth_params(seed=0, nf=nf, depth=depth)
+        m = P.denoising_sde.ConditionalUNet(3, 3, nf, depth=depth)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        m.engine_flags = flags
+        _DSDE[nf, depth, flags] = (m.to(DEV).eval(), params)
+    return _DSDE[nf, depth, flags]
+
+
+@pytest.mark.parametrize("tag", ["nf32d2_2x24x20", "nf64d4_1x64x64", "nf64d4_2x88x80"])
+def test_dsde_unet_forward_vs_reference_golden(golden, tag):
+    """forward(x, time) of the denoising-sde UNet; nf64d4_2x88x80 has 120 bottleneck tokens (key/query tile masking)."""
+    g = golden.dsde
+    nf, depth, B, H, W = (int(v) for v in g[tag + "/cfg"])
+    m, params = dsde_model(nf, depth)
+    _, xT = O.synth_inputs(1234, B, H, W, max_sigma=25)
+    x = torch.from_numpy(xT).to(DEV)
+    for t in g[tag + "/ts"]:
+        y = m(x, int(t)).cpu().numpy()
+        assert relerr(y, g[tag + "/t%d" % t]) < 1e-4, (tag, int(t))
+
+
+def test_dsde_full_attention_block_vs_oracle():
+    nf, depth, B, H, W = 32, 2, 2, 24, 20
+    m, params = dsde_model(nf, depth, flags=_lib.FLAG_KEEP_ACTIVATIONS)
+    _, xT = O.synth_inputs(1234, B, H, W, max_sigma=25)
+    taps = {}
+    ref = O.uncond_unet_forward(params, xT, 7, depth=depth, taps=taps)
+    y = m(torch.from_numpy(xT).to(DEV), 7).cpu().numpy()
+    for name in ("mid_block1", "mid_attn"):
+        assert relerr(m.debug_tap(name).numpy(), taps[name]) < 5e-5, name
+    assert relerr(y, ref) < 5e-5
+
+
+@pytest.mark.parametrize("tag,key", [("nf32d2_2x24x20", "sampler_2x16x16"), ("nf64d4_1x64x64", "sampler_1x32x32")])
+def test_dsde_sampler_vs_reference_golden(golden, tag, key):
+    """DenoisingSDE.reverse_ode / reverse_sde from the optimal timestep (denoising-sde test.py:103-107) vs the reference."""
+    g = golden.dsde
+    nf, depth = (int(v) for v in g[tag + "/cfg"][:2])
+    m, _ = dsde_model(nf, depth)
+    k = "%s/%s" % (tag, key)
+    noisy = g[k + "/noisy"]
+    sde = P.DenoisingSDE(max_sigma=75, T=100, device=DEV)
+    assert float(sde.dt) == float(g["sde/dt"]) and np.array_equal(sde.sigma_bars.cpu().numpy(), g["sde/sigma_bars"])
+    sde.set_model(m)
+    Topt = sde.get_optimal_timestep(25)
+    assert int(Topt) == int(g[k + "/T"])
+    sde.injected_noise = torch.from_numpy(O.synth_noise(7, 100, noisy.shape)).to(DEV)
+    x = torch.from_numpy(noisy).to(DEV)
+    for mode, fn in (("ode", sde.reverse_ode), ("sde", sde.reverse_sde)):
+        got = fn(x, T=Topt).cpu().numpy()
+        assert relerr(got, g[k + "/" + mode]) < 2e-3, (tag, mode)
+        sde.use_graph = False
+        assert np.array_equal(fn(x, T=Topt).cpu().numpy(), got)
+        sde.use_graph = True
+    # the x0-guided variant (real score) runs the per-step fused update
+    x0 = torch.from_numpy(noisy * 0.5).to(DEV)
+    assert torch.isfinite(sde.reverse_ode(x, x0=x0, T=5)).all()

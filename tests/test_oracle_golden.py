@@ -182,3 +182,37 @@ def test_nafnet_forward(golden, tag):
         y = O.nafnet_forward(params, xT, lq, int(t), cfg["enc_blk_nums"], cfg["middle_blk_num"], cfg["dec_blk_nums"])
         ref = g[tag + "/t%d" % t]
         assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-5, (tag, t)
+
+
+def test_dsde_schedule_and_unet(golden):
+    """denoising-sde variant: DenoisingSDE tables / optimal timestep and the unconditional UNet with full attention."""
+    g = golden.dsde
+    sch = O.dsde_schedule(75, 100)
+    assert abs(float(sch["dt"]) - float(g["sde/dt"])) <= 1e-6 * float(g["sde/dt"])
+    for n, rtol in (("thetas", 3e-5), ("sigmas", 2e-5), ("thetas_cumsum", 1e-5), ("sigma_bars", 5e-4)):
+        np.testing.assert_allclose(sch[n][1:], g["sde/" + n][1:], rtol=rtol, atol=1e-9, err_msg=n)
+    ref_sch = dict(sch, **{n: g["sde/" + n] for n in ("thetas", "sigmas", "thetas_cumsum", "sigma_bars")}, dt=g["sde/dt"])
+    assert [O.dsde_optimal_timestep(ref_sch, s) for s in (15, 25, 50)] == list(g["sde/opt_t"])
+    for tag in ("nf32d2_2x24x20", "nf64d4_2x88x80"):
+        nf, depth, B, H, W = (int(v) for v in g[tag + "/cfg"])
+        params = O.uncond_synth_params(seed=0, nf=nf, depth=depth)
+        _, xT = O.synth_inputs(1234, B, H, W, max_sigma=25)
+        for t in g[tag + "/ts"]:
+            y = O.uncond_unet_forward(params, xT, int(t), depth=depth)
+            ref = g[tag + "/t%d" % t]
+            assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-5, (tag, t)
+
+
+def test_dsde_sampler_small(golden):
+    g = golden.dsde
+    tag, key = "nf32d2_2x24x20", "nf32d2_2x24x20/sampler_2x16x16"
+    params = O.uncond_synth_params(seed=0, nf=32, depth=2)
+    T = int(g[key + "/T"])
+    gs = golden.dsde
+    sch = O.dsde_schedule(75, 100)
+    sch.update({n: gs["sde/" + n] for n in ("thetas", "sigmas", "thetas_cumsum", "sigma_bars")}, dt=gs["sde/dt"])
+    z = O.synth_noise(7, 100, (2, 3, 16, 16))
+    for mode in ("ode", "sde"):
+        y = O.dsde_sample(params, sch, g[key + "/noisy"], mode == "ode", noise=z, depth=2, T=T)
+        ref = g[key + "/" + mode]
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-3, mode
