@@ -29,6 +29,28 @@ def test_schedule_bit_identical_to_reference(golden, tag):
     assert np.array_equal(c[:, 0], g[tag + "/thetas"]) and np.array_equal(c[:, 2], g[tag + "/sigma_bars"])
 
 
+def test_denoising_sde_tables_bit_identical(golden):
+    g = golden.dsde
+    sde = P.DenoisingSDE(max_sigma=75, T=100, device="cpu")
+    assert float(sde.dt) == float(g["sde/dt"])
+    for n in ("thetas", "sigmas", "thetas_cumsum", "sigma_bars"):
+        assert np.array_equal(getattr(sde, n).numpy(), g["sde/" + n]), n
+    assert [int(sde.get_optimal_timestep(s)) for s in (15, 25, 50)] == [int(v) for v in g["sde/opt_t"]]
+    c = sde._coef.numpy()
+    assert np.array_equal(c[:, 9], np.exp(np.float32(-2) * g["sde/thetas_cumsum"] * np.float32(g["sde/dt"])).astype(np.float32)) or \
+        np.allclose(c[:, 9], np.exp(-2.0 * g["sde/thetas_cumsum"].astype(np.float64) * float(g["sde/dt"])), rtol=1e-6)
+    assert P.DenoisingSDE(1, 10).max_sigma == 1 and abs(P.DenoisingSDE(25, 10).max_sigma - 25 / 255) < 1e-12  # '>' not '>='
+
+
+def test_variant_state_dicts_are_reference_compatible():
+    sd = P.denoising_sde.ConditionalUNet(3, 3, 64, 4).state_dict()
+    sh = O.uncond_unet_param_shapes(3, 3, 64, 4)
+    assert set(sd) == set(sh) and all(tuple(sd[k].shape) == tuple(sh[k]) for k in sh)
+    sd = P.ConditionalNAFNet(3, width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1]).state_dict()
+    sh = O.naf_param_shapes(3, 64, 1, (1, 1, 1, 28), (1, 1, 1, 1))
+    assert set(sd) == set(sh) and all(tuple(sd[k].shape) == tuple(sh[k]) for k in sh)
+
+
 def test_irsde_surface_matches_reference_names():
     sde = P.IRSDE(10, 100, "cosine", 0.005, device="cpu")
     for name in ["set_mu", "set_model", "noise_state", "reverse_sde", "reverse_ode", "reverse_posterior",
