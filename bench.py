@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--mode", default="sde", choices=["sde", "ode", "posterior"])
-    ap.add_argument("--model", default="unet", choices=["unet", "nafnet"],
+    ap.add_argument("--model", default="unet", choices=["unet", "nafnet", "dsde"],
                     help="unet: IR-SDE ConditionalUNet (BASELINE configs[1]); nafnet: Refusion ConditionalNAFNet (configs[3])")
     ap.add_argument("--max-sigma", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,7 +94,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    if a.model == "nafnet":  # refusion.yml network_G
+    if a.model == "dsde":  # denoising-sde/options/test/ir-sde.yml: unconditional UNet + DenoisingSDE(max_sigma=75, T=100)
+        params = O.uncond_synth_params(seed=0, nf=64, depth=4)
+        model = P.denoising_sde.ConditionalUNet(3, 3, 64, depth=4)
+    elif a.model == "nafnet":  # refusion.yml network_G
         ncfg = dict(width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
         params = O.naf_synth_params(seed=0, img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28),
                                     dec_blk_nums=(1, 1, 1, 1))
@@ -105,11 +108,14 @@ def main():
         model = P.ConditionalUNet(3, 3, nf, depth=depth)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(dev).eval()
-    max_sigma = a.max_sigma if a.max_sigma is not None else (50 if a.model == "nafnet" else 10)
-    sde = P.IRSDE(max_sigma=max_sigma, T=a.T, schedule="cosine", eps=0.005, device=dev)
+    max_sigma = a.max_sigma if a.max_sigma is not None else {"nafnet": 50, "dsde": 75}.get(a.model, 10)
+    if a.model == "dsde":
+        sde = P.DenoisingSDE(max_sigma=max_sigma, T=a.T, device=dev)
+    else:
+        sde = P.IRSDE(max_sigma=max_sigma, T=a.T, schedule="cosine", eps=0.005, device=dev)
     sde.set_model(model)
     sde.seed = 7
-    sde.profile = not a.no_profile
+    sde.profile = (not a.no_profile) and a.model != "dsde"
     sde.use_graph = True
 
     nglobal = a.batch * world
@@ -120,8 +126,13 @@ def main():
     mu = torch.from_numpy(lq).to(dev)
     x_T = torch.from_numpy(xT).to(dev)
     sde.image_offset = rank * a.batch
-    sde.set_mu(mu)
-    fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[a.mode]
+    n_evals = a.T
+    if a.model == "dsde":  # denoising-sde/test.py:103-107: reverse_ode from the optimal timestep of the noise level (sigma 25)
+        n_evals = int(sde.get_optimal_timestep(25))
+        fn = lambda x: sde.reverse_ode(x, T=n_evals) if a.mode != "sde" else sde.reverse_sde(x, T=n_evals)  # noqa: E731
+    else:
+        sde.set_mu(mu)
+        fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[a.mode]
 
     def one_step():
         out = fn(x_T)
@@ -160,11 +171,14 @@ def main():
     if rank == 0:
         imgs = nglobal * a.steps
         res = {
-            "metric": "restored images/sec at %dx%d, %d-step IR-SDE reverse sampler" % (a.size, a.size, a.T),
+            "metric": ("restored images/sec at %dx%d, %d-step DenoisingSDE reverse sampler (optimal timestep of sigma=25)" % (a.size, a.size, n_evals)
+                       if a.model == "dsde" else "restored images/sec at %dx%d, %d-step IR-SDE reverse sampler" % (a.size, a.size, a.T)),
             "value": imgs / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("Refusion ConditionalNAFNet width=64 enc[1,1,1,28], reverse_%s, batch=%d/GPU %dx%d, T=%d, fp32 "
+            "config": {"workload": ("denoising-sde unconditional UNet nf=64 depth=4 (full attention at the bottleneck), DenoisingSDE reverse_%s from the "
+                                    "optimal timestep of sigma=25 (" + str(n_evals) + " network evaluations), batch=%d/GPU %dx%d, schedule T=%d, fp32"
+                                    if a.model == "dsde" else "Refusion ConditionalNAFNet width=64 enc[1,1,1,28], reverse_%s, batch=%d/GPU %dx%d, T=%d, fp32 "
                                     "(BASELINE.json configs[3] network)" if a.model == "nafnet" else
                                     "IR-SDE deraining ConditionalUNet nf=64 depth=4, reverse_%s, batch=%d/GPU %dx%d, "
                                     "T=%d, fp32 (BASELINE.json configs[1])") % (a.mode, a.batch, a.size, a.size, a.T),
