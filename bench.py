@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 matrix = vector peak (guides/MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide)
 
 
 def host_cores():
@@ -73,6 +74,8 @@ def main():
     ap.add_argument("--model", default="unet", choices=["unet", "nafnet", "dsde"],
                     help="unet: IR-SDE ConditionalUNet (BASELINE configs[1]); nafnet: Refusion ConditionalNAFNet (configs[3])")
     ap.add_argument("--max-sigma", type=float, default=None)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE configs[2] (conv operands bf16, fp32 accumulate); the headline metric is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="time graph replay instead of the event-instrumented loop")
     a = ap.parse_args()
@@ -108,6 +111,7 @@ def main():
         model = P.ConditionalUNet(3, 3, nf, depth=depth)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(dev).eval()
+    model.set_compute_dtype(a.dtype)
     max_sigma = a.max_sigma if a.max_sigma is not None else {"nafnet": 50, "dsde": 75}.get(a.model, 10)
     if a.model == "dsde":
         sde = P.DenoisingSDE(max_sigma=max_sigma, T=a.T, device=dev)
@@ -175,14 +179,14 @@ def main():
                        if a.model == "dsde" else "restored images/sec at %dx%d, %d-step IR-SDE reverse sampler" % (a.size, a.size, a.T)),
             "value": imgs / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16 operands / f32 accumulate+state", "data": "synthetic",
             "config": {"workload": ("denoising-sde unconditional UNet nf=64 depth=4 (full attention at the bottleneck), DenoisingSDE reverse_%s from the "
                                     "optimal timestep of sigma=25 (" + str(n_evals) + " network evaluations), batch=%d/GPU %dx%d, schedule T=%d, fp32"
                                     if a.model == "dsde" else "Refusion ConditionalNAFNet width=64 enc[1,1,1,28], reverse_%s, batch=%d/GPU %dx%d, T=%d, fp32 "
                                     "(BASELINE.json configs[3] network)" if a.model == "nafnet" else
                                     "IR-SDE deraining ConditionalUNet nf=64 depth=4, reverse_%s, batch=%d/GPU %dx%d, "
                                     "T=%d, fp32 (BASELINE.json configs[1])") % (a.mode, a.batch, a.size, a.size, a.T),
-                       "global_batch": nglobal, "parallelism": "batch-shard x%d (no collective in the T loop; final all_gather)" % world},
+                       "compute_dtype": a.dtype, "global_batch": nglobal, "parallelism": "batch-shard x%d (no collective in the T loop; final all_gather)" % world},
         }
         if sde.profile and prof["conv_ms"] > 0:
             # `achieved` = ALGORITHMIC FLOPs (direct-convolution count) / time of the convolution kernels
@@ -198,16 +202,19 @@ def main():
                     traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"]
             except (OSError, IndexError, KeyError, ValueError):
                 traffic = None
+            if a.dtype == "bf16":
+                traffic = None
+            peak = PEAK_FP32_TFLOPS if a.dtype == "fp32" else PEAK_BF16_TFLOPS
             res["roofline"] = {
-                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": traffic,
                 "traffic_unit": "bytes per conv launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes, profiles/*_bench_pmc_hbm.txt)",
                 "algorithmic_bytes_per_launch": prof["conv_bytes"] / max(prof["conv_launches"], 1),
                 "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM: direct 1x1/4x4/7x7/narrow-3x3 layers + the batched GEMMs of the Winograd F(4x4,3x3)/F(2x2,3x3) layers; %d launches per network evaluation) + wino_input/wino_output transform kernels"
                           % int(round(prof["conv_launches"] / max(prof["net_evals"], 1))),
                 "avg_launch_ms": (prof["conv_ms"] + prof["wino_ms"]) / max(prof["conv_launches"], 1),
                 "flops_per_launch": prof["conv_flops"] / max(prof["conv_launches"], 1),
-                "executed_TFLOPs": exe, "executed_frac": exe / PEAK_FP32_TFLOPS,
+                "executed_TFLOPs": exe, "executed_frac": exe / peak,
                 "executed_flops_per_launch": prof["conv_exec_flops"] / max(prof["conv_launches"], 1),
                 "kernel_time_share": {"conv": prof["conv_ms"] / prof["wall_ms"], "layernorm": prof["ln_ms"] / prof["wall_ms"],
                                       "attention": prof["attn_ms"] / prof["wall_ms"], "winograd_transforms": prof["wino_ms"] / prof["wall_ms"],
@@ -217,6 +224,14 @@ def main():
                 "hbm_frac": prof["conv_bytes"] / (prof["wall_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                 "whole_path_TFLOPs": prof["conv_flops"] / (prof["wall_ms"] * 1e-3) / 1e12,
             }
+            if a.dtype == "bf16":
+                # the bf16 kernel is fed from fp32 activations: HBM binds, so quote the HBM roof first
+                r = res["roofline"]
+                gbps = prof["conv_bytes"] / (prof["conv_ms"] * 1e-3) / 1e9
+                r.update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                          "mfma_TFLOPs": ach, "mfma_frac": ach / PEAK_BF16_TFLOPS,
+                          "kernel": "conv_igemm_kernel<bf16> (v_mfma_f32_32x32x16_bf16 implicit GEMM, fp32 activations rounded while staged; "
+                                    "achieved = ideal-fusion conv bytes / conv kernel time)"})
         if not a.no_cpu_baseline and world == 1 and a.model == "unet":
             try:
                 res["cpu_baseline"] = cpu_baseline(a.size, a.T)

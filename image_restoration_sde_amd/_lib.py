@@ -19,6 +19,7 @@ FLAG_NAIVE_CONV = 2
 FLAG_NO_WINOGRAD = 4
 FLAG_NO_WINOGRAD_F43 = 8
 FLAG_UNCOND_FULLATTN = 16
+FLAG_BF16 = 32
 SAMPLE_GRAPH = 1
 SAMPLE_PROFILE = 2
 

@@ -38,6 +38,7 @@ struct ConvParams {
     int Hin = 0, Win = 0;        // physical input height/width (both sources)
     int in_shift = 0;            // 1: fused nearest x2 upsample
     const float* w = nullptr;    // [Cout][KH*KW][C0+C1]
+    const unsigned short* w_bf = nullptr;  // same layout rounded to bf16: selects the bf16-MFMA kernel (fp32 accumulate)
     int Cout = 0;
     int KH = 1, KW = 1, stride = 1, pad_y = 0, pad_x = 0;
     int B = 0, Ho = 0, Wo = 0;
@@ -94,6 +95,7 @@ void launch_conv(const ConvParams& p, hipStream_t s);
 void conv_global_init();
 void conv_set_variant(int v);  // tuning experiments (irsde_bench_conv)
 void launch_fill_random(float* p, size_t n, unsigned seed, float scale, hipStream_t s);  // sets the dynamic-LDS attribute of every tile configuration (call before graph capture)
+void launch_f32_to_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);  // round-to-nearest-even
 // naive direct convolution on VALU (one thread per output) — debug / cross-check path only
 void launch_conv_naive(const ConvParams& p, hipStream_t s);
 

@@ -1,6 +1,9 @@
-// Implicit-GEMM NHWC convolution for gfx950 on the exact-fp32 matrix pipe
-// (v_mfma_f32_32x32x2_f32: D = A(32x2) * B(2x32) + C, one f32 A and one f32 B operand per lane,
-//  bit-for-bit an fmaf chain; 64 cycles per instruction per SIMD = the fp32 peak of 157 TFLOP/s).
+// Implicit-GEMM NHWC convolution for gfx950 on the matrix pipe, two arithmetic modes:
+//   fp32 : v_mfma_f32_32x32x2_f32 — D = A(32x2) * B(2x32) + C, one f32 A and one f32 B operand per lane,
+//          bit-for-bit an fmaf chain; 64 cycles per instruction per SIMD = the fp32 peak of 157 TFLOP/s.
+//   bf16 : v_mfma_f32_32x32x16_bf16 — activations (fp32 in HBM) are rounded to bf16 (RNE) while they are
+//          staged into LDS, weights come pre-rounded ([Cout][KH][KW][Cin] bf16), accumulation stays fp32;
+//          32 cycles per 16-deep instruction = 16x the fp32 rate, so the kernel turns L2/HBM-bound.
 //
 // Replaces every nn.Conv2d of the reference score network (3x3, 1x1, 4x4 s2, 7x7 and the
 // nearest-upsample + 3x3 pair): reference call sites module_util.py:93-105 (Upsample/Downsample/
@@ -8,15 +11,18 @@
 //
 // GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*(C0+C1).  Both operands are
 // K-contiguous in HBM (NHWC activations, [Cout][KH][KW][Cin] weights), so both LDS tiles are
-// [rows][BK] with a 16-byte pad per row (row stride 36 floats = 9 x 16-B slots, odd => the
-// 16-lane groups of ds_read_b128 hit 16 distinct slots: conflict-free).  A lane reads 4 consecutive
-// k with one ds_read_b128 and feeds 4 MFMAs; lane half h owns k = 8*sb + 4*h + {0..3}, the same
-// assignment for A and B, so the k-order inside the MFMA chain is a permutation (legal: sum over k).
+// [rows][32 k] with a 16-byte pad per row (row stride 144 B fp32 / 80 B bf16 = an odd number of 16-B
+// slots => the 16-lane groups of ds_read_b128 hit 16 distinct slots: conflict-free).  A lane reads 16
+// bytes of consecutive k with one ds_read_b128 (fp32: 4 k -> 4 MFMAs; bf16: 8 k -> one MFMA); lane half h
+// owns the second 16 bytes of every 32-byte group, the same assignment for A and B, so the k-order
+// inside the MFMA chain is a permutation (legal: sum over k).
 //
 // K loop: taps outer / 32-channel chunks inner.  The per-row pixel offset of a tap is computed once
 // per tap (not per K-step); a K-step then costs one 64-bit mad + one load per staged row.
 // global->register->LDS staging is split: the loads of K-step t+1 are issued before the MFMAs of
-// step t and written to the other LDS buffer after them; one barrier per K-step.
+// step t and written to the other LDS buffer after them; one barrier per K-step.  Two blocks share a
+// CU and cover each other's staging gaps.  (Interleaved schedules, wave priorities, LDS-DMA staging and
+// AGPR accumulators were all measured and dropped: profiles/r01_conv_tuning_notes.md.)
 //
 // Epilogue: the accumulator tile is transposed through LDS (the A/B buffers are dead by then) so
 // that every lane handles 4 consecutive output channels: bias / FiLM / residual / output move as
@@ -26,52 +32,47 @@
 namespace irsde {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int DMA = 0>
+constexpr int BK = 32;  // k per K-step (channels of one tap)
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF16>
 struct Cfg {
     static constexpr int NT = 64 * WAVES_M * WAVES_N;
-    // register staging: rows padded by 16 B (conflict-free b128 reads); LDS-DMA staging: dense 128-B rows,
-    // 16-B chunks XOR-swizzled by ((row >> 1) & 7) on the SOURCE side (the DMA destination is lane-linear)
-    static constexpr int LDS_K = DMA ? BK : BK + 4;
+    static constexpr int ROW_BYTES = BK * (BF16 ? 2 : 4) + 16;  // LDS tile row: 32 k + 16-B pad
     static constexpr int TM = BM / WAVES_M / 32;
     static constexpr int TN = BN / WAVES_N / 32;
-    static constexpr int CHUNKS = BK / 4;
-    static constexpr int ROWS = NT / CHUNKS;
-    static constexpr int A_PASSES = BM / ROWS;
-    static constexpr int B_PASSES = (BN + ROWS - 1) / ROWS;
+    // A (activations, fp32 in HBM in both modes): 8 x 16-B loads per row of 32 k
+    static constexpr int A_ROWS = NT / 8;
+    static constexpr int A_PASSES = BM / A_ROWS;
+    // B (weights): fp32 8 x 16 B per row, bf16 4 x 16 B per row
+    static constexpr int B_CHUNKS = BF16 ? 4 : 8;
+    static constexpr int B_ROWS = NT / B_CHUNKS;
+    static constexpr int B_PASSES = (BN + B_ROWS - 1) / B_ROWS;
     static constexpr int LDS_C = BN + 4;  // epilogue tile row stride (floats): 16-B aligned, odd number of slots
-    static constexpr int MAIN_BYTES = 2 * (BM + BN) * LDS_K * 4;
-    static constexpr int EPI_ROWS = BM > 128 ? 128 : BM;  // the epilogue transposes EPI_ROWS tile rows per pass
+    static constexpr int MAIN_BYTES = 2 * (BM + BN) * ROW_BYTES;
+    // the epilogue transposes EPI_ROWS tile rows per pass (bf16: smaller passes keep 3+ blocks per CU resident)
+    static constexpr int EPI_ROWS = BF16 ? BM / WAVES_M : (BM > 128 ? 128 : BM);
     static constexpr int EPI_BYTES = EPI_ROWS * LDS_C * 4;
     static_assert((BM / WAVES_M) <= EPI_ROWS && EPI_ROWS % (BM / WAVES_M) == 0, "wave rows must tile an epilogue pass");
     static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
-    static_assert(BM % ROWS == 0, "tile/pass mismatch");
-    static_assert(BN % ROWS == 0 || BN < ROWS, "tile/pass mismatch");
+    static_assert(BM % A_ROWS == 0, "tile/pass mismatch");
+    static_assert(BN % B_ROWS == 0 || BN < B_ROWS, "tile/pass mismatch");
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
-// MFMA with the accumulator pinned to the AGPR half of the register file (experiment: keeps the 16-register
-// C/D traffic off the arch-VGPR ports that LDS stores / VMEM address reads use).
-template <bool AGPR>
-__device__ __forceinline__ void mfma32(floatx16& acc, float a, float b) {
-    if (AGPR) {
-        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    } else {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-}
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MIN_WAVES_PER_SIMD, int SCHED = 0, int DMA = 0>
+// INSCALE: per-(batch, input channel) scale applied while staging (NAFNet SCA).  A template parameter, not a runtime
+// test: a branch inside the staging code makes the compiler wait for every load where the paths join, which
+// serialises the loads of a K-step and pulls the vmcnt(0) in front of the MFMAs.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD, bool BF16, bool INSCALE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void conv_igemm_kernel(
     const ConvParams pin, const int nblk_n, const int M, const int nk_total) {
-    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK, DMA>;
-    static_assert(!DMA || BK == 32, "LDS-DMA staging assumes 128-byte rows");
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16>;
     ConvParams p = pin;  // batched launch: component blockIdx.z works on its own slice of in0 / w / out
     if (pin.nz > 1) {
         const long long z = blockIdx.z;
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         p.out = pin.out + z * pin.z_out;
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + 2 * BM * C::LDS_K;
+    char* As = reinterpret_cast<char*>(smem);
+    char* Bs = As + 2 * BM * C::ROW_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -90,21 +91,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     const int wn = wave % WAVES_N;
     const int l31 = lane & 31;
     const int h = lane >> 5;
-
-    // Two blocks share a CU (one wave of each per SIMD).  Running identical code they phase-lock: they
-    // share the MFMA pipe evenly, so both leave the MFMA phase together and both sit in the staging /
-    // barrier gap together, idling the pipe (measured: 18 % idle).  Breaking the symmetry with a static
-    // priority by hardware wave slot (HW_REG_HW_ID.WAVE_ID parity: co-resident waves of one SIMD hold
-    // different slots) lets one block run its MFMA phase at full rate while the other fills its gaps.
-    if (SCHED & 2) {
-        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID[3:0] = wave slot
-        if (hwid & 1) __builtin_amdgcn_s_setprio(2);
-    }
-    if (SCHED & 8 && !(SCHED & 4)) {  // experiment: initial half-period phase offset for odd wave slots
-        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-        if (hwid & 1)
-            for (int i = 0; i < 40; ++i) __builtin_amdgcn_s_sleep(1);
-    }
 
     // XCD-aware block remap (bijective): each XCD (block id % 8) walks a contiguous range of tiles so
     // that neighbouring tiles (same activation rows, other Cout slices / halo rows) share one L2.
@@ -132,14 +118,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     const int Wv = p.Win << p.in_shift;
 
     // ---- per-thread staging coordinates (fixed for the whole K loop) ----
-    const int chunk = tid % C::CHUNKS;
-    const int row0 = tid / C::CHUNKS;
-    // logical 16-B chunk of the K slice this lane fetches (DMA: inverse of the read-side swizzle)
-    const int cchunk = DMA ? (chunk ^ ((row0 >> 1) & 7)) : chunk;
+    const int chunk = tid % 8;   // A: 16-B chunk (4 fp32 k) of the 32-k slice
+    const int row0 = tid / 8;    // A: first staged row
+    const int bchunk = tid % C::B_CHUNKS;
+    const int brow0 = tid / C::B_CHUNKS;
     int a_iy0[C::A_PASSES], a_ix0[C::A_PASSES], a_pix[C::A_PASSES], a_b[C::A_PASSES];
 #pragma unroll
     for (int ps = 0; ps < C::A_PASSES; ++ps) {
-        const int m = m0 + row0 + ps * C::ROWS;
+        const int m = m0 + row0 + ps * C::A_ROWS;
         const bool ok = m < M;
         const int mm = ok ? m : 0;
         const int ox = mm % p.Wo;
@@ -152,14 +138,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         a_pix[ps] = b * p.Hin * p.Win;
         a_b[ps] = b;
     }
-    const float* wrow[C::B_PASSES];
-    bool b_ok[C::B_PASSES];
+    // weight row (+ this lane's 16-B chunk) of every staged B row.  Rows past Cout are clamped to the last row, not
+    // zeroed: they only feed output columns n >= Cout, which the epilogue never stores.
+    const char* wrow[C::B_PASSES];
+    constexpr int WESZ = BF16 ? 2 : 4;
+    const char* wbase = BF16 ? reinterpret_cast<const char*>(p.w_bf) : reinterpret_cast<const char*>(p.w);
+    if (BF16 && pin.nz > 1) wbase += (long long)blockIdx.z * pin.z_w * WESZ;
 #pragma unroll
     for (int ps = 0; ps < C::B_PASSES; ++ps) {
-        const int r = row0 + ps * C::ROWS;
-        const int n = n0 + r;
-        b_ok[ps] = n < p.Cout && r < BN;
-        wrow[ps] = p.w + (size_t)(b_ok[ps] ? n : 0) * taps * Ctot + cchunk * 4;
+        const int n = n0 + brow0 + ps * C::B_ROWS;
+        wrow[ps] = wbase + ((size_t)(n < p.Cout ? n : p.Cout - 1) * taps * Ctot) * WESZ + bchunk * 16;
     }
 
     // ---- K-loop state: (tap, channel offset); per-tap pixel offsets of the staged rows ----
@@ -190,12 +178,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         }
     };
 
-    // ---- staging pieces: A rows (A_PASSES) then B rows (B_PASSES), one 16-byte load/store each ----
+    // ---- staging pieces: A rows (A_PASSES) then B rows (B_PASSES), one 16-byte load each ----
     constexpr int NP = C::A_PASSES + C::B_PASSES;
     float4 rs[NP];
     const float* cur_src = nullptr;  // source pointer (+channel +chunk) of the K-step being staged
     int cur_pix = 0;
-    size_t cur_wk = 0;
+    size_t cur_wk = 0;  // byte offset of the K-step inside a weight row
     auto stage_setup = [&]() {
         const float* src;
         int c;
@@ -204,49 +192,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         } else {
             src = p.in1; c = cc - p.C0; cur_pix = p.pix1;
         }
-        cur_src = src + c + cchunk * 4;
-        cur_wk = (size_t)tap * Ctot + cc;
-    };
-    // LDS-DMA: one global_load_lds_dwordx4 per piece writes 64 lanes x 16 B = 8 rows x 128 B straight into the
-    // LDS tile (destination = wave-uniform base + lane*16); out-of-image taps / rows read a zero page.
-    auto dma_piece = [&](int q, int buf) {
-        if (q < C::A_PASSES) {
-            const bool ok = a_poff[q] >= 0;
-            const float* g = ok ? cur_src + (size_t)a_poff[q] * cur_pix : p.zeros;
-            float* dst = As + buf * BM * C::LDS_K + (q * C::ROWS + wave * (64 / C::CHUNKS)) * C::LDS_K;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
-        } else {
-            const int ps = q - C::A_PASSES;
-            if (C::B_PASSES * C::ROWS == BN || ps * C::ROWS + wave * (64 / C::CHUNKS) < BN) {
-                const float* g = b_ok[ps] ? wrow[ps] + cur_wk : p.zeros;
-                float* dst = Bs + buf * BN * C::LDS_K + (ps * C::ROWS + wave * (64 / C::CHUNKS)) * C::LDS_K;
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
-            }
-        }
+        cur_src = src + c + chunk * 4;
+        cur_wk = ((size_t)tap * Ctot + cc) * WESZ;
     };
     auto load_piece = [&](int q) {
         if (q < C::A_PASSES) {
-            const bool ok = a_poff[q] >= 0;  // branch-free: out-of-image taps read pixel 0 and are zeroed
-            float4 v = *reinterpret_cast<const float4*>(cur_src + (size_t)(ok ? a_poff[q] : 0) * cur_pix);
-            if (p.in_scale) {  // per-(batch, input channel) scale applied while staging (NAFNet SCA), single source
-                const float4 sc4 = *reinterpret_cast<const float4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + cchunk * 4);
+            // branch-free: out-of-image taps (zero padding, rows past M) read the zero page instead
+            const float* g = a_poff[q] >= 0 ? cur_src + (size_t)a_poff[q] * cur_pix : p.zeros;
+            float4 v = *reinterpret_cast<const float4*>(g);
+            if (INSCALE) {  // single source (C1 == 0)
+                const float4 sc4 = *reinterpret_cast<const float4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + chunk * 4);
                 v.x *= sc4.x; v.y *= sc4.y; v.z *= sc4.z; v.w *= sc4.w;
             }
-            rs[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            rs[q] = v;
         } else {
-            const int ps = q - C::A_PASSES;
-            const float4 v = *reinterpret_cast<const float4*>(wrow[ps] + cur_wk);
-            rs[q] = b_ok[ps] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            rs[q] = *reinterpret_cast<const float4*>(wrow[q - C::A_PASSES] + cur_wk);
         }
     };
     auto store_piece = [&](int q, int buf) {
         if (q < C::A_PASSES) {
-            *reinterpret_cast<float4*>(As + buf * BM * C::LDS_K + (row0 + q * C::ROWS) * C::LDS_K + chunk * 4) = rs[q];
+            char* dst = As + (buf * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES;
+            if (BF16) {
+                const floatx4 fv = {rs[q].x, rs[q].y, rs[q].z, rs[q].w};
+                *reinterpret_cast<bf16x4*>(dst + chunk * 8) = __builtin_convertvector(fv, bf16x4);  // v_cvt_pk_bf16_f32, RNE
+            } else {
+                *reinterpret_cast<float4*>(dst + chunk * 16) = rs[q];
+            }
         } else {
             const int ps = q - C::A_PASSES;
-            if (C::B_PASSES * C::ROWS == BN || row0 + ps * C::ROWS < BN)
-                *reinterpret_cast<float4*>(Bs + buf * BN * C::LDS_K + (row0 + ps * C::ROWS) * C::LDS_K + chunk * 4) =
-                    rs[q];
+            if (C::B_PASSES * C::B_ROWS == BN || brow0 + ps * C::B_ROWS < BN)
+                *reinterpret_cast<float4*>(Bs + (buf * BN + brow0 + ps * C::B_ROWS) * C::ROW_BYTES + bchunk * 16) = rs[q];
         }
     };
 
@@ -261,170 +236,68 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     if (kt_begin < kt_end) {
         set_tap();
         stage_setup();
-        if (DMA) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) dma_piece(q, 0);
-        } else {
+        for (int q = 0; q < NP; ++q) load_piece(q);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) load_piece(q);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) store_piece(q, 0);
-        }
+        for (int q = 0; q < NP; ++q) store_piece(q, 0);
     }
     __syncthreads();
 
-    // One K-step = NG groups of 4 chained MFMAs (one accumulator tile x 8 k).  All LDS fragments of the
-    // step are read up front into distinct registers (no LDS wait inside the MFMA stream); the staging
-    // of the next K-step rides in the MFMA shadows: one global load per group in the first half of the
-    // step, one LDS write per group in the second half (counted vmcnt waits), order pinned with
-    // sched_barrier so the compiler cannot re-serialise it.  Only lgkmcnt(0)+barrier remain at the end.
-    constexpr int NSB = BK / 8;
-    constexpr int NG = C::TM * C::TN * NSB;
-    constexpr int HALF = NG / 2;
-    constexpr int PPG = (NP + HALF - 1) / HALF;  // staging pieces per group
-    static_assert(NG >= 2 && NG % 2 == 0, "group count");
-
+    // One K-step: next-tile loads issued first, then the MFMAs (the compiler streams the fragment reads
+    // between them), then the LDS writes.  The other block on the CU covers the gaps.
+    constexpr int NSB = BF16 ? 2 : 4;  // 32-byte groups per tile row
     auto k_step = [&](const int buf, const bool more) {
-        float4 fa[NSB][C::TM], fb[NSB][C::TN];
-        const float* a = As + buf * BM * C::LDS_K + (wm * C::TM * 32 + l31) * C::LDS_K + h * 4;
-        const float* b = Bs + buf * BN * C::LDS_K + (wn * C::TN * 32 + l31) * C::LDS_K + h * 4;
+        if (more) {
+            advance();
+            stage_setup();
+#pragma unroll
+            for (int q = 0; q < NP; ++q) load_piece(q);
+        }
+        const char* a = As + (buf * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
+        const char* b = Bs + (buf * BN + wn * C::TN * 32 + l31) * C::ROW_BYTES + h * 16;
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-                fa[sb][i] = *reinterpret_cast<const float4*>(a + i * 32 * C::LDS_K + sb * 8);
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j)
-                fb[sb][j] = *reinterpret_cast<const float4*>(b + j * 32 * C::LDS_K + sb * 8);
-        }
-        if (more) {
-            advance();
-            stage_setup();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int sb = g / (C::TM * C::TN);
-            const int i = (g % (C::TM * C::TN)) / C::TN;
-            const int j = g % C::TN;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].x, fb[sb][j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].y, fb[sb][j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].z, fb[sb][j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].w, fb[sb][j].w, acc[i][j], 0, 0, 0);
-            if (more) {
-                if (g < HALF) {
-#pragma unroll
-                    for (int q = g * PPG; q < (g + 1) * PPG && q < NP; ++q) load_piece(q);
-                } else {
-#pragma unroll
-                    for (int q = (g - HALF) * PPG; q < (g - HALF + 1) * PPG && q < NP; ++q) store_piece(q, buf ^ 1);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // SCHED 0: lumped schedule — next-tile loads issued first, then the MFMAs (the compiler streams the
-    // fragment reads between them), then the LDS writes.  The other block on the CU covers the gaps.
-    constexpr int ABL = (SCHED >> 4) & 7;  // ablation experiments only (results are wrong when ABL != 0)
-    // float offset of the 16-B fragment chunk (k = 8*sb + 4*h .. +3) inside a tile row
-    const int rsw = (l31 >> 1) & 7;
-    auto koff = [&](int sb) { return DMA ? (((sb * 2 + h) ^ rsw) * 4) : (sb * 8 + h * 4); };
-    auto k_step_lumped = [&](const int buf, const bool more) {
-        if (more) {
-            advance();
-            stage_setup();
-            if (DMA) {
-#pragma unroll
-                for (int q = 0; q < NP; ++q) dma_piece(q, buf ^ 1);  // lands during this step's MFMAs
-            } else if (ABL != 1 && ABL != 2 && ABL != 3) {
-#pragma unroll
-                for (int q = 0; q < NP; ++q) load_piece(q);
-            }
-        }
-        const float* a = As + buf * BM * C::LDS_K + (wm * C::TM * 32 + l31) * C::LDS_K;
-        const float* b = Bs + buf * BN * C::LDS_K + (wn * C::TN * 32 + l31) * C::LDS_K;
-        if (SCHED & 128) __builtin_amdgcn_s_setprio(1);
-        if (SCHED & 4) {
-            // all fragments of the step in distinct registers: no LDS wait inside the MFMA stream
-            float4 fa[NSB][C::TM], fb[NSB][C::TN];
-#pragma unroll
-            for (int sb = 0; sb < NSB; ++sb) {
+            if (BF16) {
+                bf16x8 fa[C::TM], fb[C::TN];
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
-                    fa[sb][i] = *reinterpret_cast<const float4*>(a + i * 32 * C::LDS_K + koff(sb));
+                    fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * C::ROW_BYTES + sb * 32);
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j)
-                    fb[sb][j] = *reinterpret_cast<const float4*>(b + j * 32 * C::LDS_K + koff(sb));
-            }
+                    fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * C::ROW_BYTES + sb * 32);
 #pragma unroll
-            for (int sb = 0; sb < NSB; ++sb) {
-                if (SCHED & 8) {
-                    // rotate accumulators: consecutive MFMAs are independent (a dependent 32x32x2 chain from one
-                    // wave issues at ~72 instead of 64 cycles)
+                for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < C::TN; ++j) {
-                                const float av = e == 0 ? fa[sb][i].x : e == 1 ? fa[sb][i].y : e == 2 ? fa[sb][i].z : fa[sb][i].w;
-                                const float bv = e == 0 ? fb[sb][j].x : e == 1 ? fb[sb][j].y : e == 2 ? fb[sb][j].z : fb[sb][j].w;
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-                            }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < C::TN; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].x, fb[sb][j].x, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].y, fb[sb][j].y, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].z, fb[sb][j].z, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sb][i].w, fb[sb][j].w, acc[i][j], 0, 0, 0);
-                        }
-                }
-            }
-        } else {
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
-            float4 fa[C::TM], fb[C::TN];
-            if (ABL == 4) {
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i) fa[i] = make_float4(lane * 0.001f, 0.5f, 0.25f, 0.125f);
-#pragma unroll
-                for (int j = 0; j < C::TN; ++j) fb[j] = make_float4(0.3f, lane * 0.002f, 0.1f, 0.7f);
+                    for (int j = 0; j < C::TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             } else {
+                float4 fa[C::TM], fb[C::TN];
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
-                    fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * C::LDS_K + koff(sb));
+                    fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * C::ROW_BYTES + sb * 32);
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j)
-                    fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * C::LDS_K + koff(sb));
+                    fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * C::ROW_BYTES + sb * 32);
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
             }
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TN; ++j) {
-                    mfma32<(SCHED & 256) != 0>(acc[i][j], fa[i].x, fb[j].x);
-                    mfma32<(SCHED & 256) != 0>(acc[i][j], fa[i].y, fb[j].y);
-                    mfma32<(SCHED & 256) != 0>(acc[i][j], fa[i].z, fb[j].z);
-                    mfma32<(SCHED & 256) != 0>(acc[i][j], fa[i].w, fb[j].w);
-                }
         }
-        }  // SCHED & 4
-        if (SCHED & 128) __builtin_amdgcn_s_setprio(0);
-        if (more && !DMA && ABL != 2 && ABL != 3) {
+        if (more) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) store_piece(q, buf ^ 1);
         }
     };
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (SCHED & 1)
-            k_step((kt - kt_begin) & 1, kt + 1 < kt_end);
-        else
-            k_step_lumped((kt - kt_begin) & 1, kt + 1 < kt_end);
-        if (ABL != 3) __syncthreads();
+        k_step((kt - kt_begin) & 1, kt + 1 < kt_end);
+        __syncthreads();
     }
 
     // ---- epilogue: transpose the accumulators through LDS (A/B buffers are dead after the last barrier) ----
@@ -599,11 +472,10 @@ __global__ void conv_naive_kernel(const ConvParams p, const int M) {
     p.out[(size_t)m * p.out_stride + n] = v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MINW, int SCHED = 0, int DMA = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false>
 void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds_override = 0) {
-    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BK, DMA>;
-    if (DMA && !p.zeros) throw HipError("launch_conv: DMA staging needs ConvParams::zeros");
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK, MINW, SCHED, DMA>;
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16>;
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE>;
     const int nblk_m = (M + BM - 1) / BM;
     const int nblk_n = (p.Cout + BN - 1) / BN;
     dim3 grid(nblk_m * nblk_n, p.splits, p.nz);
@@ -611,10 +483,10 @@ void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int MINW, int SCHED = 0, int DMA = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false>
 void init_cfg() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BK, MINW, SCHED, DMA>),
+        reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
@@ -625,26 +497,21 @@ int g_variant = 0;  // tuning experiments only (irsde_bench_conv)
 void conv_set_variant(int v) { g_variant = v; }
 
 void conv_global_init() {
-    init_cfg<128, 128, 2, 2, 32, 2>();
-    init_cfg<128, 64, 2, 2, 32, 2>();
-    init_cfg<128, 32, 4, 1, 32, 2>();
-    init_cfg<256, 128, 4, 2, 32, 2>();
-    init_cfg<128, 128, 2, 2, 32, 2, 1>();
-    init_cfg<128, 128, 2, 2, 32, 2, 2>();
-    init_cfg<128, 128, 2, 2, 32, 2, 3>();
-    init_cfg<256, 256, 2, 4, 32, 2>();
-    init_cfg<128, 128, 2, 2, 32, 2, 128>();
-    init_cfg<128, 128, 2, 2, 32, 2, 256>();
-    init_cfg<128, 128, 2, 2, 32, 2, 0, 1>();
-    init_cfg<256, 128, 4, 2, 32, 2, 0, 1>();
-    init_cfg<128, 128, 2, 2, 32, 2, 4>();
-    init_cfg<128, 128, 2, 2, 32, 2, 8>();
-    init_cfg<128, 128, 2, 2, 32, 2, 10>();
-    init_cfg<128, 128, 2, 2, 32, 2, 12>();
-    init_cfg<128, 128, 2, 2, 32, 2, 16>();
-    init_cfg<128, 128, 2, 2, 32, 2, 32>();
-    init_cfg<128, 128, 2, 2, 32, 2, 48>();
-    init_cfg<128, 128, 2, 2, 32, 2, 64>();
+    init_cfg<128, 128, 2, 2, 2, false>();
+    init_cfg<128, 64, 2, 2, 2, false>();
+    init_cfg<128, 32, 4, 1, 2, false>();
+    init_cfg<256, 128, 4, 2, 2, false>();
+    init_cfg<256, 256, 2, 4, 2, false>();
+    init_cfg<128, 128, 2, 2, 2, true>();
+    init_cfg<128, 64, 2, 2, 2, true>();
+    init_cfg<128, 32, 4, 1, 2, true>();
+    init_cfg<256, 256, 2, 4, 2, true>();
+    init_cfg<128, 128, 2, 2, 2, false, true>();
+    init_cfg<128, 64, 2, 2, 2, false, true>();
+    init_cfg<128, 32, 4, 1, 2, false, true>();
+    init_cfg<128, 128, 2, 2, 2, true, true>();
+    init_cfg<128, 64, 2, 2, 2, true, true>();
+    init_cfg<128, 32, 4, 1, 2, true, true>();
 }
 
 double conv_flops(const ConvParams& p) {
@@ -654,8 +521,7 @@ double conv_flops(const ConvParams& p) {
 // 256x256 tiles (8 waves, 128x64 per wave) halve the staging instructions per MFMA (+5..8 % on deep layers) but
 // need Cout % 256 == 0 and a tile count that fills the 256 CUs without a ragged last round.
 bool conv_use_tile256(int M, int Cout, int splits, int nk_total) {
-    static const int min_nk = getenv("IRSDE_T256_MIN_NK") ? atoi(getenv("IRSDE_T256_MIN_NK")) : 0;
-    if (splits != 1 || Cout % 256 || nk_total < min_nk) return false;
+    if (splits != 1 || Cout % 256) return false;
     const long long nb = (long long)((M + 255) / 256) * (Cout / 256);
     return nb % 256 == 0 || nb >= 1024;
 }
@@ -667,52 +533,45 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
         throw HipError("launch_conv: channel counts must be multiples of 32 (got " + std::to_string(p.C0) + "+" +
                        std::to_string(p.C1) + ")");
     if (p.splits > 1 && !p.partial) throw HipError("launch_conv: split-K needs a partial buffer");
+    if (!p.zeros) throw HipError("launch_conv: ConvParams::zeros (zero page for out-of-image taps) is not set");
     const int nk_total = p.KH * p.KW * (Ctot / 32);
-    if (p.Cout >= 128) {
+    if (p.in_scale) {  // NAFNet SCA fused into the staging (128-row tiles only)
+        if (p.C1) throw HipError("launch_conv: in_scale needs a single source");
+        if (p.w_bf) {
+            if (p.Cout >= 128) launch_cfg<128, 128, 2, 2, 2, true, true>(p, M, nk_total, s);
+            else if (p.Cout > 32) launch_cfg<128, 64, 2, 2, 2, true, true>(p, M, nk_total, s);
+            else launch_cfg<128, 32, 4, 1, 2, true, true>(p, M, nk_total, s);
+        } else {
+            if (p.Cout >= 128) launch_cfg<128, 128, 2, 2, 2, false, true>(p, M, nk_total, s);
+            else if (p.Cout > 32) launch_cfg<128, 64, 2, 2, 2, false, true>(p, M, nk_total, s);
+            else launch_cfg<128, 32, 4, 1, 2, false, true>(p, M, nk_total, s);
+        }
+    } else if (p.w_bf) {  // bf16 operands, fp32 accumulation
+        if (p.Cout >= 128) {
+            if (g_variant != 61 && (g_variant == 60 || conv_use_tile256(M, p.Cout, p.splits, nk_total)))
+                launch_cfg<256, 256, 2, 4, 2, true>(p, M, nk_total, s);
+            else
+                launch_cfg<128, 128, 2, 2, 2, true>(p, M, nk_total, s);
+        } else if (p.Cout > 32) {
+            launch_cfg<128, 64, 2, 2, 2, true>(p, M, nk_total, s);
+        } else {
+            launch_cfg<128, 32, 4, 1, 2, true>(p, M, nk_total, s);
+        }
+    } else if (p.Cout >= 128) {
         if (g_variant == 3)
-            launch_cfg<256, 128, 4, 2, 32, 2>(p, M, nk_total, s);
-        else if (g_variant == 1)
-            launch_cfg<128, 128, 2, 2, 32, 2, 1>(p, M, nk_total, s);
-        else if (g_variant == 6)
-            launch_cfg<128, 128, 2, 2, 32, 2, 2>(p, M, nk_total, s);
-        else if (g_variant == 7)
-            launch_cfg<128, 128, 2, 2, 32, 2, 3>(p, M, nk_total, s);
+            launch_cfg<256, 128, 4, 2, 2, false>(p, M, nk_total, s);
         else if (g_variant == 50)
-            launch_cfg<256, 256, 2, 4, 32, 2>(p, M, nk_total, s);
-        else if (g_variant == 41)
-            launch_cfg<128, 128, 2, 2, 32, 2, 256>(p, M, nk_total, s);
-        else if (g_variant == 40)
-            launch_cfg<128, 128, 2, 2, 32, 2, 128>(p, M, nk_total, s);
-        else if (g_variant == 30)
-            launch_cfg<128, 128, 2, 2, 32, 2, 0, 1>(p, M, nk_total, s);
-        else if (g_variant == 31)
-            launch_cfg<256, 128, 4, 2, 32, 2, 0, 1>(p, M, nk_total, s);
-        else if (g_variant == 20)
-            launch_cfg<128, 128, 2, 2, 32, 2, 8>(p, M, nk_total, s);
-        else if (g_variant == 21)
-            launch_cfg<128, 128, 2, 2, 32, 2, 10>(p, M, nk_total, s);
-        else if (g_variant == 8)
-            launch_cfg<128, 128, 2, 2, 32, 2, 4>(p, M, nk_total, s);
-        else if (g_variant == 9)
-            launch_cfg<128, 128, 2, 2, 32, 2, 12>(p, M, nk_total, s);
-        else if (g_variant == 11)
-            launch_cfg<128, 128, 2, 2, 32, 2, 16>(p, M, nk_total, s);
-        else if (g_variant == 12)
-            launch_cfg<128, 128, 2, 2, 32, 2, 32>(p, M, nk_total, s);
-        else if (g_variant == 13)
-            launch_cfg<128, 128, 2, 2, 32, 2, 48>(p, M, nk_total, s);
-        else if (g_variant == 14)
-            launch_cfg<128, 128, 2, 2, 32, 2, 64>(p, M, nk_total, s);
+            launch_cfg<256, 256, 2, 4, 2, false>(p, M, nk_total, s);
         else if (g_variant == 5)
-            launch_cfg<128, 128, 2, 2, 32, 2>(p, M, nk_total, s, 120 * 1024);  // diagnostic: force 1 block/CU
+            launch_cfg<128, 128, 2, 2, 2, false>(p, M, nk_total, s, 120 * 1024);  // diagnostic: force 1 block/CU
         else if (g_variant == 0 && conv_use_tile256(M, p.Cout, p.splits, nk_total))
-            launch_cfg<256, 256, 2, 4, 32, 2>(p, M, nk_total, s);
+            launch_cfg<256, 256, 2, 4, 2, false>(p, M, nk_total, s);
         else
-            launch_cfg<128, 128, 2, 2, 32, 2>(p, M, nk_total, s);
+            launch_cfg<128, 128, 2, 2, 2, false>(p, M, nk_total, s);
     } else if (p.Cout > 32) {
-        launch_cfg<128, 64, 2, 2, 32, 2>(p, M, nk_total, s);
+        launch_cfg<128, 64, 2, 2, 2, false>(p, M, nk_total, s);
     } else {
-        launch_cfg<128, 32, 4, 1, 32, 2>(p, M, nk_total, s);
+        launch_cfg<128, 32, 4, 1, 2, false>(p, M, nk_total, s);
     }
     if (p.splits > 1) {
         const size_t total = (size_t)M * p.Cout;

@@ -234,6 +234,18 @@ struct irsde_engine {
         dev_allocs.push_back(p);
         return p;
     }
+    // bf16 (RNE) copy of a packed fp32 weight tensor, made once per tensor (IRSDE_FLAG_BF16)
+    std::map<const float*, unsigned short*> bf16_copies;
+    const unsigned short* bf16_copy(const float* w, size_t n) {
+        auto it = bf16_copies.find(w);
+        if (it != bf16_copies.end()) return it->second;
+        unsigned short* d = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&d, n * sizeof(unsigned short)));
+        launch_f32_to_bf16(w, d, n, stream);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(stream));
+        bf16_copies[w] = d;
+        return d;
+    }
     float* upload(const std::vector<float>& v) {
         float* p = dmalloc(v.size());
         IRSDE_HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -336,7 +348,7 @@ ConvW pack_conv(irsde_engine* e, const std::string& wname, const std::string& bn
     c.w = e->upload(p);
     c.Cout = O; c.Cin = I; c.KH = KH; c.KW = KW;
     if (!bname.empty()) c.bias = e->upload(need(e, bname).data);
-    if (KH == 3 && KW == 3 && I % 32 == 0 && !(e->cfg.flags & IRSDE_FLAG_NO_WINOGRAD)) {
+    if (KH == 3 && KW == 3 && I % 32 == 0 && !(e->cfg.flags & (IRSDE_FLAG_NO_WINOGRAD | IRSDE_FLAG_BF16))) {
         for (int tile : {2, 4}) {
             if (tile == 4 && (e->cfg.flags & IRSDE_FLAG_NO_WINOGRAD_F43)) continue;
             if (I < wino_min_c(tile) || O < wino_min_c(tile)) continue;
@@ -729,19 +741,21 @@ struct Builder {
             p.partial = pl->alloc((size_t)splits * M * p.Cout, true);
         }
         p.zeros = e->zeros;
+        if (!naive && (e->cfg.flags & IRSDE_FLAG_BF16))
+            p.w_bf = e->bf16_copy(p.w, (size_t)p.Cout * p.KH * p.KW * (p.C0 + p.C1));
         Op op;
         op.kind = OP_CONV;
         op.flops = conv_flops(p);
         const double in_bytes = 4.0 * (double)p.B * (p.Hin) * (p.Win) * (double)(p.C0 + p.C1);
-        op.bytes = in_bytes + 4.0 * (double)M * p.Cout + 4.0 * (double)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
+        op.bytes = in_bytes + 4.0 * (double)M * p.Cout + (p.w_bf ? 2.0 : 4.0) * (double)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
         op.exec_flops = op.flops;
         pl->conv_flops += op.flops;
         pl->conv_exec_flops += op.exec_flops;
         pl->conv_bytes += op.bytes;
         {
             char buf[256];
-            snprintf(buf, sizeof buf, "conv M=%d Cout=%d Cin=%d k=%dx%d s=%d up=%d splits=%d blocks=%d flops=%.4g", M, p.Cout,
-                     p.C0 + p.C1, p.KH, p.KW, p.stride, p.in_shift, splits, blocks, op.flops);
+            snprintf(buf, sizeof buf, "conv%s M=%d Cout=%d Cin=%d k=%dx%d s=%d up=%d splits=%d blocks=%d flops=%.4g",
+                     p.w_bf ? "(bf16)" : "", M, p.Cout, p.C0 + p.C1, p.KH, p.KW, p.stride, p.in_shift, splits, blocks, op.flops);
             op.desc = buf;
         }
         const bool nv = naive;
@@ -1297,6 +1311,7 @@ void irsde_destroy(irsde_engine* e) {
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     for (float* p : e->dev_allocs) (void)hipFree(p);
+    for (auto& kv : e->bf16_copies) (void)hipFree(kv.second);
     if (e->coef_table) (void)hipFree(e->coef_table);
     if (e->film_table) (void)hipFree(e->film_table);
     delete e;
@@ -1672,9 +1687,17 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
         } else if (naive == 1) {
             launch_conv_naive(p, s);
         } else {
+            unsigned short* dbf = nullptr;
+            if (naive == 4 || naive == 160 || naive == 161) {  // bf16-MFMA mode (variants 60 / 61: force the 256 / 128 tile)
+                IRSDE_HIP_CHECK(hipMalloc(&dbf, pk.size() * 2));
+                launch_f32_to_bf16(dw, dbf, pk.size(), s);
+                p.w_bf = dbf;
+            }
             conv_set_variant(naive >= 100 ? naive - 100 : 0);  // test hook for experimental tile variants
             launch_conv(p, s);
             conv_set_variant(0);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            if (dbf) (void)hipFree(dbf);
         }
         IRSDE_HIP_CHECK(hipStreamSynchronize(s));
         (void)hipFree(dw);
@@ -1713,6 +1736,12 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         launch_fill_random(dres, nout, 3, 1.0f, s);
         launch_fill_random(dfilm, (size_t)2 * Cout, 4, 0.3f, s);
         p.in0 = din; p.w = dw; p.out = dout; p.out_stride = Cout;
+        unsigned short* dbf = nullptr;
+        if (variant >= 60 && variant <= 62) {  // bf16-MFMA mode: 60 = 256x256 tile, 61 = 128x128, 62 = automatic
+            IRSDE_HIP_CHECK(hipMalloc(&dbf, nw * 2));
+            launch_f32_to_bf16(dw, dbf, nw, s);
+            p.w_bf = dbf;
+        }
         if (epi == 1) { p.film = dfilm; p.silu = 1; }
         if (epi == 2) { p.silu = 1; p.res = dres; p.res_stride = Cout; }
         conv_set_variant(variant);
@@ -1730,6 +1759,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         conv_set_variant(0);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
+        if (dbf) (void)hipFree(dbf);
         (void)hipStreamDestroy(s);
     });
 }

@@ -872,4 +872,16 @@ void launch_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
+// fp32 -> bf16 (round to nearest even) copy of packed conv weights for the bf16-MFMA mode
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const __bf16 b = (__bf16)in[i];
+    out[i] = __builtin_bit_cast(unsigned short, b);
+}
+void launch_f32_to_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace irsde

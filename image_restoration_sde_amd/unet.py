@@ -145,6 +145,17 @@ class ConditionalUNet(nn.Module):
             self._engine_key = key
         return self._engine
 
+    def set_compute_dtype(self, dtype):
+        """'fp32' (default: exact-fp32 MFMA + Winograd) or 'bf16' (BASELINE configs[2]: conv operands rounded to bf16,
+        fp32 accumulation, everything else fp32).  New behaviour — the reference is fp32 only."""
+        if dtype in ("fp32", "f32", torch.float32):
+            self.engine_flags &= ~_lib.FLAG_BF16
+        elif dtype in ("bf16", torch.bfloat16):
+            self.engine_flags |= _lib.FLAG_BF16
+        else:
+            raise _lib.IrsdeError("compute dtype must be 'fp32' or 'bf16'")
+        return self
+
     # ---- reference interface -----------------------------------------------------------------
     def forward(self, xt, cond, time):
         """noise = model(xt, cond, time) — DenoisingUNet_arch.py:85-134."""

@@ -45,6 +45,10 @@ enum {
     IRSDE_FLAG_UNCOND_FULLATTN = 16, /* the denoising-sde variant of ConditionalUNet (codes/config/denoising-sde/models/modules/
                                         DenoisingUNet_arch.py:20-130): forward(x, time) without a condition input (init_conv takes
                                         in_nc channels) and full softmax Attention at the bottleneck (module_util.py:182-204) */
+    IRSDE_FLAG_BF16 = 32,            /* reduced-precision mode (BASELINE configs[2]; the reference is fp32 only): every convolution
+                                        runs on v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 (RNE) and fp32
+                                        accumulation; no Winograd; everything else (state, LayerNorm, attention, FiLM,
+                                        update step) stays fp32 */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };

@@ -130,8 +130,34 @@ def reverse_posterior_step(sch, x, mu, noise, z, t, dtype=np.float32):
 # --------------------------------------------------------------------------------------
 
 
+def round_bf16(a):
+    """Round to the nearest bfloat16 (ties to even), returned in the dtype of `a`."""
+    a = np.asarray(a)
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    u = (u + (((u >> 16) & 1) + np.uint32(0x7FFF))) & np.uint32(0xFFFF0000)
+    return u.view(np.float32).astype(a.dtype)
+
+
+CONV_OPERANDS_BF16 = False  # restatement of the engine's IRSDE_FLAG_BF16 mode: conv operands rounded, fp32+ accumulation
+
+
+class bf16_convs:
+    """Context manager: every conv2d inside rounds activations and weights to bf16 first (the Linear layers of the
+    time MLP, LayerNorm, attention and the update step stay in full precision, as in the engine)."""
+
+    def __enter__(self):
+        global CONV_OPERANDS_BF16
+        self.prev, CONV_OPERANDS_BF16 = CONV_OPERANDS_BF16, True
+
+    def __exit__(self, *a):
+        global CONV_OPERANDS_BF16
+        CONV_OPERANDS_BF16 = self.prev
+
+
 def conv2d(x, w, b=None, stride=1, pad=0):
     """nn.Conv2d forward (cross-correlation), NCHW / OIHW, zero padding."""
+    if CONV_OPERANDS_BF16:
+        x, w = round_bf16(x), round_bf16(w)
     B, C, H, W = x.shape
     O, C2, kh, kw = w.shape
     assert C == C2

@@ -158,9 +158,74 @@ def test_conv_per_sample_film():
     assert relerr(got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("name", ["3x3_64_64_film_silu", "3x3_concat_192_128", "1x1_qkv_384", "4x4_s2_down", "3x3_upsample_fused",
+                                  "3x3_final_cout3", "3x3_m_tail_odd", "3x3_deep_k_1536", "3x3_wino_res_bias"])
+def test_conv_kernel_bf16(name):
+    """IRSDE_FLAG_BF16 kernel (v_mfma_f32_32x32x16_bf16): same operands as the oracle once both round to bf16 (RNE),
+    products are exact in fp32, so only the fp32 accumulation order differs."""
+    B, C0, C1, H, W, Cout, K, stride, pad, in_shift, has_bias, has_film, silu, has_res = CONV_CASES[name]
+    rs = np.random.RandomState(hash(name) % 2 ** 31)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, K, K)) / np.sqrt((C0 + C1) * K * K)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32) if has_bias else None
+    film = (0.3 * rs.standard_normal((1, 2 * Cout))).astype(np.float32) if has_film else None
+    Ho = ((H << in_shift) + 2 * pad - K) // stride + 1
+    Wo = ((W << in_shift) + 2 * pad - K) // stride + 1
+    res = rs.standard_normal((B, Cout, Ho, Wo)).astype(np.float32) if has_res else None
+    with O.bf16_convs():
+        ref = oracle_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res)
+    full = oracle_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res)
+    got = run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=4)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert relerr(got, ref) < 2e-5, name
+    assert 1e-4 < relerr(got, full) < 2e-2, name  # and it really is the reduced-precision product
+    assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=161), ref) < 2e-5  # 128x128 tile
+    if Cout % 256 == 0:
+        assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=160), ref) < 2e-5  # 256x256 tile
+
+
 # ---------------------------------------------------------------------------------------------
 # network level
 # ---------------------------------------------------------------------------------------------
+def test_unet_bf16_mode(golden):
+    """BASELINE configs[2]: bf16 conv operands.  (a) the engine follows the oracle's restatement of the mode (operands
+    rounded, everything else full precision) to 2e-2 of max|ref| — a value that sits on a bf16 rounding boundary may
+    round the other way on the two sides; (b) it stays within 3e-2 of the fp32 reference golden; (c) deterministic ODE
+    sampling in bf16 stays within 5e-2 of the fp32 engine over 20 steps."""
+    g = golden.forward
+    tag = "nf64d4_1x64x64"
+    nf, depth, B, H, W = (int(v) for v in g[tag + "/cfg"])
+    m, params = make_model(nf, depth)
+    m.set_compute_dtype("bf16")
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    t = int(g[tag + "/ts"][1])
+    y = m(x, c, t).cpu().numpy()
+    with O.bf16_convs():
+        ref = O.unet_forward(params, xT, lq, t, depth=depth, dtype=np.float64)
+    e_oracle, e_fp32 = relerr(y, ref), relerr(y, g[tag + "/t%d" % t])
+    print("bf16 forward: vs bf16 oracle %.3g, vs fp32 reference %.3g" % (e_oracle, e_fp32))
+    assert e_oracle < 2e-2
+    assert 1e-4 < e_fp32 < 3e-2
+    import ctypes as _c
+    buf = _c.create_string_buffer(1 << 18)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, B, H, W, buf, len(buf)))
+    assert b"conv(bf16)" in buf.value and b"winograd" not in buf.value
+    # sampler: reverse_ode, bf16 vs fp32 engine (same weights)
+    m32, _ = model(nf, depth)
+    T = 20
+    outs = {}
+    for name, mm in (("bf16", m), ("fp32", m32)):
+        sde = P.IRSDE(max_sigma=10, T=T, schedule="cosine", eps=0.005, device=DEV)
+        sde.set_model(mm)
+        sde.set_mu(c)
+        outs[name] = sde.reverse_ode(x).cpu().numpy()
+    e_ode = relerr(outs["bf16"], outs["fp32"])
+    print("bf16 reverse_ode T=20 vs fp32: %.3g" % e_ode)
+    assert e_ode < 5e-2
+
+
 @pytest.mark.parametrize("tag", ["nf32d2_2x24x20", "nf64d4_1x64x64", "nf64d4_2x40x56"])
 def test_unet_forward_vs_reference_golden(golden, tag):
     g = golden.forward
