@@ -8,6 +8,7 @@ csrc/ -> libirsde_hip.so) with the reference's own Python interface on top:
     DenoisingSDE, denoising_sde.ConditionalUNet
                        codes/utils/sde_utils.py:373-593, codes/config/denoising-sde/models/modules/DenoisingUNet_arch.py
     DenoisingModel     codes/config/deraining/models/denoising_model.py (inference surface)
+    metrics            codes/utils/img_utils.py:136-234 + codes/data/util.py:177-198 (tensor2img / PSNR / SSIM / Y channel)
 """
 from ._lib import IrsdeError, IrsdeLibraryError, build_library  # noqa: F401
 from .denoising_model import DenoisingModel, create_model, define_G  # noqa: F401
@@ -17,6 +18,7 @@ from .unet import ConditionalUNet  # noqa: F401
 from .nafnet import ConditionalNAFNet  # noqa: F401
 from . import denoising_sde  # noqa: F401
 from .denoising_sde import DenoisingSDE  # noqa: F401
+from . import metrics  # noqa: F401
 
-__all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
+__all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "metrics", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
            "IrsdeError", "IrsdeLibraryError", "shard_bounds", "gather_batch", "sample_sharded"]

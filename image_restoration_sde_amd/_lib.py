@@ -29,6 +29,7 @@ SYMBOLS = [
     "irsde_weight_name", "irsde_weight_shape", "irsde_load_weight", "irsde_finalize_weights",
     "irsde_set_schedule", "irsde_unet_forward", "irsde_sample", "irsde_sde_step", "irsde_philox_normal",
     "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv", "irsde_plan_describe", "irsde_bench_conv", "irsde_op_profile",
+    "irsde_eval_metrics", "irsde_tensor2img",
 ]
 
 
@@ -98,6 +99,8 @@ def _declare(lib):
     lib.irsde_plan_describe.argtypes = [P, c.c_int, c.c_int, c.c_int, c.c_char_p, c.c_int]
     lib.irsde_op_profile.argtypes = [P, c.c_char_p, c.c_int]
     lib.irsde_bench_conv.argtypes = [c.c_int] * 11 + [c.POINTER(c.c_double)]
+    lib.irsde_eval_metrics.argtypes = [P, P, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double), P]
+    lib.irsde_tensor2img.argtypes = [P, P, c.c_int, c.c_int, c.c_int, c.c_int, P]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError here = the .so does not export what the header declares
     return lib

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace irsde {
 
@@ -195,5 +196,10 @@ struct UpdateParams {
 void launch_sde_update(const UpdateParams& p, hipStream_t s);
 // fills out[B][C][H][W] with the Philox N(0,1) draw for step t (test hook for the RNG)
 void launch_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint64_t image_offset, hipStream_t s);
+
+// Evaluation tail (eval_metrics.hip): per-image sums for PSNR / SSIM on RGB and Y.  sums_host: [B][4] =
+// {squared-error sum RGB, SSIM-map sum RGB, squared-error sum Y, SSIM-map sum Y}.  Synchronises the stream.
+void eval_metrics(const float* out, const float* gt, int B, int C, int H, int W, int crop, double* sums_host, hipStream_t s);
+void tensor2img_u8(const float* in, unsigned char* out, int B, int C, int H, int W, hipStream_t s);
 
 }  // namespace irsde

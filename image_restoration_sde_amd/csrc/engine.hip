@@ -1764,4 +1764,32 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
     });
 }
 
+int irsde_eval_metrics(const float* out, const float* gt, int B, int C, int H, int W, int crop_border, double* metrics,
+                       void* stream) {
+    return guard([&] {
+        if (!out || !gt || !metrics || B < 1) throw HipError("null argument");
+        std::vector<double> sums((size_t)B * 4);
+        eval_metrics(out, gt, B, C, H, W, crop_border, sums.data(), reinterpret_cast<hipStream_t>(stream));
+        const double Hc = H - 2 * crop_border, Wc = W - 2 * crop_border;
+        const double n_rgb = Hc * Wc * C, n_y = Hc * Wc, v_rgb = (Hc - 10) * (Wc - 10) * C, v_y = (Hc - 10) * (Wc - 10);
+        auto psnr = [](double sse, double n) {
+            const double mse = sse / n;
+            return mse == 0.0 ? INFINITY : 20.0 * log10(255.0 / sqrt(mse));
+        };
+        for (int b = 0; b < B; ++b) {
+            metrics[b * 4 + 0] = psnr(sums[b * 4 + 0], n_rgb);
+            metrics[b * 4 + 1] = sums[b * 4 + 1] / v_rgb;
+            metrics[b * 4 + 2] = C == 3 ? psnr(sums[b * 4 + 2], n_y) : NAN;
+            metrics[b * 4 + 3] = C == 3 ? sums[b * 4 + 3] / v_y : NAN;
+        }
+    });
+}
+
+int irsde_tensor2img(const float* in, unsigned char* out, int B, int C, int H, int W, void* stream) {
+    return guard([&] {
+        if (!in || !out) throw HipError("null argument");
+        tensor2img_u8(in, out, B, C, H, W, reinterpret_cast<hipStream_t>(stream));
+    });
+}
+
 }  // extern "C"

@@ -187,6 +187,18 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out);
 
+/* Evaluation tail on the device — replaces, per image of a batch, the metric block of
+ * codes/config/deraining/test.py:131-178: util.tensor2img on output and GT (codes/utils/img_utils.py:136-163),
+ * util.calculate_psnr / calculate_ssim (:182-234) on the uint8 images cropped by crop_border, and the same two on
+ * the Y channel of bgr2ycbcr (codes/data/util.py:177-198).  out, gt: device NCHW fp32 [B][C][H][W], C = 1 or 3 (RGB).
+ * metrics: HOST [B][4] = {psnr, ssim, psnr_y, ssim_y} (the Y entries are NaN for C == 1).  Synchronises `stream`. */
+int irsde_eval_metrics(const float* out, const float* gt, int B, int C, int H, int W, int crop_border, double* metrics,
+                       void* stream);
+
+/* util.tensor2img (img_utils.py:136-163) for a batch: device NCHW fp32 -> device [B][H][W][C] uint8 with the channel
+ * order reversed (RGB -> BGR, what cv2.imwrite expects): clamp to [0,1], x255, round half to even. */
+int irsde_tensor2img(const float* in, unsigned char* out, int B, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -319,6 +319,69 @@ def gen_dsde(sde_utils, ref_root):
     print("dsde.npz")
 
 
+def gen_metrics(ref_root):
+    """Evaluation tail: the reference's own tensor2img / calculate_psnr / calculate_ssim
+    (codes/utils/img_utils.py) and bgr2ycbcr (codes/data/util.py) run on synthetic output/GT pairs, following
+    deraining/test.py:110-178.  cv2 is absent in this image; the two cv2 calls ssim() makes are stubbed with their
+    published definitions — getGaussianKernel(k, s): g_i = exp(-(i-(k-1)/2)^2 / (2 s^2)) / sum, float64; filter2D(img,
+    -1, w): per-channel correlation with the anchor at the window centre (only its 'valid' interior is used, :203-208,
+    so the border mode does not matter) — everything else is reference code."""
+    import scipy.ndimage as ndi
+    cv2 = types.ModuleType("cv2")
+
+    def getGaussianKernel(k, sigma):
+        i = np.arange(k, dtype=np.float64) - (k - 1) / 2.0
+        g = np.exp(-(i * i) / (2.0 * sigma * sigma))
+        return (g / g.sum()).reshape(k, 1)
+
+    def filter2D(img, ddepth, window):
+        if img.ndim == 2:
+            return ndi.correlate(img, window, mode="mirror")
+        return np.stack([ndi.correlate(img[..., c], window, mode="mirror") for c in range(img.shape[2])], axis=-1)
+
+    cv2.getGaussianKernel, cv2.filter2D = getGaussianKernel, filter2D
+    sys.modules["cv2"] = cv2
+    sys.modules["torchvision.utils"].make_grid = lambda *a, **k: None
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref_root, rel))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    iu = load("ref_img_utils", "codes/utils/img_utils.py")
+    du = load("ref_data_util", "codes/data/util.py")
+    out = {}
+    cases = {"rgb_1x3x40x52_cb0": (1, 3, 40, 52, 0), "rgb_2x3x64x48_cb4": (2, 3, 64, 48, 4), "gray_1x1x33x37_cb0": (1, 1, 33, 37, 0)}
+    for tag, (B, C, H, W, cb) in cases.items():
+        rs = np.random.RandomState(len(tag))
+        gt = rs.rand(B, C, H, W).astype(np.float32)
+        # restored image = GT + small error, with values outside [0,1] so the clamp matters
+        o = (gt + 0.05 * rs.standard_normal(gt.shape)).astype(np.float32)
+        res = np.zeros((B, 4))
+        imgs = []
+        for b in range(B):
+            output = iu.tensor2img(torch.from_numpy(o[b:b + 1]).squeeze())      # deraining/test.py:112
+            GT_ = iu.tensor2img(torch.from_numpy(gt[b:b + 1]).squeeze())        # :114
+            imgs.append(output)
+            gt_img, sr_img = GT_ / 255.0, output / 255.0                        # :137-138
+            crop = (lambda im: im if cb == 0 else im[cb:-cb, cb:-cb])           # :140-150
+            res[b, 0] = iu.calculate_psnr(crop(sr_img) * 255, crop(gt_img) * 255)
+            res[b, 1] = iu.calculate_ssim(crop(sr_img) * 255, crop(gt_img) * 255)
+            if C == 3:                                                          # :161-178
+                sr_y, gt_y = du.bgr2ycbcr(sr_img, only_y=True), du.bgr2ycbcr(gt_img, only_y=True)
+                res[b, 2] = iu.calculate_psnr(crop(sr_y) * 255, crop(gt_y) * 255)
+                res[b, 3] = iu.calculate_ssim(crop(sr_y) * 255, crop(gt_y) * 255)
+            else:
+                res[b, 2:] = np.nan
+        out[tag + "/cfg"] = np.array([B, C, H, W, cb])
+        out[tag + "/out"], out[tag + "/gt"] = o, gt
+        out[tag + "/metrics"] = res
+        out[tag + "/img0"] = imgs[0]
+        print("metrics", tag, res[0])
+    np.savez_compressed(os.path.join(GOLD, "metrics.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -341,6 +404,8 @@ def main():
         gen_nafnet(sde_utils)
     if a.only in ("", "dsde"):
         gen_dsde(sde_utils, a.ref)
+    if a.only in ("", "metrics"):
+        gen_metrics(a.ref)
 
 
 if __name__ == "__main__":

@@ -797,3 +797,69 @@ def dsde_sample(params, sch, xT, ode, noise=None, depth=4, dtype=np.float64, T=-
         eps_hat = uncond_unet_forward(params, x, t, depth=depth, dtype=dtype)
         x = dsde_reverse_step(sch, x, eps_hat, None if ode else noise[t], t, ode, dtype)
     return x
+
+
+# ---------------------------------------------------------------------------------------------
+# Evaluation tail: codes/utils/img_utils.py:136-234, codes/data/util.py:177-198,
+# used as in codes/config/deraining/test.py:110-178.  Images are numpy HWC BGR (or HW), as in the reference.
+# ---------------------------------------------------------------------------------------------
+def tensor2img(t):
+    """img_utils.py:136-163 for a (C,H,W) or (H,W) float array: clamp, *255 in float32, round half to even, uint8,
+    RGB -> BGR, HWC."""
+    t = np.clip(np.asarray(t, np.float32), 0.0, 1.0)
+    if t.ndim == 3:
+        t = t[::-1].transpose(1, 2, 0) if t.shape[0] == 3 else t[0]
+    return np.round(t * np.float32(255.0)).astype(np.uint8)
+
+
+def calculate_psnr(img1, img2):
+    """img_utils.py:182-189."""
+    mse = np.mean((img1.astype(np.float64) - img2.astype(np.float64)) ** 2)
+    return float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
+
+
+def ssim_plane(a, b):
+    """img_utils.py:192-214 for one 2-D plane: 11x11 Gaussian (sigma 1.5) window, 'valid' region, float64."""
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    i = np.arange(11, dtype=np.float64) - 5.0
+    g = np.exp(-(i * i) / (2.0 * 1.5 * 1.5))
+    g /= g.sum()
+    win = np.outer(g, g)
+
+    def filt(x):
+        v = np.lib.stride_tricks.sliding_window_view(x, (11, 11))
+        return np.einsum("yxij,ij->yx", v, win)
+
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    mu1, mu2 = filt(a), filt(b)
+    s11, s22, s12 = filt(a * a) - mu1 ** 2, filt(b * b) - mu2 ** 2, filt(a * b) - mu1 * mu2
+    return ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s11 + s22 + C2))
+
+
+def calculate_ssim(img1, img2):
+    """img_utils.py:217-234: a 3-channel image is filtered per channel and the map is averaged over everything
+    (the reference's loop calls ssim() on the whole image three times and averages three equal numbers)."""
+    if img1.ndim == 2:
+        return float(ssim_plane(img1, img2).mean())
+    return float(np.mean([ssim_plane(img1[..., c], img2[..., c]) for c in range(img1.shape[2])]))
+
+
+def bgr2ycbcr_y(img01):
+    """data/util.py:177-198 (only_y=True) for a float image in [0,1], BGR HWC; returns Y in [0,1]."""
+    img = img01.astype(np.float64) * 255.0
+    return (np.dot(img, [24.966, 128.553, 65.481]) / 255.0 + 16.0) / 255.0
+
+
+def eval_tail(out_chw, gt_chw, crop_border=0):
+    """deraining/test.py:110-178 for one image: (psnr, ssim, psnr_y, ssim_y)."""
+    o, g = tensor2img(out_chw), tensor2img(gt_chw)
+    sr, gt = o / 255.0, g / 255.0
+    cb = crop_border
+    crop = (lambda im: im) if cb == 0 else (lambda im: im[cb:-cb, cb:-cb])
+    res = [calculate_psnr(crop(sr) * 255, crop(gt) * 255), calculate_ssim(crop(sr) * 255, crop(gt) * 255)]
+    if o.ndim == 3:
+        sy, gy = bgr2ycbcr_y(sr), bgr2ycbcr_y(gt)
+        res += [calculate_psnr(crop(sy) * 255, crop(gy) * 255), calculate_ssim(crop(sy) * 255, crop(gy) * 255)]
+    else:
+        res += [float("nan"), float("nan")]
+    return res

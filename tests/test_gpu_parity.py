@@ -652,3 +652,46 @@ def test_dsde_sampler_vs_reference_golden(golden, tag, key):
     # the x0-guided variant (real score) runs the per-step fused update
     x0 = torch.from_numpy(noisy * 0.5).to(DEV)
     assert torch.isfinite(sde.reverse_ode(x, x0=x0, T=5)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluation tail
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["rgb_1x3x40x52_cb0", "rgb_2x3x64x48_cb4", "gray_1x1x33x37_cb0"])
+def test_eval_metrics_vs_reference_golden(golden, tag):
+    """Device tensor2img / PSNR / SSIM / Y-channel metrics vs the reference's functions: the uint8 image bit-exact,
+    PSNR to 1e-12 (its squared-error sum is an exact integer), SSIM / Y metrics to 1e-10 (float64 summation order)."""
+    g = golden.metrics
+    B, C, H, W, cb = (int(v) for v in g[tag + "/cfg"])
+    out, gt, want = torch.from_numpy(g[tag + "/out"]).to(DEV), torch.from_numpy(g[tag + "/gt"]).to(DEV), g[tag + "/metrics"]
+    assert np.array_equal(P.metrics.tensor2img(out[0]), g[tag + "/img0"])
+    m = P.metrics.evaluate_batch(out, gt, crop_border=cb)
+    np.testing.assert_allclose(m["psnr"], want[:, 0], rtol=1e-12)
+    np.testing.assert_allclose(m["ssim"], want[:, 1], rtol=1e-10)
+    if C == 3:
+        np.testing.assert_allclose(m["psnr_y"], want[:, 2], rtol=1e-10)
+        np.testing.assert_allclose(m["ssim_y"], want[:, 3], rtol=1e-10)
+    else:
+        assert np.isnan(m["psnr_y"]).all() and np.isnan(m["ssim_y"]).all()
+    avg = P.metrics.reduce_metrics({"psnr": m["psnr"], "ssim": m["ssim"]})
+    assert abs(avg["psnr"] - want[:, 0].mean()) < 1e-9
+
+
+def test_eval_metrics_full_size_properties():
+    """BASELINE-sized batch (16 x 3 x 256 x 256): identical images give PSNR = inf and SSIM = 1; the metrics of image b
+    do not depend on the rest of the batch; a sampled oracle check on one image."""
+    rs = np.random.RandomState(3)
+    gt = rs.rand(16, 3, 256, 256).astype(np.float32)
+    out = np.clip(gt + 0.02 * rs.standard_normal(gt.shape), -0.1, 1.1).astype(np.float32)
+    dg, do = torch.from_numpy(gt).to(DEV), torch.from_numpy(out).to(DEV)
+    same = P.metrics.evaluate_batch(dg, dg)
+    assert np.isinf(same["psnr"]).all() and np.allclose(same["ssim"], 1.0, atol=1e-12) and np.allclose(same["ssim_y"], 1.0, atol=1e-12)
+    m = P.metrics.evaluate_batch(do, dg, crop_border=2)
+    one = P.metrics.evaluate_batch(do[5:6], dg[5:6], crop_border=2)
+    for k in m:
+        assert m[k][5] == one[k][0]
+    want = O.eval_tail(out[5], gt[5], 2)
+    np.testing.assert_allclose([m["psnr"][5], m["ssim"][5], m["psnr_y"][5], m["ssim_y"][5]], want, rtol=1e-10)
+    # gather path: BGR uint8 images of the whole batch in one call
+    imgs = P.metrics.tensor2img_batch(do)
+    assert imgs.shape == (16, 256, 256, 3) and np.array_equal(imgs[5], O.tensor2img(out[5]))

@@ -216,3 +216,18 @@ def test_dsde_sampler_small(golden):
         y = O.dsde_sample(params, sch, g[key + "/noisy"], mode == "ode", noise=z, depth=2, T=T)
         ref = g[key + "/" + mode]
         assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-3, mode
+
+
+@pytest.mark.parametrize("tag", ["rgb_1x3x40x52_cb0", "rgb_2x3x64x48_cb4", "gray_1x1x33x37_cb0"])
+def test_eval_tail_vs_reference(golden, tag):
+    """tensor2img / PSNR / SSIM / Y-channel restatement against the reference's own functions (cv2's two calls stubbed
+    with their definitions, oracle/gen_golden.py gen_metrics)."""
+    g = golden.metrics
+    B, C, H, W, cb = (int(v) for v in g[tag + "/cfg"])
+    out, gt, want = g[tag + "/out"], g[tag + "/gt"], g[tag + "/metrics"]
+    assert np.array_equal(O.tensor2img(out[0]), g[tag + "/img0"])
+    for b in range(B):
+        got = np.array(O.eval_tail(out[b], gt[b], cb))
+        k = 4 if C == 3 else 2
+        np.testing.assert_allclose(got[:k], want[b, :k], rtol=1e-10, atol=0)
+        assert C == 3 or np.isnan(got[2:]).all()
