@@ -8,6 +8,9 @@ csrc/ -> libirsde_hip.so) with the reference's own Python interface on top:
     DenoisingSDE, denoising_sde.ConditionalUNet
                        codes/utils/sde_utils.py:373-593, codes/config/denoising-sde/models/modules/DenoisingUNet_arch.py
     DenoisingModel     codes/config/deraining/models/denoising_model.py (inference surface)
+    latent.UNet / latent.ConditionalNAFNet / LatentDenoisingModel
+                       codes/config/latent-dehazing/models/{modules/UNet_arch.py, modules/DenoisingNAFNet_arch.py,
+                       latent_denoising_model.py} (encode once, sample in the latent, decode once)
     metrics            codes/utils/img_utils.py:136-234 + codes/data/util.py:177-198 (tensor2img / PSNR / SSIM / Y channel)
 """
 from ._lib import IrsdeError, IrsdeLibraryError, build_library  # noqa: F401
@@ -19,6 +22,8 @@ from .nafnet import ConditionalNAFNet  # noqa: F401
 from . import denoising_sde  # noqa: F401
 from .denoising_sde import DenoisingSDE  # noqa: F401
 from . import metrics  # noqa: F401
+from . import latent  # noqa: F401
+from .latent import LatentDenoisingModel  # noqa: F401
 
-__all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "metrics", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
+__all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "metrics", "latent", "LatentDenoisingModel", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
            "IrsdeError", "IrsdeLibraryError", "shard_bounds", "gather_batch", "sample_sharded"]

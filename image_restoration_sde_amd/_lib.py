@@ -20,6 +20,7 @@ FLAG_NO_WINOGRAD = 4
 FLAG_NO_WINOGRAD_F43 = 8
 FLAG_UNCOND_FULLATTN = 16
 FLAG_BF16 = 32
+FLAG_NAF_INTRO_SKIP = 64
 SAMPLE_GRAPH = 1
 SAMPLE_PROFILE = 2
 
@@ -30,6 +31,7 @@ SYMBOLS = [
     "irsde_set_schedule", "irsde_unet_forward", "irsde_sample", "irsde_sde_step", "irsde_philox_normal",
     "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv", "irsde_plan_describe", "irsde_bench_conv", "irsde_op_profile",
     "irsde_eval_metrics", "irsde_tensor2img",
+    "irsde_create_latent_unet", "irsde_latent_shapes", "irsde_latent_encode", "irsde_latent_decode",
 ]
 
 
@@ -50,6 +52,12 @@ class NafConfig(ctypes.Structure):
     _fields_ = [("img_channel", ctypes.c_int32), ("width", ctypes.c_int32), ("middle_blk_num", ctypes.c_int32),
                 ("n_enc", ctypes.c_int32), ("enc_blk_nums", ctypes.c_int32 * 8), ("n_dec", ctypes.c_int32),
                 ("dec_blk_nums", ctypes.c_int32 * 8), ("device", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class LatentConfig(ctypes.Structure):
+    _fields_ = [("in_ch", ctypes.c_int32), ("out_ch", ctypes.c_int32), ("ch", ctypes.c_int32), ("n_mult", ctypes.c_int32),
+                ("ch_mult", ctypes.c_int32 * 8), ("embed_dim", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
 
 
 _lib = None
@@ -101,6 +109,10 @@ def _declare(lib):
     lib.irsde_bench_conv.argtypes = [c.c_int] * 11 + [c.POINTER(c.c_double)]
     lib.irsde_eval_metrics.argtypes = [P, P, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double), P]
     lib.irsde_tensor2img.argtypes = [P, P, c.c_int, c.c_int, c.c_int, c.c_int, P]
+    lib.irsde_create_latent_unet.argtypes = [c.POINTER(LatentConfig), c.POINTER(P)]
+    lib.irsde_latent_shapes.argtypes = [P, c.c_int, c.c_int, c.POINTER(c.c_int64), c.POINTER(c.c_int64), c.POINTER(c.c_int)]
+    lib.irsde_latent_encode.argtypes = [P, P, c.c_int, c.c_int, c.c_int, P, c.POINTER(P), P]
+    lib.irsde_latent_decode.argtypes = [P, P, c.POINTER(P), c.c_int, c.c_int, c.c_int, P, P]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError here = the .so does not export what the header declares
     return lib

@@ -171,8 +171,12 @@ struct SampleCtl {
 void launch_set_ctl(SampleCtl* ctl, int mode, const float* noise, long long noise_tstride, unsigned long long seed,
                     unsigned long long image_offset, hipStream_t s);
 
-// eps_hat [B][Hp][Wp][4] (NHWC, padded) -> out [B][C][H][W] (crop)
-void launch_unpack_pred(const float* pred, float* out, int B, int C, int H, int W, int Hp, int Wp, hipStream_t s);
+// eps_hat [B][Hp][Wp][stride] (NHWC, padded) -> out [B][C][H][W] (crop)
+void launch_unpack_pred(const float* pred, float* out, int B, int C, int H, int W, int Hp, int Wp, int stride, hipStream_t s);
+void launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s);  // n % 4 == 0
+// NCHW -> NHWC with channel padding to Cp (zeros) and spatial padding to (Hp, Wp) (reflect or zero)
+void launch_nchw_to_nhwc_pad(const float* in, float* out, int B, int C, int H, int W, int Hp, int Wp, int Cp, int reflect,
+                             hipStream_t s);
 // NHWC [B][H][W][C] -> NCHW (debug taps)
 void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t s);
 

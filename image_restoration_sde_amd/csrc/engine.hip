@@ -132,7 +132,8 @@ struct Plan {
     float* xin = nullptr;     // [B][in_nc][H][W]  state x / xt
     float* cin = nullptr;     // [B][in_nc][H][W]  mu / cond
     float* x0 = nullptr;      // prepped NHWC input
-    float* pred = nullptr;    // [B][Hp][Wp][4]
+    float* pred = nullptr;    // [B][Hp][Wp][pred_stride]
+    int pred_stride = 4;      // roundup(out_nc, 4)
     std::map<std::string, Tensor> taps;
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
@@ -166,6 +167,17 @@ struct Plan {
                 return;
             }
     }
+};
+
+// One direction (encode or decode) of the latent UNet at a fixed (B,H,W): a Plan whose ops run on NHWC buffers, plus
+// the NHWC tensors that are read from / written to the caller's NCHW tensors around it.
+struct LatentPlan {
+    bool decode = false;
+    std::unique_ptr<Plan> plan;
+    Tensor image;                // encode: padded NHWC input image; decode: final_conv output [B][Hp][Wp][4]
+    Tensor latent;               // NHWC latent (channels padded to 32)
+    std::vector<Tensor> hidden;  // NHWC skips in the reference's list order h[0..2*depth]
+    std::vector<int> hidden_c;   // logical channel counts
 };
 
 }  // namespace
@@ -206,6 +218,15 @@ struct irsde_engine {
     std::vector<ConvW> naf_downs, naf_ups;
     ConvW naf_intro, naf_ending;
     std::vector<NafBlockW*> naf_all;
+
+    // latent UNet (arch == 2): codes/config/latent-dehazing/models/modules/UNet_arch.py
+    int lat_in = 0, lat_out = 0, lat_ch = 0, lat_embed = 0;
+    std::vector<int> lat_mult;
+    ConvW lat_init, lat_latent, lat_post, lat_final;
+    std::vector<ResW> lat_enc_res, lat_dec_res;  // 2 per level (decoder in module order: deepest first)
+    AttnW lat_enc_attn, lat_dec_attn;            // deepest level only
+    std::vector<ConvW> lat_down, lat_up;
+    std::vector<std::unique_ptr<LatentPlan>> lat_plans;
 
     // schedule / FiLM tables
     int T = 0;
@@ -569,10 +590,136 @@ void finalize_naf(irsde_engine* e) {
     e->film_row = off;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Latent UNet (arch == 2): inventory / packing — latent-dehazing/models/modules/UNet_arch.py:17-57.
+// Channel counts there are small and irregular (8, 40, 96 ...); every NHWC tensor is stored with its channel count
+// rounded up to 32 and the packed weights carry zero rows / zero K columns for the padding, so the padding channels
+// hold exact zeros everywhere and the implicit-GEMM kernel (32-channel K chunks) needs no special case.
+// ---------------------------------------------------------------------------------------------
+inline int rup32(int c) { return (c + 31) & ~31; }
+
+void build_inventory_latent(irsde_engine* e) {
+    const int depth = (int)e->lat_mult.size(), ch = e->lat_ch;
+    auto dim = [&](int i) { return i == 0 ? ch : ch * e->lat_mult[i - 1]; };
+    auto resb = [&](const std::string& p, int ci, int co) {
+        add_w(e, p + "block1.proj.weight", {co, ci, 3, 3});
+        add_w(e, p + "block2.proj.weight", {co, co, 3, 3});
+        if (ci != co) add_w(e, p + "res_conv.weight", {co, ci, 1, 1});
+    };
+    add_w(e, "init_conv.weight", {ch, e->lat_in, 3, 3});
+    for (int i = 0; i < depth; ++i) {
+        const int di = dim(i), dout = dim(i + 1);
+        const std::string en = "encoder." + std::to_string(i) + ".";
+        resb(en + "0.", di, di);
+        resb(en + "1.", di, di);
+        if (i == depth - 1) inv_attn(e, en + "2.", di);
+        if (i != depth - 1) {
+            add_w(e, en + "3.weight", {dout, di, 4, 4});
+            add_w(e, en + "3.bias", {dout});
+        } else {
+            add_w(e, en + "3.weight", {dout, di, 3, 3});
+        }
+        const std::string de = "decoder." + std::to_string(depth - 1 - i) + ".";
+        resb(de + "0.", dout + di, dout);
+        resb(de + "1.", dout + di, dout);
+        if (i == depth - 1) inv_attn(e, de + "2.", dout);
+        if (i != 0) {
+            add_w(e, de + "3.1.weight", {di, dout, 3, 3});
+            add_w(e, de + "3.1.bias", {di});
+        } else {
+            add_w(e, de + "3.weight", {di, dout, 3, 3});
+        }
+    }
+    const int mid = dim(depth);
+    add_w(e, "latent_conv.weight", {e->lat_embed, mid, 1, 1});
+    add_w(e, "post_latent_conv.weight", {mid, e->lat_embed, 1, 1});
+    add_w(e, "final_conv.weight", {e->lat_out, ch, 3, 3});
+    add_w(e, "final_conv.bias", {e->lat_out});
+}
+
+// OIHW -> [O_p][KH][KW][sum rup32(split)] with zero padding; `splits` = logical channels of each concatenated source
+ConvW pack_conv_pad(irsde_engine* e, const std::string& wname, const std::string& bname, const std::vector<int>& splits,
+                    bool pad_out) {
+    const HostTensor& t = need(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1], KH = (int)t.shape[2], KW = (int)t.shape[3];
+    int isum = 0, Ip = 0;
+    for (int c : splits) { isum += c; Ip += rup32(c); }
+    if (isum != I) throw HipError("pack_conv_pad: channel split mismatch for " + wname);
+    const int Op = pad_out ? rup32(O) : O;
+    std::vector<float> p((size_t)Op * KH * KW * Ip, 0.f);
+    for (int o = 0; o < O; ++o) {
+        int src = 0, dst = 0;
+        for (int c : splits) {
+            for (int i = 0; i < c; ++i)
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx)
+                        p[(((size_t)o * KH + ky) * KW + kx) * Ip + dst + i] = t.data[(((size_t)o * I + src + i) * KH + ky) * KW + kx];
+            src += c;
+            dst += rup32(c);
+        }
+    }
+    ConvW cw;
+    cw.w = e->upload(p);
+    cw.Cout = Op; cw.Cin = Ip; cw.KH = KH; cw.KW = KW;
+    if (!bname.empty()) {
+        std::vector<float> pb(Op, 0.f);
+        const HostTensor& b = need(e, bname);
+        for (int o = 0; o < O; ++o) pb[o] = b.data[o];
+        cw.bias = e->upload(pb);
+    }
+    return cw;
+}
+
+void finalize_latent(irsde_engine* e) {
+    const int depth = (int)e->lat_mult.size(), ch = e->lat_ch;
+    auto dim = [&](int i) { return i == 0 ? ch : ch * e->lat_mult[i - 1]; };
+    auto resb = [&](const std::string& p, const std::vector<int>& in_splits, int co) {
+        ResW r;
+        r.b1 = pack_conv_pad(e, p + "block1.proj.weight", "", in_splits, true);
+        r.b2 = pack_conv_pad(e, p + "block2.proj.weight", "", {co}, true);
+        r.Cout = r.b1.Cout;
+        r.has_res = e->host.count(p + "res_conv.weight") > 0;
+        if (r.has_res) r.res = pack_conv_pad(e, p + "res_conv.weight", "", in_splits, true);
+        return r;
+    };
+    e->lat_init = pack_conv_pad(e, "init_conv.weight", "", {e->lat_in}, true);
+    e->lat_dec_res.resize(2 * depth);
+    e->lat_up.resize(depth);
+    for (int i = 0; i < depth; ++i) {
+        const int di = dim(i), dout = dim(i + 1);
+        const std::string en = "encoder." + std::to_string(i) + ".";
+        e->lat_enc_res.push_back(resb(en + "0.", {di}, di));
+        e->lat_enc_res.push_back(resb(en + "1.", {di}, di));
+        if (i == depth - 1) {
+            if (di % 32) throw HipError("latent UNet: the attention level needs a channel count that is a multiple of 32");
+            e->lat_enc_attn = pack_attn(e, en + "2.");
+        }
+        e->lat_down.push_back(pack_conv_pad(e, en + "3.weight", i != depth - 1 ? en + "3.bias" : "", {di}, true));
+        const int j = depth - 1 - i;
+        const std::string de = "decoder." + std::to_string(j) + ".";
+        e->lat_dec_res[2 * j] = resb(de + "0.", {dout, di}, dout);
+        e->lat_dec_res[2 * j + 1] = resb(de + "1.", {dout, di}, dout);
+        if (i == depth - 1) {
+            if (dout % 32) throw HipError("latent UNet: the attention level needs a channel count that is a multiple of 32");
+            e->lat_dec_attn = pack_attn(e, de + "2.");
+        }
+        e->lat_up[j] = i != 0 ? pack_conv_pad(e, de + "3.1.weight", de + "3.1.bias", {dout}, true)
+                              : pack_conv_pad(e, de + "3.weight", "", {dout}, true);
+    }
+    e->lat_latent = pack_conv_pad(e, "latent_conv.weight", "", {dim(depth)}, true);
+    e->lat_post = pack_conv_pad(e, "post_latent_conv.weight", "", {e->lat_embed}, true);
+    e->lat_final = pack_conv_pad(e, "final_conv.weight", "final_conv.bias", {ch}, false);
+}
+
 void finalize(irsde_engine* e) {
     IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
     for (auto& n : e->names)
         if (!e->host[n].loaded) throw HipError("missing weight: " + n);
+    if (e->arch == 2) {
+        finalize_latent(e);
+        finalize_common(e);
+        return;
+    }
     if (e->arch == 1) {
         finalize_naf(e);
         finalize_common(e);
@@ -944,7 +1091,8 @@ struct Builder {
             R = conv(w.res, in0, in1, 1, 0, 0, nullptr, 0, nullptr);
         else
             R = in0;
-        Tensor h1 = conv(w.b1, in0, in1, 1, 1, 0, e->film_cur + w.film_off, 1, nullptr);
+        // latent UNet ResBlocks have no time MLP (UNet_arch.py:23): plain conv -> SiLU
+        Tensor h1 = conv(w.b1, in0, in1, 1, 1, 0, w.mlp_w ? e->film_cur + w.film_off : nullptr, 1, nullptr);
         Tensor out = conv(w.b2, h1, nullptr, 1, 1, 0, nullptr, 1, &R);
         tfree(h1);
         if (w.has_res) tfree(R);
@@ -1030,11 +1178,14 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
         pl->net_ops.back().flops = real;
     }
     b.tap("intro", x);
+    // latent variant (latent-dehazing/models/modules/DenoisingNAFNet_arch.py:162-176): ending(x + intro output)
+    const bool intro_skip = (e->cfg.flags & IRSDE_FLAG_NAF_INTRO_SKIP) != 0;
+    const Tensor intro = x;
     std::vector<Tensor> encs;
     for (size_t i = 0; i < e->naf_enc.size(); ++i) {
         for (auto& blk : e->naf_enc[i]) {
             Tensor y = b.nafblock(blk, x);
-            b.tfree(x);
+            if (!(intro_skip && x.p == intro.p)) b.tfree(x);
             x = y;
         }
         b.tap("encoders." + std::to_string(i), x);
@@ -1066,8 +1217,18 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
         }
         b.tap("decoders." + std::to_string(i), x);
     }
+    if (intro_skip) {
+        Tensor y = b.talloc(x.B, x.H, x.W, x.C);
+        const float *xa = x.p, *xb = intro.p;
+        float* yo = y.p;
+        const size_t n = x.numel();
+        b.push_other(OP_OTHER, [=](hipStream_t s) { launch_add(xa, xb, yo, n, s); });
+        b.tfree(x);
+        b.tfree(intro);
+        x = y;
+    }
     Builder::ConvOpts oe;
-    oe.pad = 1; oe.out_stride = 4;
+    oe.pad = 1; oe.out_stride = pl->pred_stride;
     Tensor pr = b.conv_naf(e->naf_ending, x, oe);
     b.tfree(x);
     pl->pred = pr.p;
@@ -1096,6 +1257,7 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
     pl->Hp = (H + sdiv - 1) / sdiv * sdiv;
     pl->Wp = (W + sdiv - 1) / sdiv * sdiv;
     pl->per_sample_film = per_sample_film;
+    pl->pred_stride = (e->cfg.out_nc + 3) & ~3;
     pl->last_use = ++e->use_counter;
     // F.pad 'reflect' needs pad < dim (DenoisingUNet_arch.py:82)
     if (e->arch != 1 && (pl->Hp - H >= H || pl->Wp - W >= W)) throw HipError("image too small for reflect padding");
@@ -1195,12 +1357,88 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
         Tensor f = b.resblock(e->final_res, x, &x_init);
         b.tfree(x); b.tfree(x_init);
         b.tap("final_res_block", f);
-        Tensor pr = b.conv(e->final_conv, f, nullptr, 1, 1, 0, nullptr, 0, nullptr, 4);
+        Tensor pr = b.conv(e->final_conv, f, nullptr, 1, 1, 0, nullptr, 0, nullptr, pl->pred_stride);
         b.tfree(f);
         pl->pred = pr.p;
     }
     e->plans.push_back(std::move(plan));
     return pl;
+}
+
+// UNet.encode / UNet.decode — latent-dehazing/models/modules/UNet_arch.py:59-91
+LatentPlan* get_latent_plan(irsde_engine* e, int B, int H, int W, bool decode) {
+    for (auto& lp : e->lat_plans)
+        if (lp->decode == decode && lp->plan->B == B && lp->plan->H == H && lp->plan->W == W) {
+            lp->plan->last_use = ++e->use_counter;
+            return lp.get();
+        }
+    if (e->lat_plans.size() >= 4) {
+        size_t lru = 0;
+        for (size_t i = 1; i < e->lat_plans.size(); ++i)
+            if (e->lat_plans[i]->plan->last_use < e->lat_plans[lru]->plan->last_use) lru = i;
+        IRSDE_HIP_CHECK(hipDeviceSynchronize());
+        e->lat_plans.erase(e->lat_plans.begin() + lru);
+    }
+    const int depth = (int)e->lat_mult.size(), ch = e->lat_ch;
+    auto dim = [&](int i) { return i == 0 ? ch : ch * e->lat_mult[i - 1]; };
+    const int sdiv = 1 << depth;  // check_image_size pads to 2^depth although only depth-1 levels downsample (:52-57)
+    std::unique_ptr<LatentPlan> lp(new LatentPlan());
+    lp->decode = decode;
+    lp->plan.reset(new Plan());
+    Plan* pl = lp->plan.get();
+    pl->B = B; pl->H = H; pl->W = W;
+    pl->Hp = (H + sdiv - 1) / sdiv * sdiv;
+    pl->Wp = (W + sdiv - 1) / sdiv * sdiv;
+    pl->last_use = ++e->use_counter;
+    if (pl->Hp - H >= H || pl->Wp - W >= W) throw HipError("image too small for reflect padding");
+    // skips never alias anything else: they cross the encode/decode boundary (decode: they are inputs)
+    Builder b{e, pl, false, (e->cfg.flags & IRSDE_FLAG_NAIVE_CONV) != 0, 0};
+    // hidden list geometry: h[0] = init_conv output, then two entries per level
+    std::vector<std::pair<int, int>> hgeo;  // (level, logical channels)
+    hgeo.push_back({0, ch});
+    for (int i = 0; i < depth; ++i) {
+        hgeo.push_back({i, dim(i)});
+        hgeo.push_back({i, dim(i)});
+    }
+    const int hl = pl->Hp >> (depth - 1), wl = pl->Wp >> (depth - 1);
+    if (!decode) {
+        lp->image = b.talloc(B, pl->Hp, pl->Wp, rup32(e->lat_in));
+        Tensor x = b.conv(e->lat_init, lp->image, nullptr, 1, 1, 0, nullptr, 0, nullptr);
+        lp->hidden.push_back(x);
+        for (int i = 0; i < depth; ++i) {
+            Tensor a = b.resblock(e->lat_enc_res[2 * i], x, nullptr);
+            lp->hidden.push_back(a);
+            Tensor c = b.resblock(e->lat_enc_res[2 * i + 1], a, nullptr);
+            Tensor g = i == depth - 1 ? b.attn(e->lat_enc_attn, c) : c;
+            lp->hidden.push_back(g);
+            x = i != depth - 1 ? b.conv(e->lat_down[i], g, nullptr, 2, 1, 0, nullptr, 0, nullptr)   // Downsample 4x4 s2 p1
+                               : b.conv(e->lat_down[i], g, nullptr, 1, 1, 0, nullptr, 0, nullptr);  // default_conv 3x3
+        }
+        lp->latent = b.conv(e->lat_latent, x, nullptr, 1, 0, 0, nullptr, 0, nullptr);
+    } else {
+        lp->latent = b.talloc(B, hl, wl, rup32(e->lat_embed));
+        for (auto& g : hgeo) lp->hidden.push_back(b.talloc(B, pl->Hp >> g.first, pl->Wp >> g.first, rup32(g.second)));
+        Tensor x = b.conv(e->lat_post, lp->latent, nullptr, 1, 0, 0, nullptr, 0, nullptr);
+        const int nh = (int)lp->hidden.size();
+        for (int j = 0; j < depth; ++j) {
+            Tensor a = b.resblock(e->lat_dec_res[2 * j], x, &lp->hidden[nh - (2 * j + 1)]);
+            Tensor c = b.resblock(e->lat_dec_res[2 * j + 1], a, &lp->hidden[nh - (2 * j + 2)]);
+            Tensor g = j == 0 ? b.attn(e->lat_dec_attn, c) : c;
+            x = j != depth - 1 ? b.conv(e->lat_up[j], g, nullptr, 1, 1, 1, nullptr, 0, nullptr)    // nearest x2 + 3x3 (+bias)
+                               : b.conv(e->lat_up[j], g, nullptr, 1, 1, 0, nullptr, 0, nullptr);   // default_conv 3x3
+        }
+        Tensor y = b.talloc(x.B, x.H, x.W, x.C);
+        {
+            const float *xa = x.p, *xb = lp->hidden[0].p;
+            float* yo = y.p;
+            const size_t n = x.numel();
+            b.push_other(OP_OTHER, [=](hipStream_t s) { launch_add(xa, xb, yo, n, s); });
+        }
+        lp->image = b.conv(e->lat_final, y, nullptr, 1, 1, 0, nullptr, 0, nullptr, 4);
+    }
+    for (auto& g : hgeo) lp->hidden_c.push_back(g.second);
+    e->lat_plans.push_back(std::move(lp));
+    return e->lat_plans.back().get();
 }
 
 hipEvent_t get_event(irsde_engine* e, size_t i) {
@@ -1219,7 +1457,8 @@ void run_net(Plan* pl, hipStream_t s) {
 UpdateParams make_update(irsde_engine* e, Plan* pl) {
     UpdateParams u{};
     u.x = pl->xin; u.mu = pl->cin; u.pred = pl->pred;
-    u.sb = (int64_t)pl->Hp * pl->Wp * 4; u.sc = 1; u.sy = (int64_t)pl->Wp * 4; u.sx = 4;
+    const int64_t ps = pl->pred_stride;
+    u.sb = (int64_t)pl->Hp * pl->Wp * ps; u.sc = 1; u.sy = (int64_t)pl->Wp * ps; u.sx = ps;
     u.st = e->step; u.ctl = e->ctl;
     u.B = pl->B; u.C = e->cfg.in_nc; u.H = pl->H; u.W = pl->W;
     return u;
@@ -1279,7 +1518,7 @@ int irsde_create_nafnet(const irsde_nafnet_config* cfg, irsde_engine** out) {
     return guard([&] {
         if (!cfg || !out) throw HipError("null argument");
         if (cfg->width % 32 || cfg->width < 32) throw HipError("width must be a positive multiple of 32");
-        if (cfg->img_channel < 1 || cfg->img_channel > 4) throw HipError("img_channel must be in 1..4");
+        if (cfg->img_channel < 1 || cfg->img_channel > 8) throw HipError("img_channel must be in 1..8");
         if (cfg->n_enc < 1 || cfg->n_enc > 6 || cfg->n_dec != cfg->n_enc) throw HipError("need 1..6 encoder stages and as many decoder stages");
         if ((cfg->width << cfg->n_enc) > 2048) throw HipError("width * 2^stages must be <= 2048");
         auto* e = new irsde_engine();
@@ -1306,6 +1545,7 @@ void irsde_destroy(irsde_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     e->plans.clear();
+    e->lat_plans.clear();
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
@@ -1421,7 +1661,7 @@ int irsde_unet_forward(irsde_engine* e, const float* xt, const float* cond, cons
             (void)hipFree(dtv);
         }
         run_net(pl, s);
-        launch_unpack_pred(pl->pred, out, B, e->cfg.out_nc, H, W, pl->Hp, pl->Wp, s);
+        launch_unpack_pred(pl->pred, out, B, e->cfg.out_nc, H, W, pl->Hp, pl->Wp, pl->pred_stride, s);
         IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
         IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
     });
@@ -1761,6 +2001,96 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
         if (dbf) (void)hipFree(dbf);
         (void)hipStreamDestroy(s);
+    });
+}
+
+int irsde_create_latent_unet(const irsde_latent_unet_config* cfg, irsde_engine** out) {
+    return guard([&] {
+        if (!cfg || !out) throw HipError("null argument");
+        if (cfg->in_ch < 1 || cfg->in_ch > 32 || cfg->out_ch < 1 || cfg->out_ch > 4) throw HipError("in_ch must be in 1..32 and out_ch in 1..4");
+        if (cfg->ch < 1 || cfg->n_mult < 1 || cfg->n_mult > 6) throw HipError("ch / ch_mult out of range");
+        if (cfg->embed_dim < 1 || cfg->embed_dim > 32) throw HipError("embed_dim must be in 1..32");
+        auto* e = new irsde_engine();
+        e->arch = 2;
+        e->cfg.in_nc = cfg->in_ch; e->cfg.out_nc = cfg->out_ch; e->cfg.nf = cfg->ch; e->cfg.depth = cfg->n_mult;
+        e->cfg.device = cfg->device; e->cfg.flags = cfg->flags;
+        e->lat_in = cfg->in_ch; e->lat_out = cfg->out_ch; e->lat_ch = cfg->ch; e->lat_embed = cfg->embed_dim;
+        for (int i = 0; i < cfg->n_mult; ++i) {
+            if (cfg->ch_mult[i] < 1 || cfg->ch * cfg->ch_mult[i] > 2048) throw HipError("ch * ch_mult out of range");
+            e->lat_mult.push_back(cfg->ch_mult[i]);
+        }
+        build_inventory_latent(e);
+        *out = e;
+    });
+}
+
+int irsde_latent_shapes(irsde_engine* e, int H, int W, int64_t latent_chw[3], int64_t* hidden_chw, int* n_hidden) {
+    return guard([&] {
+        if (!e || e->arch != 2 || !latent_chw || !n_hidden) throw HipError("latent_shapes: not a latent UNet engine / null argument");
+        const int depth = (int)e->lat_mult.size(), sdiv = 1 << depth;
+        const int Hp = (H + sdiv - 1) / sdiv * sdiv, Wp = (W + sdiv - 1) / sdiv * sdiv;
+        latent_chw[0] = e->lat_embed; latent_chw[1] = Hp >> (depth - 1); latent_chw[2] = Wp >> (depth - 1);
+        *n_hidden = 2 * depth + 1;
+        if (hidden_chw) {
+            auto dim = [&](int i) { return i == 0 ? e->lat_ch : e->lat_ch * e->lat_mult[i - 1]; };
+            for (int k = 0; k < 2 * depth + 1; ++k) {
+                const int lvl = k == 0 ? 0 : (k - 1) / 2;
+                hidden_chw[3 * k] = dim(lvl); hidden_chw[3 * k + 1] = Hp >> lvl; hidden_chw[3 * k + 2] = Wp >> lvl;
+            }
+        }
+    });
+}
+
+int irsde_latent_encode(irsde_engine* e, const float* x, int B, int H, int W, float* latent, float* const* hidden,
+                        void* stream) {
+    return guard([&] {
+        if (!e || e->arch != 2 || !x || !latent || !hidden) throw HipError("latent_encode: not a latent UNet engine / null argument");
+        if (!e->finalized) throw HipError("latent_encode: weights not finalized");
+        if (B < 1 || H < 2 || W < 2) throw HipError("latent_encode: bad shape");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t user = reinterpret_cast<hipStream_t>(stream), s = e->stream;
+        LatentPlan* lp = get_latent_plan(e, B, H, W, false);
+        Plan* pl = lp->plan.get();
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+        launch_nchw_to_nhwc_pad(x, lp->image.p, B, e->lat_in, H, W, pl->Hp, pl->Wp, lp->image.C, 1, s);  // F.pad 'reflect'
+        run_net(pl, s);
+        const Tensor& L = lp->latent;
+        launch_unpack_pred(L.p, latent, B, e->lat_embed, L.H, L.W, L.H, L.W, L.C, s);
+        for (size_t k = 0; k < lp->hidden.size(); ++k) {
+            const Tensor& h = lp->hidden[k];
+            if (!hidden[k]) throw HipError("latent_encode: null hidden pointer");
+            launch_unpack_pred(h.p, hidden[k], B, lp->hidden_c[k], h.H, h.W, h.H, h.W, h.C, s);
+        }
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+    });
+}
+
+int irsde_latent_decode(irsde_engine* e, const float* latent, const float* const* hidden, int B, int H, int W, float* out,
+                        void* stream) {
+    return guard([&] {
+        if (!e || e->arch != 2 || !latent || !hidden || !out) throw HipError("latent_decode: not a latent UNet engine / null argument");
+        if (!e->finalized) throw HipError("latent_decode: weights not finalized");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t user = reinterpret_cast<hipStream_t>(stream), s = e->stream;
+        LatentPlan* lp = get_latent_plan(e, B, H, W, true);
+        Plan* pl = lp->plan.get();
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+        const Tensor& L = lp->latent;
+        launch_nchw_to_nhwc_pad(latent, L.p, B, e->lat_embed, L.H, L.W, L.H, L.W, L.C, 0, s);
+        for (size_t k = 0; k < lp->hidden.size(); ++k) {
+            const Tensor& h = lp->hidden[k];
+            if (!hidden[k]) throw HipError("latent_decode: null hidden pointer");
+            launch_nchw_to_nhwc_pad(hidden[k], h.p, B, lp->hidden_c[k], h.H, h.W, h.H, h.W, h.C, 0, s);
+        }
+        run_net(pl, s);
+        launch_unpack_pred(lp->image.p, out, B, e->lat_out, H, W, pl->Hp, pl->Wp, 4, s);  // x[..., :H, :W]
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
     });
 }
 

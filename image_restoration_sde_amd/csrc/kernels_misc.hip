@@ -352,7 +352,7 @@ __global__ void prep_input_kernel(const float* __restrict__ xt, const float* __r
     const size_t t1 = idx / Wb;
     const int yb = (int)(t1 % Hb);
     const int b = (int)(t1 / Hb);
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // in_nc <= 8
     const int y = yb - 3, x = xb - 3;
     // UNet: F.pad(..., 'reflect') to a multiple of 2^depth; NAFNet: zero pad (DenoisingNAFNet_arch.py:189-194)
     if (y >= 0 && y < Hp && x >= 0 && x < Wp && (reflect || (y < H && x < W))) {
@@ -530,7 +530,7 @@ __global__ void set_ctl_kernel(SampleCtl* ctl, const int mode, const float* nois
 }
 
 __global__ void unpack_pred_kernel(const float* __restrict__ pred, float* __restrict__ out, const int B, const int C,
-                                   const int H, const int W, const int Hp, const int Wp) {
+                                   const int H, const int W, const int Hp, const int Wp, const int stride) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)B * C * H * W;
     if (idx >= total) return;
@@ -539,7 +539,7 @@ __global__ void unpack_pred_kernel(const float* __restrict__ pred, float* __rest
     const int y = (int)(r % H); r /= H;
     const int c = (int)(r % C);
     const int b = (int)(r / C);
-    out[idx] = pred[(((size_t)b * Hp + y) * Wp + x) * 4 + c];
+    out[idx] = pred[(((size_t)b * Hp + y) * Wp + x) * stride + c];
 }
 
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, const int B, const int C,
@@ -801,7 +801,7 @@ void launch_full_attention(const float* qkv, float* out, int B, int N, hipStream
 void launch_prep_input(const float* xt, const float* cond, float* x0, int B, int in_nc, int H, int W, int Hp, int Wp,
                        hipStream_t s, int reflect) {
     const int P = ((cond ? 2 : 1) * in_nc + 3) & ~3;
-    if (P > 8) throw HipError("prep_input: in_nc > 4 unsupported");
+    if (P > 16) throw HipError("prep_input: more than 8 (conditional) / 16 (unconditional) input channels unsupported");
     const size_t total = (size_t)B * (Hp + 6) * (Wp + 6);
     hipLaunchKernelGGL(prep_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xt, cond, x0, B,
                        in_nc, P, H, W, Hp, Wp, reflect);
@@ -845,10 +845,10 @@ void launch_set_ctl(SampleCtl* ctl, int mode, const float* noise, long long nois
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-void launch_unpack_pred(const float* pred, float* out, int B, int C, int H, int W, int Hp, int Wp, hipStream_t s) {
+void launch_unpack_pred(const float* pred, float* out, int B, int C, int H, int W, int Hp, int Wp, int stride, hipStream_t s) {
     const size_t total = (size_t)B * C * H * W;
     hipLaunchKernelGGL(unpack_pred_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pred, out, B, C, H,
-                       W, Hp, Wp);
+                       W, Hp, Wp, stride);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
@@ -869,6 +869,46 @@ void launch_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint
     const int quads = (CHW + 3) / 4;
     hipLaunchKernelGGL(philox_normal_kernel, dim3((quads + 255) / 256, B), dim3(256), 0, s, out, CHW, t, seed,
                        image_offset);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+// out = a + b (latent NAFNet: ending(x + intro); latent UNet: final_conv(x + h[0]))
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+void launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s) {
+    if (n % 4) throw HipError("launch_add: element count must be a multiple of 4");
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a, b, out, n / 4);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+// NCHW [B][C][H][W] -> NHWC [B][Hp][Wp][Cp]: channels >= C are zero; rows/cols >= H/W are reflect-padded (reflect=1,
+// F.pad 'reflect' on the right/bottom) or zero
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, float* __restrict__ out, const int B, const int C,
+                                        const int H, const int W, const int Hp, const int Wp, const int Cp, const int reflect) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * Hp * Wp * Cp;
+    if (idx >= total) return;
+    const int c = (int)(idx % Cp);
+    size_t r = idx / Cp;
+    const int x = (int)(r % Wp); r /= Wp;
+    const int y = (int)(r % Hp);
+    const int b = (int)(r / Hp);
+    float v = 0.f;
+    if (c < C && (reflect || (y < H && x < W))) {
+        const int sy = y < H ? y : 2 * (H - 1) - y, sx = x < W ? x : 2 * (W - 1) - x;
+        v = in[(((size_t)b * C + c) * H + sy) * W + sx];
+    }
+    out[idx] = v;
+}
+void launch_nchw_to_nhwc_pad(const float* in, float* out, int B, int C, int H, int W, int Hp, int Wp, int Cp, int reflect,
+                             hipStream_t s) {
+    const size_t total = (size_t)B * Hp * Wp * Cp;
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, B, C, H, W, Hp,
+                       Wp, Cp, reflect);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

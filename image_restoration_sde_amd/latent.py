@@ -1,0 +1,208 @@
+"""Latent-Refusion wrapper: the frozen latent compressor `UNet`, the latent-task
+`ConditionalNAFNet`, and the inference half of `latent_denoising_model.DenoisingModel`.
+
+Reference: /root/reference/codes/config/latent-dehazing/
+    models/modules/UNet_arch.py:17-96            UNet(in_ch, out_ch, ch, ch_mult, embed_dim): encode / decode / forward
+    models/modules/DenoisingNAFNet_arch.py:85-186 ConditionalNAFNet whose `ending` sees x + intro(x)
+    models/latent_denoising_model.py:40-51,146-152,177-200
+    test.py:90-100     latent_LQ, hidden = model.encode(LQ); noisy = sde.noise_state(latent_LQ);
+                       model.feed_data(noisy, latent_LQ); model.test(sde, hidden)
+(the latent-bokeh variant additionally threads `lens_info` through every NAFBlock; not built.)
+
+Modules only own parameters under the reference's state_dict names; the arithmetic runs in libirsde_hip.so.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .nafnet import ConditionalNAFNet as _ImageNAFNet
+from .unet import _Block, _Engine, _Residual
+
+
+class _PlainResBlock(nn.Module):  # module_util.ResBlock with time_emb_dim=None (latent-dehazing module_util.py:132-153)
+    def __init__(self, ci, co):
+        super().__init__()
+        self.block1 = _Block(ci, co)
+        self.block2 = _Block(co, co)
+        self.res_conv = nn.Conv2d(ci, co, 1, bias=False) if ci != co else nn.Identity()
+
+
+class UNet(nn.Module):
+    def __init__(self, in_ch=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4], embed_dim=4):
+        super().__init__()
+        self.in_ch, self.out_ch, self.ch, self.ch_mult, self.embed_dim = in_ch, out_ch, ch, list(ch_mult), embed_dim
+        self.depth = len(ch_mult)
+        self.init_conv = nn.Conv2d(in_ch, ch, 3, padding=1, bias=False)
+        self.encoder, self.decoder = nn.ModuleList([]), nn.ModuleList([])
+        mult = [1] + list(ch_mult)
+        for i in range(self.depth):
+            di, do = ch * mult[i], ch * mult[i + 1]
+            last = i == self.depth - 1
+            self.encoder.append(nn.ModuleList([
+                _PlainResBlock(di, di), _PlainResBlock(di, di), _Residual(di) if last else nn.Identity(),
+                nn.Conv2d(di, do, 4, 2, 1) if not last else nn.Conv2d(di, do, 3, padding=1, bias=False)]))
+            self.decoder.insert(0, nn.ModuleList([
+                _PlainResBlock(do + di, do), _PlainResBlock(do + di, do), _Residual(do) if last else nn.Identity(),
+                nn.Sequential(nn.Identity(), nn.Conv2d(do, di, 3, 1, 1)) if i != 0 else nn.Conv2d(do, di, 3, padding=1, bias=False)]))
+        mid = ch * mult[-1]
+        self.latent_conv = nn.Conv2d(mid, embed_dim, 1, bias=False)
+        self.post_latent_conv = nn.Conv2d(embed_dim, mid, 1, bias=False)
+        self.final_conv = nn.Conv2d(ch, out_ch, 3, 1, 1)
+        self._engine = None
+        self._engine_key = None
+        self.engine_flags = 0
+        self.H = self.W = None
+
+    # ---- engine management (as ConditionalUNet) ----------------------------------------------
+    def _create_handle(self, L, device_index, flags):
+        cfg = _lib.LatentConfig()
+        cfg.in_ch, cfg.out_ch, cfg.ch, cfg.n_mult, cfg.embed_dim = self.in_ch, self.out_ch, self.ch, self.depth, self.embed_dim
+        for i, v in enumerate(self.ch_mult):
+            cfg.ch_mult[i] = v
+        cfg.device, cfg.flags = device_index, flags
+        h = ctypes.c_void_p()
+        _lib.check(L.irsde_create_latent_unet(ctypes.byref(cfg), ctypes.byref(h)))
+        return h
+
+    def engine(self, device=None):
+        if device is None:
+            device = next(self.parameters()).device
+        if device.type != "cuda":
+            raise _lib.IrsdeError("the latent UNet runs only on an AMD GPU through libirsde_hip.so (no CPU/PyTorch fallback)")
+        key = (device.index if device.index is not None else torch.cuda.current_device(), self.engine_flags,
+               tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        if self._engine is None or self._engine_key != key:
+            self._engine = _Engine(self, key[0], self.engine_flags)
+            self._engine_key = key
+        return self._engine
+
+    def _shapes(self, eng, H, W):
+        L = _lib.lib()
+        lat = (ctypes.c_int64 * 3)()
+        n = ctypes.c_int()
+        hid = (ctypes.c_int64 * (3 * (2 * self.depth + 1)))()
+        _lib.check(L.irsde_latent_shapes(eng.h, H, W, lat, hid, ctypes.byref(n)))
+        return tuple(lat), [tuple(hid[3 * k:3 * k + 3]) for k in range(n.value)]
+
+    # ---- reference interface (UNet_arch.py:59-96) ---------------------------------------------
+    def encode(self, x):
+        if x.device.type != "cuda":
+            raise _lib.IrsdeError("UNet.encode needs CUDA(HIP) tensors; got %s" % x.device)
+        self.H, self.W = x.shape[2:]
+        B = x.shape[0]
+        eng = self.engine(x.device)
+        lat_s, hid_s = self._shapes(eng, self.H, self.W)
+        xin = x.detach().to(torch.float32).contiguous()
+        latent = torch.empty((B,) + lat_s, device=x.device, dtype=torch.float32)
+        hidden = [torch.empty((B,) + s, device=x.device, dtype=torch.float32) for s in hid_s]
+        ptrs = (ctypes.c_void_p * len(hidden))(*[h.data_ptr() for h in hidden])
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().irsde_latent_encode(eng.h, ctypes.c_void_p(xin.data_ptr()), B, self.H, self.W,
+                                                      ctypes.c_void_p(latent.data_ptr()), ptrs, _lib.stream_ptr()))
+        return latent, hidden
+
+    def decode(self, x, h):
+        if self.H is None:
+            raise _lib.IrsdeError("UNet.decode before encode: the crop size comes from the encoded image (UNet_arch.py:60,91)")
+        if x.device.type != "cuda":
+            raise _lib.IrsdeError("UNet.decode needs CUDA(HIP) tensors; got %s" % x.device)
+        B = x.shape[0]
+        eng = self.engine(x.device)
+        lat_s, hid_s = self._shapes(eng, self.H, self.W)
+        if tuple(x.shape[1:]) != lat_s or len(h) != len(hid_s) or any(tuple(t.shape[1:]) != s for t, s in zip(h, hid_s)):
+            raise _lib.IrsdeError("latent / hidden shapes do not belong to the encoded %dx%d image" % (self.H, self.W))
+        lat = x.detach().to(torch.float32).contiguous()
+        hid = [t.detach().to(torch.float32).contiguous() for t in h]
+        ptrs = (ctypes.c_void_p * len(hid))(*[t.data_ptr() for t in hid])
+        out = torch.empty((B, self.out_ch, self.H, self.W), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().irsde_latent_decode(eng.h, ctypes.c_void_p(lat.data_ptr()), ptrs, B, self.H, self.W,
+                                                      ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()))
+        return out
+
+    def forward(self, x):
+        x, h = self.encode(x)
+        return self.decode(x, h)
+
+
+class ConditionalNAFNet(_ImageNAFNet):
+    """latent-dehazing ConditionalNAFNet: same parameters as the image-space one (668 tensors for nasde.yml), but
+    `ending(x + intro(x))` (DenoisingNAFNet_arch.py:162-176) and typically img_channel = the latent's embed_dim (<= 8)."""
+
+    def _create_handle(self, L, device_index, flags):
+        return super()._create_handle(L, device_index, flags | _lib.FLAG_NAF_INTRO_SKIP)
+
+
+def define_G(opt):
+    """latent-dehazing/models/networks.py: network_G.which_model looked up by name."""
+    o = opt["network_G"]
+    name = o.get("which_model", o.get("which_model_G"))
+    if name != "ConditionalNAFNet":
+        raise NotImplementedError("latent score network [%s] is not built (ConditionalNAFNet only)" % name)
+    return ConditionalNAFNet(**o["setting"])
+
+
+def define_L(opt):
+    o = opt["network_L"]
+    if o["which_model"] != "UNet":
+        raise NotImplementedError("latent model [%s] not recognized" % o["which_model"])
+    return UNet(**o["setting"])
+
+
+class LatentDenoisingModel:
+    """Inference surface of latent_denoising_model.DenoisingModel (:40-51 construction, :146-152 feed_data,
+    :177-200 test / get_current_visuals, :222-231 load)."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.device = torch.device("cuda")
+        if opt.get("is_train", False):
+            raise NotImplementedError("training is out of scope of the MI355X sampler (SURVEY.md §2)")
+        self.model = define_G(opt).to(self.device)
+        self.latent_model = define_L(opt).to(self.device)
+        for p in self.latent_model.parameters():
+            p.requires_grad = False
+        self.load()
+        self.encode = self.latent_model.encode
+        self.decode = self.latent_model.decode
+
+    def feed_data(self, state, LQ, GT=None):
+        self.state = state.to(self.device)
+        self.condition = LQ.to(self.device)
+        self.state_0 = GT.to(self.device) if GT is not None else None
+
+    def test(self, sde=None, hidden=None, perform_ode=False, save_states=False):
+        sde.set_mu(self.condition)
+        self.model.eval()
+        with torch.no_grad():
+            if not perform_ode:
+                latent = sde.reverse_sde(self.state, save_states=save_states)
+            else:
+                latent = sde.reverse_ode(self.state, save_states=save_states)
+            self.output = self.decode(latent, hidden)
+        self.model.train()
+
+    def get_current_visuals(self, need_GT=True):
+        out = OrderedDict()
+        out["Input"] = self.condition.detach()[0].float().cpu()
+        out["Output"] = self.output.detach()[0].float().cpu()
+        if need_GT and self.state_0 is not None:
+            out["GT"] = self.state_0.detach()[0].float().cpu()
+        return out
+
+    def load(self):
+        path = self.opt.get("path") or {}
+        strict = path.get("strict_load", True)
+        if path.get("pretrain_model_G") is not None:
+            self.load_network(path["pretrain_model_G"], self.model, strict)
+        if path.get("pretrain_model_L") is not None:
+            self.load_network(path["pretrain_model_L"], self.latent_model, strict)
+
+    @staticmethod
+    def load_network(load_path, network, strict=True):
+        load_net = torch.load(load_path, map_location="cpu")
+        clean = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in load_net.items())
+        network.load_state_dict(clean, strict=strict)

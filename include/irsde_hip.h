@@ -49,6 +49,8 @@ enum {
                                         runs on v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 (RNE) and fp32
                                         accumulation; no Winograd; everything else (state, LayerNorm, attention, FiLM,
                                         update step) stays fp32 */
+    IRSDE_FLAG_NAF_INTRO_SKIP = 64,  /* ConditionalNAFNet of the latent tasks (codes/config/latent-dehazing/models/modules/
+                                        DenoisingNAFNet_arch.py:162-176): ending(x + intro(x)) instead of ending(x) */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };
@@ -82,6 +84,19 @@ typedef struct irsde_nafnet_config {
     int32_t device;
     int32_t flags;
 } irsde_nafnet_config;
+
+/* UNet(in_ch, out_ch, ch, ch_mult, embed_dim) — the frozen latent compressor of the latent tasks,
+ * codes/config/latent-dehazing/models/modules/UNet_arch.py:17-57 (nasde.yml: ch 8, ch_mult [4,8,8,16], embed_dim 8). */
+typedef struct irsde_latent_unet_config {
+    int32_t in_ch;
+    int32_t out_ch;
+    int32_t ch;
+    int32_t n_mult;
+    int32_t ch_mult[8];
+    int32_t embed_dim;
+    int32_t device;
+    int32_t flags;
+} irsde_latent_unet_config;
 
 /* Row layout of the per-step coefficient table passed to irsde_set_schedule (floats per row). */
 #define IRSDE_COEF_STRIDE 12
@@ -186,6 +201,19 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
  * variant selects an experimental tile configuration (0 = production); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out);
+
+/* Latent wrapper.  irsde_create_latent_unet replaces UNet.__init__ (UNet_arch.py:18-50); weights load
+ * through irsde_load_weight / irsde_finalize_weights with the reference's state_dict names (69 tensors for nasde.yml).
+ * irsde_latent_shapes: latent (C,h,w) and the 2*depth+1 hidden skips (C,h,w each, reference list order) for an H x W input.
+ * irsde_latent_encode replaces UNet.encode(x) (:59-77): x device NCHW [B][in_ch][H][W] -> latent [B][embed][h][w] and the
+ * hidden list (device NCHW tensors, caller-allocated).  irsde_latent_decode replaces UNet.decode(x, h) (:79-91) and crops
+ * to H x W.  Used as latent_denoising_model.py:50-51,177-189: encode once, sample in the latent, decode once. */
+int irsde_create_latent_unet(const irsde_latent_unet_config* cfg, irsde_engine** out);
+int irsde_latent_shapes(irsde_engine* e, int H, int W, int64_t latent_chw[3], int64_t* hidden_chw, int* n_hidden);
+int irsde_latent_encode(irsde_engine* e, const float* x, int B, int H, int W, float* latent, float* const* hidden,
+                        void* stream);
+int irsde_latent_decode(irsde_engine* e, const float* latent, const float* const* hidden, int B, int H, int W, float* out,
+                        void* stream);
 
 /* Evaluation tail on the device — replaces, per image of a batch, the metric block of
  * codes/config/deraining/test.py:131-178: util.tensor2img on output and GT (codes/utils/img_utils.py:136-163),

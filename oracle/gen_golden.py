@@ -319,6 +319,87 @@ def gen_dsde(sde_utils, ref_root):
     print("dsde.npz")
 
 
+def load_task_modules(task_dir, names):
+    """Import models/modules/<name>.py of one task directory without running its package __init__ (latent-dehazing's
+    pulls DiT -> timm, absent here): stand-in `models` / `models.modules` packages with the task's search path."""
+    import importlib
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
+    pk, pm = types.ModuleType("models"), types.ModuleType("models.modules")
+    pk.__path__ = [os.path.join(task_dir, "models")]
+    pm.__path__ = [os.path.join(task_dir, "models", "modules")]
+    sys.modules["models"], sys.modules["models.modules"] = pk, pm
+    return [importlib.import_module("models.modules." + n) for n in names]
+
+
+def gen_latent(sde_utils, ref_root):
+    """Latent wrapper: the reference's latent UNet (encode / decode) and latent-task ConditionalNAFNet,
+    plus the whole latent pipeline of latent-dehazing/test.py:90-100 with injected noise."""
+    ua, na = load_task_modules(os.path.join(ref_root, "codes/config/latent-dehazing"), ["UNet_arch", "DenoisingNAFNet_arch"])
+    assert "latent-dehazing" in ua.__file__ and "latent-dehazing" in na.__file__
+    out = {}
+    ucases = {"nasde_1x3x40x52": (dict(in_ch=3, out_ch=3, ch=8, ch_mult=[4, 8, 8, 16], embed_dim=8), 1, 40, 52),
+              "bokeh_2x3x24x32": (dict(in_ch=3, out_ch=3, ch=16, ch_mult=[1, 2, 4], embed_dim=4), 2, 24, 32)}
+    unets = {}
+    for tag, (cfg, B, H, W) in ucases.items():
+        params = O.latent_unet_synth_params(seed=0, **{k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items()})
+        net = ua.UNet(**cfg).eval()
+        sd = net.state_dict()
+        assert set(sd) == set(params), set(sd) ^ set(params)
+        for k in sd:
+            assert tuple(sd[k].shape) == params[k].shape, k
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        unets[tag] = (net, cfg)
+        lq, _ = O.synth_inputs(1234, B, H, W)
+        with torch.no_grad():
+            lat, hid = net.encode(torch.from_numpy(lq))
+            rec = net.decode(lat, hid)
+            lat2 = lat + 0.1 * torch.from_numpy(np.random.RandomState(5).standard_normal(tuple(lat.shape)).astype(np.float32))
+            rec2 = net.decode(lat2, hid)
+        out[tag + "/shape"] = np.array([B, H, W], dtype=np.int64)
+        out[tag + "/latent"] = lat.numpy()
+        for i, h in enumerate(hid):
+            out[tag + "/hidden%d" % i] = h.numpy()
+        out[tag + "/decode"] = rec.numpy()
+        out[tag + "/latent2"] = lat2.numpy()
+        out[tag + "/decode2"] = rec2.numpy()
+        print("latent", tag, tuple(lat.shape), float(np.abs(rec.numpy()).max()))
+    # latent-task ConditionalNAFNet (ending(x + intro(x))) on an 8-channel latent
+    ncfg = dict(width=32, enc_blk_nums=[1, 2], middle_blk_num=1, dec_blk_nums=[1, 1])
+    nparams = O.naf_synth_params(seed=0, img_channel=8, width=32, middle_blk_num=1, enc_blk_nums=(1, 2), dec_blk_nums=(1, 1))
+    nnet = na.ConditionalNAFNet(img_channel=8, **ncfg).eval()
+    assert set(nnet.state_dict()) == set(nparams)
+    nnet.load_state_dict({k: torch.from_numpy(v) for k, v in nparams.items()}, strict=True)
+    rs = np.random.RandomState(11)
+    cond = rs.standard_normal((2, 8, 12, 10)).astype(np.float32)
+    xt = (cond + 0.2 * rs.standard_normal(cond.shape)).astype(np.float32)
+    out["naf/cond"], out["naf/xt"] = cond, xt
+    for t in (4, 61):
+        with torch.no_grad():
+            out["naf/t%d" % t] = nnet(torch.from_numpy(xt), torch.from_numpy(cond), t).numpy()
+    # whole pipeline (test.py:90-100): encode -> noise_state -> reverse_sde in the latent -> decode
+    Inj = InjectedIRSDE.make(sde_utils)
+    unet, _ = unets["nasde_1x3x40x52"]
+    lq, _ = O.synth_inputs(1234, 1, 40, 52)
+    T = 12
+    with torch.no_grad():
+        lat, hid = unet.encode(torch.from_numpy(lq))
+        z = O.synth_noise(7, T, tuple(lat.shape))
+        z0 = np.random.RandomState(3).standard_normal(tuple(lat.shape)).astype(np.float32)
+        sde = Inj(max_sigma=50, T=T, schedule="cosine", eps=0.005, device="cpu")
+        sde.noise = torch.from_numpy(z)
+        sde.set_model(nnet)
+        sde.set_mu(lat)
+        noisy = lat + torch.from_numpy(z0) * sde.max_sigma          # IRSDE.noise_state (sde_utils.py:360-361)
+        for mode in ("sde", "ode"):
+            x0 = (sde.reverse_sde if mode == "sde" else sde.reverse_ode)(noisy)
+            out["pipe/latent_" + mode] = x0.numpy()
+            out["pipe/out_" + mode] = unet.decode(x0, hid).numpy()
+    out["pipe/z0"], out["pipe/T"] = z0, np.array(T)
+    np.savez_compressed(os.path.join(GOLD, "latent.npz"), **out)
+    print("latent.npz")
+
+
 def gen_metrics(ref_root):
     """Evaluation tail: the reference's own tensor2img / calculate_psnr / calculate_ssim
     (codes/utils/img_utils.py) and bgr2ycbcr (codes/data/util.py) run on synthetic output/GT pairs, following
@@ -404,6 +485,8 @@ def main():
         gen_nafnet(sde_utils)
     if a.only in ("", "dsde"):
         gen_dsde(sde_utils, a.ref)
+    if a.only in ("", "latent"):
+        gen_latent(sde_utils, a.ref)
     if a.only in ("", "metrics"):
         gen_metrics(a.ref)
 

@@ -614,8 +614,9 @@ def _pixel_shuffle2(x):
 
 
 def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_num=1, dec_blk_nums=(1, 1, 1, 1),
-                   dtype=np.float64, taps=None):
-    """ConditionalNAFNet.forward — DenoisingNAFNet_arch.py:149-187."""
+                   dtype=np.float64, taps=None, intro_skip=False):
+    """ConditionalNAFNet.forward — DenoisingNAFNet_arch.py:149-187.  intro_skip: the latent tasks' variant
+    (latent-dehazing/models/modules/DenoisingNAFNet_arch.py:162-176), `ending(x + intro(x))`."""
     p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
     xt = np.asarray(xt, dtype=dtype)
     cond = np.asarray(cond, dtype=dtype)
@@ -637,6 +638,7 @@ def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_n
             taps[name] = v
 
     tap("intro", x)
+    intro = x
     encs = []
     for i, num in enumerate(enc_blk_nums):
         for j in range(num):
@@ -655,6 +657,8 @@ def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_n
         for j in range(num):
             x = naf_block(p, "decoders.%d.%d." % (i, j), x, temb)
         tap("decoders.%d" % i, x)
+    if intro_skip:
+        x = x + intro
     x = conv2d(x, p["ending.weight"], p["ending.bias"], pad=1)
     return np.ascontiguousarray(x[..., :H, :W])
 
@@ -863,3 +867,118 @@ def eval_tail(out_chw, gt_chw, crop_border=0):
     else:
         res += [float("nan"), float("nan")]
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# Latent wrapper: codes/config/latent-dehazing/models/modules/UNet_arch.py
+# ---------------------------------------------------------------------------------------------
+def latent_unet_param_shapes(in_ch=3, out_ch=3, ch=8, ch_mult=(4, 8, 8, 16), embed_dim=8):
+    """state_dict inventory of UNet(in_ch, out_ch, ch, ch_mult, embed_dim) — UNet_arch.py:18-50 (69 tensors for nasde.yml)."""
+    depth = len(ch_mult)
+    mult = [1] + list(ch_mult)
+    s = {"init_conv.weight": (ch, in_ch, 3, 3)}
+
+    def resb(pre, ci, co):
+        s[pre + "block1.proj.weight"] = (co, ci, 3, 3)
+        s[pre + "block2.proj.weight"] = (co, co, 3, 3)
+        if ci != co:
+            s[pre + "res_conv.weight"] = (co, ci, 1, 1)
+
+    def attn(pre, c):
+        s[pre + "fn.norm.g"] = (1, c, 1, 1)
+        s[pre + "fn.fn.to_qkv.weight"] = (384, c, 1, 1)
+        s[pre + "fn.fn.to_out.0.weight"] = (c, 128, 1, 1)
+        s[pre + "fn.fn.to_out.0.bias"] = (c,)
+        s[pre + "fn.fn.to_out.1.g"] = (1, c, 1, 1)
+
+    for i in range(depth):
+        di, do = ch * mult[i], ch * mult[i + 1]
+        e, d = "encoder.%d." % i, "decoder.%d." % (depth - 1 - i)
+        resb(e + "0.", di, di)
+        resb(e + "1.", di, di)
+        resb(d + "0.", do + di, do)
+        resb(d + "1.", do + di, do)
+        if i == depth - 1:
+            attn(e + "2.", di)
+            attn(d + "2.", do)
+            s[e + "3.weight"] = (do, di, 3, 3)
+        else:
+            s[e + "3.weight"] = (do, di, 4, 4)
+            s[e + "3.bias"] = (do,)
+        if i != 0:
+            s[d + "3.1.weight"] = (di, do, 3, 3)
+            s[d + "3.1.bias"] = (di,)
+        else:
+            s[d + "3.weight"] = (di, do, 3, 3)
+    mid = ch * mult[-1]
+    s["latent_conv.weight"] = (embed_dim, mid, 1, 1)
+    s["post_latent_conv.weight"] = (mid, embed_dim, 1, 1)
+    s["final_conv.weight"] = (out_ch, ch, 3, 3)
+    s["final_conv.bias"] = (out_ch,)
+    return s
+
+
+def latent_unet_synth_params(seed=0, **cfg):
+    rs = np.random.RandomState(seed)
+    shapes = latent_unet_param_shapes(**cfg)
+    out = {}
+    for name in sorted(shapes):
+        shp = shapes[name]
+        if name.endswith(".g"):
+            a = rs.uniform(0.5, 1.5, size=shp)
+        else:
+            wshape = shapes[name[:-4] + "weight"] if name.endswith("bias") else shp
+            bound = 1.0 / math.sqrt(int(np.prod(wshape[1:])))
+            a = rs.uniform(-bound, bound, size=shp)
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def _plain_res_block(p, pre, x):
+    """ResBlock without a time MLP (latent-dehazing module_util.py:132-153): conv -> SiLU -> conv -> SiLU, + res_conv(x)."""
+    h = silu(conv2d(x, p[pre + "block1.proj.weight"], pad=1))
+    h = silu(conv2d(h, p[pre + "block2.proj.weight"], pad=1))
+    return h + (conv2d(x, p[pre + "res_conv.weight"]) if (pre + "res_conv.weight") in p else x)
+
+
+def latent_unet_encode(params, x, depth, dtype=np.float64):
+    """UNet.encode — UNet_arch.py:59-77: returns (latent, hidden list)."""
+    p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
+    x = np.asarray(x, dtype=dtype)
+    H, W = x.shape[2:]
+    s = 2 ** depth
+    x = np.pad(x, ((0, 0), (0, 0), (0, (s - H % s) % s), (0, (s - W % s) % s)), mode="reflect")
+    x = conv2d(x, p["init_conv.weight"], pad=1)
+    h = [x]
+    for i in range(depth):
+        e = "encoder.%d." % i
+        x = _plain_res_block(p, e + "0.", x)
+        h.append(x)
+        x = _plain_res_block(p, e + "1.", x)
+        if i == depth - 1:
+            x = attn_block(p, e + "2.", x)
+        h.append(x)
+        if i != depth - 1:
+            x = conv2d(x, p[e + "3.weight"], p[e + "3.bias"], stride=2, pad=1)
+        else:
+            x = conv2d(x, p[e + "3.weight"], pad=1)
+    return conv2d(x, p["latent_conv.weight"]), h
+
+
+def latent_unet_decode(params, x, h, depth, H, W, dtype=np.float64):
+    """UNet.decode — UNet_arch.py:79-91."""
+    p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
+    x = conv2d(np.asarray(x, dtype=dtype), p["post_latent_conv.weight"])
+    h = [np.asarray(t, dtype=dtype) for t in h]
+    for i in range(depth):
+        d = "decoder.%d." % i
+        x = _plain_res_block(p, d + "0.", np.concatenate([x, h[-(i * 2 + 1)]], axis=1))
+        x = _plain_res_block(p, d + "1.", np.concatenate([x, h[-(i * 2 + 2)]], axis=1))
+        if i == 0:
+            x = attn_block(p, d + "2.", x)
+        if i != depth - 1:
+            x = conv2d(upsample_nearest2(x), p[d + "3.1.weight"], p[d + "3.1.bias"], pad=1)
+        else:
+            x = conv2d(x, p[d + "3.weight"], pad=1)
+    x = conv2d(x + h[0], p["final_conv.weight"], p["final_conv.bias"], pad=1)
+    return np.ascontiguousarray(x[..., :H, :W])

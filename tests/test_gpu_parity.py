@@ -695,3 +695,66 @@ def test_eval_metrics_full_size_properties():
     # gather path: BGR uint8 images of the whole batch in one call
     imgs = P.metrics.tensor2img_batch(do)
     assert imgs.shape == (16, 256, 256, 3) and np.array_equal(imgs[5], O.tensor2img(out[5]))
+
+
+# ---------------------------------------------------------------------------------------------
+# latent wrapper
+# ---------------------------------------------------------------------------------------------
+def latent_unet(cfg):
+    m = P.latent.UNet(in_ch=3, out_ch=3, ch=cfg["ch"], ch_mult=list(cfg["ch_mult"]), embed_dim=cfg["embed_dim"])
+    params = O.latent_unet_synth_params(seed=0, in_ch=3, out_ch=3, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return m.to(DEV).eval(), params
+
+
+@pytest.mark.parametrize("tag,cfg", [("nasde_1x3x40x52", dict(ch=8, ch_mult=(4, 8, 8, 16), embed_dim=8)),
+                                     ("bokeh_2x3x24x32", dict(ch=16, ch_mult=(1, 2, 4), embed_dim=4))])
+def test_latent_unet_vs_reference_golden(golden, tag, cfg):
+    """UNet.encode / decode (latent-dehazing UNet_arch.py:59-91) vs the reference: latent, all 2*depth+1 skips, the
+    reconstruction, and a decode from reference-made (perturbed latent, skips).  1e-4 of max|ref| like one network pass."""
+    g = golden.latent
+    B, H, W = (int(v) for v in g[tag + "/shape"])
+    m, _ = latent_unet(cfg)
+    lq, _ = O.synth_inputs(1234, B, H, W)
+    lat, hid = m.encode(torch.from_numpy(lq).to(DEV))
+    assert relerr(lat.cpu().numpy(), g[tag + "/latent"]) < 1e-4
+    assert len(hid) == 2 * len(cfg["ch_mult"]) + 1
+    for i, h in enumerate(hid):
+        want = g[tag + "/hidden%d" % i]
+        assert tuple(h.shape) == want.shape and relerr(h.cpu().numpy(), want) < 1e-4, i
+    assert relerr(m.decode(lat, hid).cpu().numpy(), g[tag + "/decode"]) < 1e-4
+    assert relerr(m(torch.from_numpy(lq).to(DEV)).cpu().numpy(), g[tag + "/decode"]) < 1e-4   # forward = decode(encode)
+    hid_ref = [torch.from_numpy(g[tag + "/hidden%d" % i]).to(DEV) for i in range(len(hid))]
+    rec2 = m.decode(torch.from_numpy(g[tag + "/latent2"]).to(DEV), hid_ref)
+    assert tuple(rec2.shape) == (B, 3, H, W) and relerr(rec2.cpu().numpy(), g[tag + "/decode2"]) < 1e-4
+
+
+def test_latent_pipeline_vs_reference_golden(golden):
+    """latent-dehazing/test.py:90-100 end to end through LatentDenoisingModel: encode -> noise_state -> reverse_sde / ode
+    of the latent-task ConditionalNAFNet (ending(x + intro), 8 latent channels) -> decode, injected noise."""
+    g = golden.latent
+    opt = {"network_G": {"which_model": "ConditionalNAFNet",
+                         "setting": dict(img_channel=8, width=32, enc_blk_nums=[1, 2], middle_blk_num=1, dec_blk_nums=[1, 1])},
+           "network_L": {"which_model": "UNet", "setting": dict(in_ch=3, out_ch=3, ch=8, ch_mult=[4, 8, 8, 16], embed_dim=8)},
+           "path": {}}
+    model = P.LatentDenoisingModel(opt)
+    nparams = O.naf_synth_params(seed=0, img_channel=8, width=32, middle_blk_num=1, enc_blk_nums=(1, 2), dec_blk_nums=(1, 1))
+    model.model.load_state_dict({k: torch.from_numpy(v) for k, v in nparams.items()}, strict=True)
+    uparams = O.latent_unet_synth_params(seed=0, in_ch=3, out_ch=3, ch=8, ch_mult=(4, 8, 8, 16), embed_dim=8)
+    model.latent_model.load_state_dict({k: torch.from_numpy(v) for k, v in uparams.items()}, strict=True)
+    # the score network alone (8-channel state, intro skip)
+    xt, cond = torch.from_numpy(g["naf/xt"]).to(DEV), torch.from_numpy(g["naf/cond"]).to(DEV)
+    for t in (4, 61):
+        assert relerr(model.model(xt, cond, t).cpu().numpy(), g["naf/t%d" % t]) < 1e-4
+    T = int(g["pipe/T"])
+    sde = P.IRSDE(max_sigma=50, T=T, schedule="cosine", eps=0.005, device=DEV)
+    sde.set_model(model.model)
+    lq, _ = O.synth_inputs(1234, 1, 40, 52)
+    latent_LQ, hidden = model.encode(torch.from_numpy(lq).to(DEV))
+    noisy = latent_LQ + torch.from_numpy(g["pipe/z0"]).to(DEV) * sde.max_sigma
+    sde.injected_noise = torch.from_numpy(O.synth_noise(7, T, tuple(latent_LQ.shape))).to(DEV)
+    for mode in ("sde", "ode"):
+        model.feed_data(noisy, latent_LQ)
+        model.test(sde, hidden, perform_ode=(mode == "ode"))
+        out = model.get_current_visuals(need_GT=False)["Output"].numpy()[None]
+        assert relerr(out, g["pipe/out_" + mode]) < 2e-3, mode

@@ -6,6 +6,10 @@ import pytest
 from oracle import irsde_oracle as O
 
 
+def relerr(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
 def _sched_from_cfg(g, tag):
     ms, T, eps = g[tag + "/cfg"]
     return O.irsde_schedule(float(ms) if ms < 1 else int(ms), int(T), str(g[tag + "/sched"]), float(eps))
@@ -231,3 +235,44 @@ def test_eval_tail_vs_reference(golden, tag):
         k = 4 if C == 3 else 2
         np.testing.assert_allclose(got[:k], want[b, :k], rtol=1e-10, atol=0)
         assert C == 3 or np.isnan(got[2:]).all()
+
+
+@pytest.mark.parametrize("tag,cfg", [("nasde_1x3x40x52", dict(ch=8, ch_mult=(4, 8, 8, 16), embed_dim=8)),
+                                     ("bokeh_2x3x24x32", dict(ch=16, ch_mult=(1, 2, 4), embed_dim=4))])
+def test_latent_unet_vs_reference(golden, tag, cfg):
+    """Latent UNet encode / decode restatement vs the reference module (latent-dehazing UNet_arch.py)."""
+    g = golden.latent
+    B, H, W = (int(v) for v in g[tag + "/shape"])
+    depth = len(cfg["ch_mult"])
+    params = O.latent_unet_synth_params(seed=0, in_ch=3, out_ch=3, **cfg)
+    lq, _ = O.synth_inputs(1234, B, H, W)
+    lat, hid = O.latent_unet_encode(params, lq, depth)
+    assert relerr(lat, g[tag + "/latent"]) < 2e-5
+    assert len(hid) == 2 * depth + 1
+    for i, h in enumerate(hid):
+        assert h.shape == g[tag + "/hidden%d" % i].shape and relerr(h, g[tag + "/hidden%d" % i]) < 2e-5, i
+    assert relerr(O.latent_unet_decode(params, lat, hid, depth, H, W), g[tag + "/decode"]) < 2e-5
+    hid_ref = [g[tag + "/hidden%d" % i] for i in range(len(hid))]
+    assert relerr(O.latent_unet_decode(params, g[tag + "/latent2"], hid_ref, depth, H, W), g[tag + "/decode2"]) < 2e-5
+
+
+def test_latent_nafnet_and_pipeline_vs_reference(golden):
+    """latent-task ConditionalNAFNet (ending(x + intro)) and the encode -> reverse_sde/ode in the latent -> decode pipeline."""
+    g = golden.latent
+    nparams = O.naf_synth_params(seed=0, img_channel=8, width=32, middle_blk_num=1, enc_blk_nums=(1, 2), dec_blk_nums=(1, 1))
+    kw = dict(enc_blk_nums=(1, 2), middle_blk_num=1, dec_blk_nums=(1, 1), intro_skip=True)
+    for t in (4, 61):
+        y = O.nafnet_forward(nparams, g["naf/xt"], g["naf/cond"], t, **kw)
+        assert relerr(y, g["naf/t%d" % t]) < 2e-5
+    uparams = O.latent_unet_synth_params(seed=0, in_ch=3, out_ch=3, ch=8, ch_mult=(4, 8, 8, 16), embed_dim=8)
+    lq, _ = O.synth_inputs(1234, 1, 40, 52)
+    lat, hid = O.latent_unet_encode(uparams, lq, 4)
+    T = int(g["pipe/T"])
+    sch = O.irsde_schedule(50, T, "cosine", 0.005)
+    noisy = lat + g["pipe/z0"] * sch["max_sigma"]
+    z = O.synth_noise(7, T, lat.shape)
+    net = lambda x, mu, t: O.nafnet_forward(nparams, x, mu, t, **kw)  # noqa: E731
+    for mode in ("sde", "ode"):
+        x0 = O.sample(nparams, sch, noisy, lat, mode, noise=z, net=net)
+        assert relerr(x0, g["pipe/latent_" + mode]) < 2e-3
+        assert relerr(O.latent_unet_decode(uparams, x0, hid, 4, 40, 52), g["pipe/out_" + mode]) < 2e-3
