@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--mode", default="sde", choices=["sde", "ode", "posterior"])
-    ap.add_argument("--model", default="unet", choices=["unet", "nafnet", "dsde"],
+    ap.add_argument("--model", default="unet", choices=["unet", "nafnet", "dsde", "latent"],
                     help="unet: IR-SDE ConditionalUNet (BASELINE configs[1]); nafnet: Refusion ConditionalNAFNet (configs[3])")
     ap.add_argument("--max-sigma", type=float, default=None)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
@@ -97,7 +97,17 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    if a.model == "dsde":  # denoising-sde/options/test/ir-sde.yml: unconditional UNet + DenoisingSDE(max_sigma=75, T=100)
+    latent_model = None
+    if a.model == "latent":  # latent-bokeh/options/bokeh/test/refusion.yml: UNet ch 64 [1,2,4] embed 4 (256^2 -> 64x64x4) + NAFNet
+        ncfg = dict(width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+        params = O.naf_synth_params(seed=0, img_channel=4, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28),
+                                    dec_blk_nums=(1, 1, 1, 1))
+        model = P.latent.ConditionalNAFNet(img_channel=4, **ncfg)
+        latent_model = P.latent.UNet(in_ch=3, out_ch=3, ch=64, ch_mult=[1, 2, 4], embed_dim=4)
+        latent_model.load_state_dict({k: torch.from_numpy(v) for k, v in
+                                      O.latent_unet_synth_params(seed=1, in_ch=3, out_ch=3, ch=64, ch_mult=(1, 2, 4), embed_dim=4).items()})
+        latent_model = latent_model.to(dev).eval()
+    elif a.model == "dsde":  # denoising-sde/options/test/ir-sde.yml: unconditional UNet + DenoisingSDE(max_sigma=75, T=100)
         params = O.uncond_synth_params(seed=0, nf=64, depth=4)
         model = P.denoising_sde.ConditionalUNet(3, 3, 64, depth=4)
     elif a.model == "nafnet":  # refusion.yml network_G
@@ -112,14 +122,14 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(dev).eval()
     model.set_compute_dtype(a.dtype)
-    max_sigma = a.max_sigma if a.max_sigma is not None else {"nafnet": 50, "dsde": 75}.get(a.model, 10)
+    max_sigma = a.max_sigma if a.max_sigma is not None else {"nafnet": 50, "dsde": 75, "latent": 50}.get(a.model, 10)
     if a.model == "dsde":
         sde = P.DenoisingSDE(max_sigma=max_sigma, T=a.T, device=dev)
     else:
         sde = P.IRSDE(max_sigma=max_sigma, T=a.T, schedule="cosine", eps=0.005, device=dev)
     sde.set_model(model)
     sde.seed = 7
-    sde.profile = (not a.no_profile) and a.model != "dsde"
+    sde.profile = (not a.no_profile) and a.model not in ("dsde", "latent")
     sde.use_graph = True
 
     nglobal = a.batch * world
@@ -134,6 +144,13 @@ def main():
     if a.model == "dsde":  # denoising-sde/test.py:103-107: reverse_ode from the optimal timestep of the noise level (sigma 25)
         n_evals = int(sde.get_optimal_timestep(25))
         fn = lambda x: sde.reverse_ode(x, T=n_evals) if a.mode != "sde" else sde.reverse_sde(x, T=n_evals)  # noqa: E731
+    elif a.model == "latent":  # latent-dehazing/test.py:90-100: encode once, sample in the latent, decode once
+        sample = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[a.mode]
+
+        def fn(_unused):
+            latent_LQ, hidden = latent_model.encode(mu)
+            sde.set_mu(latent_LQ)
+            return latent_model.decode(sample(sde.noise_state(latent_LQ)), hidden)
     else:
         sde.set_mu(mu)
         fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[a.mode]
@@ -182,7 +199,9 @@ def main():
             "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16 operands / f32 accumulate+state", "data": "synthetic",
             "config": {"workload": ("denoising-sde unconditional UNet nf=64 depth=4 (full attention at the bottleneck), DenoisingSDE reverse_%s from the "
                                     "optimal timestep of sigma=25 (" + str(n_evals) + " network evaluations), batch=%d/GPU %dx%d, schedule T=%d, fp32"
-                                    if a.model == "dsde" else "Refusion ConditionalNAFNet width=64 enc[1,1,1,28], reverse_%s, batch=%d/GPU %dx%d, T=%d, fp32 "
+                                    if a.model == "dsde" else "Latent-Refusion: latent UNet ch=64 [1,2,4] embed 4 (encode + decode once per image) + latent ConditionalNAFNet "
+                                    "width=64 enc[1,1,1,28] on the 64x64x4 latent, reverse_%s, batch=%d/GPU %dx%d, T=%d (BASELINE.json configs[4] shape)"
+                                    if a.model == "latent" else "Refusion ConditionalNAFNet width=64 enc[1,1,1,28], reverse_%s, batch=%d/GPU %dx%d, T=%d, fp32 "
                                     "(BASELINE.json configs[3] network)" if a.model == "nafnet" else
                                     "IR-SDE deraining ConditionalUNet nf=64 depth=4, reverse_%s, batch=%d/GPU %dx%d, "
                                     "T=%d, fp32 (BASELINE.json configs[1])") % (a.mode, a.batch, a.size, a.size, a.T),
