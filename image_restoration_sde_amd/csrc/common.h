@@ -94,6 +94,10 @@ void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U, 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)
 void launch_conv(const ConvParams& p, hipStream_t s);
 void conv_global_init();
+// bf16 mode: 3x3 s1 p1 layers with an LDS-resident halo tile (conv_halo.hip)
+void conv_halo_global_init();
+bool conv_halo_eligible(const ConvParams& p);
+void launch_conv_halo(const ConvParams& p, hipStream_t s);
 void conv_set_variant(int v);  // tuning experiments (irsde_bench_conv)
 void launch_fill_random(float* p, size_t n, unsigned seed, float scale, hipStream_t s);  // sets the dynamic-LDS attribute of every tile configuration (call before graph capture)
 void launch_f32_to_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);  // round-to-nearest-even

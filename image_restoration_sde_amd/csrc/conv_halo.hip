@@ -1,0 +1,298 @@
+// 3x3 stride-1 pad-1 convolution with an LDS-resident halo tile — the bf16 mode's (IRSDE_FLAG_BF16) kernel for the
+// layers where the generic implicit GEMM (conv_igemm.hip) is bound by L2 -> CU traffic: there every one of the 9 taps
+// re-reads its 128 x 32-channel activation slice through L2, 24 KB per 1.05 MFLOP.  Here a block owns a 16 x 16 pixel
+// tile x BN output channels; per 32-channel chunk it stages the 18 x 18 halo ONCE (fp32 in HBM -> bf16 in LDS, RNE) and
+// the 9 taps read their A fragments from it at shifted pixel addresses, so only the weight slice of a tap (BN x 32 bf16)
+// moves per K-step: ~6 KB per MFLOP, 4x less.  Reference call sites: Block.proj (module_util.py:108-122) and the
+// 3x3 default_conv layers (DenoisingUNet_arch.py:60,67).
+//
+// 8 waves = 4 (pixel rows of 64) x 2 (BN/2 channels), each 2 x TN tiles of v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+// LDS rows are 32 bf16 + 16 B pad (80 B: an odd number of 16-byte slots => conflict-free ds_read_b128, as in
+// conv_igemm.hip); lane half h owns the second 16 bytes of each 32-byte group for A and B alike.
+// Pipeline: the weight slice of K-step s+2 and one sixth of the next chunk's halo are loaded before the MFMAs of step s
+// and written to LDS (ring of 3 slices, 2 halo buffers) after the MFMAs of step s+1: a full K-step of cover for the
+// loads; one barrier per tap.
+#include "common.h"
+
+namespace irsde {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TS = 16;                 // output tile edge (pixels)
+constexpr int HW_ = TS + 2;            // halo edge
+constexpr int HALO_PIX = HW_ * HW_;    // 324
+constexpr int ROWB = 80;               // bytes per LDS row (32 bf16 + pad)
+constexpr int NT = 512;
+constexpr int A_PASSES = (HALO_PIX * 8 + NT - 1) / NT;  // 16-byte fp32 loads per thread and chunk: 6
+constexpr int HALO_BYTES = HALO_PIX * ROWB;             // 25920
+
+__device__ __forceinline__ float silu_h(float v) { return v / (1.0f + expf(-v)); }
+
+template <int BN>
+struct HCfg {
+    static constexpr int TN = BN / 2 / 32;  // MFMA tiles per wave along N (wave tile 64 x BN/2)
+    static constexpr int B_BYTES = BN * ROWB;
+    static constexpr int MAIN_BYTES = 2 * HALO_BYTES + 3 * B_BYTES;
+    static constexpr int LDS_C = BN + 4;
+    static constexpr int EPI_BYTES = 64 * LDS_C * 4;
+    static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+};
+
+template <int BN>
+__global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvParams p, const int tiles_x, const int tiles_y,
+                                                                  const int nblk_n) {
+    using C = HCfg<BN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    char* Ah = lds;                    // 2 halo buffers
+    char* Bs = lds + 2 * HALO_BYTES;   // ring of 3 weight-slice buffers
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1;  // 0..3: pixel rows 64*wm .. +63 of the 256-pixel tile
+    const int wn = wave & 1;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    // XCD-aware bijective remap, N-blocks fastest (they share the halo in L2)
+    int wgid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int nblk = wgid % nblk_n;
+    int t = wgid / nblk_n;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int n0 = nblk * BN;
+    const int H = p.Hin, W = p.Win;
+    const int Ctot = p.C0 + p.C1;
+    const int nch = Ctot / 32;
+
+    // ---- halo staging coordinates: pass q covers 16-byte piece q*512 + tid = (halo pixel, 4-channel group) ----
+    // (the last pass wraps around: its surplus threads re-stage pieces of pass 0 with identical data — no branch)
+    // The source pixel of a piece is recomputed when it is loaded (a handful of integer ops per tap, off the MFMA
+    // path) instead of living in 6 registers: the kernel has to fit 128 VGPRs for 2 blocks per CU.
+    const int hp0 = tid >> 3;
+    auto a_src_pix = [&](int q) {  // pixel index into the sources, or -1 outside the image (zero padding)
+        const int hp = q == A_PASSES - 1 ? ((q * NT + tid) % (HALO_PIX * 8)) >> 3 : q * (NT / 8) + hp0;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int y = ty * TS - 1 + hy, x = tx * TS - 1 + hx;
+        return ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? (b * H + y) * W + x : -1;
+    };
+    const int c8 = tid & 7;  // (q * 512 + tid) % 2592 keeps the low 3 bits: 512 and 2592 are multiples of 8
+    // LDS byte offset of pass q: halo pixel q*64 + tid/8 (no wrap for q < 5) => a compile-time step of 64 rows per pass
+    const int a_lds0 = (tid >> 3) * ROWB + c8 * 8;
+    const int a_lds_last = (((A_PASSES - 1) * NT + tid) % (HALO_PIX * 8) >> 3) * ROWB + c8 * 8;
+    // ---- weight-slice staging: row = tid / 4, 16-byte piece tid % 4 (BN*4 pieces) ----
+    // (BN = 64: the upper half of the block duplicates the lower half's pieces; rows past Cout are clamped — they only
+    //  feed output columns that are never stored)
+    const int brow = (tid >> 2) % BN, bchunk = tid & 3;
+    const int bn = n0 + brow;
+    const char* wrow = reinterpret_cast<const char*>(p.w_bf) + ((size_t)(bn < p.Cout ? bn : p.Cout - 1) * 9 * Ctot) * 2 + bchunk * 16;
+    const int b_lds = brow * ROWB + bchunk * 16;
+
+    float4 ra[2];  // halo pieces in flight (pass q lives in ra[q % 2])
+    float4 rb[2];  // weight slices in flight: the slice of K-step s+2 is loaded during step s (register slot = tap parity),
+                   // written during step s+1; 9 taps per chunk flip the parity, so the two slots are swapped per chunk
+    auto a_load = [&](int q, int chunk) {
+        const int cc = chunk * 32;
+        const float* src;
+        int c, pst;
+        if (cc < p.C0) { src = p.in0; c = cc; pst = p.pix0; } else { src = p.in1; c = cc - p.C0; pst = p.pix1; }
+        const int pix = a_src_pix(q);
+        const float* g = pix >= 0 ? src + (size_t)pix * pst + c + c8 * 4 : p.zeros;
+        ra[q % 2] = *reinterpret_cast<const float4*>(g);
+    };
+    auto a_store = [&](int q, int buf) {
+        const float4 v = ra[q % 2];
+        const floatx4 fv = {v.x, v.y, v.z, v.w};
+        const int off = q == A_PASSES - 1 ? a_lds_last : a_lds0 + q * (NT / 8) * ROWB;
+        *reinterpret_cast<bf16x4*>(Ah + buf * HALO_BYTES + off) = __builtin_convertvector(fv, bf16x4);
+    };
+    const int last_step = nch * 9 - 1;
+    auto b_load = [&](int slot, int step) {  // step = chunk * 9 + tap; steps past the end re-read the last slice (unused)
+        const int st = step < last_step ? step : last_step;
+        const int chunk = st / 9, tap = st - chunk * 9;
+        rb[slot] = *reinterpret_cast<const float4*>(wrow + ((size_t)tap * Ctot + chunk * 32) * 2);
+    };
+    auto b_store = [&](int ring, int slot) { *reinterpret_cast<float4*>(Bs + ring * C::B_BYTES + b_lds) = rb[slot]; };
+
+    floatx16 acc[2][C::TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-lane fragment bases: tile row r = wm*64 + i*32 + l31 -> tile pixel (r / 16, r % 16)
+    int a_base[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        a_base[i] = ((r >> 4) * HW_ + (r & 15)) * ROWB + h * 16;
+    }
+    const int b_base = (wn * (BN / 2) + l31) * ROWB + h * 16;
+
+    // ---- prologue: halo of chunk 0, weight slice of (chunk 0, tap 0) ----
+#pragma unroll
+    for (int q0 = 0; q0 < A_PASSES; q0 += 2) {
+#pragma unroll
+        for (int q = q0; q < q0 + 2 && q < A_PASSES; ++q) a_load(q, 0);
+#pragma unroll
+        for (int q = q0; q < q0 + 2 && q < A_PASSES; ++q) a_store(q, 0);
+    }
+    b_load(0, 0);
+    b_store(0, 0);
+    b_load(1, 1);  // slice of step 1: written to the ring during step 0
+    __syncthreads();
+
+    for (int ci = 0; ci < nch; ++ci) {
+        const bool more_chunks = ci + 1 < nch;
+        const char* ah = Ah + (ci & 1) * HALO_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            b_load(tap % 2, ci * 9 + tap + 2);
+            if (more_chunks && tap < A_PASSES) a_load(tap, ci + 1);
+            const int toff = ((tap / 3) * HW_ + (tap % 3)) * ROWB;
+            const char* bs = Bs + (tap % 3) * C::B_BYTES + b_base;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                bf16x8 fa[2], fb[C::TN];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + a_base[i] + toff + sb * 32);
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * ROWB + sb * 32);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            // pass q is loaded at tap q and written one tap later (ra[q % 2] is free again before pass q + 2 loads)
+            if (more_chunks && tap >= 1 && tap - 1 < A_PASSES) a_store(tap - 1, (ci + 1) & 1);
+            b_store((tap + 1) % 3, (tap + 1) % 2);  // ring slot = step % 3 (9 taps per chunk keep it aligned)
+            __syncthreads();
+        }
+        const float4 tsw = rb[0];
+        rb[0] = rb[1];
+        rb[1] = tsw;
+    }
+
+    // ---- epilogue: 4 passes of 64 tile rows through LDS; bias -> FiLM -> SiLU -> +res, 16-byte stores ----
+    float* Cs = smem;
+    constexpr int NV = BN / 4;
+    constexpr int RSTEP = NT / NV;
+    const int c4 = tid % NV;
+    const int n = n0 + c4 * 4;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.Cout) {
+        const float* f = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) {
+                if (p.bias) bias[e] = p.bias[n + e];
+                if (f) {
+                    sc[e] = f[n + e] + 1.0f;
+                    sh[e] = f[p.Cout + n + e];
+                }
+            }
+    }
+    const bool vec_ok = (n + 3 < p.Cout) && ((p.out_stride & 3) == 0);
+    const bool res_vec = (n + 3 < p.Cout) && ((p.res_stride & 3) == 0);
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        if (pass > 0) __syncthreads();
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        Cs[row * C::LDS_C + wn * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        if (n < p.Cout) {
+            for (int row = tid / NV; row < 64; row += RSTEP) {
+                const int r = pass * 64 + row;
+                const int y = ty * TS + (r >> 4), x = tx * TS + (r & 15);
+                if (y >= H || x >= W) continue;
+                const size_t m = ((size_t)b * H + y) * W + x;
+                const float4 cv = *reinterpret_cast<const float4*>(Cs + row * C::LDS_C + c4 * 4);
+                float v[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float tv = v[e] + bias[e];
+                    if (p.film) tv = tv * sc[e] + sh[e];
+                    if (p.silu) tv = silu_h(tv);
+                    v[e] = tv;
+                }
+                if (p.res) {
+                    const float* rp = p.res + m * p.res_stride + n;
+                    if (res_vec) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(rp);
+                        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.Cout) v[e] += rp[e];
+                    }
+                }
+                float* dst = p.out + m * p.out_stride + n;
+                if (vec_ok) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Cout) dst[e] = v[e];
+                }
+            }
+        }
+    }
+}
+
+template <int BN>
+void launch_halo(const ConvParams& p, hipStream_t s) {
+    const int tiles_x = (p.Win + TS - 1) / TS, tiles_y = (p.Hin + TS - 1) / TS;
+    const int nblk_n = (p.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL(conv3x3_halo_bf16_kernel<BN>, dim3((unsigned)(p.B * tiles_y * tiles_x * nblk_n)), dim3(NT),
+                       HCfg<BN>::LDS_BYTES, s, p, tiles_x, tiles_y, nblk_n);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+void conv_halo_global_init() {
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<128>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<64>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+
+bool conv_halo_eligible(const ConvParams& p) {
+    return p.w_bf && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 && p.in_shift == 0 &&
+           p.splits == 1 && !p.gate && !p.shuffle && !p.ch_scale && !p.in_scale && p.nz == 1 && p.Cout >= 64 &&
+           p.Ho == p.Hin && p.Wo == p.Win && (!p.film || p.film_bstride >= 0) && p.zeros;
+}
+
+void launch_conv_halo(const ConvParams& p, hipStream_t s) {
+    if (!conv_halo_eligible(p)) throw HipError("launch_conv_halo: layer not eligible");
+    if (p.Cout >= 128)
+        launch_halo<128>(p, s);
+    else
+        launch_halo<64>(p, s);
+}
+
+}  // namespace irsde

@@ -497,6 +497,7 @@ int g_variant = 0;  // tuning experiments only (irsde_bench_conv)
 void conv_set_variant(int v) { g_variant = v; }
 
 void conv_global_init() {
+    conv_halo_global_init();
     init_cfg<128, 128, 2, 2, 2, false>();
     init_cfg<128, 64, 2, 2, 2, false>();
     init_cfg<128, 32, 4, 1, 2, false>();
@@ -546,6 +547,9 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
             else if (p.Cout > 32) launch_cfg<128, 64, 2, 2, 2, false, true>(p, M, nk_total, s);
             else launch_cfg<128, 32, 4, 1, 2, false, true>(p, M, nk_total, s);
         }
+    } else if (p.w_bf && g_variant != 60 && g_variant != 61 && conv_halo_eligible(p)) {
+        launch_conv_halo(p, s);  // 3x3 s1 p1: LDS-resident halo tile (conv_halo.hip)
+        return;
     } else if (p.w_bf) {  // bf16 operands, fp32 accumulation
         if (p.Cout >= 128) {
             if (g_variant != 61 && (g_variant == 60 || conv_use_tile256(M, p.Cout, p.splits, nk_total)))

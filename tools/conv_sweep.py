@@ -13,6 +13,8 @@ cases = [
     ("L0 3x3 192->128", 16, 256, 256, 192, 128, 3, 1, 0, 1),
     ("L0 3x3 128->128 res", 16, 256, 256, 128, 128, 3, 1, 0, 2),
     ("L1 3x3 128->128", 16, 128, 128, 128, 128, 3, 1, 0, 1),
+    ("L1 3x3 384->256", 16, 128, 128, 384, 256, 3, 1, 0, 1),
+    ("L2 3x3 768->512", 16, 64, 64, 768, 512, 3, 1, 0, 1),
     ("L2 3x3 256->256", 16, 64, 64, 256, 256, 3, 1, 0, 1),
     ("L3 3x3 512->512", 16, 32, 32, 512, 512, 3, 1, 0, 1),
     ("mid 3x3 1024->1024", 16, 32, 32, 1024, 1024, 3, 1, 0, 1),
