@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--model", default="unet", choices=["unet", "nafnet", "dsde", "latent"],
                     help="unet: IR-SDE ConditionalUNet (BASELINE configs[1]); nafnet: Refusion ConditionalNAFNet (configs[3])")
     ap.add_argument("--max-sigma", type=float, default=None)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16_act"],
                     help="bf16 = BASELINE configs[2] (conv operands bf16, fp32 accumulate); the headline metric is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="time graph replay instead of the event-instrumented loop")
@@ -196,7 +196,8 @@ def main():
                        if a.model == "dsde" else "restored images/sec at %dx%d, %d-step IR-SDE reverse sampler" % (a.size, a.size, a.T)),
             "value": imgs / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16 operands / f32 accumulate+state", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate+state",
+                                          "bf16_act": "bf16 operands + bf16 activation storage / f32 accumulate+state"}[a.dtype], "data": "synthetic",
             "config": {"workload": ("denoising-sde unconditional UNet nf=64 depth=4 (full attention at the bottleneck), DenoisingSDE reverse_%s from the "
                                     "optimal timestep of sigma=25 (" + str(n_evals) + " network evaluations), batch=%d/GPU %dx%d, schedule T=%d, fp32"
                                     if a.model == "dsde" else "Latent-Refusion: latent UNet ch=64 [1,2,4] embed 4 (encode + decode once per image) + latent ConditionalNAFNet "
@@ -221,7 +222,7 @@ def main():
                     traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"]
             except (OSError, IndexError, KeyError, ValueError):
                 traffic = None
-            if a.dtype == "bf16":
+            if a.dtype != "fp32":
                 traffic = None
             peak = PEAK_FP32_TFLOPS if a.dtype == "fp32" else PEAK_BF16_TFLOPS
             res["roofline"] = {
@@ -243,7 +244,7 @@ def main():
                 "hbm_frac": prof["conv_bytes"] / (prof["wall_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                 "whole_path_TFLOPs": prof["conv_flops"] / (prof["wall_ms"] * 1e-3) / 1e12,
             }
-            if a.dtype == "bf16":
+            if a.dtype != "fp32":
                 # the bf16 kernel is fed from fp32 activations: HBM binds, so quote the HBM roof first
                 r = res["roofline"]
                 gbps = prof["conv_bytes"] / (prof["conv_ms"] * 1e-3) / 1e9

@@ -21,6 +21,7 @@ FLAG_NO_WINOGRAD_F43 = 8
 FLAG_UNCOND_FULLATTN = 16
 FLAG_BF16 = 32
 FLAG_NAF_INTRO_SKIP = 64
+FLAG_BF16_ACT = 128
 SAMPLE_GRAPH = 1
 SAMPLE_PROFILE = 2
 

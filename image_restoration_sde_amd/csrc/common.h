@@ -66,6 +66,9 @@ struct ConvParams {
     // batched launch (Winograd: 16 independent GEMMs): blockIdx.z = k offsets the three tensors (floats)
     int nz = 1;
     long long z_in = 0, z_w = 0, z_out = 0;
+    // bf16 activation storage (IRSDE_FLAG_BF16_ACT, bf16-MFMA kernels only): in0/in1 resp. out/res point at bf16 tensors
+    // (strides in elements); accumulation and the epilogue arithmetic stay fp32
+    int in_bf16 = 0, out_bf16 = 0;
 };
 
 // Winograd F(m x m,3x3) transforms (wino.hip).  Tiles: T = B * TH * TW with TH = Ho/m, TW = Wo/m.
@@ -101,6 +104,7 @@ void launch_conv_halo(const ConvParams& p, hipStream_t s);
 void conv_set_variant(int v);  // tuning experiments (irsde_bench_conv)
 void launch_fill_random(float* p, size_t n, unsigned seed, float scale, hipStream_t s);  // sets the dynamic-LDS attribute of every tile configuration (call before graph capture)
 void launch_f32_to_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);  // round-to-nearest-even
+void launch_bf16_to_f32(const unsigned short* in, float* out, size_t n, hipStream_t s);
 // naive direct convolution on VALU (one thread per output) — debug / cross-check path only
 void launch_conv_naive(const ConvParams& p, hipStream_t s);
 
@@ -108,8 +112,9 @@ void launch_conv_naive(const ConvParams& p, hipStream_t s);
 // Memory-bound helpers (kernels_misc.hip)
 // ---------------------------------------------------------------------------------------------
 // Channel LayerNorm over C per pixel (gain only, eps inside rsqrt), optional residual add.
+// bf16 = true: x / res / out are bf16 tensors behind the float* (IRSDE_FLAG_BF16_ACT); arithmetic stays fp32.
 void launch_layernorm(const float* x, const float* g, const float* res, float* out, int64_t M, int C,
-                      float eps, hipStream_t s);
+                      float eps, hipStream_t s, bool bf16 = false);
 // NAFNet: y = LN(x) * g * (scale + 1) + shift with per-channel FiLM rows (row stride film_bstride per batch item, 0 = shared)
 void launch_layernorm_film(const float* x, const float* g, const float* scale, const float* shift, int film_bstride,
                            int64_t pixels_per_image, float* out, int64_t M, int C, float eps, hipStream_t s);
@@ -133,7 +138,8 @@ struct AttnWorkspace {
 };
 int attn_num_chunks(int N);
 // qkv: [B][N][384] (q | k | v, 4 heads x 32 each).  out: [B][N][128].
-void launch_linear_attention(const float* qkv, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s);
+void launch_linear_attention(const float* qkv, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s,
+                             bool bf16 = false);
 
 // Full softmax attention over N tokens (denoising-sde bottleneck): qkv [B][N][384] -> out [B][N][128].
 void launch_full_attention(const float* qkv, float* out, int B, int N, hipStream_t s);
@@ -182,7 +188,7 @@ void launch_add(const float* a, const float* b, float* out, size_t n, hipStream_
 void launch_nchw_to_nhwc_pad(const float* in, float* out, int B, int C, int H, int W, int Hp, int Wp, int Cp, int reflect,
                              hipStream_t s);
 // NHWC [B][H][W][C] -> NCHW (debug taps)
-void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t s);
+void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t s, bool bf16 = false);
 
 // Reverse-step update x <- f(x, mu, eps_hat, z) on NCHW state; eps_hat addressed by strides.
 struct UpdateParams {

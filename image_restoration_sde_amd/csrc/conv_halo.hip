@@ -28,7 +28,6 @@ constexpr int HW_ = TS + 2;            // halo edge
 constexpr int HALO_PIX = HW_ * HW_;    // 324
 constexpr int ROWB = 80;               // bytes per LDS row (32 bf16 + pad)
 constexpr int NT = 512;
-constexpr int A_PASSES = (HALO_PIX * 8 + NT - 1) / NT;  // 16-byte fp32 loads per thread and chunk: 6
 constexpr int HALO_BYTES = HALO_PIX * ROWB;             // 25920
 
 __device__ __forceinline__ float silu_h(float v) { return v / (1.0f + expf(-v)); }
@@ -43,10 +42,16 @@ struct HCfg {
     static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
 };
 
-template <int BN>
+// ABF: the activations are bf16 in HBM (IRSDE_FLAG_BF16_ACT): 4 instead of 8 16-byte pieces per halo pixel, no conversion.
+template <int BN, bool ABF>
 __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvParams p, const int tiles_x, const int tiles_y,
                                                                   const int nblk_n) {
     using C = HCfg<BN>;
+    constexpr int PPP = ABF ? 4 : 8;                            // 16-byte pieces per halo pixel (32 channels)
+    constexpr int PSH = ABF ? 2 : 3;
+    constexpr int NPIECE = HALO_PIX * PPP;
+    constexpr int A_PASSES = (NPIECE + NT - 1) / NT;           // loads per thread and chunk: 6 (fp32) / 3 (bf16)
+    constexpr int AESZ = ABF ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
     char* Ah = lds;                    // 2 halo buffers
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
     const int n0 = nblk * BN;
-    const int H = p.Hin, W = p.Win;
+    const int H = p.Ho, W = p.Wo;  // output = virtual input size (in_shift = 1: fused nearest x2 upsample of the source)
     const int Ctot = p.C0 + p.C1;
     const int nch = Ctot / 32;
 
@@ -81,17 +86,19 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
     // (the last pass wraps around: its surplus threads re-stage pieces of pass 0 with identical data — no branch)
     // The source pixel of a piece is recomputed when it is loaded (a handful of integer ops per tap, off the MFMA
     // path) instead of living in 6 registers: the kernel has to fit 128 VGPRs for 2 blocks per CU.
-    const int hp0 = tid >> 3;
+    const int hp0 = tid >> PSH;
     auto a_src_pix = [&](int q) {  // pixel index into the sources, or -1 outside the image (zero padding)
-        const int hp = q == A_PASSES - 1 ? ((q * NT + tid) % (HALO_PIX * 8)) >> 3 : q * (NT / 8) + hp0;
+        const int hp = q == A_PASSES - 1 ? ((q * NT + tid) % NPIECE) >> PSH : q * (NT / PPP) + hp0;
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int y = ty * TS - 1 + hy, x = tx * TS - 1 + hx;
-        return ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? (b * H + y) * W + x : -1;
+        return ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                   ? (b * p.Hin + (y >> p.in_shift)) * p.Win + (x >> p.in_shift) : -1;
     };
-    const int c8 = tid & 7;  // (q * 512 + tid) % 2592 keeps the low 3 bits: 512 and 2592 are multiples of 8
-    // LDS byte offset of pass q: halo pixel q*64 + tid/8 (no wrap for q < 5) => a compile-time step of 64 rows per pass
-    const int a_lds0 = (tid >> 3) * ROWB + c8 * 8;
-    const int a_lds_last = (((A_PASSES - 1) * NT + tid) % (HALO_PIX * 8) >> 3) * ROWB + c8 * 8;
+    const int c8 = tid & (PPP - 1);  // (q * 512 + tid) % NPIECE keeps the low bits: 512 and NPIECE are multiples of PPP
+    // LDS byte offset of pass q: halo pixel q*(512/PPP) + tid/PPP (no wrap before the last pass) => compile-time steps
+    constexpr int PB = 64 / PPP;  // LDS bytes per piece (fp32 pieces shrink to 8 bytes of bf16)
+    const int a_lds0 = (tid >> PSH) * ROWB + c8 * PB;
+    const int a_lds_last = (((A_PASSES - 1) * NT + tid) % NPIECE >> PSH) * ROWB + c8 * PB;
     // ---- weight-slice staging: row = tid / 4, 16-byte piece tid % 4 (BN*4 pieces) ----
     // (BN = 64: the upper half of the block duplicates the lower half's pieces; rows past Cout are clamped — they only
     //  feed output columns that are never stored)
@@ -109,14 +116,19 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
         int c, pst;
         if (cc < p.C0) { src = p.in0; c = cc; pst = p.pix0; } else { src = p.in1; c = cc - p.C0; pst = p.pix1; }
         const int pix = a_src_pix(q);
-        const float* g = pix >= 0 ? src + (size_t)pix * pst + c + c8 * 4 : p.zeros;
+        const char* g = pix >= 0 ? reinterpret_cast<const char*>(src) + ((size_t)pix * pst + c + c8 * (16 / AESZ)) * AESZ
+                                 : reinterpret_cast<const char*>(p.zeros);
         ra[q % 2] = *reinterpret_cast<const float4*>(g);
     };
     auto a_store = [&](int q, int buf) {
         const float4 v = ra[q % 2];
-        const floatx4 fv = {v.x, v.y, v.z, v.w};
-        const int off = q == A_PASSES - 1 ? a_lds_last : a_lds0 + q * (NT / 8) * ROWB;
-        *reinterpret_cast<bf16x4*>(Ah + buf * HALO_BYTES + off) = __builtin_convertvector(fv, bf16x4);
+        const int off = q == A_PASSES - 1 ? a_lds_last : a_lds0 + q * (NT / PPP) * ROWB;
+        if (ABF) {
+            *reinterpret_cast<float4*>(Ah + buf * HALO_BYTES + off) = v;
+        } else {
+            const floatx4 fv = {v.x, v.y, v.z, v.w};
+            *reinterpret_cast<bf16x4*>(Ah + buf * HALO_BYTES + off) = __builtin_convertvector(fv, bf16x4);
+        }
     };
     const int last_step = nch * 9 - 1;
     auto b_load = [&](int slot, int step) {  // step = chunk * 9 + tap; steps past the end re-read the last slice (unused)
@@ -239,6 +251,29 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
                     if (p.silu) tv = silu_h(tv);
                     v[e] = tv;
                 }
+                if (p.out_bf16) {
+                    if (p.res) {
+                        const __bf16* rp = reinterpret_cast<const __bf16*>(p.res) + m * p.res_stride + n;
+                        if (res_vec) {
+                            const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(rp);
+                            v[0] += (float)t4[0]; v[1] += (float)t4[1]; v[2] += (float)t4[2]; v[3] += (float)t4[3];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < p.Cout) v[e] += (float)rp[e];
+                        }
+                    }
+                    __bf16* dst = reinterpret_cast<__bf16*>(p.out) + m * p.out_stride + n;
+                    if (vec_ok) {
+                        const floatx4 fv = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<bf16x4*>(dst) = __builtin_convertvector(fv, bf16x4);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.Cout) dst[e] = (__bf16)v[e];
+                    }
+                    continue;
+                }
                 if (p.res) {
                     const float* rp = p.res + m * p.res_stride + n;
                     if (res_vec) {
@@ -263,11 +298,11 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
     }
 }
 
-template <int BN>
+template <int BN, bool ABF>
 void launch_halo(const ConvParams& p, hipStream_t s) {
-    const int tiles_x = (p.Win + TS - 1) / TS, tiles_y = (p.Hin + TS - 1) / TS;
+    const int tiles_x = (p.Wo + TS - 1) / TS, tiles_y = (p.Ho + TS - 1) / TS;
     const int nblk_n = (p.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL(conv3x3_halo_bf16_kernel<BN>, dim3((unsigned)(p.B * tiles_y * tiles_x * nblk_n)), dim3(NT),
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, ABF>), dim3((unsigned)(p.B * tiles_y * tiles_x * nblk_n)), dim3(NT),
                        HCfg<BN>::LDS_BYTES, s, p, tiles_x, tiles_y, nblk_n);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
@@ -275,24 +310,29 @@ void launch_halo(const ConvParams& p, hipStream_t s) {
 }  // namespace
 
 void conv_halo_global_init() {
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<128>),
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<128, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<64>),
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<64, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<128, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<64, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
 bool conv_halo_eligible(const ConvParams& p) {
-    return p.w_bf && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 && p.in_shift == 0 &&
+    return p.w_bf && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 && (p.in_shift == 0 || p.in_shift == 1) &&
            p.splits == 1 && !p.gate && !p.shuffle && !p.ch_scale && !p.in_scale && p.nz == 1 && p.Cout >= 64 &&
-           p.Ho == p.Hin && p.Wo == p.Win && (!p.film || p.film_bstride >= 0) && p.zeros;
+           p.Ho == (p.Hin << p.in_shift) && p.Wo == (p.Win << p.in_shift) && (!p.film || p.film_bstride >= 0) && p.zeros;
 }
 
 void launch_conv_halo(const ConvParams& p, hipStream_t s) {
     if (!conv_halo_eligible(p)) throw HipError("launch_conv_halo: layer not eligible");
-    if (p.Cout >= 128)
-        launch_halo<128>(p, s);
-    else
-        launch_halo<64>(p, s);
+    if (p.in_bf16) {
+        if (p.Cout >= 128) launch_halo<128, true>(p, s); else launch_halo<64, true>(p, s);
+    } else {
+        if (p.Cout >= 128) launch_halo<128, false>(p, s); else launch_halo<64, false>(p, s);
+    }
 }
 
 }  // namespace irsde

@@ -40,14 +40,15 @@ namespace {
 
 constexpr int BK = 32;  // k per K-step (channels of one tap)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF16>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF16, bool ABF = false>
 struct Cfg {
     static constexpr int NT = 64 * WAVES_M * WAVES_N;
     static constexpr int ROW_BYTES = BK * (BF16 ? 2 : 4) + 16;  // LDS tile row: 32 k + 16-B pad
     static constexpr int TM = BM / WAVES_M / 32;
     static constexpr int TN = BN / WAVES_N / 32;
-    // A (activations, fp32 in HBM in both modes): 8 x 16-B loads per row of 32 k
-    static constexpr int A_ROWS = NT / 8;
+    // A (activations): fp32 in HBM = 8 x 16-B loads per row of 32 k; bf16 in HBM (ABF, IRSDE_FLAG_BF16_ACT) = 4
+    static constexpr int A_CHUNKS = ABF ? 4 : 8;
+    static constexpr int A_ROWS = NT / A_CHUNKS;
     static constexpr int A_PASSES = BM / A_ROWS;
     // B (weights): fp32 8 x 16 B per row, bf16 4 x 16 B per row
     static constexpr int B_CHUNKS = BF16 ? 4 : 8;
@@ -69,10 +70,11 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v));
 // INSCALE: per-(batch, input channel) scale applied while staging (NAFNet SCA).  A template parameter, not a runtime
 // test: a branch inside the staging code makes the compiler wait for every load where the paths join, which
 // serialises the loads of a K-step and pulls the vmcnt(0) in front of the MFMAs.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD, bool BF16, bool INSCALE>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD, bool BF16, bool INSCALE, bool ABF = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void conv_igemm_kernel(
     const ConvParams pin, const int nblk_n, const int M, const int nk_total) {
-    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16>;
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16, ABF>;
+    static_assert(!ABF || (BF16 && !INSCALE), "bf16 activation storage belongs to the bf16-MFMA mode");
     ConvParams p = pin;  // batched launch: component blockIdx.z works on its own slice of in0 / w / out
     if (pin.nz > 1) {
         const long long z = blockIdx.z;
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     const int Wv = p.Win << p.in_shift;
 
     // ---- per-thread staging coordinates (fixed for the whole K loop) ----
-    const int chunk = tid % 8;   // A: 16-B chunk (4 fp32 k) of the 32-k slice
-    const int row0 = tid / 8;    // A: first staged row
+    const int chunk = tid % C::A_CHUNKS;  // A: 16-B chunk (4 fp32 / 8 bf16 k) of the 32-k slice
+    const int row0 = tid / C::A_CHUNKS;   // A: first staged row
     const int bchunk = tid % C::B_CHUNKS;
     const int brow0 = tid / C::B_CHUNKS;
     int a_iy0[C::A_PASSES], a_ix0[C::A_PASSES], a_pix[C::A_PASSES], a_b[C::A_PASSES];
@@ -181,24 +183,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     // ---- staging pieces: A rows (A_PASSES) then B rows (B_PASSES), one 16-byte load each ----
     constexpr int NP = C::A_PASSES + C::B_PASSES;
     float4 rs[NP];
-    const float* cur_src = nullptr;  // source pointer (+channel +chunk) of the K-step being staged
-    int cur_pix = 0;
+    constexpr int AESZ = ABF ? 2 : 4;        // bytes per activation element in HBM
+    constexpr int ACE = 16 / AESZ;           // elements per 16-byte chunk
+    const char* cur_src = nullptr;  // source pointer (+channel +chunk) of the K-step being staged
+    int cur_pix = 0;                // bytes between consecutive pixels of that source
     size_t cur_wk = 0;  // byte offset of the K-step inside a weight row
     auto stage_setup = [&]() {
         const float* src;
         int c;
         if (cc < p.C0) {
-            src = p.in0; c = cc; cur_pix = p.pix0;
+            src = p.in0; c = cc; cur_pix = p.pix0 * AESZ;
         } else {
-            src = p.in1; c = cc - p.C0; cur_pix = p.pix1;
+            src = p.in1; c = cc - p.C0; cur_pix = p.pix1 * AESZ;
         }
-        cur_src = src + c + chunk * 4;
+        cur_src = reinterpret_cast<const char*>(src) + (size_t)(c + chunk * ACE) * AESZ;
         cur_wk = ((size_t)tap * Ctot + cc) * WESZ;
     };
     auto load_piece = [&](int q) {
         if (q < C::A_PASSES) {
             // branch-free: out-of-image taps (zero padding, rows past M) read the zero page instead
-            const float* g = a_poff[q] >= 0 ? cur_src + (size_t)a_poff[q] * cur_pix : p.zeros;
+            const char* g = a_poff[q] >= 0 ? cur_src + (size_t)a_poff[q] * cur_pix : reinterpret_cast<const char*>(p.zeros);
             float4 v = *reinterpret_cast<const float4*>(g);
             if (INSCALE) {  // single source (C1 == 0)
                 const float4 sc4 = *reinterpret_cast<const float4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + chunk * 4);
@@ -212,7 +216,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     auto store_piece = [&](int q, int buf) {
         if (q < C::A_PASSES) {
             char* dst = As + (buf * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES;
-            if (BF16) {
+            if (ABF) {
+                *reinterpret_cast<float4*>(dst + chunk * 16) = rs[q];  // already bf16: 8 k per piece
+            } else if (BF16) {
                 const floatx4 fv = {rs[q].x, rs[q].y, rs[q].z, rs[q].w};
                 *reinterpret_cast<bf16x4*>(dst + chunk * 8) = __builtin_convertvector(fv, bf16x4);  // v_cvt_pk_bf16_f32, RNE
             } else {
@@ -394,6 +400,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
                 *reinterpret_cast<float2*>(dst) = make_float2(v[0] * v[1], v[2] * v[3]);
                 continue;
             }
+            if (BF16 && p.out_bf16) {  // bf16 activation storage: residual and output tensors are bf16
+                if (p.res) {
+                    const __bf16* rp = reinterpret_cast<const __bf16*>(p.res) + opix * p.res_stride + ocol;
+                    if (n + 3 < p.Cout && (p.res_stride & 3) == 0) {
+                        const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(rp);
+                        v[0] += (float)t4[0]; v[1] += (float)t4[1]; v[2] += (float)t4[2]; v[3] += (float)t4[3];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.Cout) v[e] += (float)rp[e];
+                    }
+                }
+                __bf16* dst = reinterpret_cast<__bf16*>(p.out) + opix * p.out_stride + ocol;
+                if (vec_ok) {
+                    const floatx4 fv = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<bf16x4*>(dst) = __builtin_convertvector(fv, bf16x4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Cout) dst[e] = (__bf16)v[e];
+                }
+                continue;
+            }
             if (p.res) {
                 const float* rp = p.res + opix * p.res_stride + ocol;
                 if (n + 3 < p.Cout && (p.res_stride & 3) == 0) {
@@ -434,6 +463,11 @@ __global__ void conv_splitk_reduce(const ConvParams p, const int M) {
     }
     if (p.silu) v = silu_f(v);
     if (p.ch_scale) v *= p.ch_scale[n];
+    if (p.out_bf16) {
+        if (p.res) v += (float)reinterpret_cast<const __bf16*>(p.res)[(size_t)m * p.res_stride + n];
+        reinterpret_cast<__bf16*>(p.out)[(size_t)m * p.out_stride + n] = (__bf16)v;
+        return;
+    }
     if (p.res) v += p.res[(size_t)m * p.res_stride + n];
     p.out[(size_t)m * p.out_stride + n] = v;
 }
@@ -472,10 +506,10 @@ __global__ void conv_naive_kernel(const ConvParams p, const int M) {
     p.out[(size_t)m * p.out_stride + n] = v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false, bool ABF = false>
 void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds_override = 0) {
-    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16>;
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE>;
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16, ABF>;
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE, ABF>;
     const int nblk_m = (M + BM - 1) / BM;
     const int nblk_n = (p.Cout + BN - 1) / BN;
     dim3 grid(nblk_m * nblk_n, p.splits, p.nz);
@@ -483,10 +517,10 @@ void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false, bool ABF = false>
 void init_cfg() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE>),
+        reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE, ABF>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
@@ -507,6 +541,10 @@ void conv_global_init() {
     init_cfg<128, 64, 2, 2, 2, true>();
     init_cfg<128, 32, 4, 1, 2, true>();
     init_cfg<256, 256, 2, 4, 2, true>();
+    init_cfg<128, 128, 2, 2, 2, true, false, true>();
+    init_cfg<128, 64, 2, 2, 2, true, false, true>();
+    init_cfg<128, 32, 4, 1, 2, true, false, true>();
+    init_cfg<256, 256, 2, 4, 2, true, false, true>();
     init_cfg<128, 128, 2, 2, 2, false, true>();
     init_cfg<128, 64, 2, 2, 2, false, true>();
     init_cfg<128, 32, 4, 1, 2, false, true>();
@@ -536,6 +574,8 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.splits > 1 && !p.partial) throw HipError("launch_conv: split-K needs a partial buffer");
     if (!p.zeros) throw HipError("launch_conv: ConvParams::zeros (zero page for out-of-image taps) is not set");
     const int nk_total = p.KH * p.KW * (Ctot / 32);
+    if ((p.in_bf16 || p.out_bf16) && !p.w_bf) throw HipError("launch_conv: bf16 activation storage needs the bf16-MFMA mode");
+    if (p.in_bf16 && (p.in_scale || p.gate || p.shuffle)) throw HipError("launch_conv: NAFNet fusions are fp32-storage only");
     if (p.in_scale) {  // NAFNet SCA fused into the staging (128-row tiles only)
         if (p.C1) throw HipError("launch_conv: in_scale needs a single source");
         if (p.w_bf) {
@@ -550,6 +590,17 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     } else if (p.w_bf && g_variant != 60 && g_variant != 61 && conv_halo_eligible(p)) {
         launch_conv_halo(p, s);  // 3x3 s1 p1: LDS-resident halo tile (conv_halo.hip)
         return;
+    } else if (p.w_bf && p.in_bf16) {  // bf16 operands AND bf16 activation storage
+        if (p.Cout >= 128) {
+            if (g_variant != 61 && (g_variant == 60 || conv_use_tile256(M, p.Cout, p.splits, nk_total)))
+                launch_cfg<256, 256, 2, 4, 2, true, false, true>(p, M, nk_total, s);
+            else
+                launch_cfg<128, 128, 2, 2, 2, true, false, true>(p, M, nk_total, s);
+        } else if (p.Cout > 32) {
+            launch_cfg<128, 64, 2, 2, 2, true, false, true>(p, M, nk_total, s);
+        } else {
+            launch_cfg<128, 32, 4, 1, 2, true, false, true>(p, M, nk_total, s);
+        }
     } else if (p.w_bf) {  // bf16 operands, fp32 accumulation
         if (p.Cout >= 128) {
             if (g_variant != 61 && (g_variant == 60 || conv_use_tile256(M, p.Cout, p.splits, nk_total)))

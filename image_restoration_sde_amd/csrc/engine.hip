@@ -113,8 +113,9 @@ inline bool wino_shape_ok(const ConvParams& d, int tile) {
 }
 
 struct Tensor {
-    float* p = nullptr;
+    float* p = nullptr;  // bf16 == true: really a bf16 tensor (IRSDE_FLAG_BF16_ACT)
     int B = 0, H = 0, W = 0, C = 0;
+    bool bf16 = false;
     size_t numel() const { return (size_t)B * H * W * C; }
 };
 
@@ -861,10 +862,12 @@ struct Builder {
     bool naive;
     int film_bstride;
 
-    Tensor talloc(int B, int H, int W, int C) {
+    bool act_bf16() const { return (e->cfg.flags & IRSDE_FLAG_BF16_ACT) != 0; }
+    Tensor talloc(int B, int H, int W, int C, int force_f32 = 0) {
         Tensor t;
         t.B = B; t.H = H; t.W = W; t.C = C;
-        t.p = pl->alloc(t.numel(), reuse);
+        t.bf16 = act_bf16() && !force_f32;
+        t.p = pl->alloc(t.bf16 ? (t.numel() + 1) / 2 : t.numel(), reuse);
         return t;
     }
     void tfree(const Tensor& t) {
@@ -893,8 +896,9 @@ struct Builder {
         Op op;
         op.kind = OP_CONV;
         op.flops = conv_flops(p);
-        const double in_bytes = 4.0 * (double)p.B * (p.Hin) * (p.Win) * (double)(p.C0 + p.C1);
-        op.bytes = in_bytes + 4.0 * (double)M * p.Cout + (p.w_bf ? 2.0 : 4.0) * (double)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
+        const double in_bytes = (p.in_bf16 ? 2.0 : 4.0) * (double)p.B * (p.Hin) * (p.Win) * (double)(p.C0 + p.C1);
+        op.bytes = in_bytes + (p.out_bf16 ? 2.0 : 4.0) * (double)M * p.Cout +
+                   (p.w_bf ? 2.0 : 4.0) * (double)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
         op.exec_flops = op.flops;
         pl->conv_flops += op.flops;
         pl->conv_exec_flops += op.exec_flops;
@@ -931,8 +935,10 @@ struct Builder {
         p.Ho = (Hv + 2 * pad - w.KH) / stride + 1;
         p.Wo = (Wv + 2 * pad - w.KW) / stride + 1;
         const int ostr = out_stride ? out_stride : w.Cout;
-        Tensor out = talloc(p.B, p.Ho, p.Wo, ostr);
+        Tensor out = talloc(p.B, p.Ho, p.Wo, ostr, out_stride != 0);  // an explicit stride = the fp32 eps_hat tensor
         p.out = out.p; p.out_stride = ostr;
+        p.in_bf16 = in0.bf16; p.out_bf16 = out.bf16;
+        if ((in1 && in1->bf16 != in0.bf16) || (res && res->bf16 != out.bf16)) throw HipError("conv: mixed activation storage types");
         p.bias = w.bias;
         p.film = film; p.film_bstride = film ? film_bstride : 0;
         p.silu = silu;
@@ -1108,7 +1114,8 @@ struct Builder {
             const float *xp = x.p, *g = w.g1;
             float* o = xn.p;
             const int C = x.C;
-            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(xp, g, nullptr, o, M, C, 1e-5f, s); });
+            const bool bf = x.bf16;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(xp, g, nullptr, o, M, C, 1e-5f, s, bf); });
         }
         Tensor qkv = conv(w.qkv, xn, nullptr, 1, 0, 0, nullptr, 0, nullptr);
         tfree(xn);
@@ -1134,7 +1141,8 @@ struct Builder {
             const float* q = qkv.p;
             float* o = a.p;
             const int B = x.B;
-            push_other(OP_ATTN, [=](hipStream_t s) { launch_linear_attention(q, o, B, N, ws, s); });
+            const bool bf = x.bf16;
+            push_other(OP_ATTN, [=](hipStream_t s) { launch_linear_attention(q, o, B, N, ws, s, bf); });
         }
         tfree(qkv);
         Tensor o = conv(w.out, a, nullptr, 1, 0, 0, nullptr, 0, nullptr);
@@ -1144,7 +1152,8 @@ struct Builder {
             const float *op = o.p, *g = w.g2, *r = x.p;
             float* yp = y.p;
             const int C = x.C;
-            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(op, g, r, yp, M, C, 1e-5f, s); });
+            const bool bf = x.bf16;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(op, g, r, yp, M, C, 1e-5f, s, bf); });
         }
         tfree(o);
         return y;
@@ -1294,7 +1303,7 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
         p.w = e->init_conv.w; p.Cout = nf; p.KH = 7; p.KW = 1; p.stride = 1; p.pad_y = 0; p.pad_x = 0;
         p.B = B; p.Ho = pl->Hp; p.Wo = pl->Wp;
         x = b.talloc(B, pl->Hp, pl->Wp, nf);
-        p.out = x.p; p.out_stride = nf;
+        p.out = x.p; p.out_stride = nf; p.out_bf16 = x.bf16;  // the prepped input x0 stays fp32
         b.push_conv(p);
         // algorithmic accounting: 7x7 x (2*in_nc) real MACs, not the padded 7 x 64
         const double real = 2.0 * (double)B * pl->Hp * pl->Wp * nf * 49.0 * ((uncond ? 1.0 : 2.0) * in_nc);
@@ -1508,6 +1517,13 @@ int irsde_create(const irsde_config* cfg, irsde_engine** out) {
         if ((cfg->nf << cfg->depth) > 2048) throw HipError("nf * 2^depth must be <= 2048");
         auto* e = new irsde_engine();
         e->cfg = *cfg;
+        if (cfg->flags & IRSDE_FLAG_BF16_ACT) {
+            if (cfg->flags & (IRSDE_FLAG_UNCOND_FULLATTN | IRSDE_FLAG_NAIVE_CONV)) {
+                delete e;
+                throw HipError("IRSDE_FLAG_BF16_ACT: only the conditional UNet on the MFMA kernels stores bf16 activations");
+            }
+            e->cfg.flags |= IRSDE_FLAG_BF16;
+        }
         e->time_dim = cfg->nf * 4;
         build_inventory(e);
         *out = e;
@@ -1521,6 +1537,7 @@ int irsde_create_nafnet(const irsde_nafnet_config* cfg, irsde_engine** out) {
         if (cfg->img_channel < 1 || cfg->img_channel > 8) throw HipError("img_channel must be in 1..8");
         if (cfg->n_enc < 1 || cfg->n_enc > 6 || cfg->n_dec != cfg->n_enc) throw HipError("need 1..6 encoder stages and as many decoder stages");
         if ((cfg->width << cfg->n_enc) > 2048) throw HipError("width * 2^stages must be <= 2048");
+        if (cfg->flags & IRSDE_FLAG_BF16_ACT) throw HipError("IRSDE_FLAG_BF16_ACT: conditional UNet only");
         auto* e = new irsde_engine();
         e->arch = 1;
         e->cfg.in_nc = e->cfg.out_nc = cfg->img_channel;
@@ -1820,7 +1837,7 @@ int irsde_debug_tap(irsde_engine* e, const char* name, float* dst, int64_t dims[
         IRSDE_HIP_CHECK(hipDeviceSynchronize());
         float* tmp = nullptr;
         IRSDE_HIP_CHECK(hipMalloc(&tmp, t.numel() * 4));
-        launch_nhwc_to_nchw(t.p, tmp, t.B, t.C, t.H, t.W, e->stream);
+        launch_nhwc_to_nchw(t.p, tmp, t.B, t.C, t.H, t.W, e->stream, t.bf16);
         IRSDE_HIP_CHECK(hipStreamSynchronize(e->stream));
         IRSDE_HIP_CHECK(hipMemcpy(dst, tmp, t.numel() * 4, hipMemcpyDeviceToHost));
         (void)hipFree(tmp);
@@ -1927,17 +1944,36 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
         } else if (naive == 1) {
             launch_conv_naive(p, s);
         } else {
-            unsigned short* dbf = nullptr;
-            if (naive == 4 || naive == 160 || naive == 161) {  // bf16-MFMA mode (variants 60 / 61: force the 256 / 128 tile)
+            unsigned short *dbf = nullptr, *a0 = nullptr, *a1 = nullptr, *ar = nullptr, *ao = nullptr;
+            const bool act = naive == 204 || naive == 260 || naive == 261;  // + bf16 activation storage (IRSDE_FLAG_BF16_ACT)
+            if (naive == 4 || naive == 160 || naive == 161 || act) {  // bf16-MFMA mode (variants 60 / 61: force the 256 / 128 tile)
                 IRSDE_HIP_CHECK(hipMalloc(&dbf, pk.size() * 2));
                 launch_f32_to_bf16(dw, dbf, pk.size(), s);
                 p.w_bf = dbf;
             }
-            conv_set_variant(naive >= 100 ? naive - 100 : 0);  // test hook for experimental tile variants
+            const size_t npix_in = (size_t)B * Hin * Win, nout = (size_t)B * p.Ho * p.Wo * Cout;
+            if (act) {  // the caller's fp32 tensors are rounded into bf16 copies; the bf16 result is widened back
+                auto to_bf = [&](const float* src, size_t n) {
+                    unsigned short* d = nullptr;
+                    IRSDE_HIP_CHECK(hipMalloc(&d, n * 2 + 64));
+                    launch_f32_to_bf16(src, d, n, s);
+                    return d;
+                };
+                a0 = to_bf(in0, npix_in * C0);
+                p.in0 = reinterpret_cast<const float*>(a0);
+                if (in1) { a1 = to_bf(in1, npix_in * C1); p.in1 = reinterpret_cast<const float*>(a1); }
+                if (res) { ar = to_bf(res, nout); p.res = reinterpret_cast<const float*>(ar); }
+                IRSDE_HIP_CHECK(hipMalloc(&ao, nout * 2 + 64));
+                p.out = reinterpret_cast<float*>(ao);
+                p.in_bf16 = p.out_bf16 = 1;
+            }
+            conv_set_variant(act ? (naive == 204 ? 0 : naive - 200) : (naive >= 100 ? naive - 100 : 0));  // tile variants
             launch_conv(p, s);
             conv_set_variant(0);
+            if (act) launch_bf16_to_f32(ao, out, nout, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
-            if (dbf) (void)hipFree(dbf);
+            for (unsigned short* q : {dbf, a0, a1, ar, ao})
+                if (q) (void)hipFree(q);
         }
         IRSDE_HIP_CHECK(hipStreamSynchronize(s));
         (void)hipFree(dw);
@@ -2010,6 +2046,7 @@ int irsde_create_latent_unet(const irsde_latent_unet_config* cfg, irsde_engine**
         if (cfg->in_ch < 1 || cfg->in_ch > 32 || cfg->out_ch < 1 || cfg->out_ch > 4) throw HipError("in_ch must be in 1..32 and out_ch in 1..4");
         if (cfg->ch < 1 || cfg->n_mult < 1 || cfg->n_mult > 6) throw HipError("ch / ch_mult out of range");
         if (cfg->embed_dim < 1 || cfg->embed_dim > 32) throw HipError("embed_dim must be in 1..32");
+        if (cfg->flags & IRSDE_FLAG_BF16_ACT) throw HipError("IRSDE_FLAG_BF16_ACT: conditional UNet only");
         auto* e = new irsde_engine();
         e->arch = 2;
         e->cfg.in_nc = cfg->in_ch; e->cfg.out_nc = cfg->out_ch; e->cfg.nf = cfg->ch; e->cfg.depth = cfg->n_mult;

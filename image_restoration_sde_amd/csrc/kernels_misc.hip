@@ -9,8 +9,27 @@
 namespace irsde {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// Activation storage type T (fp32, or bf16 under IRSDE_FLAG_BF16_ACT): arithmetic is fp32 either way.
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)v; }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    const floatx4 f = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(f, bf16x4);  // RNE
+}
 
 __device__ __forceinline__ float wave_xor_sum(float v, int width) {
     for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -24,8 +43,9 @@ __device__ __forceinline__ float wave_xor_sum(float v, int width) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kLnMaxVec = 8;  // float4 vectors per lane -> C <= 2048
 
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                        const float* __restrict__ res, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ g,
+                                                        const T* __restrict__ res, T* __restrict__ out,
                                                         const long long M, const int C, const int L, const float eps,
                                                         const float* __restrict__ fscale = nullptr,
                                                         const float* __restrict__ fshift = nullptr,
@@ -41,14 +61,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (long long base = wave_id * ppw; base < M; base += nwaves * ppw) {
         const long long pix = base + sub;
         const bool ok = pix < M;
-        const float4* xp = reinterpret_cast<const float4*>(x + (ok ? pix : 0) * C);
+        const T* xp = x + (ok ? pix : 0) * C;
         float4 v[kLnMaxVec];
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < kLnMaxVec; ++k) {
             const int vi = li + k * L;
             if (vi < nvec) {
-                v[k] = xp[vi];
+                v[k] = ld4(xp + 4 * vi);
                 s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
             }
         }
@@ -66,9 +86,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         q = wave_xor_sum(q, L);
         const float rstd = 1.0f / sqrtf(q * invC + eps);
         if (ok) {
-            float4* op = reinterpret_cast<float4*>(out + pix * C);
+            T* op = out + pix * C;
             const float4* gp = reinterpret_cast<const float4*>(g);
-            const float4* rp = res ? reinterpret_cast<const float4*>(res + pix * C) : nullptr;
+            const T* rp = res ? res + pix * C : nullptr;
             const size_t frow = fscale ? (size_t)(film_bstride ? pix / ppi : 0) * film_bstride : 0;
 #pragma unroll
             for (int k = 0; k < kLnMaxVec; ++k) {
@@ -87,10 +107,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                         o.z = o.z * (s4.z + 1.0f) + h4.z; o.w = o.w * (s4.w + 1.0f) + h4.w;
                     }
                     if (rp) {
-                        const float4 r = rp[vi];
+                        const float4 r = ld4(rp + 4 * vi);
                         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                     }
-                    op[vi] = o;
+                    st4(op + 4 * vi, o);
                 }
             }
         }
@@ -113,22 +133,24 @@ constexpr int kDh = 32;
 constexpr int kHid = kHeads * kDh;  // 128
 constexpr int kQkv = 3 * kHid;      // 384
 
-__global__ __launch_bounds__(256) void attn_kmax_kernel(const float* __restrict__ qkv, float* __restrict__ pmax,
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kmax_kernel(const T* __restrict__ qkv, float* __restrict__ pmax,
                                                         const int N, const int chunk_len, const int nch) {
     __shared__ float red[256];
     const int ch = blockIdx.x, b = blockIdx.y;
     const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
     const int n0 = ch * chunk_len;
     const int n1 = min(N, n0 + chunk_len);
-    const float* kp = qkv + (size_t)b * N * kQkv + kHid + c;
+    const T* kp = qkv + (size_t)b * N * kQkv + kHid + c;
     float m = -INFINITY;
-    for (int n = n0 + half; n < n1; n += 2) m = fmaxf(m, kp[(size_t)n * kQkv]);
+    for (int n = n0 + half; n < n1; n += 2) m = fmaxf(m, ld1(kp + (size_t)n * kQkv));
     red[threadIdx.x] = m;
     __syncthreads();
     if (half == 0) pmax[((size_t)b * nch + ch) * kHid + c] = fmaxf(red[c], red[c + 128]);
 }
 
-__global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const float* __restrict__ qkv,
+template <typename T>
+__global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restrict__ qkv,
                                                                const float* __restrict__ pmax,
                                                                float* __restrict__ pctx, float* __restrict__ psum,
                                                                const int N, const int chunk_len, const int nch) {
@@ -144,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const float* __re
 
     const int n0 = ch * chunk_len;
     const int n1 = min(N, n0 + chunk_len);
-    const float* base = qkv + (size_t)b * N * kQkv + head * kDh + l31;
+    const T* base = qkv + (size_t)b * N * kQkv + head * kDh + l31;
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -157,9 +179,9 @@ __global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const float* __re
         for (int u = 0; u < U; ++u) {
             const int n = n0 + 2 * (pr + 4 * u) + h;
             const bool ok = n < n1;
-            const float* pp = base + (size_t)(ok ? n : n0) * kQkv;
-            const float kx = pp[kHid];
-            const float vx = pp[2 * kHid];
+            const T* pp = base + (size_t)(ok ? n : n0) * kQkv;
+            const float kx = ld1(pp + kHid);
+            const float vx = ld1(pp + 2 * kHid);
             kv[u] = ok ? expf(kx - mx) : 0.f;
             vv[u] = ok ? vx : 0.f;
         }
@@ -202,8 +224,9 @@ __global__ __launch_bounds__(1024) void attn_ctx_finalize_kernel(const float* __
 
 constexpr int kOutTilesPerBlock = 8;  // 256 pixels per block
 
-__global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
-                                                       float* __restrict__ out, const int N) {
+template <typename T>
+__global__ __launch_bounds__(256) void attn_out_kernel(const T* __restrict__ qkv, const float* __restrict__ ctx,
+                                                       T* __restrict__ out, const int N) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, head = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -218,12 +241,11 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
         if (nbase >= N) break;
         const int n = nbase + l31;
         const bool ok = n < N;
-        const float4* qp =
-            reinterpret_cast<const float4*>(qkv + ((size_t)b * N + (ok ? n : nbase)) * kQkv + head * kDh + 16 * h);
+        const T* qp = qkv + ((size_t)b * N + (ok ? n : nbase)) * kQkv + head * kDh + 16 * h;
         float q[16];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const float4 t4 = qp[v];
+            const float4 t4 = ld4(qp + 4 * v);
             q[4 * v + 0] = t4.x; q[4 * v + 1] = t4.y; q[4 * v + 2] = t4.z; q[4 * v + 3] = t4.w;
         }
         float m = q[0];
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int nn = nbase + row;
-            if (nn < N) out[((size_t)b * N + nn) * kHid + head * kDh + l31] = acc[r];
+            if (nn < N) st1(out + ((size_t)b * N + nn) * kHid + head * kDh + l31, acc[r]);
         }
     }
 }
@@ -542,7 +564,8 @@ __global__ void unpack_pred_kernel(const float* __restrict__ pred, float* __rest
     out[idx] = pred[(((size_t)b * Hp + y) * Wp + x) * stride + c];
 }
 
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, const int B, const int C,
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, const int B, const int C,
                                     const int H, const int W) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)B * C * H * W;
@@ -552,7 +575,7 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restr
     const int y = (int)(r % H); r /= H;
     const int c = (int)(r % C);
     const int b = (int)(r / C);
-    out[idx] = in[(((size_t)b * H + y) * W + x) * C + c];
+    out[idx] = ld1(in + (((size_t)b * H + y) * W + x) * C + c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -712,7 +735,7 @@ __global__ void philox_normal_kernel(float* out, const int CHW, const int t, con
 // Launchers
 // ---------------------------------------------------------------------------------------------
 void launch_layernorm(const float* x, const float* g, const float* res, float* out, int64_t M, int C, float eps,
-                      hipStream_t s) {
+                      hipStream_t s, bool bf16) {
     if (C % 4 || C > 4 * 64 * kLnMaxVec) throw HipError("layernorm: unsupported channel count " + std::to_string(C));
     int L = 1;
     while (L * 2 <= 64 && L * 2 <= C / 4) L *= 2;
@@ -722,8 +745,13 @@ void launch_layernorm(const float* x, const float* g, const float* res, float* o
     int64_t blocks = (waves + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, g, res, out, (long long)M, C, L,
-                       eps, (const float*)nullptr, (const float*)nullptr, 0, (long long)1);
+    if (bf16)
+        hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(x), g,
+                           reinterpret_cast<const bf16_t*>(res), reinterpret_cast<bf16_t*>(out), (long long)M, C, L, eps,
+                           (const float*)nullptr, (const float*)nullptr, 0, (long long)1);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, g, res, out, (long long)M, C, L,
+                           eps, (const float*)nullptr, (const float*)nullptr, 0, (long long)1);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
@@ -738,7 +766,7 @@ void launch_layernorm_film(const float* x, const float* g, const float* scale, c
     int64_t blocks = (waves + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, g, (const float*)nullptr, out,
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, g, (const float*)nullptr, out,
                        (long long)M, C, L, eps, scale, shift, film_bstride, (long long)pixels_per_image);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
@@ -776,19 +804,26 @@ int attn_num_chunks(int N) {
     return (N + len - 1) / len;
 }
 
-void launch_linear_attention(const float* qkv, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s) {
+template <typename T>
+static void linear_attention_t(const T* qkv, T* out, int B, int N, const AttnWorkspace& ws, hipStream_t s) {
     const int len = attn_chunk_len(N);
     const int nch = attn_num_chunks(N);
     if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
-    hipLaunchKernelGGL(attn_kmax_kernel, dim3(nch, B), dim3(256), 0, s, qkv, ws.pmax, N, len, nch);
-    hipLaunchKernelGGL(attn_ctx_partial_kernel, dim3(nch, B * kHeads), dim3(256), 0, s, qkv, ws.pmax, ws.pctx, ws.psum,
+    hipLaunchKernelGGL(attn_kmax_kernel<T>, dim3(nch, B), dim3(256), 0, s, qkv, ws.pmax, N, len, nch);
+    hipLaunchKernelGGL(attn_ctx_partial_kernel<T>, dim3(nch, B * kHeads), dim3(256), 0, s, qkv, ws.pmax, ws.pctx, ws.psum,
                        N, len, nch);
     hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, ws.pctx, ws.psum, ws.ctx, nch,
                        1.0f / (float)N, 1.0f / sqrtf((float)kDh));
     const int tiles = (N + 31) / 32;
-    hipLaunchKernelGGL(attn_out_kernel, dim3((tiles + kOutTilesPerBlock - 1) / kOutTilesPerBlock, B), dim3(256), 0, s,
+    hipLaunchKernelGGL(attn_out_kernel<T>, dim3((tiles + kOutTilesPerBlock - 1) / kOutTilesPerBlock, B), dim3(256), 0, s,
                        qkv, ws.ctx, out, N);
     IRSDE_HIP_CHECK(hipGetLastError());
+}
+void launch_linear_attention(const float* qkv, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s, bool bf16) {
+    if (bf16)
+        linear_attention_t(reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(out), B, N, ws, s);
+    else
+        linear_attention_t(qkv, out, B, N, ws, s);
 }
 
 void launch_full_attention(const float* qkv, float* out, int B, int N, hipStream_t s) {
@@ -852,10 +887,14 @@ void launch_unpack_pred(const float* pred, float* out, int B, int C, int H, int 
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t s) {
+void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t s, bool bf16) {
     const size_t total = (size_t)B * C * H * W;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, B, C, H,
-                       W);
+    if (bf16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const bf16_t*>(in), out, B, C, H, W);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, B, C, H,
+                           W);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
@@ -869,6 +908,15 @@ void launch_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint
     const int quads = (CHW + 3) / 4;
     hipLaunchKernelGGL(philox_normal_kernel, dim3((quads + 255) / 256, B), dim3(256), 0, s, out, CHW, t, seed,
                        image_offset);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+void launch_bf16_to_f32(const unsigned short* in, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(in), out, n);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

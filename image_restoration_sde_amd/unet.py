@@ -148,12 +148,15 @@ class ConditionalUNet(nn.Module):
     def set_compute_dtype(self, dtype):
         """'fp32' (default: exact-fp32 MFMA + Winograd) or 'bf16' (BASELINE configs[2]: conv operands rounded to bf16,
         fp32 accumulation, everything else fp32).  New behaviour — the reference is fp32 only."""
+        self.engine_flags &= ~(_lib.FLAG_BF16 | _lib.FLAG_BF16_ACT)
         if dtype in ("fp32", "f32", torch.float32):
-            self.engine_flags &= ~_lib.FLAG_BF16
+            pass
         elif dtype in ("bf16", torch.bfloat16):
             self.engine_flags |= _lib.FLAG_BF16
+        elif dtype == "bf16_act":  # + bf16 storage of the activation tensors (conditional UNet only)
+            self.engine_flags |= _lib.FLAG_BF16 | _lib.FLAG_BF16_ACT
         else:
-            raise _lib.IrsdeError("compute dtype must be 'fp32' or 'bf16'")
+            raise _lib.IrsdeError("compute dtype must be 'fp32', 'bf16' or 'bf16_act'")
         return self
 
     # ---- reference interface -----------------------------------------------------------------

@@ -49,6 +49,9 @@ enum {
                                         runs on v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 (RNE) and fp32
                                         accumulation; no Winograd; everything else (state, LayerNorm, attention, FiLM,
                                         update step) stays fp32 */
+    IRSDE_FLAG_BF16_ACT = 128,       /* IRSDE_FLAG_BF16 plus bf16 storage of every activation tensor between the prepped input
+                                        and eps_hat (conditional ConditionalUNet only): halves the HBM/L2 traffic of the
+                                        bandwidth-bound layers; LayerNorm / attention / epilogue arithmetic stays fp32 */
     IRSDE_FLAG_NAF_INTRO_SKIP = 64,  /* ConditionalNAFNet of the latent tasks (codes/config/latent-dehazing/models/modules/
                                         DenoisingNAFNet_arch.py:162-176): ending(x + intro(x)) instead of ending(x) */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128

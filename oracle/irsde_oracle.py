@@ -141,17 +141,31 @@ def round_bf16(a):
 CONV_OPERANDS_BF16 = False  # restatement of the engine's IRSDE_FLAG_BF16 mode: conv operands rounded, fp32+ accumulation
 
 
+ACT_STORAGE_BF16 = False    # restatement of IRSDE_FLAG_BF16_ACT: every stored activation tensor is rounded to bf16
+
+
 class bf16_convs:
     """Context manager: every conv2d inside rounds activations and weights to bf16 first (the Linear layers of the
-    time MLP, LayerNorm, attention and the update step stay in full precision, as in the engine)."""
+    time MLP, LayerNorm, attention and the update step stay in full precision, as in the engine).  store_bf16=True also
+    rounds every tensor the engine keeps in HBM between kernels (IRSDE_FLAG_BF16_ACT): fused-epilogue conv outputs,
+    LayerNorm outputs, the attention core's output."""
+
+    def __init__(self, store_bf16=False):
+        self.store = store_bf16
 
     def __enter__(self):
-        global CONV_OPERANDS_BF16
-        self.prev, CONV_OPERANDS_BF16 = CONV_OPERANDS_BF16, True
+        global CONV_OPERANDS_BF16, ACT_STORAGE_BF16
+        self.prev = (CONV_OPERANDS_BF16, ACT_STORAGE_BF16)
+        CONV_OPERANDS_BF16, ACT_STORAGE_BF16 = True, self.store
 
     def __exit__(self, *a):
-        global CONV_OPERANDS_BF16
-        CONV_OPERANDS_BF16 = self.prev
+        global CONV_OPERANDS_BF16, ACT_STORAGE_BF16
+        CONV_OPERANDS_BF16, ACT_STORAGE_BF16 = self.prev
+
+
+def _st(x):
+    """A tensor the engine writes to HBM (identity unless the bf16 storage mode is being restated)."""
+    return round_bf16(x) if ACT_STORAGE_BF16 else x
 
 
 def conv2d(x, w, b=None, stride=1, pad=0):
@@ -193,6 +207,12 @@ def layer_norm_c(x, g):
     return (x - mean) / np.sqrt(var + x.dtype.type(1e-5)) * g
 
 
+def _ln_st(x, g, res=None):
+    """LayerNorm kernel of the engine: normalise (+ residual), then store."""
+    y = layer_norm_c(x, g)
+    return _st(y if res is None else y + res)
+
+
 def sinusoidal_pos_emb(t, dim, dtype):
     """SinusoidalPosEmb — module_util.py:29-41.  t: array [b] of ints."""
     half = dim // 2
@@ -211,7 +231,7 @@ def linear_attention(p, prefix, x, heads=4, dim_head=32):
     """LinearAttention.forward — module_util.py:163-178."""
     B, C, H, W = x.shape
     N = H * W
-    qkv = conv2d(x, p[prefix + "to_qkv.weight"])
+    qkv = _st(conv2d(x, p[prefix + "to_qkv.weight"]))
     q, k, v = (qkv[:, i * heads * dim_head:(i + 1) * heads * dim_head].reshape(B, heads, dim_head, N)
                for i in range(3))
     q = np.exp(q - q.max(axis=2, keepdims=True))
@@ -222,14 +242,14 @@ def linear_attention(p, prefix, x, heads=4, dim_head=32):
     v = v / x.dtype.type(N)
     context = np.einsum("bhdn,bhen->bhde", k, v)
     out = np.einsum("bhde,bhdn->bhen", context, q)
-    out = out.reshape(B, heads * dim_head, H, W)
-    out = conv2d(out, p[prefix + "to_out.0.weight"], p[prefix + "to_out.0.bias"])
+    out = _st(out.reshape(B, heads * dim_head, H, W))
+    out = _st(conv2d(out, p[prefix + "to_out.0.weight"], p[prefix + "to_out.0.bias"]))
     return layer_norm_c(out, p[prefix + "to_out.1.g"])
 
 
 def attn_block(p, prefix, x):
     """Residual(PreNorm(dim, LinearAttention(dim))) — module_util.py:20-26,82-90."""
-    return linear_attention(p, prefix + "fn.fn.", layer_norm_c(x, p[prefix + "fn.norm.g"])) + x
+    return _st(linear_attention(p, prefix + "fn.fn.", _ln_st(x, p[prefix + "fn.norm.g"])) + x)
 
 
 def res_block(p, prefix, x, temb):
@@ -239,11 +259,11 @@ def res_block(p, prefix, x, temb):
     scale = ss[:, :C, None, None]
     shift = ss[:, C:, None, None]
     h = conv2d(x, p[prefix + "block1.proj.weight"], pad=1)
-    h = silu(h * (scale + 1) + shift)
+    h = _st(silu(h * (scale + 1) + shift))
     h = silu(conv2d(h, p[prefix + "block2.proj.weight"], pad=1))
     if (prefix + "res_conv.weight") in p:
-        return h + conv2d(x, p[prefix + "res_conv.weight"])
-    return h + x
+        return _st(h + _st(conv2d(x, p[prefix + "res_conv.weight"])))
+    return _st(h + x)
 
 
 def upsample_nearest2(x):
@@ -267,7 +287,7 @@ def unet_forward(params, xt, cond, t, depth=4, dtype=np.float64, taps=None):
     s = 2 ** depth
     ph, pw = (s - H % s) % s, (s - W % s) % s
     x = np.pad(x, ((0, 0), (0, 0), (0, ph), (0, pw)), mode="reflect")  # :78-83
-    x = conv2d(x, p["init_conv.weight"], pad=3)  # :96
+    x = _st(conv2d(x, p["init_conv.weight"], pad=3))  # :96
     x_ = x
     nf = p["init_conv.weight"].shape[0]
     temb = sinusoidal_pos_emb(t, nf, dtype)  # :99
@@ -292,9 +312,9 @@ def unet_forward(params, xt, cond, t, depth=4, dtype=np.float64, taps=None):
         tap("downs.%d.2" % i, x)
         h.append(x)
         if i != depth - 1:
-            x = conv2d(x, p["downs.%d.3.weight" % i], p["downs.%d.3.bias" % i], stride=2, pad=1)
+            x = _st(conv2d(x, p["downs.%d.3.weight" % i], p["downs.%d.3.bias" % i], stride=2, pad=1))
         else:
-            x = conv2d(x, p["downs.%d.3.weight" % i], pad=1)
+            x = _st(conv2d(x, p["downs.%d.3.weight" % i], pad=1))
         tap("downs.%d.3" % i, x)
     x = res_block(p, "mid_block1.", x, temb)  # :113-115
     tap("mid_block1", x)
@@ -312,9 +332,9 @@ def unet_forward(params, xt, cond, t, depth=4, dtype=np.float64, taps=None):
         x = attn_block(p, "ups.%d.2." % j, x)
         tap("ups.%d.2" % j, x)
         if j != depth - 1:
-            x = conv2d(upsample_nearest2(x), p["ups.%d.3.1.weight" % j], p["ups.%d.3.1.bias" % j], pad=1)
+            x = _st(conv2d(upsample_nearest2(x), p["ups.%d.3.1.weight" % j], p["ups.%d.3.1.bias" % j], pad=1))
         else:
-            x = conv2d(x, p["ups.%d.3.weight" % j], pad=1)
+            x = _st(conv2d(x, p["ups.%d.3.weight" % j], pad=1))
         tap("ups.%d.3" % j, x)
     x = np.concatenate([x, x_], axis=1)  # :127
     x = res_block(p, "final_res_block.", x, temb)
@@ -733,7 +753,7 @@ def full_attention(p, prefix, x, heads=4, dim_head=32):
     """Attention.forward — module_util.py:193-204."""
     B, C, H, W = x.shape
     N = H * W
-    qkv = conv2d(x, p[prefix + "to_qkv.weight"])
+    qkv = _st(conv2d(x, p[prefix + "to_qkv.weight"]))
     q, k, v = (qkv[:, i * heads * dim_head:(i + 1) * heads * dim_head].reshape(B, heads, dim_head, N) for i in range(3))
     q = q * x.dtype.type(dim_head ** -0.5)
     sim = np.einsum("bhdi,bhdj->bhij", q, k)

@@ -185,9 +185,76 @@ def test_conv_kernel_bf16(name):
         assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=160), ref) < 2e-5  # 256x256 tile
 
 
+@pytest.mark.parametrize("name", ["3x3_64_64_film_silu", "3x3_64_64_silu_res", "3x3_concat_192_128", "1x1_qkv_384", "4x4_s2_down",
+                                  "3x3_upsample_fused", "3x3_m_tail_odd", "3x3_deep_k_1536", "3x3_wino_res_bias"])
+def test_conv_kernel_bf16_storage(name):
+    """IRSDE_FLAG_BF16_ACT kernels: bf16 tensors in HBM on both sides (inputs, residual, output).  Against the oracle with
+    the same roundings (operands, residual; fp32+ arithmetic; one final rounding of the stored result): one bf16 ulp
+    (2^-8 relative to the value) is the most a different accumulation order can move a stored element."""
+    B, C0, C1, H, W, Cout, K, stride, pad, in_shift, has_bias, has_film, silu, has_res = CONV_CASES[name]
+    rs = np.random.RandomState(hash(name) % 2 ** 31)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, K, K)) / np.sqrt((C0 + C1) * K * K)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32) if has_bias else None
+    film = (0.3 * rs.standard_normal((1, 2 * Cout))).astype(np.float32) if has_film else None
+    Ho = ((H << in_shift) + 2 * pad - K) // stride + 1
+    Wo = ((W << in_shift) + 2 * pad - K) // stride + 1
+    res = rs.standard_normal((B, Cout, Ho, Wo)).astype(np.float32) if has_res else None
+    with O.bf16_convs():
+        ref = oracle_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, None if res is None else O.round_bf16(res))
+    ref_st = O.round_bf16(ref)
+    for code in (204, 261) + ((260,) if Cout % 256 == 0 else ()):   # automatic (halo for 3x3) / generic 128 / generic 256 tile
+        got = run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=code)
+        assert np.isfinite(got).all()
+        assert np.array_equal(got, O.round_bf16(got))                       # what comes back was stored as bf16
+        err = np.abs(got - ref_st)
+        assert (err <= np.abs(ref_st) * 2.0 ** -7 + 1e-6).all(), (name, code, float(err.max()))
+        assert (err > 0).mean() < 0.02, (name, code)                         # and almost every element is identical
+
+
 # ---------------------------------------------------------------------------------------------
 # network level
 # ---------------------------------------------------------------------------------------------
+def test_unet_bf16_act_mode(golden):
+    """IRSDE_FLAG_BF16_ACT (bf16 conv operands + bf16 storage of every activation tensor): follows the oracle's restatement
+    of the mode, stays close to the fp32 reference, and the ODE sampler stays close to the fp32 engine."""
+    g = golden.forward
+    tag = "nf64d4_1x64x64"
+    nf, depth, B, H, W = (int(v) for v in g[tag + "/cfg"])
+    m, params = make_model(nf, depth)
+    m.set_compute_dtype("bf16_act")
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    t = int(g[tag + "/ts"][1])
+    y = m(x, c, t).cpu().numpy()
+    with O.bf16_convs(store_bf16=True):
+        ref = O.unet_forward(params, xT, lq, t, depth=depth, dtype=np.float64)
+    e_oracle, e_fp32 = relerr(y, ref), relerr(y, g[tag + "/t%d" % t])
+    print("bf16_act forward: vs oracle %.3g, vs fp32 reference %.3g" % (e_oracle, e_fp32))
+    assert e_oracle < 3e-2
+    assert 1e-4 < e_fp32 < 5e-2
+    m32, _ = model(nf, depth)
+    T = 20
+    outs = {}
+    for name, mm in (("bf16_act", m), ("fp32", m32)):
+        sde = P.IRSDE(max_sigma=10, T=T, schedule="cosine", eps=0.005, device=DEV)
+        sde.set_model(mm)
+        sde.set_mu(c)
+        outs[name] = sde.reverse_ode(x).cpu().numpy()
+    e_ode = relerr(outs["bf16_act"], outs["fp32"])
+    print("bf16_act reverse_ode T=20 vs fp32: %.3g" % e_ode)
+    assert e_ode < 5e-2
+    # debug taps read the bf16 tensors back correctly (first ResBlock vs the oracle's stored value)
+    mk, _ = make_model(nf, depth, flags=_lib.FLAG_KEEP_ACTIVATIONS | _lib.FLAG_BF16 | _lib.FLAG_BF16_ACT)
+    taps = {}
+    with O.bf16_convs(store_bf16=True):
+        O.unet_forward(params, xT, lq, t, depth=depth, dtype=np.float64, taps=taps)
+    mk(x, c, t)
+    for name in ("init_conv", "downs.0.0", "downs.0.2"):
+        assert relerr(mk.debug_tap(name).numpy(), taps[name]) < 2e-2, name
+
+
 def test_unet_bf16_mode(golden):
     """BASELINE configs[2]: bf16 conv operands.  (a) the engine follows the oracle's restatement of the mode (operands
     rounded, everything else full precision) to 2e-2 of max|ref| — a value that sits on a bf16 rounding boundary may
