@@ -28,6 +28,7 @@
 // that every lane handles 4 consecutive output channels: bias / FiLM / residual / output move as
 // 16-byte accesses, 512 contiguous bytes per output pixel row of a 128-wide tile.
 #include "common.h"
+#include <type_traits>
 
 namespace irsde {
 
@@ -66,6 +67,17 @@ struct Cfg {
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+// compile-time loop: the index is a constant already in the front end, so register arrays indexed by it are promoted to
+// registers no matter when the optimiser unrolls (a `#pragma unroll` loop over a staging array inside a lambda was
+// seen to leave the array in scratch memory, with a vmcnt(0) after every load)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 // INSCALE: per-(batch, input channel) scale applied while staging (NAFNet SCA).  A template parameter, not a runtime
 // test: a branch inside the staging code makes the compiler wait for every load where the paths join, which
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
 
     // ---- staging pieces: A rows (A_PASSES) then B rows (B_PASSES), one 16-byte load each ----
     constexpr int NP = C::A_PASSES + C::B_PASSES;
-    float4 rs[NP];
+    floatx4 rs[NP];  // (ext_vector: HIP's float4 struct copies become memcpys that can pin the array to scratch)
     constexpr int AESZ = ABF ? 2 : 4;        // bytes per activation element in HBM
     constexpr int ACE = 16 / AESZ;           // elements per 16-byte chunk
     const char* cur_src = nullptr;  // source pointer (+channel +chunk) of the K-step being staged
@@ -203,31 +215,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         if (q < C::A_PASSES) {
             // branch-free: out-of-image taps (zero padding, rows past M) read the zero page instead
             const char* g = a_poff[q] >= 0 ? cur_src + (size_t)a_poff[q] * cur_pix : reinterpret_cast<const char*>(p.zeros);
-            float4 v = *reinterpret_cast<const float4*>(g);
-            if (INSCALE) {  // single source (C1 == 0)
-                const float4 sc4 = *reinterpret_cast<const float4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + chunk * 4);
-                v.x *= sc4.x; v.y *= sc4.y; v.z *= sc4.z; v.w *= sc4.w;
-            }
+            floatx4 v = *reinterpret_cast<const floatx4*>(g);
+            if (INSCALE)  // single source (C1 == 0)
+                v *= *reinterpret_cast<const floatx4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + chunk * 4);
             rs[q] = v;
         } else {
-            rs[q] = *reinterpret_cast<const float4*>(wrow[q - C::A_PASSES] + cur_wk);
+            rs[q] = *reinterpret_cast<const floatx4*>(wrow[q - C::A_PASSES] + cur_wk);
         }
     };
     auto store_piece = [&](int q, int buf) {
         if (q < C::A_PASSES) {
             char* dst = As + (buf * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES;
             if (ABF) {
-                *reinterpret_cast<float4*>(dst + chunk * 16) = rs[q];  // already bf16: 8 k per piece
+                *reinterpret_cast<floatx4*>(dst + chunk * 16) = rs[q];  // already bf16: 8 k per piece
             } else if (BF16) {
-                const floatx4 fv = {rs[q].x, rs[q].y, rs[q].z, rs[q].w};
-                *reinterpret_cast<bf16x4*>(dst + chunk * 8) = __builtin_convertvector(fv, bf16x4);  // v_cvt_pk_bf16_f32, RNE
+                *reinterpret_cast<bf16x4*>(dst + chunk * 8) = __builtin_convertvector(rs[q], bf16x4);  // v_cvt_pk_bf16_f32, RNE
             } else {
-                *reinterpret_cast<float4*>(dst + chunk * 16) = rs[q];
+                *reinterpret_cast<floatx4*>(dst + chunk * 16) = rs[q];
             }
         } else {
             const int ps = q - C::A_PASSES;
             if (C::B_PASSES * C::B_ROWS == BN || brow0 + ps * C::B_ROWS < BN)
-                *reinterpret_cast<float4*>(Bs + (buf * BN + brow0 + ps * C::B_ROWS) * C::ROW_BYTES + bchunk * 16) = rs[q];
+                *reinterpret_cast<floatx4*>(Bs + (buf * BN + brow0 + ps * C::B_ROWS) * C::ROW_BYTES + bchunk * 16) = rs[q];
         }
     };
 
@@ -447,6 +456,136 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batched GEMM with the batch loop INSIDE the block — the (m+2)^2 component GEMMs of a Winograd layer when K = Cin is
+// short.  M_z[t][n] = sum_k V_z[t][k] * U_z[n][k]: launched through the kernel above, every (z, tile) is its own block
+// with only K/32 = 4..12 K-steps between a cold prologue and an LDS-transposed epilogue (71-95 TFLOP/s measured).  Here a
+// block keeps its (row tile, column tile) and walks ZB consecutive components as ONE software-pipelined K loop: the
+// double-buffered staging runs straight across component boundaries, and at a boundary the accumulators go to HBM
+// directly from registers (per MFMA register: 2 rows x 32 consecutive columns = two full 128-byte lines per store
+// instruction), are zeroed, and the MFMAs of the next component start — no LDS round trip, no extra barrier.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void gemm_zloop_kernel(
+    const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ Mo, const int T, const int N, const int K,
+    const int ZB, const int nblk_n, const long long zV, const long long zU, const long long zM, const float* zeros) {
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, false>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* As = reinterpret_cast<char*>(smem);
+    char* Bs = As + 2 * BM * C::ROW_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, h = lane >> 5;
+    int wgid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int mblk = wgid / nblk_n, nblk = wgid - mblk * nblk_n;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+    const int z0 = blockIdx.y * ZB;
+    const int nk = K / BK;
+    const int steps = ZB * nk;
+
+    const int chunk = tid % 8, row0 = tid / 8;
+    // rows past T / N are clamped (their products land in rows / columns that are never stored)
+    const float* arow[C::A_PASSES];
+    const float* brow[C::B_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < C::A_PASSES; ++ps) {
+        const int m = m0 + row0 + ps * C::A_ROWS;
+        arow[ps] = V + (size_t)z0 * zV + (size_t)(m < T ? m : T - 1) * K + chunk * 4;
+    }
+#pragma unroll
+    for (int ps = 0; ps < C::B_PASSES; ++ps) {
+        const int n = n0 + row0 + ps * C::B_ROWS;
+        brow[ps] = U + (size_t)z0 * zU + (size_t)(n < N ? n : N - 1) * K + chunk * 4;
+    }
+    (void)zeros;
+    constexpr int NP = C::A_PASSES + C::B_PASSES;
+    floatx4 rs[NP];  // (an ext_vector, not HIP's float4 struct: struct copies become memcpys that pin the array to scratch)
+    long long offA = 0, offB = 0;  // float offset of the K-step being staged relative to (z0, k = 0)
+    int kk = 0;                    // its k position inside the component
+    auto advance = [&]() {
+        kk += BK; offA += BK; offB += BK;
+        if (kk == K) { kk = 0; offA += zV - K; offB += zU - K; }
+    };
+    auto load_all = [&]() {
+        static_for<C::A_PASSES>([&](auto q) { rs[q()] = *reinterpret_cast<const floatx4*>(arow[q()] + offA); });
+        static_for<C::B_PASSES>([&](auto q) { rs[C::A_PASSES + q()] = *reinterpret_cast<const floatx4*>(brow[q()] + offB); });
+    };
+    auto store_all = [&](int buf) {
+        static_for<C::A_PASSES>([&](auto q) {
+            *reinterpret_cast<floatx4*>(As + (buf * BM + row0 + q() * C::A_ROWS) * C::ROW_BYTES + chunk * 16) = rs[q()];
+        });
+        static_for<C::B_PASSES>([&](auto q) {
+            *reinterpret_cast<floatx4*>(Bs + (buf * BN + row0 + q() * C::B_ROWS) * C::ROW_BYTES + chunk * 16) = rs[C::A_PASSES + q()];
+        });
+    };
+
+    floatx16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_all();
+    store_all(0);
+    __syncthreads();
+
+    int kdone = 0;  // K-steps finished inside the current component
+    int z = z0;
+    for (int st = 0; st < steps; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < steps;
+        if (more) {
+            advance();
+            load_all();
+        }
+        const char* a = As + (buf * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
+        const char* b = Bs + (buf * BN + wn * C::TN * 32 + l31) * C::ROW_BYTES + h * 16;
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            float4 fa[C::TM], fb[C::TN];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * C::ROW_BYTES + sb * 32);
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * C::ROW_BYTES + sb * 32);
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) store_all(buf ^ 1);
+        if (++kdone == nk) {  // component finished: registers -> HBM, restart the accumulation
+            kdone = 0;
+            float* oz = Mo + (size_t)z * zM;
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) {
+                    const int col = n0 + wn * C::TN * 32 + j * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < T && col < N) oz[(size_t)row * N + col] = acc[i][j][r];
+                        acc[i][j][r] = 0.f;
+                    }
+                }
+            ++z;
+        }
+        __syncthreads();
+    }
+}
+
 // split-K second stage: sum partials, run the epilogue (memory-bound, tiny layers only)
 __global__ void conv_splitk_reduce(const ConvParams p, const int M) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -526,12 +665,39 @@ void init_cfg() {
 
 int g_variant = 0;  // tuning experiments only (irsde_bench_conv)
 
+// components per block for gemm_zloop_kernel, or 0 = use one block per (component, tile)
+int zloop_batch(const ConvParams& p) {
+    if (p.nz <= 1 || p.w_bf || p.KH != 1 || p.KW != 1 || p.C1 || p.bias || p.film || p.silu || p.res || p.splits != 1 ||
+        p.gate || p.shuffle || p.ch_scale || p.in_scale || p.stride != 1 || p.out_stride != p.Cout || p.pix0 != p.C0 ||
+        p.B != 1 || p.Ho != 1)
+        return 0;
+    static const int env_force = getenv("IRSDE_ZLOOP") ? atoi(getenv("IRSDE_ZLOOP")) : -1;  // tuning: 0 = off, n = fixed batch
+    // test hooks: variant 71 = all components in one block, 72 = batches of 2 (F2: 16, F4: 36 components), 70 = off
+    const int force = g_variant == 70 ? 0 : g_variant == 71 ? p.nz : g_variant == 72 ? 2 : env_force;
+    if (force == 0) return 0;
+    const int nk = p.C0 / 32;
+    const long long tiles = (long long)((p.Wo + 127) / 128) * ((p.Cout + 127) / 128);
+    if (force > 0) return p.nz % force == 0 ? force : 0;
+    static const int max_nk = getenv("IRSDE_ZLOOP_MAXNK") ? atoi(getenv("IRSDE_ZLOOP_MAXNK")) : 32;
+    static const int min_blocks = getenv("IRSDE_ZLOOP_MINBLK") ? atoi(getenv("IRSDE_ZLOOP_MINBLK")) : 1024;
+    if (nk > max_nk) return 0;  // long K: the per-block overhead is already amortised (measured: 12 / 32 / 48 -> 2.82 / 2.87 / 2.83 img/s)
+    int best = 0;
+    for (int zb = p.nz; zb >= 2; --zb) {  // largest batch that still fills the 2 x 256 block slots evenly
+        if (p.nz % zb) continue;
+        const long long blocks = tiles * (p.nz / zb);
+        if (blocks >= 512 && (blocks % 512 == 0 || blocks >= min_blocks)) { best = zb; break; }
+    }
+    return best;
+}
+
 }  // namespace
 
 void conv_set_variant(int v) { g_variant = v; }
 
 void conv_global_init() {
     conv_halo_global_init();
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<128, 128, 2, 2, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     init_cfg<128, 128, 2, 2, 2, false>();
     init_cfg<128, 64, 2, 2, 2, false>();
     init_cfg<128, 32, 4, 1, 2, false>();
@@ -573,6 +739,15 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
                        std::to_string(p.C1) + ")");
     if (p.splits > 1 && !p.partial) throw HipError("launch_conv: split-K needs a partial buffer");
     if (!p.zeros) throw HipError("launch_conv: ConvParams::zeros (zero page for out-of-image taps) is not set");
+    if (const int zb = zloop_batch(p)) {  // short-K Winograd component GEMMs: batch loop inside the block
+        using C = Cfg<128, 128, 2, 2, false>;
+        const int nblk_n = (p.Cout + 127) / 128;
+        dim3 grid(((p.Wo + 127) / 128) * nblk_n, p.nz / zb);
+        hipLaunchKernelGGL((gemm_zloop_kernel<128, 128, 2, 2, 2>), grid, dim3(C::NT), C::MAIN_BYTES, s, p.in0, p.w, p.out, p.Wo,
+                           p.Cout, p.C0, zb, nblk_n, p.z_in, p.z_w, p.z_out, p.zeros);
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
     const int nk_total = p.KH * p.KW * (Ctot / 32);
     if ((p.in_bf16 || p.out_bf16) && !p.w_bf) throw HipError("launch_conv: bf16 activation storage needs the bf16-MFMA mode");
     if (p.in_bf16 && (p.in_scale || p.gate || p.shuffle)) throw HipError("launch_conv: NAFNet fusions are fp32-storage only");

@@ -1919,13 +1919,14 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
         IRSDE_HIP_CHECK(hipMalloc(&dz, 1024));
         IRSDE_HIP_CHECK(hipMemset(dz, 0, 1024));
         p.zeros = dz;
-        if (splits > 1 && naive != 1 && naive != 2 && naive != 3) {
+        const int wino_tile = (naive == 2 || naive == 12 || naive == 22) ? 2 : (naive == 3 || naive == 13 || naive == 23) ? 4 : 0;
+        if (splits > 1 && naive != 1 && !wino_tile) {
             p.splits = splits;
             IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
             p.partial = dp;
         }
-        if (naive == 2 || naive == 3) {
-            const int tile = naive == 3 ? 4 : 2, ncomp = (tile + 2) * (tile + 2);
+        if (wino_tile) {  // naive / 10: 0 = production dispatch, 1 / 2 = force the batch-loop GEMM kernel (all / 2 components per block)
+            const int tile = wino_tile, ncomp = (tile + 2) * (tile + 2);
             if (!wino_shape_ok(p, tile)) throw HipError("debug_conv: shape not eligible for Winograd");
             std::vector<float> U((size_t)ncomp * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), tile);
@@ -1937,7 +1938,9 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)ncomp * T * Cout * 4));
             const WinoPlan wp = make_wino(p, dU, dV, dM, tile);
             launch_wino_input(wp.in, s);
+            conv_set_variant(naive >= 20 ? 72 : naive >= 10 ? 71 : 0);
             launch_conv(wp.gemm, s);
+            conv_set_variant(0);
             launch_wino_output(wp.out, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dU); (void)hipFree(dV); (void)hipFree(dM);

@@ -143,9 +143,14 @@ def test_conv_kernel(name):
     if K == 3 and stride == 1 and pad == 1 and Cout % 4 == 0 and Ho % 2 == 0 and Wo % 2 == 0:
         # Winograd F(2x2,3x3) path (input transform -> 16 batched MFMA GEMMs -> output transform + epilogue)
         assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=2), ref) < 2e-5
+        # same with the component GEMMs on the batch-loop kernel (all 16 / 2 components per block)
+        assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=12), ref) < 2e-5
+        assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=22), ref) < 2e-5
     if K == 3 and stride == 1 and pad == 1 and Cout % 4 == 0 and Ho % 4 == 0 and Wo % 4 == 0:
         # Winograd F(4x4,3x3): 36 batched GEMMs, 4x fewer multiplies, larger transform constants
         assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=3), ref) < 5e-5
+        assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=13), ref) < 5e-5
+        assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=23), ref) < 5e-5
 
 
 def test_conv_per_sample_film():
