@@ -536,14 +536,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
     store_all(0);
     __syncthreads();
 
+    // The finished component is written at the START of the following K-step, after that step's loads have been issued:
+    // the stores then have a whole MFMA phase to drain before the next vmcnt wait (written at the end of its own step,
+    // the loads of the next step — which the compiler orders behind all older memory operations — stalled on them).
+    auto flush = [&](int zc) {
+        float* oz = Mo + (size_t)zc * zM;
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) {
+                const int col = n0 + wn * C::TN * 32 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < T && col < N) oz[(size_t)row * N + col] = acc[i][j][r];
+                    acc[i][j][r] = 0.f;
+                }
+            }
+    };
     int kdone = 0;  // K-steps finished inside the current component
     int z = z0;
+    bool pending = false;
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
         const bool more = st + 1 < steps;
         if (more) {
             advance();
             load_all();
+        }
+        if (pending) {
+            flush(z - 1);
+            pending = false;
         }
         const char* a = As + (buf * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
         const char* b = Bs + (buf * BN + wn * C::TN * 32 + l31) * C::ROW_BYTES + h * 16;
@@ -565,25 +588,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
                 }
         }
         if (more) store_all(buf ^ 1);
-        if (++kdone == nk) {  // component finished: registers -> HBM, restart the accumulation
+        if (++kdone == nk) {  // component finished
             kdone = 0;
-            float* oz = Mo + (size_t)z * zM;
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TN; ++j) {
-                    const int col = n0 + wn * C::TN * 32 + j * 32 + l31;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < T && col < N) oz[(size_t)row * N + col] = acc[i][j][r];
-                        acc[i][j][r] = 0.f;
-                    }
-                }
             ++z;
+            pending = true;
         }
         __syncthreads();
     }
+    flush(z - 1);
 }
 
 // split-K second stage: sum partials, run the epilogue (memory-bound, tiny layers only)

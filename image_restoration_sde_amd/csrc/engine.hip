@@ -26,11 +26,12 @@ namespace {
 
 thread_local std::string g_last_error;
 // Winograd only where the transforms' extra HBM traffic is small next to the GEMM: F(2x2) moves 4x the input and
-// 4x the output through HBM and pays from 256 channels, F(4x4) 2.25x and pays from 128 (measured, profiles/).
+// 4x the output through HBM and pays from 256 channels, F(4x4) 2.25x and pays from 128 — from 64 (+1.6 %) since the
+// component GEMMs run on the batch-loop kernel (measured, profiles/).
 // IRSDE_WINO2_MINC / IRSDE_WINO4_MINC override the thresholds (tuning experiments).
 static int wino_min_c(int tile) {
     const char* v = getenv(tile == 4 ? "IRSDE_WINO4_MINC" : "IRSDE_WINO2_MINC");
-    return v ? atoi(v) : (tile == 4 ? 128 : 256);
+    return v ? atoi(v) : (tile == 4 ? 64 : 256);
 }
 
 struct HostTensor {
