@@ -230,7 +230,7 @@ def main():
                 "frac": ach / peak, "traffic": traffic,
                 "traffic_unit": "bytes per conv launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes, profiles/*_bench_pmc_hbm.txt)",
                 "algorithmic_bytes_per_launch": prof["conv_bytes"] / max(prof["conv_launches"], 1),
-                "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM: direct 1x1/4x4/7x7/narrow-3x3 layers + the batched GEMMs of the Winograd F(4x4,3x3)/F(2x2,3x3) layers; %d launches per network evaluation) + wino_input/wino_output transform kernels"
+                "kernel": "conv_igemm_kernel + gemm_zloop_kernel (fp32 v_mfma_f32_32x32x2_f32: direct 1x1/4x4/7x7 layers as implicit GEMM, the 3x3 layers as Winograd F(4x4,3x3)/F(2x2,3x3) component GEMMs; %d launches per network evaluation) + wino_input/wino_output transform kernels"
                           % int(round(prof["conv_launches"] / max(prof["net_evals"], 1))),
                 "avg_launch_ms": (prof["conv_ms"] + prof["wino_ms"]) / max(prof["conv_launches"], 1),
                 "flops_per_launch": prof["conv_flops"] / max(prof["conv_launches"], 1),
