@@ -22,6 +22,7 @@ FLAG_UNCOND_FULLATTN = 16
 FLAG_BF16 = 32
 FLAG_NAF_INTRO_SKIP = 64
 FLAG_BF16_ACT = 128
+FLAG_NO_FUSED_LN = 256
 SAMPLE_GRAPH = 1
 SAMPLE_PROFILE = 2
 

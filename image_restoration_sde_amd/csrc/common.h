@@ -69,6 +69,11 @@ struct ConvParams {
     // bf16 activation storage (IRSDE_FLAG_BF16_ACT, bf16-MFMA kernels only): in0/in1 resp. out/res point at bf16 tensors
     // (strides in elements); accumulation and the epilogue arithmetic stay fp32
     int in_bf16 = 0, out_bf16 = 0;
+    // channel LayerNorm fused into the epilogue (LinearAttention.to_out = Conv2d + LayerNorm, module_util.py:158-161, then the
+    // Residual add): v = (v - mean_n v) * rsqrt(var_n v + eps) * ln_g[n], applied after bias and before +res.  Needs the
+    // whole output row in one tile: Cout == 64 or 128, no split-K.
+    const float* ln_g = nullptr;
+    float ln_eps = 1e-5f;
 };
 
 // Winograd F(m x m,3x3) transforms (wino.hip).  Tiles: T = B * TH * TW with TH = Ho/m, TW = Wo/m.

@@ -322,7 +322,7 @@ void conv_halo_global_init() {
 
 bool conv_halo_eligible(const ConvParams& p) {
     return p.w_bf && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 && (p.in_shift == 0 || p.in_shift == 1) &&
-           p.splits == 1 && !p.gate && !p.shuffle && !p.ch_scale && !p.in_scale && p.nz == 1 && p.Cout >= 64 &&
+           p.splits == 1 && !p.gate && !p.shuffle && !p.ch_scale && !p.in_scale && !p.ln_g && p.nz == 1 && p.Cout >= 64 &&
            p.Ho == (p.Hin << p.in_shift) && p.Wo == (p.Win << p.in_shift) && (!p.film || p.film_bstride >= 0) && p.zeros;
 }
 

@@ -404,6 +404,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
                 if (p.silu) t = silu_f(t);
                 v[e] = t * cs[e];
             }
+            if (p.ln_g) {  // fused channel LayerNorm: the NV lanes of this row group hold the whole row (Cout == BN)
+                float sum = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+                for (int o = NV / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                const float mean = sum * (1.0f / (float)BN);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                float sq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+                for (int o = NV / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / (float)BN) + p.ln_eps);
+                const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + n);
+                v[0] = d0 * rstd * g4.x; v[1] = d1 * rstd * g4.y; v[2] = d2 * rstd * g4.z; v[3] = d3 * rstd * g4.w;
+            }
             if (p.gate) {  // SimpleGate: pairs are adjacent by construction of the packed weights
                 float* dst = p.out + opix * p.out_stride + ocol;
                 *reinterpret_cast<float2*>(dst) = make_float2(v[0] * v[1], v[2] * v[3]);
@@ -750,6 +763,8 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
         throw HipError("launch_conv: channel counts must be multiples of 32 (got " + std::to_string(p.C0) + "+" +
                        std::to_string(p.C1) + ")");
     if (p.splits > 1 && !p.partial) throw HipError("launch_conv: split-K needs a partial buffer");
+    if (p.ln_g && (p.splits != 1 || (p.Cout != 64 && p.Cout != 128) || p.nz != 1 || (p.out_stride & 3)))
+        throw HipError("launch_conv: fused LayerNorm needs Cout == 64 or 128 in one tile, no split-K");
     if (!p.zeros) throw HipError("launch_conv: ConvParams::zeros (zero page for out-of-image taps) is not set");
     if (const int zb = zloop_batch(p)) {  // short-K Winograd component GEMMs: batch loop inside the block
         using C = Cfg<128, 128, 2, 2, false>;

@@ -862,6 +862,7 @@ struct Builder {
     bool reuse;
     bool naive;
     int film_bstride;
+    const float* fused_ln_g = nullptr;  // set around a conv() call: LayerNorm gain applied in that conv's epilogue
 
     bool act_bf16() const { return (e->cfg.flags & IRSDE_FLAG_BF16_ACT) != 0; }
     Tensor talloc(int B, int H, int W, int C, int force_f32 = 0) {
@@ -939,6 +940,7 @@ struct Builder {
         Tensor out = talloc(p.B, p.Ho, p.Wo, ostr, out_stride != 0);  // an explicit stride = the fp32 eps_hat tensor
         p.out = out.p; p.out_stride = ostr;
         p.in_bf16 = in0.bf16; p.out_bf16 = out.bf16;
+        p.ln_g = fused_ln_g;
         if ((in1 && in1->bf16 != in0.bf16) || (res && res->bf16 != out.bf16)) throw HipError("conv: mixed activation storage types");
         p.bias = w.bias;
         p.film = film; p.film_bstride = film ? film_bstride : 0;
@@ -1146,6 +1148,14 @@ struct Builder {
             push_other(OP_ATTN, [=](hipStream_t s) { launch_linear_attention(q, o, B, N, ws, s, bf); });
         }
         tfree(qkv);
+        if (!naive && (x.C == 64 || x.C == 128) && !(e->cfg.flags & IRSDE_FLAG_NO_FUSED_LN)) {
+            // to_out conv + LayerNorm + residual in one kernel: the conv tile holds the whole channel row
+            fused_ln_g = w.g2;
+            Tensor y = conv(w.out, a, nullptr, 1, 0, 0, nullptr, 0, &x);
+            fused_ln_g = nullptr;
+            tfree(a);
+            return y;
+        }
         Tensor o = conv(w.out, a, nullptr, 1, 0, 0, nullptr, 0, nullptr);
         tfree(a);
         Tensor y = talloc(x.B, x.H, x.W, x.C);

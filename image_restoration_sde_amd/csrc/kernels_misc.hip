@@ -122,47 +122,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 //   q <- softmax over d (32, per pixel) * 32^-0.5 ; k <- softmax over N (per channel) ; v <- v / N
 //   ctx[d][e] = sum_n k[d][n] v[e][n]          (32 x N) x (N x 32)   -> one 32x32 MFMA tile per head
 //   out[e][n] = sum_d ctx[d][e] q[d][n]        (N x 32) x (32 x 32)
-// Pass 1: per-channel max of k over N (partials per N-chunk).
-// Pass 2: sum_n exp(k-max) and sum_n exp(k-max) v^T per chunk on v_mfma_f32_32x32x2_f32
-//         (A[i=d][k=n] and B[k=n][j=e] are both 128-B coalesced rows straight from HBM).
-// Pass 3: combine chunks, fold 1/(S_d N) and the q scale into ctx.
-// Pass 4: per 32-pixel tile: softmax(q) in registers (16 d per lane half + one permute), 16 MFMAs.
+// Pass 1: per N-chunk, sum_n exp(k-m) and sum_n exp(k-m) v^T on v_mfma_f32_32x32x2_f32 with a running maximum m
+//         (A[i=d][k=n] and B[k=n][j=e] are both 128-B coalesced rows straight from HBM; k and v are read once).
+// Pass 2: combine chunks (exp(m_chunk - m) factors), fold 1/(S_d N) and the q scale into ctx.
+// Pass 3: per 32-pixel tile: softmax(q) in registers (16 d per lane half + one permute), 16 MFMAs.
 // ---------------------------------------------------------------------------------------------
 constexpr int kHeads = 4;
 constexpr int kDh = 32;
 constexpr int kHid = kHeads * kDh;  // 128
 constexpr int kQkv = 3 * kHid;      // 384
 
+// Pass 1+2 fused: one read of k and v.  Every wave keeps a running maximum of its pixels' k (per channel d) and rescales
+// its context accumulator when the maximum grows (online softmax over N); the four waves and later the N-chunks are
+// merged with exp(m_part - m_total) factors — the same sums as the two-pass form, without the separate max pass over k.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_kmax_kernel(const T* __restrict__ qkv, float* __restrict__ pmax,
-                                                        const int N, const int chunk_len, const int nch) {
-    __shared__ float red[256];
-    const int ch = blockIdx.x, b = blockIdx.y;
-    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-    const int n0 = ch * chunk_len;
-    const int n1 = min(N, n0 + chunk_len);
-    const T* kp = qkv + (size_t)b * N * kQkv + kHid + c;
-    float m = -INFINITY;
-    for (int n = n0 + half; n < n1; n += 2) m = fmaxf(m, ld1(kp + (size_t)n * kQkv));
-    red[threadIdx.x] = m;
-    __syncthreads();
-    if (half == 0) pmax[((size_t)b * nch + ch) * kHid + c] = fmaxf(red[c], red[c + 128]);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restrict__ qkv,
-                                                               const float* __restrict__ pmax,
+__global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restrict__ qkv, float* __restrict__ pmax,
                                                                float* __restrict__ pctx, float* __restrict__ psum,
                                                                const int N, const int chunk_len, const int nch) {
-    __shared__ float red[4][1024 + 32];
+    __shared__ float red[4][1024 + 64];
     const int ch = blockIdx.x;
     const int bh = blockIdx.y;  // b*4 + head
     const int b = bh >> 2, head = bh & 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-
-    float mx = -INFINITY;  // global (over all chunks) max of k[d = l31]
-    for (int c = 0; c < nch; ++c) mx = fmaxf(mx, pmax[((size_t)b * nch + c) * kHid + head * kDh + l31]);
 
     const int n0 = ch * chunk_len;
     const int n1 = min(N, n0 + chunk_len);
@@ -171,53 +153,82 @@ __global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float ssum = 0.f;
+    float mrun = -INFINITY;  // running max of k[d = l31] over this wave's pixels (same value in both lane halves)
     // wave w takes pixel pairs w, w+4, ...; lane half h takes pixel 2*pair + h
     constexpr int U = 4;
     for (int pr = wave; 2 * pr < n1 - n0; pr += 4 * U) {
-        float kv[U], vv[U];
+        float kx[U], vv[U];
+        float mit = -INFINITY;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int n = n0 + 2 * (pr + 4 * u) + h;
             const bool ok = n < n1;
             const T* pp = base + (size_t)(ok ? n : n0) * kQkv;
-            const float kx = ld1(pp + kHid);
-            const float vx = ld1(pp + 2 * kHid);
-            kv[u] = ok ? expf(kx - mx) : 0.f;
-            vv[u] = ok ? vx : 0.f;
+            const float kl = ld1(pp + kHid), vl = ld1(pp + 2 * kHid);  // unconditional loads (clamped address), then select
+            kx[u] = ok ? kl : -INFINITY;
+            vv[u] = ok ? vl : 0.f;
+            mit = fmaxf(mit, kx[u]);
+        }
+        mit = fmaxf(mit, __shfl_xor(mit, 32, 64));
+        if (__any(mit > mrun)) {  // wave-uniform: after the first few iterations the maxima rarely move
+            const float mnew = fmaxf(mrun, mit);  // finite: the first pixel pair of every wave-iteration exists
+            const float alpha = expf(mrun - mnew);  // 0 on the first iteration (mrun = -inf)
+            mrun = mnew;
+            // the accumulator tile is ctx[d][e]: row d = (r&3) + 8(r>>2) + 4h needs the factor of channel d, which lives
+            // in lane d of either half => fetch it with a lane read
+            ssum *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+                acc[r] *= __shfl(alpha, d, 64);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[u], vv[u], acc, 0, 0, 0);
-            ssum += kv[u];
+            const float e = expf(kx[u] - mrun);  // exp(-inf) = 0 for pixels past the chunk
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e, vv[u], acc, 0, 0, 0);
+            ssum += e;
         }
     }
     ssum += __shfl_xor(ssum, 32, 64);
+    // merge the four waves: M = max_w m_w, scale wave w by exp(m_w - M)
+    if (h == 0) red[wave][1024 + 32 + l31] = mrun;
+    __syncthreads();
+    float mblk = fmaxf(fmaxf(red[0][1024 + 32 + l31], red[1][1024 + 32 + l31]),
+                       fmaxf(red[2][1024 + 32 + l31], red[3][1024 + 32 + l31]));
+    const float wscale = mrun == -INFINITY ? 0.f : expf(mrun - mblk);  // a wave without pixels contributes nothing
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
-        red[wave][d * 32 + l31] = acc[r];
+        red[wave][d * 32 + l31] = acc[r] * __shfl(wscale, d, 64);
     }
-    if (h == 0) red[wave][1024 + l31] = ssum;
+    if (h == 0) red[wave][1024 + l31] = ssum * wscale;
     __syncthreads();
     float* oc = pctx + ((size_t)bh * nch + ch) * 1024;
     for (int i = threadIdx.x; i < 1024; i += 256) oc[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
     if (threadIdx.x < 32) {
         const int i = 1024 + threadIdx.x;
         psum[((size_t)bh * nch + ch) * 32 + threadIdx.x] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        pmax[((size_t)b * nch + ch) * kHid + head * kDh + threadIdx.x] = mblk;
     }
 }
 
 __global__ __launch_bounds__(1024) void attn_ctx_finalize_kernel(const float* __restrict__ pctx,
                                                                  const float* __restrict__ psum,
+                                                                 const float* __restrict__ pmax,
                                                                  float* __restrict__ ctx, const int nch,
                                                                  const float inv_n, const float scale) {
     const int bh = blockIdx.x;
+    const int b = bh >> 2, head = bh & 3;
     const int i = threadIdx.x;  // d*32 + e
     const int d = i >> 5;
+    float mx = -INFINITY;
+    for (int c = 0; c < nch; ++c) mx = fmaxf(mx, pmax[((size_t)b * nch + c) * kHid + head * kDh + d]);
     float s = 0.f, z = 0.f;
     for (int c = 0; c < nch; ++c) {
-        s += pctx[((size_t)bh * nch + c) * 1024 + i];
-        z += psum[((size_t)bh * nch + c) * 32 + d];
+        const float w = expf(pmax[((size_t)b * nch + c) * kHid + head * kDh + d] - mx);
+        s += pctx[((size_t)bh * nch + c) * 1024 + i] * w;
+        z += psum[((size_t)bh * nch + c) * 32 + d] * w;
     }
     ctx[(size_t)bh * 1024 + i] = s / z * inv_n * scale;
 }
@@ -809,10 +820,9 @@ static void linear_attention_t(const T* qkv, T* out, int B, int N, const AttnWor
     const int len = attn_chunk_len(N);
     const int nch = attn_num_chunks(N);
     if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
-    hipLaunchKernelGGL(attn_kmax_kernel<T>, dim3(nch, B), dim3(256), 0, s, qkv, ws.pmax, N, len, nch);
     hipLaunchKernelGGL(attn_ctx_partial_kernel<T>, dim3(nch, B * kHeads), dim3(256), 0, s, qkv, ws.pmax, ws.pctx, ws.psum,
                        N, len, nch);
-    hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, ws.pctx, ws.psum, ws.ctx, nch,
+    hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
                        1.0f / (float)N, 1.0f / sqrtf((float)kDh));
     const int tiles = (N + 31) / 32;
     hipLaunchKernelGGL(attn_out_kernel<T>, dim3((tiles + kOutTilesPerBlock - 1) / kOutTilesPerBlock, B), dim3(256), 0, s,

@@ -52,6 +52,8 @@ enum {
     IRSDE_FLAG_BF16_ACT = 128,       /* IRSDE_FLAG_BF16 plus bf16 storage of every activation tensor between the prepped input
                                         and eps_hat (conditional ConditionalUNet only): halves the HBM/L2 traffic of the
                                         bandwidth-bound layers; LayerNorm / attention / epilogue arithmetic stays fp32 */
+    IRSDE_FLAG_NO_FUSED_LN = 256,    /* keep LinearAttention.to_out's LayerNorm + residual as a separate kernel (default: fused into the
+                                        1x1 conv's epilogue when the channel row fits one tile, C = 64 or 128) */
     IRSDE_FLAG_NAF_INTRO_SKIP = 64,  /* ConditionalNAFNet of the latent tasks (codes/config/latent-dehazing/models/modules/
                                         DenoisingNAFNet_arch.py:162-176): ending(x + intro(x)) instead of ending(x) */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
