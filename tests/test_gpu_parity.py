@@ -260,6 +260,26 @@ def test_unet_bf16_act_mode(golden):
         assert relerr(mk.debug_tap(name).numpy(), taps[name]) < 2e-2, name
 
 
+def test_unet_bf16_act_batch_and_padding_properties():
+    """bf16-storage mode on a reflect-padded odd size with per-image timesteps ([B] tensor -> per-sample FiLM rows in the
+    halo / generic / split-K epilogues): image b of the batch agrees with the single-image call with scalar t, and the result
+    stays close to fp32."""
+    B, H, W = 3, 40, 56
+    m, _ = make_model(64, 4)
+    m.set_compute_dtype("bf16_act")
+    m32, _ = model(64, 4)
+    lq, xT = O.synth_inputs(77, B, H, W)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    ts = torch.tensor([5, 60, 99])
+    yb = m(x, c, ts).cpu().numpy()
+    assert np.isfinite(yb).all()
+    for b in range(B):
+        y1 = m(x[b:b + 1], c[b:b + 1], int(ts[b])).cpu().numpy()
+        assert relerr(y1, yb[b:b + 1]) < 2e-2   # tile geometry (hence fp32 summation order + bf16 flips) differs with B
+    y32 = m32(x, c, ts).cpu().numpy()
+    assert relerr(yb, y32) < 5e-2
+
+
 def test_unet_bf16_mode(golden):
     """BASELINE configs[2]: bf16 conv operands.  (a) the engine follows the oracle's restatement of the mode (operands
     rounded, everything else full precision) to 2e-2 of max|ref| — a value that sits on a bf16 rounding boundary may
