@@ -91,3 +91,34 @@ def test_single_process_passthrough():
     x = torch.ones(3, 3, 2, 2)
     out = P.sample_sharded(sde, "sde", x, x)
     assert out.shape == x.shape and sde.calls == 1
+
+
+def _metrics_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0 evaluated 3 images, rank 1 two: the dataset average is the count-weighted mean, not the mean of means
+        local = {"psnr": np.array([30.0, 31.0, 32.0]) if rank == 0 else np.array([20.0, 21.0]),
+                 "ssim": np.array([0.9, 0.8, 0.7]) if rank == 0 else np.array([0.5, 0.6])}
+        q.put((rank, P.metrics.reduce_metrics(local)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduce_metrics_world2_gloo():
+    """The optional scalar reduction of the evaluation tail: sum/count all_reduce across ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metrics_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert abs(res[r]["psnr"] - (30 + 31 + 32 + 20 + 21) / 5) < 1e-12
+        assert abs(res[r]["ssim"] - (0.9 + 0.8 + 0.7 + 0.5 + 0.6) / 5) < 1e-12
+    assert P.metrics.reduce_metrics({"psnr": np.array([1.0, 3.0])})["psnr"] == 2.0  # single process

@@ -156,3 +156,39 @@ def test_create_model_boundary_without_gpu():
     with pytest.raises(Exception):
         P.create_model(opt)  # .to('cuda') fails loudly on a CPU-only box; no silent CPU model
     assert P.define_G(opt).__class__.__name__ == "ConditionalUNet"
+
+
+def test_latent_modules_are_reference_compatible():
+    """latent.UNet / latent.ConditionalNAFNet own exactly the reference's parameters (nasde.yml: 69 and 668 tensors)."""
+    m = P.latent.UNet(in_ch=3, out_ch=3, ch=8, ch_mult=[4, 8, 8, 16], embed_dim=8)
+    sd, sh = m.state_dict(), O.latent_unet_param_shapes(3, 3, 8, (4, 8, 8, 16), 8)
+    assert len(sd) == 69 and set(sd) == set(sh) and all(tuple(sd[k].shape) == tuple(sh[k]) for k in sh)
+    m = P.latent.UNet(in_ch=3, out_ch=3, ch=64, ch_mult=[1, 2, 4], embed_dim=4)   # latent-bokeh refusion.yml network_L
+    sh = O.latent_unet_param_shapes(3, 3, 64, (1, 2, 4), 4)
+    assert set(m.state_dict()) == set(sh)
+    n = P.latent.ConditionalNAFNet(img_channel=8, width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+    sh = O.naf_param_shapes(8, 64, 1, (1, 1, 1, 28), (1, 1, 1, 1))
+    sd = n.state_dict()
+    assert len(sd) == 668 and set(sd) == set(sh) and all(tuple(sd[k].shape) == tuple(sh[k]) for k in sh)
+    with pytest.raises(P.IrsdeError):
+        P.latent.UNet().decode(torch.zeros(1, 4, 8, 8), [])       # decode before encode / CPU tensors: loud, no fallback
+    with pytest.raises(P.IrsdeError):
+        P.latent.UNet().encode(torch.zeros(1, 3, 16, 16))
+
+
+def test_compute_dtype_flags_and_metrics_fail_loudly_on_cpu():
+    from image_restoration_sde_amd import _lib
+    m = P.ConditionalUNet(3, 3, 32, depth=2)
+    assert m.engine_flags == 0
+    m.set_compute_dtype("bf16")
+    assert m.engine_flags == _lib.FLAG_BF16
+    m.set_compute_dtype("bf16_act")
+    assert m.engine_flags == _lib.FLAG_BF16 | _lib.FLAG_BF16_ACT
+    m.set_compute_dtype("fp32")
+    assert m.engine_flags == 0
+    with pytest.raises(P.IrsdeError):
+        m.set_compute_dtype("fp8")
+    with pytest.raises(P.IrsdeError):
+        P.metrics.evaluate_batch(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
+    with pytest.raises(P.IrsdeError):
+        P.metrics.tensor2img(torch.zeros(3, 16, 16))
