@@ -101,8 +101,8 @@ def main():
     if a.model == "latent":  # latent-bokeh/options/bokeh/test/refusion.yml: UNet ch 64 [1,2,4] embed 4 (256^2 -> 64x64x4) + NAFNet
         ncfg = dict(width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
         params = O.naf_synth_params(seed=0, img_channel=4, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28),
-                                    dec_blk_nums=(1, 1, 1, 1))
-        model = P.latent.ConditionalNAFNet(img_channel=4, **ncfg)
+                                    dec_blk_nums=(1, 1, 1, 1), lens=True)
+        model = P.latent_bokeh.ConditionalNAFNet(img_channel=4, **ncfg)   # lens-conditioned (lens_info kwargs)
         latent_model = P.latent.UNet(in_ch=3, out_ch=3, ch=64, ch_mult=[1, 2, 4], embed_dim=4)
         latent_model.load_state_dict({k: torch.from_numpy(v) for k, v in
                                       O.latent_unet_synth_params(seed=1, in_ch=3, out_ch=3, ch=64, ch_mult=(1, 2, 4), embed_dim=4).items()})
@@ -147,10 +147,13 @@ def main():
     elif a.model == "latent":  # latent-dehazing/test.py:90-100: encode once, sample in the latent, decode once
         sample = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[a.mode]
 
+        lens_rs = np.random.RandomState(5 + rank)   # per image: src_lens, tgt_lens, disparity (latent-bokeh/test.py:91)
+        lens_info = [torch.from_numpy(lens_rs.uniform(lo, hi, a.batch).astype(np.float32)) for lo, hi in ((1.4, 2.8), (1.8, 16.0), (0.0, 100.0))]
+
         def fn(_unused):
             latent_LQ, hidden = latent_model.encode(mu)
             sde.set_mu(latent_LQ)
-            return latent_model.decode(sample(sde.noise_state(latent_LQ)), hidden)
+            return latent_model.decode(sample(sde.noise_state(latent_LQ), lens_info=lens_info), hidden)
     else:
         sde.set_mu(mu)
         fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[a.mode]
@@ -200,7 +203,7 @@ def main():
                                           "bf16_act": "bf16 operands + bf16 activation storage / f32 accumulate+state"}[a.dtype], "data": "synthetic",
             "config": {"workload": ("denoising-sde unconditional UNet nf=64 depth=4 (full attention at the bottleneck), DenoisingSDE reverse_%s from the "
                                     "optimal timestep of sigma=25 (" + str(n_evals) + " network evaluations), batch=%d/GPU %dx%d, schedule T=%d, fp32"
-                                    if a.model == "dsde" else "Latent-Refusion: latent UNet ch=64 [1,2,4] embed 4 (encode + decode once per image) + latent ConditionalNAFNet "
+                                    if a.model == "dsde" else "Latent-Refusion (latent-bokeh): latent UNet ch=64 [1,2,4] embed 4 (encode + decode once per image) + lens-conditioned ConditionalNAFNet "
                                     "width=64 enc[1,1,1,28] on the 64x64x4 latent, reverse_%s, batch=%d/GPU %dx%d, T=%d (BASELINE.json configs[4] shape)"
                                     if a.model == "latent" else "Refusion ConditionalNAFNet width=64 enc[1,1,1,28], reverse_%s, batch=%d/GPU %dx%d, T=%d, fp32 "
                                     "(BASELINE.json configs[3] network)" if a.model == "nafnet" else

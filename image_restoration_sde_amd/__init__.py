@@ -23,7 +23,8 @@ from . import denoising_sde  # noqa: F401
 from .denoising_sde import DenoisingSDE  # noqa: F401
 from . import metrics  # noqa: F401
 from . import latent  # noqa: F401
+from . import latent_bokeh  # noqa: F401
 from .latent import LatentDenoisingModel  # noqa: F401
 
-__all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "metrics", "latent", "LatentDenoisingModel", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
+__all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "metrics", "latent", "latent_bokeh", "LatentDenoisingModel", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
            "IrsdeError", "IrsdeLibraryError", "shard_bounds", "gather_batch", "sample_sharded"]

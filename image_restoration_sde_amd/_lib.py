@@ -23,6 +23,7 @@ FLAG_BF16 = 32
 FLAG_NAF_INTRO_SKIP = 64
 FLAG_BF16_ACT = 128
 FLAG_NO_FUSED_LN = 256
+FLAG_NAF_LENS = 512
 SAMPLE_GRAPH = 1
 SAMPLE_PROFILE = 2
 
@@ -33,7 +34,7 @@ SYMBOLS = [
     "irsde_set_schedule", "irsde_unet_forward", "irsde_sample", "irsde_sde_step", "irsde_philox_normal",
     "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv", "irsde_plan_describe", "irsde_bench_conv", "irsde_op_profile",
     "irsde_eval_metrics", "irsde_tensor2img",
-    "irsde_create_latent_unet", "irsde_latent_shapes", "irsde_latent_encode", "irsde_latent_decode",
+    "irsde_set_lens_info", "irsde_create_latent_unet", "irsde_latent_shapes", "irsde_latent_encode", "irsde_latent_decode",
 ]
 
 
@@ -111,6 +112,7 @@ def _declare(lib):
     lib.irsde_bench_conv.argtypes = [c.c_int] * 11 + [c.POINTER(c.c_double)]
     lib.irsde_eval_metrics.argtypes = [P, P, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double), P]
     lib.irsde_tensor2img.argtypes = [P, P, c.c_int, c.c_int, c.c_int, c.c_int, P]
+    lib.irsde_set_lens_info.argtypes = [P, c.POINTER(c.c_float), c.c_int]
     lib.irsde_create_latent_unet.argtypes = [c.POINTER(LatentConfig), c.POINTER(P)]
     lib.irsde_latent_shapes.argtypes = [P, c.c_int, c.c_int, c.POINTER(c.c_int64), c.POINTER(c.c_int64), c.POINTER(c.c_int)]
     lib.irsde_latent_encode.argtypes = [P, P, c.c_int, c.c_int, c.c_int, P, c.POINTER(P), P]

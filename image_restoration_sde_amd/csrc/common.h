@@ -61,6 +61,8 @@ struct ConvParams {
     const float* in_scale = nullptr;  // [B][C0]: input element (b, k) is multiplied by in_scale[b][k] while staged (SCA)
     int gate = 0;      // SimpleGate epilogue: weight rows are interleaved (2j <- j, 2j+1 <- j + Cout/2); writes the Cout/2
                        // products out[m][j] = v[2j] * v[2j+1]  (out_stride counts the gated width)
+    const float* gate_film = nullptr;  // gate epilogue only: product j *= (gate_film[b][j] + 1), += gate_film[b][Cout/2 + j]
+    int gate_film_bstride = 0;         // floats between the rows of different batch items (latent-bokeh lens FiLM)
     int shuffle = 0;   // PixelShuffle(2) epilogue: weight rows ordered n' = (dy*2+dx)*Cout/4 + co; writes (and adds res at)
                        // out[b][2y+dy][2x+dx][co]  (out/res tensors are [B][2Ho][2Wo][Cout/4])
     // batched launch (Winograd: 16 independent GEMMs): blockIdx.z = k offsets the three tensors (floats)

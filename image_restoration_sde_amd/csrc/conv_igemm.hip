@@ -419,7 +419,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
             }
             if (p.gate) {  // SimpleGate: pairs are adjacent by construction of the packed weights
                 float* dst = p.out + opix * p.out_stride + ocol;
-                *reinterpret_cast<float2*>(dst) = make_float2(v[0] * v[1], v[2] * v[3]);
+                float g0 = v[0] * v[1], g1 = v[2] * v[3];
+                if (p.gate_film) {  // per-image FiLM on the gated channels (latent-bokeh cam_mlp)
+                    const float* f = p.gate_film + (size_t)(m / HW) * p.gate_film_bstride;
+                    const int ch = p.Cout >> 1;
+                    g0 = g0 * (f[ocol] + 1.0f) + f[ch + ocol];
+                    g1 = g1 * (f[ocol + 1] + 1.0f) + f[ch + ocol + 1];
+                }
+                *reinterpret_cast<float2*>(dst) = make_float2(g0, g1);
                 continue;
             }
             if (BF16 && p.out_bf16) {  // bf16 activation storage: residual and output tensors are bf16

@@ -72,6 +72,8 @@ struct NafBlockW {
     float *beta = nullptr, *gamma = nullptr;
     float *mlp_w = nullptr, *mlp_b = nullptr;    // mlp.1: Linear(time_dim/2, 4c)
     int film_off = 0;                            // [shift_att | scale_att | shift_ffn | scale_ffn]
+    float *cam_w = nullptr, *cam_b = nullptr;    // latent-bokeh: cam_mlp.1: Linear(time_dim/2, 2c)
+    int cam_off = 0;                             // [cam_scale | cam_shift] inside a row of the lens table
 };
 
 enum OpKind { OP_CONV = 0, OP_LN = 1, OP_ATTN = 2, OP_OTHER = 3, OP_WINO = 4, OP_NKINDS = 5 };
@@ -220,6 +222,12 @@ struct irsde_engine {
     std::vector<ConvW> naf_downs, naf_ups;
     ConvW naf_intro, naf_ending;
     std::vector<NafBlockW*> naf_all;
+    // latent-bokeh variant (IRSDE_FLAG_NAF_LENS): lens-information FiLM, one row per image of the batch
+    float *cm_w1 = nullptr, *cm_b1 = nullptr, *cm_w3 = nullptr, *cm_b3 = nullptr;  // cam_mlp.0 / cam_mlp.2
+    int cam_row = 0;            // sum over blocks of 2c
+    float* cam_cur = nullptr;   // [cam_rows][cam_row]
+    int cam_rows = 0;           // capacity (images)
+    int cam_set = 0;            // images covered by the last irsde_set_lens_info
 
     // latent UNet (arch == 2): codes/config/latent-dehazing/models/modules/UNet_arch.py
     int lat_in = 0, lat_out = 0, lat_ch = 0, lat_embed = 0;
@@ -426,10 +434,18 @@ AttnW pack_attn(irsde_engine* e, const std::string& p) {
 // ---------------------------------------------------------------------------------------------
 // ConditionalNAFNet (Refusion): inventory, packing — DenoisingNAFNet_arch.py:85-147
 // ---------------------------------------------------------------------------------------------
+inline bool naf_lens(const irsde_engine* e) { return (e->cfg.flags & IRSDE_FLAG_NAF_LENS) != 0; }
+
 void inv_nafblock(irsde_engine* e, const std::string& p, int c) {
     const int td = e->time_dim;
-    add_w(e, p + "mlp.1.weight", {4 * c, td / 2});
-    add_w(e, p + "mlp.1.bias", {4 * c});
+    // latent-bokeh names the block's time MLP `time_mlp` and adds `cam_mlp` (latent-bokeh DenoisingNAFNet_arch.py:18-24)
+    const std::string tm = naf_lens(e) ? "time_mlp.1." : "mlp.1.";
+    add_w(e, p + tm + "weight", {4 * c, td / 2});
+    add_w(e, p + tm + "bias", {4 * c});
+    if (naf_lens(e)) {
+        add_w(e, p + "cam_mlp.1.weight", {2 * c, td / 2});
+        add_w(e, p + "cam_mlp.1.bias", {2 * c});
+    }
     add_w(e, p + "conv1.weight", {2 * c, c, 1, 1});
     add_w(e, p + "conv1.bias", {2 * c});
     add_w(e, p + "conv2.weight", {2 * c, 1, 3, 3});
@@ -449,10 +465,18 @@ void inv_nafblock(irsde_engine* e, const std::string& p, int c) {
 }
 void build_inventory_naf(irsde_engine* e) {
     const int width = e->cfg.nf, ic = e->cfg.in_nc, td = e->time_dim;
-    add_w(e, "time_mlp.1.weight", {td * 2, width});
-    add_w(e, "time_mlp.1.bias", {td * 2});
-    add_w(e, "time_mlp.3.weight", {td, td});
-    add_w(e, "time_mlp.3.bias", {td});
+    // latent-bokeh keeps SinusoidalPosEmb outside the Sequential: indices 0 / 2 instead of 1 / 3 (:103-108)
+    const std::string t1 = naf_lens(e) ? "time_mlp.0." : "time_mlp.1.", t3 = naf_lens(e) ? "time_mlp.2." : "time_mlp.3.";
+    add_w(e, t1 + "weight", {td * 2, width});
+    add_w(e, t1 + "bias", {td * 2});
+    add_w(e, t3 + "weight", {td, td});
+    add_w(e, t3 + "bias", {td});
+    if (naf_lens(e)) {
+        add_w(e, "cam_mlp.0.weight", {td * 2, 3 * width});
+        add_w(e, "cam_mlp.0.bias", {td * 2});
+        add_w(e, "cam_mlp.2.weight", {td, td});
+        add_w(e, "cam_mlp.2.bias", {td});
+    }
     add_w(e, "intro.weight", {width, 2 * ic, 3, 3});
     add_w(e, "intro.bias", {width});
     add_w(e, "ending.weight", {ic, width, 3, 3});
@@ -524,17 +548,29 @@ NafBlockW pack_nafblock(irsde_engine* e, const std::string& p, int c) {
     b.sca_b = e->upload(need(e, p + "sca.1.bias").data);
     b.beta = e->upload(need(e, p + "beta").data);
     b.gamma = e->upload(need(e, p + "gamma").data);
-    b.mlp_w = e->upload(need(e, p + "mlp.1.weight").data);
-    b.mlp_b = e->upload(need(e, p + "mlp.1.bias").data);
+    const std::string tm = naf_lens(e) ? "time_mlp.1." : "mlp.1.";
+    b.mlp_w = e->upload(need(e, p + tm + "weight").data);
+    b.mlp_b = e->upload(need(e, p + tm + "bias").data);
+    if (naf_lens(e)) {
+        b.cam_w = e->upload(need(e, p + "cam_mlp.1.weight").data);
+        b.cam_b = e->upload(need(e, p + "cam_mlp.1.bias").data);
+    }
     return b;
 }
 
 void finalize_naf(irsde_engine* e) {
     const int width = e->cfg.nf, ic = e->cfg.in_nc;
-    e->tm_w1 = e->upload(need(e, "time_mlp.1.weight").data);
-    e->tm_b1 = e->upload(need(e, "time_mlp.1.bias").data);
-    e->tm_w3 = e->upload(need(e, "time_mlp.3.weight").data);
-    e->tm_b3 = e->upload(need(e, "time_mlp.3.bias").data);
+    const std::string t1 = naf_lens(e) ? "time_mlp.0." : "time_mlp.1.", t3 = naf_lens(e) ? "time_mlp.2." : "time_mlp.3.";
+    e->tm_w1 = e->upload(need(e, t1 + "weight").data);
+    e->tm_b1 = e->upload(need(e, t1 + "bias").data);
+    e->tm_w3 = e->upload(need(e, t3 + "weight").data);
+    e->tm_b3 = e->upload(need(e, t3 + "bias").data);
+    if (naf_lens(e)) {
+        e->cm_w1 = e->upload(need(e, "cam_mlp.0.weight").data);
+        e->cm_b1 = e->upload(need(e, "cam_mlp.0.bias").data);
+        e->cm_w3 = e->upload(need(e, "cam_mlp.2.weight").data);
+        e->cm_b3 = e->upload(need(e, "cam_mlp.2.bias").data);
+    }
     {
         const int half = width / 2;
         std::vector<float> f(half);
@@ -584,12 +620,15 @@ void finalize_naf(irsde_engine* e) {
     for (auto& v : e->naf_enc) for (auto& b : v) e->naf_all.push_back(&b);
     for (auto& b : e->naf_mid) e->naf_all.push_back(&b);
     for (auto& v : e->naf_dec) for (auto& b : v) e->naf_all.push_back(&b);
-    int off = 0;
+    int off = 0, coff = 0;
     for (NafBlockW* b : e->naf_all) {
         b->film_off = off;
         off += 4 * b->c;
+        b->cam_off = coff;
+        coff += 2 * b->c;
     }
     e->film_row = off;
+    e->cam_row = coff;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1011,6 +1050,7 @@ struct Builder {
         const Tensor* res = nullptr;
         const float* ch_scale = nullptr;
         const float* in_scale = nullptr;
+        const float* gate_film = nullptr;
         int gate = 0, shuffle = 0, out_stride = 0;
     };
     // 1x1 / KxK conv with the NAFNet fusions (bias from the ConvW; no FiLM / SiLU in NAFNet convs)
@@ -1033,6 +1073,7 @@ struct Builder {
         p.out = out.p; p.out_stride = out.C;
         p.bias = w.bias;
         p.ch_scale = o.ch_scale; p.in_scale = o.in_scale; p.gate = o.gate; p.shuffle = o.shuffle;
+        p.gate_film = o.gate_film; p.gate_film_bstride = o.gate_film ? e->cam_row : 0;
         if (o.res) { p.res = o.res->p; p.res_stride = o.res->C; }
         push_conv(p);
         return out;
@@ -1083,6 +1124,7 @@ struct Builder {
         }
         ConvOpts o4;
         o4.gate = 1;
+        if (naf_lens(e)) o4.gate_film = e->cam_cur + w.cam_off;  // x * (cam_scale + 1) + cam_shift after the gate (:82-83)
         Tensor v = conv_naf(w.conv4, t2, o4);
         tfree(t2);
         ConvOpts o5;
@@ -1268,6 +1310,10 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
         e->plans.erase(e->plans.begin() + lru);
     }
     ensure_film_cur(e, per_sample_film ? B : 1);
+    if (naf_lens(e)) {
+        if (e->cam_set < B) throw HipError("latent-bokeh ConditionalNAFNet: irsde_set_lens_info must cover the batch first");
+        if (e->cam_rows < B) throw HipError("internal: lens table smaller than the batch");
+    }
 
     const int depth = e->cfg.depth, nf = e->cfg.nf, in_nc = e->cfg.in_nc;
     const int sdiv = 1 << depth;
@@ -2142,6 +2188,44 @@ int irsde_latent_decode(irsde_engine* e, const float* latent, const float* const
         launch_unpack_pred(lp->image.p, out, B, e->lat_out, H, W, pl->Hp, pl->Wp, 4, s);  // x[..., :H, :W]
         IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
         IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+    });
+}
+
+int irsde_set_lens_info(irsde_engine* e, const float* info, int B) {
+    return guard([&] {
+        if (!e || !info || B < 1) throw HipError("null argument");
+        if (e->arch != 1 || !naf_lens(e)) throw HipError("set_lens_info: not a latent-bokeh ConditionalNAFNet engine");
+        if (!e->finalized) throw HipError("set_lens_info: weights not finalized");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t s = e->stream;
+        if (e->cam_rows < B) {  // plans bake the table pointer: drop them when it moves
+            IRSDE_HIP_CHECK(hipDeviceSynchronize());
+            e->plans.clear();
+            e->cam_cur = e->dmalloc((size_t)B * e->cam_row);
+            e->cam_rows = B;
+        }
+        const int width = e->cfg.nf, td = e->time_dim;
+        // cam_embed = cam_mlp(cat_i SinusoidalPosEmb(lens_info_i))  (:172-173); rows b*3+i of the sinusoid table are row b
+        float *dv = nullptr, *emb = nullptr, *w1 = nullptr, *g1 = nullptr, *h2 = nullptr, *g2 = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&dv, (size_t)B * 3 * 4));
+        IRSDE_HIP_CHECK(hipMemcpy(dv, info, (size_t)B * 3 * 4, hipMemcpyHostToDevice));
+        IRSDE_HIP_CHECK(hipMalloc(&emb, (size_t)B * 3 * width * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&w1, (size_t)B * 2 * td * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&g1, (size_t)B * td * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&h2, (size_t)B * td * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&g2, (size_t)B * (td / 2) * 4));
+        launch_sinusoid(dv, e->freqs, emb, B * 3, width / 2, s);
+        launch_row_linear(emb, 3 * width, e->cm_w1, e->cm_b1, w1, 2 * td, B, 3 * width, 2 * td, ACT_NONE, ACT_NONE, s);
+        launch_row_gate(w1, g1, B, td, s);
+        launch_row_linear(g1, td, e->cm_w3, e->cm_b3, h2, td, B, td, td, ACT_NONE, ACT_NONE, s);
+        launch_row_gate(h2, g2, B, td / 2, s);  // the block's cam_mlp starts with SimpleGate (:22-24)
+        for (NafBlockW* b : e->naf_all)
+            launch_row_linear(g2, td / 2, b->cam_w, b->cam_b, e->cam_cur + b->cam_off, e->cam_row, B, td / 2, 2 * b->c, ACT_NONE,
+                              ACT_NONE, s);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+        for (float* q : {dv, emb, w1, g1, h2, g2}) (void)hipFree(q);
+        e->cam_set = B;
     });
 }
 

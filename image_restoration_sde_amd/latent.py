@@ -137,11 +137,15 @@ class ConditionalNAFNet(_ImageNAFNet):
 
 
 def define_G(opt):
-    """latent-dehazing/models/networks.py: network_G.which_model looked up by name."""
+    """latent-*/models/networks.py: network_G.which_model looked up by name in the task's own modules package — the
+    latent-bokeh task (`distortion: bokeh`, options/bokeh/test/refusion.yml:4) has the lens-conditioned ConditionalNAFNet."""
     o = opt["network_G"]
     name = o.get("which_model", o.get("which_model_G"))
     if name != "ConditionalNAFNet":
         raise NotImplementedError("latent score network [%s] is not built (ConditionalNAFNet only)" % name)
+    if opt.get("distortion") == "bokeh":
+        from .latent_bokeh import ConditionalNAFNet as BokehNAFNet
+        return BokehNAFNet(**o["setting"])
     return ConditionalNAFNet(**o["setting"])
 
 
@@ -169,19 +173,24 @@ class LatentDenoisingModel:
         self.encode = self.latent_model.encode
         self.decode = self.latent_model.decode
 
-    def feed_data(self, state, LQ, GT=None):
+    def feed_data(self, state, LQ, GT=None, src_lens=None, tgt_lens=None, disparity=None, alpha=None):
+        """latent-dehazing :146-152; latent-bokeh adds the lens triple (:143-153)."""
         self.state = state.to(self.device)
         self.condition = LQ.to(self.device)
         self.state_0 = GT.to(self.device) if GT is not None else None
+        self.src_lens, self.tgt_lens, self.disparity, self.alpha = src_lens, tgt_lens, disparity, alpha
 
     def test(self, sde=None, hidden=None, perform_ode=False, save_states=False):
         sde.set_mu(self.condition)
+        kw = {}
+        if getattr(self, "src_lens", None) is not None:  # latent-bokeh :183-189 (there only reverse_sde gets the kwargs; the
+            kw["lens_info"] = [self.src_lens, self.tgt_lens, self.disparity]  # ODE branch would fail without them)
         self.model.eval()
         with torch.no_grad():
             if not perform_ode:
-                latent = sde.reverse_sde(self.state, save_states=save_states)
+                latent = sde.reverse_sde(self.state, save_states=save_states, **kw)
             else:
-                latent = sde.reverse_ode(self.state, save_states=save_states)
+                latent = sde.reverse_ode(self.state, save_states=save_states, **kw)
             self.output = self.decode(latent, hidden)
         self.model.train()
 

@@ -157,8 +157,12 @@ class IRSDE:
         out = torch.empty_like(x_in)
         z, _ = self._noise_ptr(x_in, mode != "ode")
         zp = ctypes.c_void_p(z.data_ptr()) if z is not None else None
-        eng = None if kwargs else self._engine_for(x_in)
         B, C, H, W = x_in.shape
+        if set(kwargs) == {"lens_info"} and hasattr(_unwrap(self.model), "set_lens_info"):
+            # latent-bokeh: the lens FiLM is constant over the loop -> evaluate it once and stay on the engine path
+            _unwrap(self.model).set_lens_info(kwargs["lens_info"], B, x_in.device)
+            kwargs = {}
+        eng = None if kwargs else self._engine_for(x_in)
         L = _lib.lib()
         interval = max(self.T // 100, 1)
         with torch.cuda.device(xt.device):

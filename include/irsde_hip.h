@@ -54,6 +54,9 @@ enum {
                                         bandwidth-bound layers; LayerNorm / attention / epilogue arithmetic stays fp32 */
     IRSDE_FLAG_NO_FUSED_LN = 256,    /* keep LinearAttention.to_out's LayerNorm + residual as a separate kernel (default: fused into the
                                         1x1 conv's epilogue when the channel row fits one tile, C = 64 or 128) */
+    IRSDE_FLAG_NAF_LENS = 512,       /* ConditionalNAFNet of latent-bokeh (codes/config/latent-bokeh/models/modules/DenoisingNAFNet_arch.py):
+                                        time_mlp.{0,2} / block time_mlp.1 names, a lens-information embedding (cam_mlp) and a
+                                        per-block FiLM on the gated FFN activation; needs irsde_set_lens_info before forward/sample */
     IRSDE_FLAG_NAF_INTRO_SKIP = 64,  /* ConditionalNAFNet of the latent tasks (codes/config/latent-dehazing/models/modules/
                                         DenoisingNAFNet_arch.py:162-176): ending(x + intro(x)) instead of ending(x) */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
@@ -219,6 +222,12 @@ int irsde_latent_encode(irsde_engine* e, const float* x, int B, int H, int W, fl
                         void* stream);
 int irsde_latent_decode(irsde_engine* e, const float* latent, const float* const* hidden, int B, int H, int W, float* out,
                         void* stream);
+
+/* latent-bokeh only (IRSDE_FLAG_NAF_LENS): replaces the `lens_info` kwargs of ConditionalNAFNet.forward(inp, cond, time,
+ * lens_info=[src_lens, tgt_lens, disparity]) that latent_denoising_model.py:183-189 threads through sde.reverse_sde(**kwargs).
+ * info: HOST [B][3] = (src_lens, tgt_lens, disparity) of every image; evaluates cam_mlp and every block's cam_mlp once; the
+ * rows stay valid for all following forward / sample calls with batch <= B. */
+int irsde_set_lens_info(irsde_engine* e, const float* info, int B);
 
 /* Evaluation tail on the device — replaces, per image of a batch, the metric block of
  * codes/config/deraining/test.py:131-178: util.tensor2img on output and GT (codes/utils/img_utils.py:136-163),

@@ -396,6 +396,32 @@ def gen_latent(sde_utils, ref_root):
             out["pipe/latent_" + mode] = x0.numpy()
             out["pipe/out_" + mode] = unet.decode(x0, hid).numpy()
     out["pipe/z0"], out["pipe/T"] = z0, np.array(T)
+    # latent-bokeh score network: lens-conditioned ConditionalNAFNet (4 latent channels), forward + reverse_sde with kwargs
+    (nb,) = load_task_modules(os.path.join(ref_root, "codes/config/latent-bokeh"), ["DenoisingNAFNet_arch"])
+    assert "latent-bokeh" in nb.__file__
+    bcfg = dict(width=32, enc_blk_nums=[1, 2], middle_blk_num=1, dec_blk_nums=[1, 1])
+    bparams = O.naf_synth_params(seed=3, img_channel=4, width=32, middle_blk_num=1, enc_blk_nums=(1, 2), dec_blk_nums=(1, 1), lens=True)
+    bnet = nb.ConditionalNAFNet(img_channel=4, **bcfg).eval()
+    assert set(bnet.state_dict()) == set(bparams), set(bnet.state_dict()) ^ set(bparams)
+    bnet.load_state_dict({k: torch.from_numpy(v) for k, v in bparams.items()}, strict=True)
+    rs = np.random.RandomState(12)
+    cond = rs.standard_normal((2, 4, 12, 10)).astype(np.float32)
+    xt = (cond + 0.2 * rs.standard_normal(cond.shape)).astype(np.float32)
+    lens = np.array([[1.8, 16.0, 30.0], [2.0, 8.0, 75.5]], dtype=np.float32)   # per image: src_lens, tgt_lens, disparity
+    out["bokeh/cond"], out["bokeh/xt"], out["bokeh/lens"] = cond, xt, lens
+    with torch.no_grad():
+        li = [torch.from_numpy(lens[:, i].copy()) for i in range(3)]
+        out["bokeh/tvec"] = bnet(torch.from_numpy(xt), torch.from_numpy(cond), torch.tensor([5, 60]), lens_info=li).numpy()
+        li1 = [torch.from_numpy(lens[:1, i].copy()) for i in range(3)]                     # test.py path: int time, one image
+        out["bokeh/t33"] = bnet(torch.from_numpy(xt[:1]), torch.from_numpy(cond[:1]), 33, lens_info=li1).numpy()
+        Tb = 10
+        zb = O.synth_noise(9, Tb, (1, 4, 12, 10))
+        sde = Inj(max_sigma=50, T=Tb, schedule="cosine", eps=0.005, device="cpu")
+        sde.noise = torch.from_numpy(zb)
+        sde.set_model(bnet)
+        sde.set_mu(torch.from_numpy(cond[:1]))
+        out["bokeh/sde"] = sde.reverse_sde(torch.from_numpy(xt[:1]), lens_info=li1).numpy()
+    out["bokeh/T"] = np.array(Tb)
     np.savez_compressed(os.path.join(GOLD, "latent.npz"), **out)
     print("latent.npz")
 

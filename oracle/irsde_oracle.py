@@ -517,22 +517,34 @@ def device_normal(seed, t, image_index, n_elems):
 # --------------------------------------------------------------------------------------
 
 
-def naf_param_shapes(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28), dec_blk_nums=(1, 1, 1, 1)):
-    """Names/shapes of ConditionalNAFNet's state_dict — DenoisingNAFNet_arch.py:85-147 (NAFBlock :15-49)."""
+def naf_param_shapes(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28), dec_blk_nums=(1, 1, 1, 1), lens=False):
+    """Names/shapes of ConditionalNAFNet's state_dict — DenoisingNAFNet_arch.py:85-147 (NAFBlock :15-49).  lens=True: the
+    latent-bokeh variant (latent-bokeh/models/modules/DenoisingNAFNet_arch.py): time_mlp.{0,2}, cam_mlp.{0,2}, and per block
+    time_mlp.1 / cam_mlp.1 instead of mlp.1."""
     sh = {}
     td = width * 4
-    sh["time_mlp.1.weight"] = (td * 2, width)
-    sh["time_mlp.1.bias"] = (td * 2,)
-    sh["time_mlp.3.weight"] = (td, td)
-    sh["time_mlp.3.bias"] = (td,)
+    t1, t3 = ("time_mlp.0.", "time_mlp.2.") if lens else ("time_mlp.1.", "time_mlp.3.")
+    sh[t1 + "weight"] = (td * 2, width)
+    sh[t1 + "bias"] = (td * 2,)
+    sh[t3 + "weight"] = (td, td)
+    sh[t3 + "bias"] = (td,)
+    if lens:
+        sh["cam_mlp.0.weight"] = (td * 2, width * 3)
+        sh["cam_mlp.0.bias"] = (td * 2,)
+        sh["cam_mlp.2.weight"] = (td, td)
+        sh["cam_mlp.2.bias"] = (td,)
     sh["intro.weight"] = (width, img_channel * 2, 3, 3)
     sh["intro.bias"] = (width,)
     sh["ending.weight"] = (img_channel, width, 3, 3)
     sh["ending.bias"] = (img_channel,)
 
     def block(p, c):
-        sh[p + "mlp.1.weight"] = (4 * c, td // 2)
-        sh[p + "mlp.1.bias"] = (4 * c,)
+        tm = "time_mlp.1." if lens else "mlp.1."
+        sh[p + tm + "weight"] = (4 * c, td // 2)
+        sh[p + tm + "bias"] = (4 * c,)
+        if lens:
+            sh[p + "cam_mlp.1.weight"] = (2 * c, td // 2)
+            sh[p + "cam_mlp.1.bias"] = (2 * c,)
         sh[p + "conv1.weight"] = (2 * c, c, 1, 1)
         sh[p + "conv1.bias"] = (2 * c,)
         sh[p + "conv2.weight"] = (2 * c, 1, 3, 3)
@@ -603,10 +615,11 @@ def _simple_gate(x):
     return x[:, :c] * x[:, c:]
 
 
-def naf_block(p, pre, x, temb):
-    """NAFBlock.forward — DenoisingNAFNet_arch.py:56-82."""
+def naf_block(p, pre, x, temb, cam=None):
+    """NAFBlock.forward — DenoisingNAFNet_arch.py:56-82; cam (latent-bokeh :60-91): lens embedding -> FiLM after the FFN gate."""
     half = temb.shape[1] // 2
-    tt = linear(temb[:, :half] * temb[:, half:], p[pre + "mlp.1.weight"], p[pre + "mlp.1.bias"])[:, :, None, None]
+    tm = "time_mlp.1." if cam is not None else "mlp.1."
+    tt = linear(temb[:, :half] * temb[:, half:], p[pre + tm + "weight"], p[pre + tm + "bias"])[:, :, None, None]
     c = x.shape[1]
     shift_att, scale_att, shift_ffn, scale_ffn = (tt[:, i * c:(i + 1) * c] for i in range(4))
     inp = x
@@ -623,6 +636,9 @@ def naf_block(p, pre, x, temb):
     x = x * (scale_ffn + 1) + shift_ffn
     x = conv2d(x, p[pre + "conv4.weight"], p[pre + "conv4.bias"])
     x = _simple_gate(x)
+    if cam is not None:
+        cc = linear(cam[:, :half] * cam[:, half:], p[pre + "cam_mlp.1.weight"], p[pre + "cam_mlp.1.bias"])[:, :, None, None]
+        x = x * (cc[:, :c] + 1) + cc[:, c:]
     x = conv2d(x, p[pre + "conv5.weight"], p[pre + "conv5.bias"])
     return y + x * p[pre + "gamma"]
 
@@ -634,9 +650,10 @@ def _pixel_shuffle2(x):
 
 
 def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_num=1, dec_blk_nums=(1, 1, 1, 1),
-                   dtype=np.float64, taps=None, intro_skip=False):
+                   dtype=np.float64, taps=None, intro_skip=False, lens_info=None):
     """ConditionalNAFNet.forward — DenoisingNAFNet_arch.py:149-187.  intro_skip: the latent tasks' variant
-    (latent-dehazing/models/modules/DenoisingNAFNet_arch.py:162-176), `ending(x + intro(x))`."""
+    (latent-dehazing/models/modules/DenoisingNAFNet_arch.py:162-176), `ending(x + intro(x))`.  lens_info = [src_lens,
+    tgt_lens, disparity] (arrays of 1 or B values): the latent-bokeh variant (its DenoisingNAFNet_arch.py:159-198)."""
     p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
     xt = np.asarray(xt, dtype=dtype)
     cond = np.asarray(cond, dtype=dtype)
@@ -644,10 +661,19 @@ def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_n
         t = np.array([int(t)])
     x = np.concatenate([xt - cond, cond], axis=1)
     width = p["intro.weight"].shape[0]
+    lens = lens_info is not None
+    t1, t3 = ("time_mlp.0.", "time_mlp.2.") if lens else ("time_mlp.1.", "time_mlp.3.")
     temb = sinusoidal_pos_emb(t, width, dtype)
-    temb = linear(temb, p["time_mlp.1.weight"], p["time_mlp.1.bias"])
+    temb = linear(temb, p[t1 + "weight"], p[t1 + "bias"])
     h2 = temb.shape[1] // 2
-    temb = linear(temb[:, :h2] * temb[:, h2:], p["time_mlp.3.weight"], p["time_mlp.3.bias"])
+    temb = linear(temb[:, :h2] * temb[:, h2:], p[t3 + "weight"], p[t3 + "bias"])
+    cam = None
+    if lens:
+        nb = max(len(np.atleast_1d(v)) for v in lens_info)
+        emb = np.concatenate([sinusoidal_pos_emb(np.broadcast_to(np.atleast_1d(np.asarray(v, dtype=np.float64)), (nb,)), width, dtype)
+                              for v in lens_info], axis=1)
+        cam = linear(emb, p["cam_mlp.0.weight"], p["cam_mlp.0.bias"])
+        cam = linear(cam[:, :h2] * cam[:, h2:], p["cam_mlp.2.weight"], p["cam_mlp.2.bias"])
     B, C, H, W = x.shape
     ps = 2 ** len(enc_blk_nums)
     x = np.pad(x, ((0, 0), (0, 0), (0, (ps - H % ps) % ps), (0, (ps - W % ps) % ps)))  # zero pad (:189-194)
@@ -662,20 +688,20 @@ def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_n
     encs = []
     for i, num in enumerate(enc_blk_nums):
         for j in range(num):
-            x = naf_block(p, "encoders.%d.%d." % (i, j), x, temb)
+            x = naf_block(p, "encoders.%d.%d." % (i, j), x, temb, cam)
         tap("encoders.%d" % i, x)
         encs.append(x)
         x = conv2d(x, p["downs.%d.weight" % i], p["downs.%d.bias" % i], stride=2, pad=0)
         tap("downs.%d" % i, x)
     for j in range(middle_blk_num):
-        x = naf_block(p, "middle_blks.%d." % j, x, temb)
+        x = naf_block(p, "middle_blks.%d." % j, x, temb, cam)
     tap("middle", x)
     for i, num in enumerate(dec_blk_nums):
         x = _pixel_shuffle2(conv2d(x, p["ups.%d.0.weight" % i]))
         x = x + encs[len(encs) - 1 - i]
         tap("ups.%d" % i, x)
         for j in range(num):
-            x = naf_block(p, "decoders.%d.%d." % (i, j), x, temb)
+            x = naf_block(p, "decoders.%d.%d." % (i, j), x, temb, cam)
         tap("decoders.%d" % i, x)
     if intro_skip:
         x = x + intro

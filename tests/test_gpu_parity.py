@@ -850,3 +850,37 @@ def test_latent_pipeline_vs_reference_golden(golden):
         model.test(sde, hidden, perform_ode=(mode == "ode"))
         out = model.get_current_visuals(need_GT=False)["Output"].numpy()[None]
         assert relerr(out, g["pipe/out_" + mode]) < 2e-3, mode
+
+
+def test_latent_bokeh_nafnet_vs_reference_golden(golden):
+    """latent-bokeh ConditionalNAFNet (lens_info kwargs, IRSDE_FLAG_NAF_LENS): forward with per-image lens triples and [B]
+    timesteps, the reference's one-image int-time call, and reverse_sde(..., lens_info=...) on the engine fast path."""
+    g = golden.latent
+    m = P.latent_bokeh.ConditionalNAFNet(img_channel=4, width=32, enc_blk_nums=[1, 2], middle_blk_num=1, dec_blk_nums=[1, 1])
+    bp = O.naf_synth_params(seed=3, img_channel=4, width=32, middle_blk_num=1, enc_blk_nums=(1, 2), dec_blk_nums=(1, 1), lens=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in bp.items()}, strict=True)
+    m = m.to(DEV).eval()
+    xt, cond, lens = torch.from_numpy(g["bokeh/xt"]).to(DEV), torch.from_numpy(g["bokeh/cond"]).to(DEV), g["bokeh/lens"]
+    li = [torch.from_numpy(lens[:, i].copy()) for i in range(3)]
+    y = m(xt, cond, torch.tensor([5, 60]), lens_info=li).cpu().numpy()
+    assert relerr(y, g["bokeh/tvec"]) < 1e-4
+    li1 = [torch.from_numpy(lens[:1, i].copy()) for i in range(3)]
+    assert relerr(m(xt[:1], cond[:1], 33, lens_info=li1).cpu().numpy(), g["bokeh/t33"]) < 1e-4
+    with pytest.raises(P.IrsdeError):
+        m(xt, cond, 5)                                   # the reference raises KeyError without lens_info; loud here too
+    T = int(g["bokeh/T"])
+    sde = P.IRSDE(max_sigma=50, T=T, schedule="cosine", eps=0.005, device=DEV)
+    sde.set_model(m)
+    sde.set_mu(cond[:1])
+    sde.injected_noise = torch.from_numpy(O.synth_noise(9, T, (1, 4, 12, 10))).to(DEV)
+    out = sde.reverse_sde(xt[:1], lens_info=li1).cpu().numpy()
+    assert relerr(out, g["bokeh/sde"]) < 2e-3
+    # batch of two with different lens triples == the two single-image runs (per-image FiLM rows)
+    sde.set_mu(cond)
+    sde.injected_noise = None
+    sde.seed = 3
+    both = sde.reverse_ode(xt, lens_info=li).cpu().numpy()
+    sde.set_mu(cond[1:2])
+    sde.image_offset = 1
+    one = sde.reverse_ode(xt[1:2], lens_info=[t[1:2] for t in li]).cpu().numpy()
+    assert relerr(one, both[1:2]) < 1e-4

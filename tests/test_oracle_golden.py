@@ -276,3 +276,21 @@ def test_latent_nafnet_and_pipeline_vs_reference(golden):
         x0 = O.sample(nparams, sch, noisy, lat, mode, noise=z, net=net)
         assert relerr(x0, g["pipe/latent_" + mode]) < 2e-3
         assert relerr(O.latent_unet_decode(uparams, x0, hid, 4, 40, 52), g["pipe/out_" + mode]) < 2e-3
+
+
+def test_latent_bokeh_nafnet_vs_reference(golden):
+    """Lens-conditioned ConditionalNAFNet (latent-bokeh): forward with per-image lens triples and the kwargs sampler path."""
+    g = golden.latent
+    bp = O.naf_synth_params(seed=3, img_channel=4, width=32, middle_blk_num=1, enc_blk_nums=(1, 2), dec_blk_nums=(1, 1), lens=True)
+    kw = dict(enc_blk_nums=(1, 2), middle_blk_num=1, dec_blk_nums=(1, 1))
+    lens = g["bokeh/lens"]
+    y = O.nafnet_forward(bp, g["bokeh/xt"], g["bokeh/cond"], np.array([5, 60]), lens_info=[lens[:, i] for i in range(3)], **kw)
+    assert relerr(y, g["bokeh/tvec"]) < 2e-5
+    li1 = [lens[:1, i] for i in range(3)]
+    y = O.nafnet_forward(bp, g["bokeh/xt"][:1], g["bokeh/cond"][:1], 33, lens_info=li1, **kw)
+    assert relerr(y, g["bokeh/t33"]) < 2e-5
+    T = int(g["bokeh/T"])
+    sch = O.irsde_schedule(50, T, "cosine", 0.005)
+    net = lambda x, mu, t: O.nafnet_forward(bp, x, mu, t, lens_info=li1, **kw)  # noqa: E731
+    x0 = O.sample(bp, sch, g["bokeh/xt"][:1], g["bokeh/cond"][:1], "sde", noise=O.synth_noise(9, T, (1, 4, 12, 10)), net=net)
+    assert relerr(x0, g["bokeh/sde"]) < 2e-3
