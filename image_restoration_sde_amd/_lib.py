@@ -71,7 +71,7 @@ def build_library(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into libirsde_hip.so (hipcc cross-compiles without a GPU)."""
     if force:
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
-    r = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j8", "-C", CSRC], capture_output=True, text=True)
     if r.returncode != 0:
         raise IrsdeLibraryError("building libirsde_hip.so failed:\n" + r.stdout + r.stderr)
     if verbose:

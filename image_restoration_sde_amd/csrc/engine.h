@@ -1,0 +1,300 @@
+// libirsde_hip.so — engine internals shared by engine_weights.hip / engine_plan.hip / engine_api.hip.
+//
+// Host-side structure (all C++; PyTorch never appears here):
+//   Engine      weights in kernel layout, FiLM/time table, coefficient table, plans
+//   Plan        per (B,H,W): static activation arena + the launch list of ONE network evaluation
+//               (ConditionalUNet.forward, DenoisingUNet_arch.py:85-134) built once, replayed T times
+//   sample()    the reverse loop (sde_utils.py:252-299): [step_begin, prep, net, update] per t, either
+//               eager or as one captured hipGraph replayed T times; the step index lives in device
+//               memory (StepState) so the graph is t-invariant.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/irsde_hip.h"
+#include "common.h"
+
+namespace irsde {
+
+// Winograd only where the transforms' extra HBM traffic is small next to the GEMM: F(2x2) moves 4x the input and
+// 4x the output through HBM and pays from 256 channels, F(4x4) 2.25x and pays from 128 — from 64 (+1.6 %) since the
+// component GEMMs run on the batch-loop kernel (measured, profiles/).
+// IRSDE_WINO2_MINC / IRSDE_WINO4_MINC override the thresholds (tuning experiments).
+inline int wino_min_c(int tile) {
+    const char* v = getenv(tile == 4 ? "IRSDE_WINO4_MINC" : "IRSDE_WINO2_MINC");
+    return v ? atoi(v) : (tile == 4 ? 64 : 256);
+}
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool loaded = false;
+};
+
+struct ConvW {
+    float* w = nullptr;  // device [Cout][KH*KW][Cin]
+    float* bias = nullptr;
+    int Cout = 0, Cin = 0, KH = 1, KW = 1;
+    float* wino_u2 = nullptr;  // device [16][Cout][Cin] = G g G^T of F(2x2,3x3)  (3x3 layers with Cin,Cout >= 256)
+    float* wino_u4 = nullptr;  // device [36][Cout][Cin]              F(4x4,3x3)  (3x3 layers with Cin,Cout >= 128)
+};
+struct ResW {
+    ConvW b1, b2, res;
+    bool has_res = false;
+    float* mlp_w = nullptr;  // [2*Cout][time_dim]
+    float* mlp_b = nullptr;
+    int film_off = 0;
+    int Cout = 0;
+};
+struct AttnW {
+    float* g1 = nullptr;
+    ConvW qkv, out;
+    float* g2 = nullptr;
+    int C = 0;
+};
+
+// NAFBlock weights (DenoisingNAFNet_arch.py:15-49) in kernel layout
+struct NafBlockW {
+    int c = 0;
+    float *g1 = nullptr, *g2 = nullptr;          // norm1.g / norm2.g
+    ConvW conv1, conv3, conv4, conv5;            // 1x1: c->2c, c->c, c->2c (rows interleaved for the gate), c->c
+    float *dw_w = nullptr, *dw_b = nullptr;      // conv2 depthwise 3x3: [9][2c], [2c]
+    float *sca_w = nullptr, *sca_b = nullptr;    // sca.1: [c][c], [c]
+    float *beta = nullptr, *gamma = nullptr;
+    float *mlp_w = nullptr, *mlp_b = nullptr;    // mlp.1: Linear(time_dim/2, 4c)
+    int film_off = 0;                            // [shift_att | scale_att | shift_ffn | scale_ffn]
+    float *cam_w = nullptr, *cam_b = nullptr;    // latent-bokeh: cam_mlp.1: Linear(time_dim/2, 2c)
+    int cam_off = 0;                             // [cam_scale | cam_shift] inside a row of the lens table
+};
+
+enum OpKind { OP_CONV = 0, OP_LN = 1, OP_ATTN = 2, OP_OTHER = 3, OP_WINO = 4, OP_NKINDS = 5 };
+
+struct Op {
+    std::function<void(hipStream_t)> fn;
+    OpKind kind;
+    double flops = 0, bytes = 0;  // algorithmic (direct-convolution) work attributed to this launch group
+    double exec_flops = 0;        // multiply-adds actually issued to the MFMA pipe (differs for Winograd)
+    std::string desc;
+};
+
+// Winograd F(2x2,3x3) launch triple derived from the direct-form parameters of a 3x3 stride-1 pad-1 convolution
+struct WinoPlan {
+    WinoParams in, out;
+    ConvParams gemm;
+};
+inline WinoPlan make_wino(const ConvParams& d, const float* U, float* V, float* Mb, int tile) {
+    WinoPlan w;
+    const int Ctot = d.C0 + d.C1;
+    const int TH = d.Ho / tile, TW = d.Wo / tile, T = d.B * TH * TW;
+    const int ncomp = (tile + 2) * (tile + 2);
+    w.in.tile = tile;
+    w.in.in0 = d.in0; w.in.in1 = d.in1; w.in.C0 = d.C0; w.in.C1 = d.C1; w.in.Hin = d.Hin; w.in.Win = d.Win;
+    w.in.in_shift = d.in_shift; w.in.B = d.B; w.in.TH = TH; w.in.TW = TW; w.in.T = T; w.in.V = V;
+    w.out = w.in;
+    w.out.M = Mb; w.out.Cout = d.Cout; w.out.out = d.out; w.out.out_stride = d.out_stride; w.out.bias = d.bias;
+    w.out.film = d.film; w.out.film_bstride = d.film_bstride; w.out.silu = d.silu; w.out.res = d.res;
+    w.out.res_stride = d.res_stride;
+    ConvParams& g = w.gemm;
+    g.in0 = V; g.C0 = Ctot; g.pix0 = Ctot; g.Hin = 1; g.Win = T; g.w = U; g.Cout = d.Cout;
+    g.KH = g.KW = 1; g.stride = 1; g.pad_y = g.pad_x = 0; g.B = 1; g.Ho = 1; g.Wo = T;
+    g.out = Mb; g.out_stride = d.Cout; g.zeros = d.zeros;
+    g.nz = ncomp; g.z_in = (long long)T * Ctot; g.z_w = (long long)d.Cout * Ctot; g.z_out = (long long)T * d.Cout;
+    return w;
+}
+inline bool wino_shape_ok(const ConvParams& d, int tile) {
+    return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.Ho % tile == 0 && d.Wo % tile == 0 &&
+           (d.C0 + d.C1) % 32 == 0 && d.Cout % 4 == 0 && d.out_stride % 4 == 0 && (!d.res || d.res_stride % 4 == 0);
+}
+
+struct Tensor {
+    float* p = nullptr;  // bf16 == true: really a bf16 tensor (IRSDE_FLAG_BF16_ACT)
+    int B = 0, H = 0, W = 0, C = 0;
+    bool bf16 = false;
+    size_t numel() const { return (size_t)B * H * W * C; }
+};
+
+struct PoolBlock {
+    float* p;
+    size_t n;
+    bool free;
+};
+
+struct Plan {
+    int B = 0, H = 0, W = 0, Hp = 0, Wp = 0;
+    bool per_sample_film = false;
+    std::vector<PoolBlock> pool;
+    std::vector<Op> net_ops;  // prep + network (one evaluation)
+    float* xin = nullptr;     // [B][in_nc][H][W]  state x / xt
+    float* cin = nullptr;     // [B][in_nc][H][W]  mu / cond
+    float* x0 = nullptr;      // prepped NHWC input
+    float* pred = nullptr;    // [B][Hp][Wp][pred_stride]
+    int pred_stride = 4;      // roundup(out_nc, 4)
+    std::map<std::string, Tensor> taps;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    double conv_flops = 0, conv_bytes = 0, conv_exec_flops = 0;
+    uint64_t last_use = 0;
+
+    ~Plan() {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        for (auto& b : pool) (void)hipFree(b.p);
+    }
+    float* alloc(size_t n, bool reuse) {
+        if (reuse) {
+            int best = -1;
+            for (int i = 0; i < (int)pool.size(); ++i)
+                if (pool[i].free && pool[i].n >= n && (best < 0 || pool[i].n < pool[best].n)) best = i;
+            if (best >= 0 && pool[best].n <= n + n / 2 + 1024) {
+                pool[best].free = false;
+                return pool[best].p;
+            }
+        }
+        float* p = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 64) * sizeof(float)));
+        pool.push_back({p, n, false});
+        return p;
+    }
+    void release(float* p) {
+        for (auto& b : pool)
+            if (b.p == p) {
+                b.free = true;
+                return;
+            }
+    }
+};
+
+// One direction (encode or decode) of the latent UNet at a fixed (B,H,W): a Plan whose ops run on NHWC buffers, plus
+// the NHWC tensors that are read from / written to the caller's NCHW tensors around it.
+struct LatentPlan {
+    bool decode = false;
+    std::unique_ptr<Plan> plan;
+    Tensor image;                // encode: padded NHWC input image; decode: final_conv output [B][Hp][Wp][4]
+    Tensor latent;               // NHWC latent (channels padded to 32)
+    std::vector<Tensor> hidden;  // NHWC skips in the reference's list order h[0..2*depth]
+    std::vector<int> hidden_c;   // logical channel counts
+};
+
+}  // namespace irsde
+
+using namespace irsde;  // internal header: included only by the three engine_*.hip translation units
+
+struct irsde_engine {
+    irsde_config cfg{};
+    int time_dim = 0;
+    std::vector<std::string> names;  // weight inventory, reference state_dict order-independent
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    std::vector<float*> dev_allocs;
+
+    // packed weights
+    ConvW init_conv, final_conv;
+    float *tm_w1 = nullptr, *tm_b1 = nullptr, *tm_w3 = nullptr, *tm_b3 = nullptr, *freqs = nullptr;
+    std::vector<ResW> down_res;   // 2 per level
+    std::vector<AttnW> down_attn;
+    std::vector<ConvW> down_conv;
+    ResW mid1, mid2;
+    AttnW mid_attn;
+    std::vector<ResW> up_res;
+    std::vector<AttnW> up_attn;
+    std::vector<ConvW> up_conv;
+    ResW final_res;
+    std::vector<ResW*> all_res;
+    int film_row = 0;
+
+    // ConditionalNAFNet (arch == 1)
+    int arch = 0;
+    std::vector<int> naf_enc_nums, naf_dec_nums;
+    int naf_mid_num = 0;
+    std::vector<std::vector<NafBlockW>> naf_enc, naf_dec;
+    std::vector<NafBlockW> naf_mid;
+    std::vector<ConvW> naf_downs, naf_ups;
+    ConvW naf_intro, naf_ending;
+    std::vector<NafBlockW*> naf_all;
+    // latent-bokeh variant (IRSDE_FLAG_NAF_LENS): lens-information FiLM, one row per image of the batch
+    float *cm_w1 = nullptr, *cm_b1 = nullptr, *cm_w3 = nullptr, *cm_b3 = nullptr;  // cam_mlp.0 / cam_mlp.2
+    int cam_row = 0;            // sum over blocks of 2c
+    float* cam_cur = nullptr;   // [cam_rows][cam_row]
+    int cam_rows = 0;           // capacity (images)
+    int cam_set = 0;            // images covered by the last irsde_set_lens_info
+
+    // latent UNet (arch == 2): codes/config/latent-dehazing/models/modules/UNet_arch.py
+    int lat_in = 0, lat_out = 0, lat_ch = 0, lat_embed = 0;
+    std::vector<int> lat_mult;
+    ConvW lat_init, lat_latent, lat_post, lat_final;
+    std::vector<ResW> lat_enc_res, lat_dec_res;  // 2 per level (decoder in module order: deepest first)
+    AttnW lat_enc_attn, lat_dec_attn;            // deepest level only
+    std::vector<ConvW> lat_down, lat_up;
+    std::vector<std::unique_ptr<LatentPlan>> lat_plans;
+
+    // schedule / FiLM tables
+    int T = 0;
+    float* coef_table = nullptr;  // [(T+1)][12]
+    float* film_table = nullptr;  // [(T+1)][film_row]
+    float* film_cur = nullptr;    // [max_rows][film_row]
+    int film_cur_rows = 0;
+    StepState* step = nullptr;
+    SampleCtl* ctl = nullptr;
+
+    float* zeros = nullptr;        // zero page for LDS-DMA staging of out-of-image taps
+    hipStream_t stream = nullptr;  // engine stream (graph capture needs a non-default stream)
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    std::vector<std::unique_ptr<Plan>> plans;
+    uint64_t use_counter = 0;
+    double profile[12] = {0};
+    std::vector<double> op_ms;          // per launch group of the last profiled plan (summed over steps)
+    std::vector<std::string> op_desc;
+    int op_steps = 0;
+    std::vector<hipEvent_t> ev_pool;
+    std::mutex mu;
+
+    float* dmalloc(size_t n) {
+        float* p = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 16) * sizeof(float)));
+        dev_allocs.push_back(p);
+        return p;
+    }
+    // bf16 (RNE) copy of a packed fp32 weight tensor, made once per tensor (IRSDE_FLAG_BF16)
+    std::map<const float*, unsigned short*> bf16_copies;
+    const unsigned short* bf16_copy(const float* w, size_t n) {
+        auto it = bf16_copies.find(w);
+        if (it != bf16_copies.end()) return it->second;
+        unsigned short* d = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&d, n * sizeof(unsigned short)));
+        launch_f32_to_bf16(w, d, n, stream);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(stream));
+        bf16_copies[w] = d;
+        return d;
+    }
+    float* upload(const std::vector<float>& v) {
+        float* p = dmalloc(v.size());
+        IRSDE_HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        return p;
+    }
+};
+
+namespace irsde {
+
+inline bool naf_lens(const irsde_engine* e) { return (e->cfg.flags & IRSDE_FLAG_NAF_LENS) != 0; }
+inline int rup32(int c) { return (c + 31) & ~31; }
+
+// engine_weights.hip: weight inventory (reference state_dict names), packing into kernel layouts, FiLM rows
+void build_inventory(irsde_engine* e);
+void build_inventory_naf(irsde_engine* e);
+void build_inventory_latent(irsde_engine* e);
+void finalize(irsde_engine* e);
+void compute_film_rows(irsde_engine* e, const float* tvals, int rows, float* dst, hipStream_t s);
+void ensure_film_cur(irsde_engine* e, int rows);
+
+// engine_plan.hip: one network evaluation as a static launch list over a static arena
+Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film);
+LatentPlan* get_latent_plan(irsde_engine* e, int B, int H, int W, bool decode);
+
+}  // namespace irsde

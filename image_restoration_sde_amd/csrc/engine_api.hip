@@ -1,0 +1,769 @@
+// libirsde_hip.so — the C ABI (include/irsde_hip.h) and the sampler loop.
+//
+// Host-side structure (all C++; PyTorch never appears here):
+//   Engine      weights in kernel layout, FiLM/time table, coefficient table, plans
+//   Plan        per (B,H,W): static activation arena + the launch list of ONE network evaluation
+//               (ConditionalUNet.forward, DenoisingUNet_arch.py:85-134) built once, replayed T times
+//   sample()    the reverse loop (sde_utils.py:252-299): [step_begin, prep, net, update] per t, either
+//               eager or as one captured hipGraph replayed T times; the step index lives in device
+//               memory (StepState) so the graph is t-invariant.
+#include "engine.h"
+
+using namespace irsde;
+
+namespace irsde {
+namespace {
+
+thread_local std::string g_last_error;
+
+hipEvent_t get_event(irsde_engine* e, size_t i) {
+    while (e->ev_pool.size() <= i) {
+        hipEvent_t ev;
+        IRSDE_HIP_CHECK(hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
+    return e->ev_pool[i];
+}
+
+void run_net(Plan* pl, hipStream_t s) {
+    for (auto& op : pl->net_ops) op.fn(s);
+}
+
+UpdateParams make_update(irsde_engine* e, Plan* pl) {
+    UpdateParams u{};
+    u.x = pl->xin; u.mu = pl->cin; u.pred = pl->pred;
+    const int64_t ps = pl->pred_stride;
+    u.sb = (int64_t)pl->Hp * pl->Wp * ps; u.sc = 1; u.sy = (int64_t)pl->Wp * ps; u.sx = ps;
+    u.st = e->step; u.ctl = e->ctl;
+    u.B = pl->B; u.C = e->cfg.in_nc; u.H = pl->H; u.W = pl->W;
+    return u;
+}
+
+void one_step(irsde_engine* e, Plan* pl, hipStream_t s) {
+    launch_step_begin(e->step, e->film_table, e->film_row, e->film_cur, e->coef_table, s);
+    run_net(pl, s);
+    launch_sde_update(make_update(e, pl), s);
+}
+
+int guard(const std::function<void()>& f) {
+    try {
+        f();
+        return IRSDE_OK;
+    } catch (const HipError& ex) {
+        g_last_error = ex.what();
+        const std::string m = ex.what();
+        if (m.find("weight") != std::string::npos) return IRSDE_ERR_WEIGHT;
+        if (m.find(" failed: ") != std::string::npos) return IRSDE_ERR_HIP;
+        return IRSDE_ERR_INVALID;
+    } catch (const std::exception& ex) {
+        g_last_error = ex.what();
+        return IRSDE_ERR_INVALID;
+    }
+}
+
+}  // namespace
+}  // namespace irsde
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* irsde_last_error(void) { return g_last_error.c_str(); }
+int irsde_version(void) { return 100; }
+
+int irsde_create(const irsde_config* cfg, irsde_engine** out) {
+    return guard([&] {
+        if (!cfg || !out) throw HipError("null argument");
+        if (cfg->nf % 32 || cfg->nf < 32) throw HipError("nf must be a positive multiple of 32");
+        if (cfg->depth < 1 || cfg->depth > 6) throw HipError("depth out of range");
+        if (cfg->in_nc < 1 || cfg->in_nc > 4 || cfg->out_nc < 1 || cfg->out_nc > 4)
+            throw HipError("in_nc/out_nc must be in 1..4");
+        if (cfg->in_nc != cfg->out_nc) throw HipError("sampler needs in_nc == out_nc");
+        if ((cfg->nf << cfg->depth) > 2048) throw HipError("nf * 2^depth must be <= 2048");
+        auto* e = new irsde_engine();
+        e->cfg = *cfg;
+        if (cfg->flags & IRSDE_FLAG_BF16_ACT) {
+            if (cfg->flags & (IRSDE_FLAG_UNCOND_FULLATTN | IRSDE_FLAG_NAIVE_CONV)) {
+                delete e;
+                throw HipError("IRSDE_FLAG_BF16_ACT: only the conditional UNet on the MFMA kernels stores bf16 activations");
+            }
+            e->cfg.flags |= IRSDE_FLAG_BF16;
+        }
+        e->time_dim = cfg->nf * 4;
+        build_inventory(e);
+        *out = e;
+    });
+}
+
+int irsde_create_nafnet(const irsde_nafnet_config* cfg, irsde_engine** out) {
+    return guard([&] {
+        if (!cfg || !out) throw HipError("null argument");
+        if (cfg->width % 32 || cfg->width < 32) throw HipError("width must be a positive multiple of 32");
+        if (cfg->img_channel < 1 || cfg->img_channel > 8) throw HipError("img_channel must be in 1..8");
+        if (cfg->n_enc < 1 || cfg->n_enc > 6 || cfg->n_dec != cfg->n_enc) throw HipError("need 1..6 encoder stages and as many decoder stages");
+        if ((cfg->width << cfg->n_enc) > 2048) throw HipError("width * 2^stages must be <= 2048");
+        if (cfg->flags & IRSDE_FLAG_BF16_ACT) throw HipError("IRSDE_FLAG_BF16_ACT: conditional UNet only");
+        auto* e = new irsde_engine();
+        e->arch = 1;
+        e->cfg.in_nc = e->cfg.out_nc = cfg->img_channel;
+        e->cfg.nf = cfg->width;
+        e->cfg.depth = cfg->n_enc;  // pad multiple 2^stages (padder_size, DenoisingNAFNet_arch.py:147)
+        e->cfg.device = cfg->device;
+        e->cfg.flags = cfg->flags;
+        e->time_dim = cfg->width * 4;
+        for (int i = 0; i < cfg->n_enc; ++i) {
+            if (cfg->enc_blk_nums[i] < 0 || cfg->dec_blk_nums[i] < 0) throw HipError("negative block count");
+            e->naf_enc_nums.push_back(cfg->enc_blk_nums[i]);
+            e->naf_dec_nums.push_back(cfg->dec_blk_nums[i]);
+        }
+        e->naf_mid_num = cfg->middle_blk_num;
+        build_inventory_naf(e);
+        *out = e;
+    });
+}
+
+void irsde_destroy(irsde_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    e->plans.clear();
+    e->lat_plans.clear();
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    for (float* p : e->dev_allocs) (void)hipFree(p);
+    for (auto& kv : e->bf16_copies) (void)hipFree(kv.second);
+    if (e->coef_table) (void)hipFree(e->coef_table);
+    if (e->film_table) (void)hipFree(e->film_table);
+    delete e;
+}
+
+int irsde_num_weights(const irsde_engine* e) { return e ? (int)e->names.size() : 0; }
+const char* irsde_weight_name(const irsde_engine* e, int i) {
+    if (!e || i < 0 || i >= (int)e->names.size()) return nullptr;
+    return e->names[i].c_str();
+}
+int irsde_weight_shape(const irsde_engine* e, int i, int64_t shape[4], int* ndim) {
+    if (!e || i < 0 || i >= (int)e->names.size()) return IRSDE_ERR_INVALID;
+    const auto& t = e->host.at(e->names[i]);
+    *ndim = (int)t.shape.size();
+    for (size_t k = 0; k < t.shape.size(); ++k) shape[k] = t.shape[k];
+    return IRSDE_OK;
+}
+
+int irsde_load_weight(irsde_engine* e, const char* name, const float* data, const int64_t* shape, int ndim) {
+    return guard([&] {
+        if (!e || !name || !data) throw HipError("null argument");
+        if (e->finalized) throw HipError("weights already finalized: create a new engine to reload weights");
+        auto it = e->host.find(name);
+        if (it == e->host.end()) throw HipError(std::string("unknown weight name: ") + name);
+        HostTensor& t = it->second;
+        size_t n = 1;
+        bool same = ndim == (int)t.shape.size();
+        for (int k = 0; k < ndim; ++k) {
+            n *= (size_t)shape[k];
+            if (same && shape[k] != t.shape[k]) same = false;
+        }
+        if (!same) throw HipError(std::string("weight shape mismatch for ") + name);
+        t.data.assign(data, data + n);
+        t.loaded = true;
+    });
+}
+
+int irsde_finalize_weights(irsde_engine* e) {
+    return guard([&] {
+        if (!e) throw HipError("null engine");
+        if (e->finalized) return;
+        finalize(e);
+    });
+}
+
+int irsde_set_schedule(irsde_engine* e, int T, const float* coef) {
+    return guard([&] {
+        if (!e || !coef || T < 1) throw HipError("bad schedule arguments");
+        if (!e->finalized) throw HipError("set_schedule: weights not finalized");
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        IRSDE_HIP_CHECK(hipDeviceSynchronize());
+        std::lock_guard<std::mutex> lk(e->mu);
+        // captured graphs bake the table pointers into their kernel nodes: drop them with the old tables
+        for (auto& pl : e->plans) {
+            if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
+            if (pl->graph) (void)hipGraphDestroy(pl->graph);
+            pl->graph_exec = nullptr;
+            pl->graph = nullptr;
+        }
+        if (e->coef_table) (void)hipFree(e->coef_table);
+        if (e->film_table) (void)hipFree(e->film_table);
+        e->coef_table = e->film_table = nullptr;
+        e->T = T;
+        IRSDE_HIP_CHECK(hipMalloc(&e->coef_table, (size_t)(T + 1) * IRSDE_COEF_STRIDE * 4));
+        IRSDE_HIP_CHECK(hipMemcpy(e->coef_table, coef, (size_t)(T + 1) * IRSDE_COEF_STRIDE * 4, hipMemcpyHostToDevice));
+        IRSDE_HIP_CHECK(hipMalloc(&e->film_table, (size_t)(T + 1) * e->film_row * 4));
+        std::vector<float> tv(T + 1);
+        for (int t = 0; t <= T; ++t) tv[t] = (float)t;
+        float* dtv = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&dtv, (T + 1) * sizeof(float)));
+        IRSDE_HIP_CHECK(hipMemcpy(dtv, tv.data(), (T + 1) * sizeof(float), hipMemcpyHostToDevice));
+        compute_film_rows(e, dtv, T + 1, e->film_table, e->stream);
+        (void)hipFree(dtv);
+    });
+}
+
+int irsde_unet_forward(irsde_engine* e, const float* xt, const float* cond, const int64_t* t_host, int nt, int B, int H,
+                       int W, float* out, void* stream) {
+    return guard([&] {
+        const bool uncond_e = e && e->arch == 0 && (e->cfg.flags & IRSDE_FLAG_UNCOND_FULLATTN);
+        if (!e || !xt || (!cond && !uncond_e) || !t_host || !out) throw HipError("null argument");
+        if (!e->finalized) throw HipError("unet_forward: weights not finalized");
+        if (nt != 1 && nt != B) throw HipError("unet_forward: need 1 or B timesteps");
+        if (B < 1 || H < 2 || W < 2) throw HipError("unet_forward: bad shape");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t user = reinterpret_cast<hipStream_t>(stream);
+        const bool per_sample = nt > 1;
+        Plan* pl = get_plan(e, B, H, W, per_sample);
+        hipStream_t s = e->stream;
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+        const size_t img = (size_t)B * e->cfg.in_nc * H * W * sizeof(float);
+        IRSDE_HIP_CHECK(hipMemcpyAsync(pl->xin, xt, img, hipMemcpyDeviceToDevice, s));
+        if (cond) IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, cond, img, hipMemcpyDeviceToDevice, s));
+        const bool in_table = nt == 1 && e->film_table && t_host[0] >= 0 && t_host[0] <= e->T;
+        if (in_table) {
+            IRSDE_HIP_CHECK(hipMemcpyAsync(e->film_cur, e->film_table + (size_t)t_host[0] * e->film_row,
+                                           (size_t)e->film_row * 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            std::vector<float> tv(nt);
+            for (int i = 0; i < nt; ++i) tv[i] = (float)t_host[i];
+            float* dtv = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dtv, nt * sizeof(float)));
+            IRSDE_HIP_CHECK(hipMemcpy(dtv, tv.data(), nt * sizeof(float), hipMemcpyHostToDevice));
+            compute_film_rows(e, dtv, nt, e->film_cur, s);
+            (void)hipFree(dtv);
+        }
+        run_net(pl, s);
+        launch_unpack_pred(pl->pred, out, B, e->cfg.out_nc, H, W, pl->Hp, pl->Wp, pl->pred_stride, s);
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+    });
+}
+
+int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, const float* noise, uint64_t seed,
+                 uint64_t image_offset, int B, int H, int W, int T, int t_stop, float* out, void* stream,
+                 int flags) {
+    return guard([&] {
+        if (!e || !xT || !out) throw HipError("null argument");
+        if (!e->finalized || !e->film_table) throw HipError("sample: weights/schedule not set");
+        if (mode < 0 || mode > 4) throw HipError("sample: bad mode");
+        const bool uncond_e = e->arch == 0 && (e->cfg.flags & IRSDE_FLAG_UNCOND_FULLATTN);
+        if ((mode >= 3) != uncond_e) throw HipError("sample: DenoisingSDE modes (3,4) go with the unconditional network and vice versa");
+        if (!mu && !uncond_e) throw HipError("null argument");
+        if (T <= 0) T = e->T;
+        if (T > e->T) throw HipError("sample: T exceeds the schedule length");
+        if (t_stop < 0 || t_stop >= T) throw HipError("sample: t_stop must be in [0, T)");
+        const int nsteps = T - t_stop;
+        if (B < 1 || H < 2 || W < 2) throw HipError("sample: bad shape");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t user = reinterpret_cast<hipStream_t>(stream);
+        Plan* pl = get_plan(e, B, H, W, false);
+        hipStream_t s = e->stream;
+        const bool profile = (flags & IRSDE_SAMPLE_PROFILE) != 0;
+        const bool graph = (flags & IRSDE_SAMPLE_GRAPH) != 0 && !profile;
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+        const size_t img = (size_t)B * e->cfg.in_nc * H * W;
+        IRSDE_HIP_CHECK(hipMemcpyAsync(pl->xin, xT, img * 4, hipMemcpyDeviceToDevice, s));
+        if (mu) IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, mu, img * 4, hipMemcpyDeviceToDevice, s));
+        launch_set_ctl(e->ctl, mode, noise, (long long)img, seed, image_offset, s);
+        launch_set_step(e->step, T, s);
+
+        if (graph) {
+            if (!pl->graph_exec) {
+                IRSDE_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                try {
+                    one_step(e, pl, s);
+                } catch (...) {
+                    hipGraph_t g = nullptr;
+                    (void)hipStreamEndCapture(s, &g);
+                    if (g) (void)hipGraphDestroy(g);
+                    throw;
+                }
+                IRSDE_HIP_CHECK(hipStreamEndCapture(s, &pl->graph));
+                IRSDE_HIP_CHECK(hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0));
+            }
+            for (int i = 0; i < nsteps; ++i) IRSDE_HIP_CHECK(hipGraphLaunch(pl->graph_exec, s));
+        } else if (!profile) {
+            for (int i = 0; i < nsteps; ++i) one_step(e, pl, s);
+        } else {
+            // eager with an event before every kernel group; interval k..k+1 belongs to group k
+            std::vector<int> kinds;
+            size_t ei = 0;
+            auto mark = [&](int kind) {
+                IRSDE_HIP_CHECK(hipEventRecord(get_event(e, ei++), s));
+                kinds.push_back(kind);
+            };
+            for (int i = 0; i < nsteps; ++i) {
+                mark(OP_OTHER);
+                launch_step_begin(e->step, e->film_table, e->film_row, e->film_cur, e->coef_table, s);
+                for (auto& op : pl->net_ops) {
+                    mark(op.kind);
+                    op.fn(s);
+                }
+                mark(OP_OTHER);
+                launch_sde_update(make_update(e, pl), s);
+            }
+            IRSDE_HIP_CHECK(hipEventRecord(get_event(e, ei++), s));
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            double ms[OP_NKINDS] = {0, 0, 0, 0, 0};
+            const size_t per_step = pl->net_ops.size() + 2;
+            e->op_ms.assign(pl->net_ops.size(), 0.0);
+            e->op_desc.clear();
+            for (auto& op : pl->net_ops) e->op_desc.push_back(op.desc);
+            e->op_steps = nsteps;
+            for (size_t k = 0; k < kinds.size(); ++k) {
+                float t;
+                IRSDE_HIP_CHECK(hipEventElapsedTime(&t, e->ev_pool[k], e->ev_pool[k + 1]));
+                ms[kinds[k]] += t;
+                const size_t in_step = k % per_step;
+                if (in_step >= 1 && in_step <= pl->net_ops.size()) e->op_ms[in_step - 1] += t;
+            }
+            hipEvent_t e0 = e->ev_pool[0], e1 = e->ev_pool[kinds.size()];
+            float wall;
+            IRSDE_HIP_CHECK(hipEventElapsedTime(&wall, e0, e1));
+            size_t nconv = 0;
+            for (auto& op : pl->net_ops) nconv += op.kind == OP_CONV;
+            e->profile[0] = ms[OP_CONV];
+            e->profile[1] = pl->conv_flops * nsteps;
+            e->profile[2] = (double)nconv * nsteps;
+            e->profile[3] = pl->conv_bytes * nsteps;
+            e->profile[4] = ms[OP_LN];
+            e->profile[5] = ms[OP_ATTN];
+            e->profile[6] = ms[OP_OTHER];
+            e->profile[7] = wall;
+            e->profile[8] = nsteps;
+            e->profile[9] = ms[OP_WINO];
+            e->profile[10] = pl->conv_exec_flops * nsteps;
+            e->profile[11] = 0;
+        }
+        IRSDE_HIP_CHECK(hipMemcpyAsync(out, pl->xin, img * 4, hipMemcpyDeviceToDevice, s));
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+    });
+}
+
+int irsde_sde_step(int mode, int t, const float* coef_row, float* x, const float* mu, const float* eps_hat,
+                   const float* noise_t, uint64_t seed, uint64_t image_offset, int B, int C, int H, int W,
+                   void* stream) {
+    return guard([&] {
+        if (!coef_row || !x || !eps_hat || (!mu && mode < 3)) throw HipError("null argument");
+        if (!mu) mu = x;  // DenoisingSDE has no mu term; the kernel still reads the pointer
+        if (mode < 0 || mode > 4) throw HipError("sde_step: bad mode");
+        UpdateParams u{};
+        u.x = x; u.mu = mu; u.pred = eps_hat;
+        u.sb = (int64_t)C * H * W; u.sc = (int64_t)H * W; u.sy = W; u.sx = 1;
+        // noise_t is the draw for this step: index it with tstride 0
+        u.noise = noise_t; u.noise_tstride = 0;
+        u.st = nullptr; u.ctl = nullptr; u.t_imm = t;
+        for (int i = 0; i < IRSDE_COEF_STRIDE; ++i) u.coef_imm[i] = coef_row[i];
+        u.mode = mode; u.B = B; u.C = C; u.H = H; u.W = W; u.seed = seed; u.image_offset = image_offset;
+        launch_sde_update(u, reinterpret_cast<hipStream_t>(stream));
+    });
+}
+
+int irsde_philox_normal(float* out, int B, int CHW, int t, uint64_t seed, uint64_t image_offset, void* stream) {
+    return guard([&] {
+        if (!out) throw HipError("null argument");
+        launch_philox_normal(out, B, CHW, t, seed, image_offset, reinterpret_cast<hipStream_t>(stream));
+    });
+}
+
+int irsde_get_profile(const irsde_engine* e, double out[12]) {
+    if (!e || !out) return IRSDE_ERR_INVALID;
+    for (int i = 0; i < 12; ++i) out[i] = e->profile[i];
+    return IRSDE_OK;
+}
+
+int irsde_debug_tap(irsde_engine* e, const char* name, float* dst, int64_t dims[4]) {
+    return guard([&] {
+        if (!e || !name || !dims) throw HipError("null argument");
+        if (!(e->cfg.flags & IRSDE_FLAG_KEEP_ACTIVATIONS)) throw HipError("debug_tap needs IRSDE_FLAG_KEEP_ACTIVATIONS");
+        Plan* pl = nullptr;
+        for (auto& p : e->plans)
+            if (!pl || p->last_use > pl->last_use) pl = p.get();
+        if (!pl) throw HipError("debug_tap: no forward has run");
+        auto it = pl->taps.find(name);
+        if (it == pl->taps.end()) throw HipError(std::string("debug_tap: unknown tap ") + name);
+        const Tensor& t = it->second;
+        dims[0] = t.B; dims[1] = t.C; dims[2] = t.H; dims[3] = t.W;
+        if (!dst) return;
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        IRSDE_HIP_CHECK(hipDeviceSynchronize());
+        float* tmp = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&tmp, t.numel() * 4));
+        launch_nhwc_to_nchw(t.p, tmp, t.B, t.C, t.H, t.W, e->stream, t.bf16);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(e->stream));
+        IRSDE_HIP_CHECK(hipMemcpy(dst, tmp, t.numel() * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(tmp);
+    });
+}
+
+int irsde_op_profile(irsde_engine* e, char* buf, int buflen) {
+    return guard([&] {
+        if (!e || !buf || buflen < 1) throw HipError("null argument");
+        std::string out;
+        char line[512];
+        for (size_t i = 0; i < e->op_ms.size(); ++i) {
+            snprintf(line, sizeof line, "%9.4f ms  %s\n", e->op_ms[i] / std::max(e->op_steps, 1), e->op_desc[i].c_str());
+            out += line;
+        }
+        strncpy(buf, out.c_str(), buflen - 1);
+        buf[buflen - 1] = 0;
+    });
+}
+
+int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buflen) {
+    return guard([&] {
+        if (!e || !buf || buflen < 1) throw HipError("null argument");
+        if (!e->finalized) throw HipError("plan_describe: weights not finalized");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        Plan* pl = get_plan(e, B, H, W, false);
+        std::string out;
+        for (auto& op : pl->net_ops) out += op.desc + "\n";
+        strncpy(buf, out.c_str(), buflen - 1);
+        buf[buflen - 1] = 0;
+    });
+}
+
+int irsde_work_model(irsde_engine* e, int B, int H, int W, double out[2]) {
+    return guard([&] {
+        if (!e || !out) throw HipError("null argument");
+        if (!e->finalized) throw HipError("work_model: weights not finalized");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        Plan* pl = get_plan(e, B, H, W, false);
+        out[0] = pl->conv_flops;
+        out[1] = pl->conv_bytes;
+    });
+}
+
+int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int in_shift,
+                     const float* w_oihw, int Cout, int KH, int KW, int stride, int pad, const float* bias,
+                     const float* film, int film_bstride, int silu, const float* res, float* out, int naive,
+                     int splits, void* stream) {
+    return guard([&] {
+        if (!in0 || !w_oihw || !out) throw HipError("null argument");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        conv_global_init();
+        const int Cin = C0 + C1;
+        std::vector<float> pk((size_t)Cout * KH * KW * Cin);
+        for (int o = 0; o < Cout; ++o)
+            for (int i = 0; i < Cin; ++i)
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx)
+                        pk[(((size_t)o * KH + ky) * KW + kx) * Cin + i] = w_oihw[(((size_t)o * Cin + i) * KH + ky) * KW + kx];
+        float *dw = nullptr, *db = nullptr, *dp = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&dw, pk.size() * 4));
+        IRSDE_HIP_CHECK(hipMemcpy(dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        if (bias) {
+            IRSDE_HIP_CHECK(hipMalloc(&db, Cout * 4));
+            IRSDE_HIP_CHECK(hipMemcpy(db, bias, Cout * 4, hipMemcpyHostToDevice));
+        }
+        ConvParams p;
+        p.in0 = in0; p.C0 = C0; p.pix0 = C0; p.in1 = in1; p.C1 = C1; p.pix1 = C1;
+        p.Hin = Hin; p.Win = Win; p.in_shift = in_shift;
+        p.w = dw; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad_y = pad; p.pad_x = pad;
+        p.B = B;
+        p.Ho = ((Hin << in_shift) + 2 * pad - KH) / stride + 1;
+        p.Wo = ((Win << in_shift) + 2 * pad - KW) / stride + 1;
+        p.out = out; p.out_stride = Cout; p.bias = db; p.film = film; p.film_bstride = film_bstride; p.silu = silu;
+        p.res = res; p.res_stride = Cout;
+        float* dz = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&dz, 1024));
+        IRSDE_HIP_CHECK(hipMemset(dz, 0, 1024));
+        p.zeros = dz;
+        const int wino_tile = (naive == 2 || naive == 12 || naive == 22) ? 2 : (naive == 3 || naive == 13 || naive == 23) ? 4 : 0;
+        if (splits > 1 && naive != 1 && !wino_tile) {
+            p.splits = splits;
+            IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
+            p.partial = dp;
+        }
+        if (wino_tile) {  // naive / 10: 0 = production dispatch, 1 / 2 = force the batch-loop GEMM kernel (all / 2 components per block)
+            const int tile = wino_tile, ncomp = (tile + 2) * (tile + 2);
+            if (!wino_shape_ok(p, tile)) throw HipError("debug_conv: shape not eligible for Winograd");
+            std::vector<float> U((size_t)ncomp * Cout * Cin);
+            wino_transform_weights(pk.data(), Cout, Cin, U.data(), tile);
+            const long long T = (long long)B * (p.Ho / tile) * (p.Wo / tile);
+            float *dU = nullptr, *dV = nullptr, *dM = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dU, U.size() * 4));
+            IRSDE_HIP_CHECK(hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+            IRSDE_HIP_CHECK(hipMalloc(&dV, (size_t)ncomp * T * Cin * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)ncomp * T * Cout * 4));
+            const WinoPlan wp = make_wino(p, dU, dV, dM, tile);
+            launch_wino_input(wp.in, s);
+            conv_set_variant(naive >= 20 ? 72 : naive >= 10 ? 71 : 0);
+            launch_conv(wp.gemm, s);
+            conv_set_variant(0);
+            launch_wino_output(wp.out, s);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(dU); (void)hipFree(dV); (void)hipFree(dM);
+        } else if (naive == 1) {
+            launch_conv_naive(p, s);
+        } else {
+            unsigned short *dbf = nullptr, *a0 = nullptr, *a1 = nullptr, *ar = nullptr, *ao = nullptr;
+            const bool act = naive == 204 || naive == 260 || naive == 261;  // + bf16 activation storage (IRSDE_FLAG_BF16_ACT)
+            if (naive == 4 || naive == 160 || naive == 161 || act) {  // bf16-MFMA mode (variants 60 / 61: force the 256 / 128 tile)
+                IRSDE_HIP_CHECK(hipMalloc(&dbf, pk.size() * 2));
+                launch_f32_to_bf16(dw, dbf, pk.size(), s);
+                p.w_bf = dbf;
+            }
+            const size_t npix_in = (size_t)B * Hin * Win, nout = (size_t)B * p.Ho * p.Wo * Cout;
+            if (act) {  // the caller's fp32 tensors are rounded into bf16 copies; the bf16 result is widened back
+                auto to_bf = [&](const float* src, size_t n) {
+                    unsigned short* d = nullptr;
+                    IRSDE_HIP_CHECK(hipMalloc(&d, n * 2 + 64));
+                    launch_f32_to_bf16(src, d, n, s);
+                    return d;
+                };
+                a0 = to_bf(in0, npix_in * C0);
+                p.in0 = reinterpret_cast<const float*>(a0);
+                if (in1) { a1 = to_bf(in1, npix_in * C1); p.in1 = reinterpret_cast<const float*>(a1); }
+                if (res) { ar = to_bf(res, nout); p.res = reinterpret_cast<const float*>(ar); }
+                IRSDE_HIP_CHECK(hipMalloc(&ao, nout * 2 + 64));
+                p.out = reinterpret_cast<float*>(ao);
+                p.in_bf16 = p.out_bf16 = 1;
+            }
+            conv_set_variant(act ? (naive == 204 ? 0 : naive - 200) : (naive >= 100 ? naive - 100 : 0));  // tile variants
+            launch_conv(p, s);
+            conv_set_variant(0);
+            if (act) launch_bf16_to_f32(ao, out, nout, s);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            for (unsigned short* q : {dbf, a0, a1, ar, ao})
+                if (q) (void)hipFree(q);
+        }
+        IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(dw);
+        (void)hipFree(dz);
+        if (db) (void)hipFree(db);
+        if (dp) (void)hipFree(dp);
+    });
+}
+
+int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
+                     double* ms_out) {
+    return guard([&] {
+        if (!ms_out || iters < 1) throw HipError("bad argument");
+        conv_global_init();
+        hipStream_t s = nullptr;
+        IRSDE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        ConvParams p;
+        const int pad = K / 2 - (stride == 2 ? 1 : 0) + (K == 4 ? 0 : 0);
+        p.B = B; p.Hin = H; p.Win = W; p.in_shift = up; p.C0 = Cin; p.pix0 = Cin;
+        p.Cout = Cout; p.KH = K; p.KW = K; p.stride = stride; p.pad_y = p.pad_x = (K == 4 ? 1 : K / 2);
+        (void)pad;
+        p.Ho = ((H << up) + 2 * p.pad_y - K) / stride + 1;
+        p.Wo = ((W << up) + 2 * p.pad_x - K) / stride + 1;
+        const size_t nin = (size_t)B * H * W * Cin, nw = (size_t)Cout * K * K * Cin, nout = (size_t)B * p.Ho * p.Wo * Cout;
+        float *din = nullptr, *dw = nullptr, *dout = nullptr, *dres = nullptr, *dfilm = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&din, nin * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dw, nw * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dout, nout * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dres, nout * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dfilm, (size_t)2 * Cout * 4 + 1024));
+        float* dz = dfilm + 2 * Cout;
+        IRSDE_HIP_CHECK(hipMemset(dz, 0, 1024));
+        p.zeros = dz;
+        launch_fill_random(din, nin, 1, 1.0f, s);
+        launch_fill_random(dw, nw, 2, 1.0f / sqrtf((float)(K * K * Cin)), s);
+        launch_fill_random(dres, nout, 3, 1.0f, s);
+        launch_fill_random(dfilm, (size_t)2 * Cout, 4, 0.3f, s);
+        p.in0 = din; p.w = dw; p.out = dout; p.out_stride = Cout;
+        unsigned short* dbf = nullptr;
+        if (variant >= 60 && variant <= 62) {  // bf16-MFMA mode: 60 = 256x256 tile, 61 = 128x128, 62 = automatic
+            IRSDE_HIP_CHECK(hipMalloc(&dbf, nw * 2));
+            launch_f32_to_bf16(dw, dbf, nw, s);
+            p.w_bf = dbf;
+        }
+        if (epi == 1) { p.film = dfilm; p.silu = 1; }
+        if (epi == 2) { p.silu = 1; p.res = dres; p.res_stride = Cout; }
+        conv_set_variant(variant);
+        hipEvent_t e0, e1;
+        IRSDE_HIP_CHECK(hipEventCreate(&e0));
+        IRSDE_HIP_CHECK(hipEventCreate(&e1));
+        for (int i = 0; i < 2; ++i) launch_conv(p, s);
+        IRSDE_HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) launch_conv(p, s);
+        IRSDE_HIP_CHECK(hipEventRecord(e1, s));
+        IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0;
+        IRSDE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        conv_set_variant(0);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
+        if (dbf) (void)hipFree(dbf);
+        (void)hipStreamDestroy(s);
+    });
+}
+
+int irsde_create_latent_unet(const irsde_latent_unet_config* cfg, irsde_engine** out) {
+    return guard([&] {
+        if (!cfg || !out) throw HipError("null argument");
+        if (cfg->in_ch < 1 || cfg->in_ch > 32 || cfg->out_ch < 1 || cfg->out_ch > 4) throw HipError("in_ch must be in 1..32 and out_ch in 1..4");
+        if (cfg->ch < 1 || cfg->n_mult < 1 || cfg->n_mult > 6) throw HipError("ch / ch_mult out of range");
+        if (cfg->embed_dim < 1 || cfg->embed_dim > 32) throw HipError("embed_dim must be in 1..32");
+        if (cfg->flags & IRSDE_FLAG_BF16_ACT) throw HipError("IRSDE_FLAG_BF16_ACT: conditional UNet only");
+        auto* e = new irsde_engine();
+        e->arch = 2;
+        e->cfg.in_nc = cfg->in_ch; e->cfg.out_nc = cfg->out_ch; e->cfg.nf = cfg->ch; e->cfg.depth = cfg->n_mult;
+        e->cfg.device = cfg->device; e->cfg.flags = cfg->flags;
+        e->lat_in = cfg->in_ch; e->lat_out = cfg->out_ch; e->lat_ch = cfg->ch; e->lat_embed = cfg->embed_dim;
+        for (int i = 0; i < cfg->n_mult; ++i) {
+            if (cfg->ch_mult[i] < 1 || cfg->ch * cfg->ch_mult[i] > 2048) throw HipError("ch * ch_mult out of range");
+            e->lat_mult.push_back(cfg->ch_mult[i]);
+        }
+        build_inventory_latent(e);
+        *out = e;
+    });
+}
+
+int irsde_latent_shapes(irsde_engine* e, int H, int W, int64_t latent_chw[3], int64_t* hidden_chw, int* n_hidden) {
+    return guard([&] {
+        if (!e || e->arch != 2 || !latent_chw || !n_hidden) throw HipError("latent_shapes: not a latent UNet engine / null argument");
+        const int depth = (int)e->lat_mult.size(), sdiv = 1 << depth;
+        const int Hp = (H + sdiv - 1) / sdiv * sdiv, Wp = (W + sdiv - 1) / sdiv * sdiv;
+        latent_chw[0] = e->lat_embed; latent_chw[1] = Hp >> (depth - 1); latent_chw[2] = Wp >> (depth - 1);
+        *n_hidden = 2 * depth + 1;
+        if (hidden_chw) {
+            auto dim = [&](int i) { return i == 0 ? e->lat_ch : e->lat_ch * e->lat_mult[i - 1]; };
+            for (int k = 0; k < 2 * depth + 1; ++k) {
+                const int lvl = k == 0 ? 0 : (k - 1) / 2;
+                hidden_chw[3 * k] = dim(lvl); hidden_chw[3 * k + 1] = Hp >> lvl; hidden_chw[3 * k + 2] = Wp >> lvl;
+            }
+        }
+    });
+}
+
+int irsde_latent_encode(irsde_engine* e, const float* x, int B, int H, int W, float* latent, float* const* hidden,
+                        void* stream) {
+    return guard([&] {
+        if (!e || e->arch != 2 || !x || !latent || !hidden) throw HipError("latent_encode: not a latent UNet engine / null argument");
+        if (!e->finalized) throw HipError("latent_encode: weights not finalized");
+        if (B < 1 || H < 2 || W < 2) throw HipError("latent_encode: bad shape");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t user = reinterpret_cast<hipStream_t>(stream), s = e->stream;
+        LatentPlan* lp = get_latent_plan(e, B, H, W, false);
+        Plan* pl = lp->plan.get();
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+        launch_nchw_to_nhwc_pad(x, lp->image.p, B, e->lat_in, H, W, pl->Hp, pl->Wp, lp->image.C, 1, s);  // F.pad 'reflect'
+        run_net(pl, s);
+        const Tensor& L = lp->latent;
+        launch_unpack_pred(L.p, latent, B, e->lat_embed, L.H, L.W, L.H, L.W, L.C, s);
+        for (size_t k = 0; k < lp->hidden.size(); ++k) {
+            const Tensor& h = lp->hidden[k];
+            if (!hidden[k]) throw HipError("latent_encode: null hidden pointer");
+            launch_unpack_pred(h.p, hidden[k], B, lp->hidden_c[k], h.H, h.W, h.H, h.W, h.C, s);
+        }
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+    });
+}
+
+int irsde_latent_decode(irsde_engine* e, const float* latent, const float* const* hidden, int B, int H, int W, float* out,
+                        void* stream) {
+    return guard([&] {
+        if (!e || e->arch != 2 || !latent || !hidden || !out) throw HipError("latent_decode: not a latent UNet engine / null argument");
+        if (!e->finalized) throw HipError("latent_decode: weights not finalized");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t user = reinterpret_cast<hipStream_t>(stream), s = e->stream;
+        LatentPlan* lp = get_latent_plan(e, B, H, W, true);
+        Plan* pl = lp->plan.get();
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+        const Tensor& L = lp->latent;
+        launch_nchw_to_nhwc_pad(latent, L.p, B, e->lat_embed, L.H, L.W, L.H, L.W, L.C, 0, s);
+        for (size_t k = 0; k < lp->hidden.size(); ++k) {
+            const Tensor& h = lp->hidden[k];
+            if (!hidden[k]) throw HipError("latent_decode: null hidden pointer");
+            launch_nchw_to_nhwc_pad(hidden[k], h.p, B, lp->hidden_c[k], h.H, h.W, h.H, h.W, h.C, 0, s);
+        }
+        run_net(pl, s);
+        launch_unpack_pred(lp->image.p, out, B, e->lat_out, H, W, pl->Hp, pl->Wp, 4, s);  // x[..., :H, :W]
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+    });
+}
+
+int irsde_set_lens_info(irsde_engine* e, const float* info, int B) {
+    return guard([&] {
+        if (!e || !info || B < 1) throw HipError("null argument");
+        if (e->arch != 1 || !naf_lens(e)) throw HipError("set_lens_info: not a latent-bokeh ConditionalNAFNet engine");
+        if (!e->finalized) throw HipError("set_lens_info: weights not finalized");
+        std::lock_guard<std::mutex> lk(e->mu);
+        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        hipStream_t s = e->stream;
+        if (e->cam_rows < B) {  // plans bake the table pointer: drop them when it moves
+            IRSDE_HIP_CHECK(hipDeviceSynchronize());
+            e->plans.clear();
+            e->cam_cur = e->dmalloc((size_t)B * e->cam_row);
+            e->cam_rows = B;
+        }
+        const int width = e->cfg.nf, td = e->time_dim;
+        // cam_embed = cam_mlp(cat_i SinusoidalPosEmb(lens_info_i))  (:172-173); rows b*3+i of the sinusoid table are row b
+        float *dv = nullptr, *emb = nullptr, *w1 = nullptr, *g1 = nullptr, *h2 = nullptr, *g2 = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&dv, (size_t)B * 3 * 4));
+        IRSDE_HIP_CHECK(hipMemcpy(dv, info, (size_t)B * 3 * 4, hipMemcpyHostToDevice));
+        IRSDE_HIP_CHECK(hipMalloc(&emb, (size_t)B * 3 * width * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&w1, (size_t)B * 2 * td * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&g1, (size_t)B * td * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&h2, (size_t)B * td * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&g2, (size_t)B * (td / 2) * 4));
+        launch_sinusoid(dv, e->freqs, emb, B * 3, width / 2, s);
+        launch_row_linear(emb, 3 * width, e->cm_w1, e->cm_b1, w1, 2 * td, B, 3 * width, 2 * td, ACT_NONE, ACT_NONE, s);
+        launch_row_gate(w1, g1, B, td, s);
+        launch_row_linear(g1, td, e->cm_w3, e->cm_b3, h2, td, B, td, td, ACT_NONE, ACT_NONE, s);
+        launch_row_gate(h2, g2, B, td / 2, s);  // the block's cam_mlp starts with SimpleGate (:22-24)
+        for (NafBlockW* b : e->naf_all)
+            launch_row_linear(g2, td / 2, b->cam_w, b->cam_b, e->cam_cur + b->cam_off, e->cam_row, B, td / 2, 2 * b->c, ACT_NONE,
+                              ACT_NONE, s);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+        for (float* q : {dv, emb, w1, g1, h2, g2}) (void)hipFree(q);
+        e->cam_set = B;
+    });
+}
+
+int irsde_eval_metrics(const float* out, const float* gt, int B, int C, int H, int W, int crop_border, double* metrics,
+                       void* stream) {
+    return guard([&] {
+        if (!out || !gt || !metrics || B < 1) throw HipError("null argument");
+        std::vector<double> sums((size_t)B * 4);
+        eval_metrics(out, gt, B, C, H, W, crop_border, sums.data(), reinterpret_cast<hipStream_t>(stream));
+        const double Hc = H - 2 * crop_border, Wc = W - 2 * crop_border;
+        const double n_rgb = Hc * Wc * C, n_y = Hc * Wc, v_rgb = (Hc - 10) * (Wc - 10) * C, v_y = (Hc - 10) * (Wc - 10);
+        auto psnr = [](double sse, double n) {
+            const double mse = sse / n;
+            return mse == 0.0 ? INFINITY : 20.0 * log10(255.0 / sqrt(mse));
+        };
+        for (int b = 0; b < B; ++b) {
+            metrics[b * 4 + 0] = psnr(sums[b * 4 + 0], n_rgb);
+            metrics[b * 4 + 1] = sums[b * 4 + 1] / v_rgb;
+            metrics[b * 4 + 2] = C == 3 ? psnr(sums[b * 4 + 2], n_y) : NAN;
+            metrics[b * 4 + 3] = C == 3 ? sums[b * 4 + 3] / v_y : NAN;
+        }
+    });
+}
+
+int irsde_tensor2img(const float* in, unsigned char* out, int B, int C, int H, int W, void* stream) {
+    return guard([&] {
+        if (!in || !out) throw HipError("null argument");
+        tensor2img_u8(in, out, B, C, H, W, reinterpret_cast<hipStream_t>(stream));
+    });
+}
+
+}  // extern "C"

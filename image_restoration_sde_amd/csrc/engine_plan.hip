@@ -1,0 +1,624 @@
+// Plan construction: one network evaluation as a static launch list over a static activation arena
+// (ConditionalUNet / ConditionalNAFNet forward, latent UNet encode / decode).
+#include "engine.h"
+
+using namespace irsde;
+
+namespace irsde {
+
+// ---------------------------------------------------------------------------------------------
+// Plan construction: one network evaluation as a static launch list over a static arena
+// ---------------------------------------------------------------------------------------------
+struct Builder {
+    irsde_engine* e;
+    Plan* pl;
+    bool reuse;
+    bool naive;
+    int film_bstride;
+    const float* fused_ln_g = nullptr;  // set around a conv() call: LayerNorm gain applied in that conv's epilogue
+
+    bool act_bf16() const { return (e->cfg.flags & IRSDE_FLAG_BF16_ACT) != 0; }
+    Tensor talloc(int B, int H, int W, int C, int force_f32 = 0) {
+        Tensor t;
+        t.B = B; t.H = H; t.W = W; t.C = C;
+        t.bf16 = act_bf16() && !force_f32;
+        t.p = pl->alloc(t.bf16 ? (t.numel() + 1) / 2 : t.numel(), reuse);
+        return t;
+    }
+    void tfree(const Tensor& t) {
+        if (reuse) pl->release(t.p);
+    }
+    void tap(const std::string& name, const Tensor& t) { pl->taps[name] = t; }
+
+    void push_conv(ConvParams p) {
+        const int M = p.B * p.Ho * p.Wo;
+        // split-K for under-filled grids (small batch / deep levels)
+        const int bn = p.Cout >= 128 ? 128 : (p.Cout > 32 ? 64 : 32);
+        const int blocks = ((M + 127) / 128) * ((p.Cout + bn - 1) / bn);
+        const int nk = p.KH * p.KW * ((p.C0 + p.C1) / 32);
+        int splits = 1;
+        if (!naive && blocks < 256 && nk >= 16 && !p.gate && !p.shuffle) {
+            splits = std::min(std::min(nk / 8, (512 + blocks - 1) / blocks), 16);
+            if (splits < 2) splits = 1;
+        }
+        if (splits > 1) {
+            p.splits = splits;
+            p.partial = pl->alloc((size_t)splits * M * p.Cout, true);
+        }
+        p.zeros = e->zeros;
+        if (!naive && (e->cfg.flags & IRSDE_FLAG_BF16))
+            p.w_bf = e->bf16_copy(p.w, (size_t)p.Cout * p.KH * p.KW * (p.C0 + p.C1));
+        Op op;
+        op.kind = OP_CONV;
+        op.flops = conv_flops(p);
+        const double in_bytes = (p.in_bf16 ? 2.0 : 4.0) * (double)p.B * (p.Hin) * (p.Win) * (double)(p.C0 + p.C1);
+        op.bytes = in_bytes + (p.out_bf16 ? 2.0 : 4.0) * (double)M * p.Cout +
+                   (p.w_bf ? 2.0 : 4.0) * (double)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
+        op.exec_flops = op.flops;
+        pl->conv_flops += op.flops;
+        pl->conv_exec_flops += op.exec_flops;
+        pl->conv_bytes += op.bytes;
+        {
+            char buf[256];
+            snprintf(buf, sizeof buf, "conv%s M=%d Cout=%d Cin=%d k=%dx%d s=%d up=%d splits=%d blocks=%d flops=%.4g",
+                     p.w_bf ? "(bf16)" : "", M, p.Cout, p.C0 + p.C1, p.KH, p.KW, p.stride, p.in_shift, splits, blocks, op.flops);
+            op.desc = buf;
+        }
+        const bool nv = naive;
+        op.fn = [p, nv](hipStream_t s) {
+            if (nv)
+                launch_conv_naive(p, s);
+            else
+                launch_conv(p, s);
+        };
+        pl->net_ops.push_back(std::move(op));
+        // the split-K scratch is dead once this op's reduce kernel has run (same stream): recycle it
+        if (p.partial) pl->release(p.partial);
+    }
+
+    // generic KxK conv over (in0 | in1)
+    Tensor conv(const ConvW& w, const Tensor& in0, const Tensor* in1, int stride, int pad, int in_shift,
+                const float* film, int silu, const Tensor* res, int out_stride = 0) {
+        ConvParams p;
+        p.in0 = in0.p; p.C0 = in0.C; p.pix0 = in0.C;
+        if (in1) { p.in1 = in1->p; p.C1 = in1->C; p.pix1 = in1->C; }
+        if (p.C0 + p.C1 != w.Cin) throw HipError("conv: channel mismatch");
+        p.Hin = in0.H; p.Win = in0.W; p.in_shift = in_shift;
+        p.w = w.w; p.Cout = w.Cout; p.KH = w.KH; p.KW = w.KW; p.stride = stride; p.pad_y = pad; p.pad_x = pad;
+        const int Hv = in0.H << in_shift, Wv = in0.W << in_shift;
+        p.B = in0.B;
+        p.Ho = (Hv + 2 * pad - w.KH) / stride + 1;
+        p.Wo = (Wv + 2 * pad - w.KW) / stride + 1;
+        const int ostr = out_stride ? out_stride : w.Cout;
+        Tensor out = talloc(p.B, p.Ho, p.Wo, ostr, out_stride != 0);  // an explicit stride = the fp32 eps_hat tensor
+        p.out = out.p; p.out_stride = ostr;
+        p.in_bf16 = in0.bf16; p.out_bf16 = out.bf16;
+        p.ln_g = fused_ln_g;
+        if ((in1 && in1->bf16 != in0.bf16) || (res && res->bf16 != out.bf16)) throw HipError("conv: mixed activation storage types");
+        p.bias = w.bias;
+        p.film = film; p.film_bstride = film ? film_bstride : 0;
+        p.silu = silu;
+        if (res) { p.res = res->p; p.res_stride = res->C; }
+        if (!naive) {  // prefer F(4x4,3x3), then F(2x2,3x3), then the direct implicit GEMM
+            if (w.wino_u4 && wino_shape_ok(p, 4) && push_wino(p, w.wino_u4, 4)) return out;
+            if (w.wino_u2 && wino_shape_ok(p, 2) && push_wino(p, w.wino_u2, 2)) return out;
+        }
+        push_conv(p);
+        return out;
+    }
+
+    // Winograd F(2x2,3x3): input transform -> 16 batched GEMMs on the MFMA kernel -> output transform + epilogue
+    bool push_wino(const ConvParams& d, const float* U, int tile) {
+        const int Ctot = d.C0 + d.C1;
+        const int ncomp = (tile + 2) * (tile + 2);
+        const long long T = (long long)d.B * (d.Ho / tile) * (d.Wo / tile);
+        const long long gemm_blocks = ncomp * ((T + 127) / 128) * ((d.Cout + 127) / 128);
+        if (gemm_blocks < 256) return false;  // tiny layers: direct conv + split-K
+        ConvParams dd = d;
+        dd.zeros = e->zeros;
+        float* V = pl->alloc((size_t)ncomp * T * Ctot, true);
+        float* Mb = pl->alloc((size_t)ncomp * T * d.Cout, true);
+        const WinoPlan wp = make_wino(dd, U, V, Mb, tile);
+        const double direct = conv_flops(d);
+        {
+            Op op;
+            op.kind = OP_WINO;
+            op.desc = "wino_input T=" + std::to_string(T) + " C=" + std::to_string(Ctot);
+            const WinoParams ip = wp.in;
+            op.fn = [ip](hipStream_t s) { launch_wino_input(ip, s); };
+            pl->net_ops.push_back(std::move(op));
+        }
+        {
+            Op op;
+            op.kind = OP_CONV;
+            op.flops = direct;
+            op.exec_flops = ncomp * 2.0 * (double)T * Ctot * d.Cout;
+            const double in_bytes = 4.0 * (double)d.B * d.Hin * d.Win * Ctot;
+            op.bytes = in_bytes + 4.0 * (double)d.B * d.Ho * d.Wo * d.Cout + 4.0 * 9.0 * (double)d.Cout * Ctot;
+            pl->conv_flops += op.flops;
+            pl->conv_exec_flops += op.exec_flops;
+            pl->conv_bytes += op.bytes;
+            char buf[256];
+            snprintf(buf, sizeof buf, "conv(winograd F%d gemm x%d) T=%lld Cout=%d Cin=%d flops=%.4g exec=%.4g", tile, ncomp, T,
+                     d.Cout, Ctot, op.flops, op.exec_flops);
+            op.desc = buf;
+            const ConvParams g = wp.gemm;
+            op.fn = [g](hipStream_t s) { launch_conv(g, s); };
+            pl->net_ops.push_back(std::move(op));
+        }
+        {
+            Op op;
+            op.kind = OP_WINO;
+            op.desc = "wino_output T=" + std::to_string(T) + " Cout=" + std::to_string(d.Cout);
+            const WinoParams oparm = wp.out;
+            op.fn = [oparm](hipStream_t s) { launch_wino_output(oparm, s); };
+            pl->net_ops.push_back(std::move(op));
+        }
+        pl->release(V);
+        pl->release(Mb);
+        return true;
+    }
+
+    struct ConvOpts {
+        int stride = 1, pad = 0;
+        const Tensor* res = nullptr;
+        const float* ch_scale = nullptr;
+        const float* in_scale = nullptr;
+        const float* gate_film = nullptr;
+        int gate = 0, shuffle = 0, out_stride = 0;
+    };
+    // 1x1 / KxK conv with the NAFNet fusions (bias from the ConvW; no FiLM / SiLU in NAFNet convs)
+    Tensor conv_naf(const ConvW& w, const Tensor& in, const ConvOpts& o) {
+        ConvParams p;
+        p.in0 = in.p; p.C0 = in.C; p.pix0 = in.C;
+        if (in.C != w.Cin) throw HipError("conv_naf: channel mismatch");
+        p.Hin = in.H; p.Win = in.W;
+        p.w = w.w; p.Cout = w.Cout; p.KH = w.KH; p.KW = w.KW; p.stride = o.stride; p.pad_y = o.pad; p.pad_x = o.pad;
+        p.B = in.B;
+        p.Ho = (in.H + 2 * o.pad - w.KH) / o.stride + 1;
+        p.Wo = (in.W + 2 * o.pad - w.KW) / o.stride + 1;
+        Tensor out;
+        if (o.shuffle)
+            out = talloc(p.B, 2 * p.Ho, 2 * p.Wo, w.Cout / 4);
+        else if (o.gate)
+            out = talloc(p.B, p.Ho, p.Wo, w.Cout / 2);
+        else
+            out = talloc(p.B, p.Ho, p.Wo, o.out_stride ? o.out_stride : w.Cout);
+        p.out = out.p; p.out_stride = out.C;
+        p.bias = w.bias;
+        p.ch_scale = o.ch_scale; p.in_scale = o.in_scale; p.gate = o.gate; p.shuffle = o.shuffle;
+        p.gate_film = o.gate_film; p.gate_film_bstride = o.gate_film ? e->cam_row : 0;
+        if (o.res) { p.res = o.res->p; p.res_stride = o.res->C; }
+        push_conv(p);
+        return out;
+    }
+
+    // NAFBlock.forward — DenoisingNAFNet_arch.py:56-82
+    Tensor nafblock(const NafBlockW& w, const Tensor& x) {
+        const int64_t M = (int64_t)x.B * x.H * x.W;
+        const int64_t ppi = (int64_t)x.H * x.W;
+        const int c = w.c;
+        const float* film = e->film_cur + w.film_off;  // [shift_att | scale_att | shift_ffn | scale_ffn]
+        const int fb = film_bstride;
+        Tensor t1 = talloc(x.B, x.H, x.W, c);
+        {
+            const float *xp = x.p, *g = w.g1;
+            float* o = t1.p;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm_film(xp, g, film + c, film, fb, ppi, o, M, c, 1e-5f, s); });
+        }
+        Tensor u = conv_naf(w.conv1, t1, ConvOpts());
+        tfree(t1);
+        Tensor gt = talloc(x.B, x.H, x.W, c);
+        const int nt = dwgate_tiles(x.H * x.W);
+        float* partial = pl->alloc((size_t)x.B * nt * c, true);
+        float* sca = pl->alloc((size_t)x.B * c, true);
+        float* mean = pl->alloc((size_t)x.B * c, true);
+        {
+            const float *up = u.p, *dw = w.dw_w, *db = w.dw_b, *sw = w.sca_w, *sb = w.sca_b;
+            float* gp = gt.p;
+            const int B = x.B, H = x.H, W = x.W;
+            push_other(OP_OTHER, [=](hipStream_t s) {
+                launch_dwconv_gate(up, dw, db, gp, partial, B, H, W, c, s);
+                launch_sca(partial, nt, sw, sb, mean, sca, B, c, H * W, s);
+            });
+        }
+        tfree(u);
+        ConvOpts o3;
+        o3.in_scale = sca; o3.ch_scale = w.beta; o3.res = &x;
+        Tensor y = conv_naf(w.conv3, gt, o3);
+        tfree(gt);
+        pl->release(partial);
+        pl->release(sca);
+        pl->release(mean);
+        Tensor t2 = talloc(x.B, x.H, x.W, c);
+        {
+            const float *yp = y.p, *g = w.g2;
+            float* o = t2.p;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm_film(yp, g, film + 3 * c, film + 2 * c, fb, ppi, o, M, c, 1e-5f, s); });
+        }
+        ConvOpts o4;
+        o4.gate = 1;
+        if (naf_lens(e)) o4.gate_film = e->cam_cur + w.cam_off;  // x * (cam_scale + 1) + cam_shift after the gate (:82-83)
+        Tensor v = conv_naf(w.conv4, t2, o4);
+        tfree(t2);
+        ConvOpts o5;
+        o5.ch_scale = w.gamma; o5.res = &y;
+        Tensor out = conv_naf(w.conv5, v, o5);
+        tfree(v);
+        tfree(y);
+        return out;
+    }
+
+    // ResBlock.forward — module_util.py:136-146
+    Tensor resblock(const ResW& w, const Tensor& in0, const Tensor* in1) {
+        Tensor R;
+        if (w.has_res)
+            R = conv(w.res, in0, in1, 1, 0, 0, nullptr, 0, nullptr);
+        else
+            R = in0;
+        // latent UNet ResBlocks have no time MLP (UNet_arch.py:23): plain conv -> SiLU
+        Tensor h1 = conv(w.b1, in0, in1, 1, 1, 0, w.mlp_w ? e->film_cur + w.film_off : nullptr, 1, nullptr);
+        Tensor out = conv(w.b2, h1, nullptr, 1, 1, 0, nullptr, 1, &R);
+        tfree(h1);
+        if (w.has_res) tfree(R);
+        return out;
+    }
+
+    // Residual(PreNorm(dim, LinearAttention(dim))) — module_util.py:20-26,82-90,150-178
+    Tensor attn(const AttnW& w, const Tensor& x) {
+        const int64_t M = (int64_t)x.B * x.H * x.W;
+        const int N = x.H * x.W;
+        Tensor xn = talloc(x.B, x.H, x.W, x.C);
+        {
+            const float *xp = x.p, *g = w.g1;
+            float* o = xn.p;
+            const int C = x.C;
+            const bool bf = x.bf16;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(xp, g, nullptr, o, M, C, 1e-5f, s, bf); });
+        }
+        Tensor qkv = conv(w.qkv, xn, nullptr, 1, 0, 0, nullptr, 0, nullptr);
+        tfree(xn);
+        Tensor a = talloc(x.B, x.H, x.W, 128);
+        if (!w.g2) {
+            // Residual(PreNorm(dim, Attention(dim))): full softmax attention, to_out without LayerNorm, + x
+            const float* q = qkv.p;
+            float* o = a.p;
+            const int B = x.B;
+            push_other(OP_ATTN, [=](hipStream_t s) { launch_full_attention(q, o, B, N, s); });
+            tfree(qkv);
+            Tensor y = conv(w.out, a, nullptr, 1, 0, 0, nullptr, 0, &x);
+            tfree(a);
+            return y;
+        }
+        {
+            AttnWorkspace ws;
+            ws.nch = attn_num_chunks(N);
+            ws.pmax = pl->alloc((size_t)x.B * ws.nch * 128, false);
+            ws.pctx = pl->alloc((size_t)x.B * 4 * ws.nch * 1024, false);
+            ws.psum = pl->alloc((size_t)x.B * 4 * ws.nch * 32, false);
+            ws.ctx = pl->alloc((size_t)x.B * 4 * 1024, false);
+            const float* q = qkv.p;
+            float* o = a.p;
+            const int B = x.B;
+            const bool bf = x.bf16;
+            push_other(OP_ATTN, [=](hipStream_t s) { launch_linear_attention(q, o, B, N, ws, s, bf); });
+        }
+        tfree(qkv);
+        if (!naive && (x.C == 64 || x.C == 128) && !(e->cfg.flags & IRSDE_FLAG_NO_FUSED_LN)) {
+            // to_out conv + LayerNorm + residual in one kernel: the conv tile holds the whole channel row
+            fused_ln_g = w.g2;
+            Tensor y = conv(w.out, a, nullptr, 1, 0, 0, nullptr, 0, &x);
+            fused_ln_g = nullptr;
+            tfree(a);
+            return y;
+        }
+        Tensor o = conv(w.out, a, nullptr, 1, 0, 0, nullptr, 0, nullptr);
+        tfree(a);
+        Tensor y = talloc(x.B, x.H, x.W, x.C);
+        {
+            const float *op = o.p, *g = w.g2, *r = x.p;
+            float* yp = y.p;
+            const int C = x.C;
+            const bool bf = x.bf16;
+            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(op, g, r, yp, M, C, 1e-5f, s, bf); });
+        }
+        tfree(o);
+        return y;
+    }
+
+    void push_other(OpKind k, std::function<void(hipStream_t)> fn) {
+        Op op;
+        op.kind = k;
+        op.desc = k == OP_LN ? "layernorm" : (k == OP_ATTN ? "linear_attention" : "other");
+        op.fn = std::move(fn);
+        pl->net_ops.push_back(std::move(op));
+    }
+};
+
+// ConditionalNAFNet.forward — DenoisingNAFNet_arch.py:149-187
+void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
+    const int B = pl->B;
+    Tensor x;
+    {   // intro 3x3 (+bias) as 3 row taps over the zero-bordered NHWC input (border 3: first tap row/col = +2)
+        ConvParams p;
+        p.in0 = pl->x0; p.C0 = e->naf_intro.Cin; p.pix0 = P;
+        p.Hin = pl->Hp + 6; p.Win = pl->Wp + 6;
+        p.w = e->naf_intro.w; p.Cout = e->naf_intro.Cout; p.KH = 3; p.KW = 1; p.stride = 1; p.pad_y = -2; p.pad_x = -2;
+        p.B = B; p.Ho = pl->Hp; p.Wo = pl->Wp;
+        p.bias = e->naf_intro.bias;
+        x = b.talloc(B, pl->Hp, pl->Wp, p.Cout);
+        p.out = x.p; p.out_stride = p.Cout;
+        b.push_conv(p);
+        const double real = 2.0 * (double)B * pl->Hp * pl->Wp * p.Cout * 9.0 * (2.0 * e->cfg.in_nc);
+        pl->conv_flops += real - pl->net_ops.back().flops;
+        pl->net_ops.back().flops = real;
+    }
+    b.tap("intro", x);
+    // latent variant (latent-dehazing/models/modules/DenoisingNAFNet_arch.py:162-176): ending(x + intro output)
+    const bool intro_skip = (e->cfg.flags & IRSDE_FLAG_NAF_INTRO_SKIP) != 0;
+    const Tensor intro = x;
+    std::vector<Tensor> encs;
+    for (size_t i = 0; i < e->naf_enc.size(); ++i) {
+        for (auto& blk : e->naf_enc[i]) {
+            Tensor y = b.nafblock(blk, x);
+            if (!(intro_skip && x.p == intro.p)) b.tfree(x);
+            x = y;
+        }
+        b.tap("encoders." + std::to_string(i), x);
+        encs.push_back(x);
+        Builder::ConvOpts od;
+        od.stride = 2;
+        x = b.conv_naf(e->naf_downs[i], x, od);  // Conv2d(chan, 2 chan, 2, 2)
+        b.tap("downs." + std::to_string(i), x);
+    }
+    for (auto& blk : e->naf_mid) {
+        Tensor y = b.nafblock(blk, x);
+        b.tfree(x);
+        x = y;
+    }
+    b.tap("middle", x);
+    for (size_t i = 0; i < e->naf_dec.size(); ++i) {
+        Tensor skip = encs[encs.size() - 1 - i];
+        Builder::ConvOpts ou;
+        ou.shuffle = 1; ou.res = &skip;  // Conv2d(chan, 2 chan, 1) -> PixelShuffle(2) -> + enc_skip
+        Tensor y = b.conv_naf(e->naf_ups[i], x, ou);
+        b.tfree(x);
+        b.tfree(skip);
+        x = y;
+        b.tap("ups." + std::to_string(i), x);
+        for (auto& blk : e->naf_dec[i]) {
+            Tensor z = b.nafblock(blk, x);
+            b.tfree(x);
+            x = z;
+        }
+        b.tap("decoders." + std::to_string(i), x);
+    }
+    if (intro_skip) {
+        Tensor y = b.talloc(x.B, x.H, x.W, x.C);
+        const float *xa = x.p, *xb = intro.p;
+        float* yo = y.p;
+        const size_t n = x.numel();
+        b.push_other(OP_OTHER, [=](hipStream_t s) { launch_add(xa, xb, yo, n, s); });
+        b.tfree(x);
+        b.tfree(intro);
+        x = y;
+    }
+    Builder::ConvOpts oe;
+    oe.pad = 1; oe.out_stride = pl->pred_stride;
+    Tensor pr = b.conv_naf(e->naf_ending, x, oe);
+    b.tfree(x);
+    pl->pred = pr.p;
+}
+
+Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
+    for (auto& p : e->plans)
+        if (p->B == B && p->H == H && p->W == W && p->per_sample_film == per_sample_film) {
+            p->last_use = ++e->use_counter;
+            return p.get();
+        }
+    if (e->plans.size() >= 4) {  // LRU eviction
+        size_t lru = 0;
+        for (size_t i = 1; i < e->plans.size(); ++i)
+            if (e->plans[i]->last_use < e->plans[lru]->last_use) lru = i;
+        IRSDE_HIP_CHECK(hipDeviceSynchronize());
+        e->plans.erase(e->plans.begin() + lru);
+    }
+    ensure_film_cur(e, per_sample_film ? B : 1);
+    if (naf_lens(e)) {
+        if (e->cam_set < B) throw HipError("latent-bokeh ConditionalNAFNet: irsde_set_lens_info must cover the batch first");
+        if (e->cam_rows < B) throw HipError("internal: lens table smaller than the batch");
+    }
+
+    const int depth = e->cfg.depth, nf = e->cfg.nf, in_nc = e->cfg.in_nc;
+    const int sdiv = 1 << depth;
+    std::unique_ptr<Plan> plan(new Plan());
+    Plan* pl = plan.get();
+    pl->B = B; pl->H = H; pl->W = W;
+    pl->Hp = (H + sdiv - 1) / sdiv * sdiv;
+    pl->Wp = (W + sdiv - 1) / sdiv * sdiv;
+    pl->per_sample_film = per_sample_film;
+    pl->pred_stride = (e->cfg.out_nc + 3) & ~3;
+    pl->last_use = ++e->use_counter;
+    // F.pad 'reflect' needs pad < dim (DenoisingUNet_arch.py:82)
+    if (e->arch != 1 && (pl->Hp - H >= H || pl->Wp - W >= W)) throw HipError("image too small for reflect padding");
+
+    const size_t img = (size_t)B * in_nc * H * W;
+    pl->xin = pl->alloc(img, false);
+    pl->cin = pl->alloc(img, false);
+    const bool uncond = e->arch == 0 && (e->cfg.flags & IRSDE_FLAG_UNCOND_FULLATTN) != 0;
+    const int P = ((uncond ? 1 : 2) * in_nc + 3) & ~3;
+    const size_t x0n = (size_t)B * (pl->Hp + 6) * (pl->Wp + 6) * P + 64;
+    pl->x0 = pl->alloc(x0n, false);
+    IRSDE_HIP_CHECK(hipMemset(pl->x0, 0, x0n * sizeof(float)));
+
+    Builder b{e, pl, (e->cfg.flags & IRSDE_FLAG_KEEP_ACTIVATIONS) == 0, (e->cfg.flags & IRSDE_FLAG_NAIVE_CONV) != 0,
+              per_sample_film ? e->film_row : 0};
+    {
+        const float *xi = pl->xin, *ci = uncond ? nullptr : pl->cin;
+        float* x0 = pl->x0;
+        const int Hp = pl->Hp, Wp = pl->Wp;
+        const int reflect = e->arch == 1 ? 0 : 1;  // NAFNet zero-pads (DenoisingNAFNet_arch.py:189-194)
+        b.push_other(OP_OTHER, [=](hipStream_t s) { launch_prep_input(xi, ci, x0, B, in_nc, H, W, Hp, Wp, s, reflect); });
+    }
+    if (e->arch == 1) {
+        build_naf_plan(e, pl, b, P);
+        e->plans.push_back(std::move(plan));
+        return pl;
+    }
+    // init_conv 7x7 (DenoisingUNet_arch.py:96) as 7 row taps over the zero-bordered input
+    Tensor x;
+    {
+        ConvParams p;
+        p.in0 = pl->x0; p.C0 = e->init_conv.Cin; p.pix0 = P;
+        p.Hin = pl->Hp + 6; p.Win = pl->Wp + 6;
+        p.w = e->init_conv.w; p.Cout = nf; p.KH = 7; p.KW = 1; p.stride = 1; p.pad_y = 0; p.pad_x = 0;
+        p.B = B; p.Ho = pl->Hp; p.Wo = pl->Wp;
+        x = b.talloc(B, pl->Hp, pl->Wp, nf);
+        p.out = x.p; p.out_stride = nf; p.out_bf16 = x.bf16;  // the prepped input x0 stays fp32
+        b.push_conv(p);
+        // algorithmic accounting: 7x7 x (2*in_nc) real MACs, not the padded 7 x 64
+        const double real = 2.0 * (double)B * pl->Hp * pl->Wp * nf * 49.0 * ((uncond ? 1.0 : 2.0) * in_nc);
+        pl->conv_flops += real - pl->net_ops.back().flops;
+        pl->net_ops.back().flops = real;  // (exec_flops keeps the padded 7 x 64 K that is actually issued)
+    }
+    b.tap("init_conv", x);
+    Tensor x_init = x;
+    std::vector<Tensor> hs;
+    for (int i = 0; i < depth; ++i) {
+        const std::string d = "downs." + std::to_string(i) + ".";
+        Tensor a = b.resblock(e->down_res[2 * i], x, nullptr);
+        if (x.p != x_init.p) b.tfree(x);
+        b.tap(d + "0", a);
+        hs.push_back(a);
+        Tensor c = b.resblock(e->down_res[2 * i + 1], a, nullptr);
+        b.tap(d + "1", c);
+        Tensor g = b.attn(e->down_attn[i], c);
+        b.tfree(c);
+        b.tap(d + "2", g);
+        hs.push_back(g);
+        if (i != depth - 1)
+            x = b.conv(e->down_conv[i], g, nullptr, 2, 1, 0, nullptr, 0, nullptr);  // Downsample 4x4 s2 p1
+        else
+            x = b.conv(e->down_conv[i], g, nullptr, 1, 1, 0, nullptr, 0, nullptr);
+        b.tap(d + "3", x);
+    }
+    {
+        Tensor a = b.resblock(e->mid1, x, nullptr);
+        b.tfree(x);
+        b.tap("mid_block1", a);
+        Tensor g = b.attn(e->mid_attn, a);
+        b.tfree(a);
+        b.tap("mid_attn", g);
+        x = b.resblock(e->mid2, g, nullptr);
+        b.tfree(g);
+        b.tap("mid_block2", x);
+    }
+    for (int j = 0; j < depth; ++j) {
+        const std::string u = "ups." + std::to_string(j) + ".";
+        Tensor s1 = hs.back(); hs.pop_back();
+        Tensor a = b.resblock(e->up_res[2 * j], x, &s1);
+        b.tfree(x); b.tfree(s1);
+        b.tap(u + "0", a);
+        Tensor s2 = hs.back(); hs.pop_back();
+        Tensor c = b.resblock(e->up_res[2 * j + 1], a, &s2);
+        b.tfree(a); b.tfree(s2);
+        b.tap(u + "1", c);
+        Tensor g = b.attn(e->up_attn[j], c);
+        b.tfree(c);
+        b.tap(u + "2", g);
+        if (j != depth - 1)
+            x = b.conv(e->up_conv[j], g, nullptr, 1, 1, 1, nullptr, 0, nullptr);  // nearest x2 fused into the 3x3
+        else
+            x = b.conv(e->up_conv[j], g, nullptr, 1, 1, 0, nullptr, 0, nullptr);
+        b.tfree(g);
+        b.tap(u + "3", x);
+    }
+    {
+        Tensor f = b.resblock(e->final_res, x, &x_init);
+        b.tfree(x); b.tfree(x_init);
+        b.tap("final_res_block", f);
+        Tensor pr = b.conv(e->final_conv, f, nullptr, 1, 1, 0, nullptr, 0, nullptr, pl->pred_stride);
+        b.tfree(f);
+        pl->pred = pr.p;
+    }
+    e->plans.push_back(std::move(plan));
+    return pl;
+}
+
+// UNet.encode / UNet.decode — latent-dehazing/models/modules/UNet_arch.py:59-91
+LatentPlan* get_latent_plan(irsde_engine* e, int B, int H, int W, bool decode) {
+    for (auto& lp : e->lat_plans)
+        if (lp->decode == decode && lp->plan->B == B && lp->plan->H == H && lp->plan->W == W) {
+            lp->plan->last_use = ++e->use_counter;
+            return lp.get();
+        }
+    if (e->lat_plans.size() >= 4) {
+        size_t lru = 0;
+        for (size_t i = 1; i < e->lat_plans.size(); ++i)
+            if (e->lat_plans[i]->plan->last_use < e->lat_plans[lru]->plan->last_use) lru = i;
+        IRSDE_HIP_CHECK(hipDeviceSynchronize());
+        e->lat_plans.erase(e->lat_plans.begin() + lru);
+    }
+    const int depth = (int)e->lat_mult.size(), ch = e->lat_ch;
+    auto dim = [&](int i) { return i == 0 ? ch : ch * e->lat_mult[i - 1]; };
+    const int sdiv = 1 << depth;  // check_image_size pads to 2^depth although only depth-1 levels downsample (:52-57)
+    std::unique_ptr<LatentPlan> lp(new LatentPlan());
+    lp->decode = decode;
+    lp->plan.reset(new Plan());
+    Plan* pl = lp->plan.get();
+    pl->B = B; pl->H = H; pl->W = W;
+    pl->Hp = (H + sdiv - 1) / sdiv * sdiv;
+    pl->Wp = (W + sdiv - 1) / sdiv * sdiv;
+    pl->last_use = ++e->use_counter;
+    if (pl->Hp - H >= H || pl->Wp - W >= W) throw HipError("image too small for reflect padding");
+    // skips never alias anything else: they cross the encode/decode boundary (decode: they are inputs)
+    Builder b{e, pl, false, (e->cfg.flags & IRSDE_FLAG_NAIVE_CONV) != 0, 0};
+    // hidden list geometry: h[0] = init_conv output, then two entries per level
+    std::vector<std::pair<int, int>> hgeo;  // (level, logical channels)
+    hgeo.push_back({0, ch});
+    for (int i = 0; i < depth; ++i) {
+        hgeo.push_back({i, dim(i)});
+        hgeo.push_back({i, dim(i)});
+    }
+    const int hl = pl->Hp >> (depth - 1), wl = pl->Wp >> (depth - 1);
+    if (!decode) {
+        lp->image = b.talloc(B, pl->Hp, pl->Wp, rup32(e->lat_in));
+        Tensor x = b.conv(e->lat_init, lp->image, nullptr, 1, 1, 0, nullptr, 0, nullptr);
+        lp->hidden.push_back(x);
+        for (int i = 0; i < depth; ++i) {
+            Tensor a = b.resblock(e->lat_enc_res[2 * i], x, nullptr);
+            lp->hidden.push_back(a);
+            Tensor c = b.resblock(e->lat_enc_res[2 * i + 1], a, nullptr);
+            Tensor g = i == depth - 1 ? b.attn(e->lat_enc_attn, c) : c;
+            lp->hidden.push_back(g);
+            x = i != depth - 1 ? b.conv(e->lat_down[i], g, nullptr, 2, 1, 0, nullptr, 0, nullptr)   // Downsample 4x4 s2 p1
+                               : b.conv(e->lat_down[i], g, nullptr, 1, 1, 0, nullptr, 0, nullptr);  // default_conv 3x3
+        }
+        lp->latent = b.conv(e->lat_latent, x, nullptr, 1, 0, 0, nullptr, 0, nullptr);
+    } else {
+        lp->latent = b.talloc(B, hl, wl, rup32(e->lat_embed));
+        for (auto& g : hgeo) lp->hidden.push_back(b.talloc(B, pl->Hp >> g.first, pl->Wp >> g.first, rup32(g.second)));
+        Tensor x = b.conv(e->lat_post, lp->latent, nullptr, 1, 0, 0, nullptr, 0, nullptr);
+        const int nh = (int)lp->hidden.size();
+        for (int j = 0; j < depth; ++j) {
+            Tensor a = b.resblock(e->lat_dec_res[2 * j], x, &lp->hidden[nh - (2 * j + 1)]);
+            Tensor c = b.resblock(e->lat_dec_res[2 * j + 1], a, &lp->hidden[nh - (2 * j + 2)]);
+            Tensor g = j == 0 ? b.attn(e->lat_dec_attn, c) : c;
+            x = j != depth - 1 ? b.conv(e->lat_up[j], g, nullptr, 1, 1, 1, nullptr, 0, nullptr)    // nearest x2 + 3x3 (+bias)
+                               : b.conv(e->lat_up[j], g, nullptr, 1, 1, 0, nullptr, 0, nullptr);   // default_conv 3x3
+        }
+        Tensor y = b.talloc(x.B, x.H, x.W, x.C);
+        {
+            const float *xa = x.p, *xb = lp->hidden[0].p;
+            float* yo = y.p;
+            const size_t n = x.numel();
+            b.push_other(OP_OTHER, [=](hipStream_t s) { launch_add(xa, xb, yo, n, s); });
+        }
+        lp->image = b.conv(e->lat_final, y, nullptr, 1, 1, 0, nullptr, 0, nullptr, 4);
+    }
+    for (auto& g : hgeo) lp->hidden_c.push_back(g.second);
+    e->lat_plans.push_back(std::move(lp));
+    return e->lat_plans.back().get();
+}
+
+}  // namespace irsde

@@ -10,7 +10,7 @@
 //   conv_igemm_kernel   M[k][tile][n]  = sum_c V[k][tile][c] * U[k][n][c], (m+2)^2 independent GEMMs (blockIdx.z = k) on
 //                                         the fp32 MFMA pipe — the same kernel as the direct path, run as a 1x1 conv
 //   wino_output_kernel  y = A^T M A (m x m pixels per tile) + bias / FiLM / SiLU / residual            (HBM bound)
-// U = G g G^T is computed once at weight-load time (engine.hip).
+// U = G g G^T is computed once at weight-load time (engine_weights.hip).
 #include "common.h"
 
 namespace irsde {
