@@ -13,6 +13,7 @@ reference timed on this box's host cores on a bounded sample).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -37,9 +38,42 @@ def host_cores():
     return n
 
 
+def synth_state_dict(module, seed):
+    """Deterministic synthetic weights straight from the module's own parameter shapes (values do not affect speed):
+    conv / linear ~ U(+-1/sqrt(fan_in)) like PyTorch's default init, LayerNorm gains ~ U(0.5, 1.5), NAFNet beta / gamma
+    ~ U(-0.5, 0.5) (zero in the reference, which would turn every block into the identity)."""
+    import numpy as np
+    import torch
+    rs = np.random.RandomState(seed)
+    sd = module.state_dict()
+    out = {}
+    for name in sorted(sd):
+        shp = tuple(sd[name].shape)
+        if name.endswith(".g"):
+            a = rs.uniform(0.5, 1.5, size=shp)
+        elif name.endswith("beta") or name.endswith("gamma"):
+            a = rs.uniform(-0.5, 0.5, size=shp)
+        else:
+            wshape = tuple(sd[name[:-4] + "weight"].shape) if name.endswith("bias") else shp
+            bound = 1.0 / math.sqrt(int(np.prod(wshape[1:])))
+            a = rs.uniform(-bound, bound, size=shp)
+        out[name] = torch.from_numpy(a.astype(np.float32))
+    return out
+
+
+def synth_inputs(seed, B, H, W, max_sigma):
+    """LQ ~ U[0,1), x_T = LQ + N(0,1) * max_sigma / 255  (IRSDE.noise_state, sde_utils.py:360-361)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    lq = rs.rand(B, 3, H, W).astype(np.float32)
+    xT = (lq + rs.standard_normal(lq.shape).astype(np.float32) * np.float32(max_sigma / 255.0)).astype(np.float32)
+    return lq, xT
+
+
 def cpu_baseline(size, T, budget_s=20.0):
     """Reference CPU path (torch CPU ops, oracle/torch_cpu_port.py) on a bounded sample: B=1 image of
-    size x size, as many reverse_sde steps as fit in ~budget_s (min 2, max 10), extrapolated to T steps."""
+    size x size, as many reverse_sde steps as fit in ~budget_s (min 2, max 10), extrapolated to T steps.
+    The only place bench.py touches oracle/ (the reported baseline; never the thing measured as `value`)."""
     import torch
     from oracle import irsde_oracle as O
     from oracle import torch_cpu_port as TP
@@ -84,7 +118,6 @@ def main():
     import torch
     import torch.distributed as dist
     import image_restoration_sde_amd as P
-    from oracle import irsde_oracle as O  # synthetic weight/input generators only (shared with the tests)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -100,26 +133,19 @@ def main():
     latent_model = None
     if a.model == "latent":  # latent-bokeh/options/bokeh/test/refusion.yml: UNet ch 64 [1,2,4] embed 4 (256^2 -> 64x64x4) + NAFNet
         ncfg = dict(width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
-        params = O.naf_synth_params(seed=0, img_channel=4, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28),
-                                    dec_blk_nums=(1, 1, 1, 1), lens=True)
         model = P.latent_bokeh.ConditionalNAFNet(img_channel=4, **ncfg)   # lens-conditioned (lens_info kwargs)
         latent_model = P.latent.UNet(in_ch=3, out_ch=3, ch=64, ch_mult=[1, 2, 4], embed_dim=4)
-        latent_model.load_state_dict({k: torch.from_numpy(v) for k, v in
-                                      O.latent_unet_synth_params(seed=1, in_ch=3, out_ch=3, ch=64, ch_mult=(1, 2, 4), embed_dim=4).items()})
+        latent_model.load_state_dict(synth_state_dict(latent_model, 1))
         latent_model = latent_model.to(dev).eval()
     elif a.model == "dsde":  # denoising-sde/options/test/ir-sde.yml: unconditional UNet + DenoisingSDE(max_sigma=75, T=100)
-        params = O.uncond_synth_params(seed=0, nf=64, depth=4)
         model = P.denoising_sde.ConditionalUNet(3, 3, 64, depth=4)
     elif a.model == "nafnet":  # refusion.yml network_G
         ncfg = dict(width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
-        params = O.naf_synth_params(seed=0, img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28),
-                                    dec_blk_nums=(1, 1, 1, 1))
         model = P.ConditionalNAFNet(img_channel=3, **ncfg)
     else:
         nf, depth = 64, 4
-        params = O.synth_params(seed=0, nf=nf, depth=depth)
         model = P.ConditionalUNet(3, 3, nf, depth=depth)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model.load_state_dict(synth_state_dict(model, 0))
     model = model.to(dev).eval()
     model.set_compute_dtype(a.dtype)
     max_sigma = a.max_sigma if a.max_sigma is not None else {"nafnet": 50, "dsde": 75, "latent": 50}.get(a.model, 10)
@@ -134,7 +160,7 @@ def main():
 
     nglobal = a.batch * world
     # every rank materialises only its shard of the synthetic global batch (same generator => same images)
-    lq, xT = O.synth_inputs(1234, a.batch, a.size, a.size)
+    lq, xT = synth_inputs(1234, a.batch, a.size, a.size, max_sigma)
     rs = np.random.RandomState(1000 + rank)
     lq = np.clip(lq + 0.01 * rs.standard_normal(lq.shape).astype(np.float32), 0, 1)
     mu = torch.from_numpy(lq).to(dev)
