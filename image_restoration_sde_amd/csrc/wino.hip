@@ -20,48 +20,60 @@ __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_fl
 __device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 __device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }
+// V = float4 (4 channels per thread) or float (1 channel per thread: ~90 instead of 170-220 VGPRs, so that transform waves
+// can share a SIMD with the resident GEMM waves of another stream; 64 lanes x 4 B is still a 256-byte coalesced access)
+template <typename V> struct VecOps;
+template <> struct VecOps<float4> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ float4 one() { return make_float4(1.f, 1.f, 1.f, 1.f); }
+    static __device__ __forceinline__ float4 mad(float4 v, float4 a, float4 b) { return make_float4(v.x * a.x + b.x, v.y * a.y + b.y, v.z * a.z + b.z, v.w * a.w + b.w); }
+    static __device__ __forceinline__ float4 silu(float4 v) { return make_float4(silu1(v.x), silu1(v.y), silu1(v.z), silu1(v.w)); }
+};
+template <> struct VecOps<float> {
+    static constexpr int N = 1;
+    static __device__ __forceinline__ float zero() { return 0.f; }
+    static __device__ __forceinline__ float one() { return 1.f; }
+    static __device__ __forceinline__ float mad(float v, float a, float b) { return v * a + b; }
+    static __device__ __forceinline__ float silu(float v) { return silu1(v); }
+};
 
 // one application of B^T (input side) / A^T (output side) along one axis
-template <int TILE>
-__device__ __forceinline__ void bt_apply(const float4* d, float4* t);
-template <>
-__device__ __forceinline__ void bt_apply<2>(const float4* d, float4* t) {  // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-    t[0] = d[0] - d[2];
-    t[1] = d[1] + d[2];
-    t[2] = d[2] - d[1];
-    t[3] = d[1] - d[3];
+template <int TILE, typename V>
+__device__ __forceinline__ void bt_apply(const V* d, V* t) {
+    if constexpr (TILE == 2) {  // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        t[0] = d[0] - d[2];
+        t[1] = d[1] + d[2];
+        t[2] = d[2] - d[1];
+        t[3] = d[1] - d[3];
+    } else {  // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+        t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+        t[1] = (d[3] + d[4]) - 4.0f * (d[1] + d[2]);
+        t[2] = 4.0f * (d[1] - d[2]) + (d[4] - d[3]);
+        t[3] = 2.0f * (d[3] - d[1]) + (d[4] - d[2]);
+        t[4] = 2.0f * (d[1] - d[3]) + (d[4] - d[2]);
+        t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+    }
 }
-template <>
-__device__ __forceinline__ void bt_apply<4>(const float4* d, float4* t) {
-    // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-    t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
-    t[1] = (d[3] + d[4]) - 4.0f * (d[1] + d[2]);
-    t[2] = 4.0f * (d[1] - d[2]) + (d[4] - d[3]);
-    t[3] = 2.0f * (d[3] - d[1]) + (d[4] - d[2]);
-    t[4] = 2.0f * (d[1] - d[3]) + (d[4] - d[2]);
-    t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
-}
-template <int TILE>
-__device__ __forceinline__ void at_apply(const float4* m, float4* y);
-template <>
-__device__ __forceinline__ void at_apply<2>(const float4* m, float4* y) {  // A^T = [1 1 1 0; 0 1 -1 -1]
-    y[0] = m[0] + m[1] + m[2];
-    y[1] = m[1] - m[2] - m[3];
-}
-template <>
-__device__ __forceinline__ void at_apply<4>(const float4* m, float4* y) {
-    // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-    const float4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-    y[0] = m[0] + s12 + s34;
-    y[1] = d12 + 2.0f * d34;
-    y[2] = s12 + 4.0f * s34;
-    y[3] = d12 + 8.0f * d34 + m[5];
+template <int TILE, typename V>
+__device__ __forceinline__ void at_apply(const V* m, V* y) {
+    if constexpr (TILE == 2) {  // A^T = [1 1 1 0; 0 1 -1 -1]
+        y[0] = m[0] + m[1] + m[2];
+        y[1] = m[1] - m[2] - m[3];
+    } else {  // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+        const V s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        y[0] = m[0] + s12 + s34;
+        y[1] = d12 + 2.0f * d34;
+        y[2] = s12 + 4.0f * s34;
+        y[3] = d12 + 8.0f * d34 + m[5];
+    }
 }
 
-template <int TILE>
+template <int TILE, typename V>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     constexpr int A = TILE + 2;
-    const int C4 = (p.C0 + p.C1) >> 2;
+    constexpr int VN = VecOps<V>::N;
+    const int C4 = (p.C0 + p.C1) / VN;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)p.T * C4;
     if (idx >= total) return;
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     const int t1 = t / p.TW;
     const int ty = t1 % p.TH;
     const int b = t1 / p.TH;
-    const int c = cg * 4;
+    const int c = cg * VN;
     const float* src;
     int pix;
     if (c < p.C0) {
@@ -80,9 +92,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
         src = p.in1 + (c - p.C0); pix = p.C1;
     }
     const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
-    float4 w[A][A];  // after the row pass: w[r][s] = (B^T d)[r][s]
+    V w[A][A];  // after the row pass: w[r][s] = (B^T d)[r][s]
     {
-        float4 d[A][A];
+        V d[A][A];
 #pragma unroll
         for (int r = 0; r < A; ++r) {
             const int iy = TILE * ty - 1 + r;
@@ -92,16 +104,16 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
                 const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
                 const size_t pixel = (size_t)b * p.Hin * p.Win + (size_t)((ok ? iy : 0) >> p.in_shift) * p.Win +
                                      ((ok ? ix : 0) >> p.in_shift);
-                const float4 v = *reinterpret_cast<const float4*>(src + pixel * pix);
-                d[r][s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                const V v = *reinterpret_cast<const V*>(src + pixel * pix);
+                d[r][s] = ok ? v : VecOps<V>::zero();
             }
         }
 #pragma unroll
         for (int s = 0; s < A; ++s) {
-            float4 col[A], tc[A];
+            V col[A], tc[A];
 #pragma unroll
             for (int r = 0; r < A; ++r) col[r] = d[r][s];
-            bt_apply<TILE>(col, tc);
+            bt_apply<TILE, V>(col, tc);
 #pragma unroll
             for (int r = 0; r < A; ++r) w[r][s] = tc[r];
         }
@@ -111,17 +123,18 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     const size_t kstride = (size_t)p.T * Ctot;
 #pragma unroll
     for (int r = 0; r < A; ++r) {
-        float4 o[A];
-        bt_apply<TILE>(w[r], o);
+        V o[A];
+        bt_apply<TILE, V>(w[r], o);
 #pragma unroll
-        for (int s = 0; s < A; ++s) *reinterpret_cast<float4*>(vp + (size_t)(r * A + s) * kstride) = o[s];
+        for (int s = 0; s < A; ++s) *reinterpret_cast<V*>(vp + (size_t)(r * A + s) * kstride) = o[s];
     }
 }
 
-template <int TILE>
+template <int TILE, typename V>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
     constexpr int A = TILE + 2;
-    const int N4 = p.Cout >> 2;
+    constexpr int VN = VecOps<V>::N;
+    const int N4 = p.Cout / VN;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)p.T * N4;
     if (idx >= total) return;
@@ -131,77 +144,83 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
     const int t1 = t / p.TW;
     const int ty = t1 % p.TH;
     const int b = t1 / p.TH;
-    const int n = ng * 4;
+    const int n = ng * VN;
     const float* mp = p.M + (size_t)t * p.Cout + n;
     const size_t kstride = (size_t)p.T * p.Cout;
-    float4 u[TILE][A];  // u = A^T m (row pass)
+    V u[TILE][A];  // u = A^T m (row pass)
     {
-        float4 m[A][A];
+        V m[A][A];
 #pragma unroll
         for (int r = 0; r < A; ++r)
 #pragma unroll
-            for (int s = 0; s < A; ++s) m[r][s] = *reinterpret_cast<const float4*>(mp + (size_t)(r * A + s) * kstride);
+            for (int s = 0; s < A; ++s) m[r][s] = *reinterpret_cast<const V*>(mp + (size_t)(r * A + s) * kstride);
 #pragma unroll
         for (int s = 0; s < A; ++s) {
-            float4 col[A], yc[TILE];
+            V col[A], yc[TILE];
 #pragma unroll
             for (int r = 0; r < A; ++r) col[r] = m[r][s];
-            at_apply<TILE>(col, yc);
+            at_apply<TILE, V>(col, yc);
 #pragma unroll
             for (int i = 0; i < TILE; ++i) u[i][s] = yc[i];
         }
     }
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bias;
-    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
+    V bias = VecOps<V>::zero(), sc = VecOps<V>::one(), sh = VecOps<V>::zero();
+    if (p.bias) bias = *reinterpret_cast<const V*>(p.bias + n);
     if (p.film) {
         const float* f = p.film + (size_t)(p.film_bstride ? b : 0) * p.film_bstride;
-        const float4 s4 = *reinterpret_cast<const float4*>(f + n);
-        sc = make_float4(s4.x + 1.0f, s4.y + 1.0f, s4.z + 1.0f, s4.w + 1.0f);
-        sh = *reinterpret_cast<const float4*>(f + p.Cout + n);
+        sc = *reinterpret_cast<const V*>(f + n) + VecOps<V>::one();
+        sh = *reinterpret_cast<const V*>(f + p.Cout + n);
     }
     const int Ho = TILE * p.TH, Wo = TILE * p.TW;
 #pragma unroll
     for (int i = 0; i < TILE; ++i) {
-        float4 y[TILE];
-        at_apply<TILE>(u[i], y);
+        V y[TILE];
+        at_apply<TILE, V>(u[i], y);
 #pragma unroll
         for (int j = 0; j < TILE; ++j) {
             const size_t pixel = ((size_t)b * Ho + TILE * ty + i) * Wo + TILE * tx + j;
-            float v[4] = {y[j].x + bias.x, y[j].y + bias.y, y[j].z + bias.z, y[j].w + bias.w};
-            if (p.film) {
-                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-            }
-            if (p.silu) {
-                v[0] = silu1(v[0]); v[1] = silu1(v[1]); v[2] = silu1(v[2]); v[3] = silu1(v[3]);
-            }
-            if (p.res) {
-                const float4 r4 = *reinterpret_cast<const float4*>(p.res + pixel * p.res_stride + n);
-                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-            }
-            *reinterpret_cast<float4*>(p.out + pixel * p.out_stride + n) = make_float4(v[0], v[1], v[2], v[3]);
+            V v = y[j] + bias;
+            if (p.film) v = VecOps<V>::mad(v, sc, sh);
+            if (p.silu) v = VecOps<V>::silu(v);
+            if (p.res) v = v + *reinterpret_cast<const V*>(p.res + pixel * p.res_stride + n);
+            *reinterpret_cast<V*>(p.out + pixel * p.out_stride + n) = v;
         }
     }
 }
 
 }  // namespace
 
+// IRSDE_WINO_VEC=1 (experiment): one channel per thread instead of four
+static int wino_vec() {
+    static const int v = getenv("IRSDE_WINO_VEC") ? atoi(getenv("IRSDE_WINO_VEC")) : 4;
+    return v;
+}
+
 void launch_wino_input(const WinoParams& p, hipStream_t s) {
-    const long long total = (long long)p.T * ((p.C0 + p.C1) >> 2);
+    const int vn = wino_vec() == 1 ? 1 : 4;
+    const long long total = (long long)p.T * ((p.C0 + p.C1) / vn);
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (p.tile == 4)
-        hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, s, p);
+    if (p.tile == 4) {
+        if (vn == 1) hipLaunchKernelGGL((wino_input_kernel<4, float>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((wino_input_kernel<4, float4>), grid, dim3(256), 0, s, p);
+    } else {
+        if (vn == 1) hipLaunchKernelGGL((wino_input_kernel<2, float>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((wino_input_kernel<2, float4>), grid, dim3(256), 0, s, p);
+    }
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
 void launch_wino_output(const WinoParams& p, hipStream_t s) {
-    const long long total = (long long)p.T * (p.Cout >> 2);
+    const int vn = wino_vec() == 1 ? 1 : 4;
+    const long long total = (long long)p.T * (p.Cout / vn);
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (p.tile == 4)
-        hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, s, p);
+    if (p.tile == 4) {
+        if (vn == 1) hipLaunchKernelGGL((wino_output_kernel<4, float>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((wino_output_kernel<4, float4>), grid, dim3(256), 0, s, p);
+    } else {
+        if (vn == 1) hipLaunchKernelGGL((wino_output_kernel<2, float>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((wino_output_kernel<2, float4>), grid, dim3(256), 0, s, p);
+    }
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
