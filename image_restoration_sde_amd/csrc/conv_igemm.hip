@@ -477,18 +477,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Batched GEMM with the batch loop INSIDE the block — the (m+2)^2 component GEMMs of a Winograd layer when K = Cin is
-// short.  M_z[t][n] = sum_k V_z[t][k] * U_z[n][k]: launched through the kernel above, every (z, tile) is its own block
-// with only K/32 = 4..12 K-steps between a cold prologue and an LDS-transposed epilogue (71-95 TFLOP/s measured).  Here a
-// block keeps its (row tile, column tile) and walks ZB consecutive components as ONE software-pipelined K loop: the
-// double-buffered staging runs straight across component boundaries, and at a boundary the accumulators go to HBM
-// directly from registers (per MFMA register: 2 rows x 32 consecutive columns = two full 128-byte lines per store
-// instruction), are zeroed, and the MFMAs of the next component start — no LDS round trip, no extra barrier.
+// GEMM with a tile loop INSIDE the block — for the layers whose K is short (2..32 K-steps per output tile):
+//   * the (m+2)^2 component GEMMs of a Winograd layer, M_z[t][n] = sum_k V_z[t][k] * U_z[n][k]  (K = Cin);
+//   * 1x1 convolutions (to_qkv, res_conv, to_out) with K = Cin = 64..384.
+// Launched through conv_igemm_kernel every output tile is its own block with a cold prologue and an LDS-transposed epilogue
+// around those few K-steps (55-95 TFLOP/s measured).  Here a block walks a sequence of output tiles — Winograd: the same
+// (row tile, column tile) of ZB consecutive components; 1x1: all column tiles of several consecutive row tiles — as ONE
+// software-pipelined K loop: the double-buffered staging runs straight across tile boundaries, and at a boundary the
+// accumulators go to HBM directly from registers (per MFMA register: 2 rows x 32 consecutive columns = two full 128-byte
+// lines per store instruction; + bias), are zeroed, and the MFMAs of the next tile start — no LDS round trip, no barrier.
 // ---------------------------------------------------------------------------------------------------------------
+struct ZLoopArgs {
+    const float* a0; const float* a1;  // A sources, concatenated along K (a1 may be null): row m at a + m * lda (+ k)
+    int C0, C1, lda0, lda1;
+    const float* b;                    // B rows (weights): row n at b + n * K
+    float* out; const float* bias;     // out[row * ldc + col] (+ bias[col])
+    int M, N, K, ldc;                  // valid rows / columns, K = C0 + C1
+    int n_inner, n_outer;              // tiles per block: inner (fastest) x outer
+    long long pA, pB, pO;              // per inner step: plane offsets of A / B / out (floats)   (Winograd components)
+    int col_step;                      // per inner step: column offset (1x1: 128 = next column tile)
+    int row_step;                      // per outer step: row offset   (1x1: 128 = next row tile)
+    int nblk_n;                        // column tiles across blockIdx.x (Winograd) or 1
+};
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void gemm_zloop_kernel(
-    const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ Mo, const int T, const int N, const int K,
-    const int ZB, const int nblk_n, const long long zV, const long long zU, const long long zM, const float* zeros) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void gemm_zloop_kernel(const ZLoopArgs g) {
     using C = Cfg<BM, BN, WAVES_M, WAVES_N, false>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);
@@ -502,38 +515,50 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
         const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int mblk = wgid / nblk_n, nblk = wgid - mblk * nblk_n;
-    const int m0 = mblk * BM, n0 = nblk * BN;
-    const int z0 = blockIdx.y * ZB;
-    const int nk = K / BK;
-    const int steps = ZB * nk;
+    const int mblk = wgid / g.nblk_n, nblk = wgid - mblk * g.nblk_n;
+    const int m0 = mblk * BM * (g.row_step ? g.n_outer : 1), n0 = nblk * BN;
+    const int plane0 = blockIdx.y * g.n_inner;  // Winograd: first component of this block
+    const int nk = g.K / BK;
+    const int steps = g.n_inner * g.n_outer * nk;
 
     const int chunk = tid % 8, row0 = tid / 8;
-    // rows past T / N are clamped (their products land in rows / columns that are never stored)
-    const float* arow[C::A_PASSES];
+    // staging pointers of the tile being staged (rows past M / N are clamped: their products land in rows / columns that
+    // are never stored); recomputed when the staging crosses into the next tile
+    const float* arow0[C::A_PASSES];
+    const float* arow1[C::A_PASSES];
     const float* brow[C::B_PASSES];
-#pragma unroll
-    for (int ps = 0; ps < C::A_PASSES; ++ps) {
-        const int m = m0 + row0 + ps * C::A_ROWS;
-        arow[ps] = V + (size_t)z0 * zV + (size_t)(m < T ? m : T - 1) * K + chunk * 4;
-    }
-#pragma unroll
-    for (int ps = 0; ps < C::B_PASSES; ++ps) {
-        const int n = n0 + row0 + ps * C::B_ROWS;
-        brow[ps] = U + (size_t)z0 * zU + (size_t)(n < N ? n : N - 1) * K + chunk * 4;
-    }
-    (void)zeros;
+    int st_i = 0, st_o = 0;  // tile (inner, outer) being staged
+    auto set_tile_ptrs = [&]() {
+        const int rowb = m0 + st_o * g.row_step, colb = n0 + st_i * g.col_step;
+        const long long pl = (long long)(plane0 + (g.col_step ? 0 : st_i));
+        static_for<C::A_PASSES>([&](auto ps) {
+            int m = rowb + row0 + ps() * C::A_ROWS;
+            m = m < g.M ? m : g.M - 1;
+            arow0[ps()] = g.a0 + pl * g.pA + (size_t)m * g.lda0 + chunk * 4;
+            arow1[ps()] = g.a1 ? g.a1 + (size_t)m * g.lda1 + chunk * 4 - g.C0 : arow0[ps()];
+        });
+        static_for<C::B_PASSES>([&](auto ps) {
+            int n = colb + row0 + ps() * C::B_ROWS;
+            n = n < g.N ? n : g.N - 1;
+            brow[ps()] = g.b + pl * g.pB + (size_t)n * g.K + chunk * 4;
+        });
+    };
+    set_tile_ptrs();
     constexpr int NP = C::A_PASSES + C::B_PASSES;
     floatx4 rs[NP];  // (an ext_vector, not HIP's float4 struct: struct copies become memcpys that pin the array to scratch)
-    long long offA = 0, offB = 0;  // float offset of the K-step being staged relative to (z0, k = 0)
-    int kk = 0;                    // its k position inside the component
+    int kk = 0;      // k position of the K-step being staged inside its tile
     auto advance = [&]() {
-        kk += BK; offA += BK; offB += BK;
-        if (kk == K) { kk = 0; offA += zV - K; offB += zU - K; }
+        kk += BK;
+        if (kk == g.K) {
+            kk = 0;
+            if (++st_i == g.n_inner) { st_i = 0; ++st_o; }
+            set_tile_ptrs();
+        }
     };
     auto load_all = [&]() {
-        static_for<C::A_PASSES>([&](auto q) { rs[q()] = *reinterpret_cast<const floatx4*>(arow[q()] + offA); });
-        static_for<C::B_PASSES>([&](auto q) { rs[C::A_PASSES + q()] = *reinterpret_cast<const floatx4*>(brow[q()] + offB); });
+        const bool first = kk < g.C0;  // wave-uniform: which concatenated source this K-step reads
+        static_for<C::A_PASSES>([&](auto q) { rs[q()] = *reinterpret_cast<const floatx4*>((first ? arow0[q()] : arow1[q()]) + kk); });
+        static_for<C::B_PASSES>([&](auto q) { rs[C::A_PASSES + q()] = *reinterpret_cast<const floatx4*>(brow[q()] + kk); });
     };
     auto store_all = [&](int buf) {
         static_for<C::A_PASSES>([&](auto q) {
@@ -556,26 +581,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
     store_all(0);
     __syncthreads();
 
-    // The finished component is written at the START of the following K-step, after that step's loads have been issued:
-    // the stores then have a whole MFMA phase to drain before the next vmcnt wait (written at the end of its own step,
-    // the loads of the next step — which the compiler orders behind all older memory operations — stalled on them).
-    auto flush = [&](int zc) {
-        float* oz = Mo + (size_t)zc * zM;
+    // The finished tile is written at the START of the following K-step, after that step's loads have been issued: the
+    // stores then have a whole MFMA phase to drain before the next vmcnt wait.
+    // bias of every column this block will produce, kept in LDS behind the staging buffers: a global load inside (or
+    // one K-step before) the store sequence makes the compiler put vmcnt waits in front of every store, which serialises
+    // the stores themselves; LDS reads are counted separately (lgkmcnt)
+    float* bias_s = reinterpret_cast<float*>(Bs + 2 * BN * C::ROW_BYTES);
+    if (g.bias) {  // kernel-uniform
+        const int ncols = g.col_step ? g.n_inner * g.col_step : BN;
+        for (int c = tid; c < ncols; c += C::NT) bias_s[c] = (n0 + c < g.N) ? g.bias[n0 + c] : 0.f;
+    }
+    auto flush = [&](int fi, int fo) {
+        const int rowb = m0 + fo * g.row_step, colb = n0 + fi * g.col_step;
+        float* oz = g.out + (long long)(plane0 + (g.col_step ? 0 : fi)) * g.pO;
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
 #pragma unroll
             for (int j = 0; j < C::TN; ++j) {
-                const int col = n0 + wn * C::TN * 32 + j * 32 + l31;
+                const int col = colb + wn * C::TN * 32 + j * 32 + l31;
+                const float bvj = g.bias ? bias_s[col - n0] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < T && col < N) oz[(size_t)row * N + col] = acc[i][j][r];
+                    const int row = rowb + wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < g.M && col < g.N) oz[(size_t)row * g.ldc + col] = acc[i][j][r] + bvj;
                     acc[i][j][r] = 0.f;
                 }
             }
     };
-    int kdone = 0;  // K-steps finished inside the current component
-    int z = z0;
+    int kdone = 0;          // K-steps finished inside the current tile
+    int cu_i = 0, cu_o = 0;  // tile being computed
+    int fl_i = 0, fl_o = 0;
     bool pending = false;
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
@@ -585,7 +620,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
             load_all();
         }
         if (pending) {
-            flush(z - 1);
+            flush(fl_i, fl_o);
             pending = false;
         }
         const char* a = As + (buf * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
@@ -608,14 +643,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
                 }
         }
         if (more) store_all(buf ^ 1);
-        if (++kdone == nk) {  // component finished
+        if (++kdone == nk) {  // tile finished
             kdone = 0;
-            ++z;
+            fl_i = cu_i; fl_o = cu_o;
+            if (++cu_i == g.n_inner) { cu_i = 0; ++cu_o; }
             pending = true;
         }
         __syncthreads();
     }
-    flush(z - 1);
+    flush(fl_i, fl_o);
 }
 
 // split-K second stage: sum partials, run the epilogue (memory-bound, tiny layers only)
@@ -697,6 +733,23 @@ void init_cfg() {
 
 int g_variant = 0;  // tuning experiments only (irsde_bench_conv)
 
+// 1x1 convolutions with a short K on the tile-loop kernel: row tiles per block, or 0 = generic kernel.
+int zloop_1x1_rows(const ConvParams& p) {
+    if (p.nz != 1 || p.w_bf || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_y || p.pad_x || p.in_shift || p.film || p.silu ||
+        p.res || p.splits != 1 || p.gate || p.shuffle || p.ch_scale || p.in_scale || p.ln_g || p.in_bf16 || p.out_bf16)
+        return 0;
+    static const int env = getenv("IRSDE_ZLOOP_1X1") ? atoi(getenv("IRSDE_ZLOOP_1X1")) : -1;  // tuning: 0 = off, n = rows tiles
+    if (g_variant == 70 || env == 0) return 0;
+    const int M = p.B * p.Ho * p.Wo, K = p.C0 + p.C1;
+    const int mtiles = (M + 127) / 128, ntiles = (p.Cout + 127) / 128, nk = K / 32;
+    if (g_variant == 73) return 2;  // test hook: force the path on small shapes
+    if (env > 0) return env;
+    if (nk > 12 || mtiles < 1024) return 0;  // long K amortises the per-tile overhead already; small M: not enough blocks
+    int mb = 1;
+    while (mb < 8 && mtiles / (mb * 2) >= 1024 && mb * ntiles * nk < 24) mb *= 2;
+    return mb;
+}
+
 // components per block for gemm_zloop_kernel, or 0 = use one block per (component, tile)
 int zloop_batch(const ConvParams& p) {
     if (p.nz <= 1 || p.w_bf || p.KH != 1 || p.KW != 1 || p.C1 || p.bias || p.film || p.silu || p.res || p.splits != 1 ||
@@ -773,12 +826,32 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.ln_g && (p.splits != 1 || (p.Cout != 64 && p.Cout != 128) || p.nz != 1 || (p.out_stride & 3)))
         throw HipError("launch_conv: fused LayerNorm needs Cout == 64 or 128 in one tile, no split-K");
     if (!p.zeros) throw HipError("launch_conv: ConvParams::zeros (zero page for out-of-image taps) is not set");
-    if (const int zb = zloop_batch(p)) {  // short-K Winograd component GEMMs: batch loop inside the block
+    if (const int zb = zloop_batch(p)) {  // short-K Winograd component GEMMs: component loop inside the block
         using C = Cfg<128, 128, 2, 2, false>;
-        const int nblk_n = (p.Cout + 127) / 128;
-        dim3 grid(((p.Wo + 127) / 128) * nblk_n, p.nz / zb);
-        hipLaunchKernelGGL((gemm_zloop_kernel<128, 128, 2, 2, 2>), grid, dim3(C::NT), C::MAIN_BYTES, s, p.in0, p.w, p.out, p.Wo,
-                           p.Cout, p.C0, zb, nblk_n, p.z_in, p.z_w, p.z_out, p.zeros);
+        ZLoopArgs g{};
+        g.a0 = p.in0; g.a1 = nullptr; g.C0 = p.C0; g.C1 = 0; g.lda0 = p.C0; g.lda1 = 0;
+        g.b = p.w; g.out = p.out; g.bias = nullptr;
+        g.M = p.Wo; g.N = p.Cout; g.K = p.C0; g.ldc = p.Cout;
+        g.n_inner = zb; g.n_outer = 1; g.pA = p.z_in; g.pB = p.z_w; g.pO = p.z_out; g.col_step = 0; g.row_step = 0;
+        g.nblk_n = (p.Cout + 127) / 128;
+        dim3 grid(((p.Wo + 127) / 128) * g.nblk_n, p.nz / zb);
+        hipLaunchKernelGGL((gemm_zloop_kernel<128, 128, 2, 2, 2>), grid, dim3(C::NT), C::MAIN_BYTES, s, g);
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (const int mb = zloop_1x1_rows(p)) {  // short-K 1x1 convolutions: (row tiles x all column tiles) loop inside the block
+        using C = Cfg<128, 128, 2, 2, false>;
+        const int M = p.B * p.Ho * p.Wo;
+        ZLoopArgs g{};
+        g.a0 = p.in0; g.a1 = p.C1 ? p.in1 : nullptr; g.C0 = p.C0; g.C1 = p.C1; g.lda0 = p.pix0; g.lda1 = p.pix1;
+        g.b = p.w; g.out = p.out; g.bias = p.bias;
+        g.M = M; g.N = p.Cout; g.K = p.C0 + p.C1; g.ldc = p.out_stride;
+        g.n_inner = (p.Cout + 127) / 128; g.n_outer = mb; g.pA = g.pB = g.pO = 0; g.col_step = 128; g.row_step = 128;
+        g.nblk_n = 1;
+        const int mtiles = (M + 127) / 128;
+        dim3 grid((mtiles + mb - 1) / mb, 1);
+        const int lds = C::MAIN_BYTES + (p.bias ? g.n_inner * 128 * 4 : 0);  // + the block's bias columns
+        hipLaunchKernelGGL((gemm_zloop_kernel<128, 128, 2, 2, 2>), grid, dim3(C::NT), lds, s, g);
         IRSDE_HIP_CHECK(hipGetLastError());
         return;
     }
