@@ -766,6 +766,8 @@ int zloop_batch(const ConvParams& p) {
     static const int max_nk = getenv("IRSDE_ZLOOP_MAXNK") ? atoi(getenv("IRSDE_ZLOOP_MAXNK")) : 32;
     static const int min_blocks = getenv("IRSDE_ZLOOP_MINBLK") ? atoi(getenv("IRSDE_ZLOOP_MINBLK")) : 1024;
     if (nk > max_nk) return 0;  // long K: the per-block overhead is already amortised (measured: 12 / 32 / 48 -> 2.82 / 2.87 / 2.83 img/s)
+    static const int deep_rule = getenv("IRSDE_ZLOOP_DEEP") ? atoi(getenv("IRSDE_ZLOOP_DEEP")) : 1;
+    if (deep_rule && nk > 16 && (p.Wo + 127) / 128 < 32) return 0;  // few row tiles + long K (32x32 level): generic kernel is ahead
     int best = 0;
     for (int zb = p.nz; zb >= 2; --zb) {  // largest batch that still fills the 2 x 256 block slots evenly
         if (p.nz % zb) continue;
