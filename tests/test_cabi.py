@@ -80,3 +80,20 @@ def test_load_weight_errors():
         assert L.irsde_set_schedule(h, 10, buf) != 0
     finally:
         L.irsde_destroy(h)
+
+
+def test_plain_c_host(tmp_path):
+    """include/irsde_hip.h is valid C99 and a plain C program (no HIP / torch headers) can drive the library."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "cabi_host")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c", "cabi_host.c"), "-o", exe, "-L", libdir, "-lirsde_hip",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c host ok" in r.stdout
