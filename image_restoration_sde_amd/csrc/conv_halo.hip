@@ -45,7 +45,7 @@ struct HCfg {
 // ABF: the activations are bf16 in HBM (IRSDE_FLAG_BF16_ACT): 4 instead of 8 16-byte pieces per halo pixel, no conversion.
 template <int BN, bool ABF>
 __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvParams p, const int tiles_x, const int tiles_y,
-                                                                  const int nblk_n) {
+                                                                  const int nblk_n, const int n_slow) {
     using C = HCfg<BN>;
     constexpr int PPP = ABF ? 4 : 8;                            // 16-byte pieces per halo pixel (32 channels)
     constexpr int PSH = ABF ? 2 : 3;
@@ -72,8 +72,12 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
         const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int nblk = wgid % nblk_n;
-    int t = wgid / nblk_n;
+    // Tile order inside an XCD's contiguous range.  Few output-channel blocks: N-blocks fastest (they share the halo in
+    // L2).  Wide layers whose weights exceed an L2 (n_slow): N-blocks SLOWEST, so that an XCD keeps one weight slice
+    // resident and streams the (much smaller) activation tiles of every image past it.
+    const int ntile = gridDim.x / nblk_n;
+    const int nblk = n_slow ? wgid / ntile : wgid % nblk_n;
+    int t = n_slow ? wgid % ntile : wgid / nblk_n;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
@@ -302,8 +306,11 @@ template <int BN, bool ABF>
 void launch_halo(const ConvParams& p, hipStream_t s) {
     const int tiles_x = (p.Wo + TS - 1) / TS, tiles_y = (p.Ho + TS - 1) / TS;
     const int nblk_n = (p.Cout + BN - 1) / BN;
+    static const int env = getenv("IRSDE_HALO_NSLOW") ? atoi(getenv("IRSDE_HALO_NSLOW")) : -1;
+    const double wbytes = 2.0 * p.Cout * 9.0 * (p.C0 + p.C1);
+    const int n_slow = env >= 0 ? (env && nblk_n > 1) : (nblk_n >= 2 && wbytes > 4.0e6);  // one XCD L2 = 4 MiB
     hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, ABF>), dim3((unsigned)(p.B * tiles_y * tiles_x * nblk_n)), dim3(NT),
-                       HCfg<BN>::LDS_BYTES, s, p, tiles_x, tiles_y, nblk_n);
+                       HCfg<BN>::LDS_BYTES, s, p, tiles_x, tiles_y, nblk_n, n_slow);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
