@@ -763,6 +763,7 @@ int zloop_batch(const ConvParams& p) {
     const int nk = p.C0 / 32;
     const long long tiles = (long long)((p.Wo + 127) / 128) * ((p.Cout + 127) / 128);
     if (force > 0) return p.nz % force == 0 ? force : 0;
+    if (p.Wo <= 64) return nk >= 4 ? 1 : 0;  // single-image deep levels: 64-row tiles (a 128-row tile would be half empty)
     static const int max_nk = getenv("IRSDE_ZLOOP_MAXNK") ? atoi(getenv("IRSDE_ZLOOP_MAXNK")) : 32;
     static const int min_blocks = getenv("IRSDE_ZLOOP_MINBLK") ? atoi(getenv("IRSDE_ZLOOP_MINBLK")) : 1024;
     if (nk > max_nk) return 0;  // long K: the per-block overhead is already amortised (measured: 12 / 32 / 48 -> 2.82 / 2.87 / 2.83 img/s)
@@ -784,6 +785,8 @@ void conv_set_variant(int v) { g_variant = v; }
 void conv_global_init() {
     conv_halo_global_init();
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<128, 128, 2, 2, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<64, 128, 1, 2, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     init_cfg<128, 128, 2, 2, 2, false>();
     init_cfg<128, 64, 2, 2, 2, false>();
@@ -836,6 +839,13 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
         g.M = p.Wo; g.N = p.Cout; g.K = p.C0; g.ldc = p.Cout;
         g.n_inner = zb; g.n_outer = 1; g.pA = p.z_in; g.pB = p.z_w; g.pO = p.z_out; g.col_step = 0; g.row_step = 0;
         g.nblk_n = (p.Cout + 127) / 128;
+        if (p.Wo <= 64) {  // 64 x 128 tiles, 2 waves
+            using C64 = Cfg<64, 128, 1, 2, false>;
+            dim3 grid64(g.nblk_n, p.nz / zb);
+            hipLaunchKernelGGL((gemm_zloop_kernel<64, 128, 1, 2, 2>), grid64, dim3(C64::NT), C64::MAIN_BYTES, s, g);
+            IRSDE_HIP_CHECK(hipGetLastError());
+            return;
+        }
         dim3 grid(((p.Wo + 127) / 128) * g.nblk_n, p.nz / zb);
         hipLaunchKernelGGL((gemm_zloop_kernel<128, 128, 2, 2, 2>), grid, dim3(C::NT), C::MAIN_BYTES, s, g);
         IRSDE_HIP_CHECK(hipGetLastError());
