@@ -786,7 +786,7 @@ void conv_global_init() {
     conv_halo_global_init();
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<128, 128, 2, 2, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<64, 128, 1, 2, 2>),
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<64, 128, 1, 4, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     init_cfg<128, 128, 2, 2, 2, false>();
     init_cfg<128, 64, 2, 2, 2, false>();
@@ -839,10 +839,10 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
         g.M = p.Wo; g.N = p.Cout; g.K = p.C0; g.ldc = p.Cout;
         g.n_inner = zb; g.n_outer = 1; g.pA = p.z_in; g.pB = p.z_w; g.pO = p.z_out; g.col_step = 0; g.row_step = 0;
         g.nblk_n = (p.Cout + 127) / 128;
-        if (p.Wo <= 64) {  // 64 x 128 tiles, 2 waves
-            using C64 = Cfg<64, 128, 1, 2, false>;
+        if (p.Wo <= 64) {  // 64 x 128 tiles, 4 waves of 64 x 32 (all four SIMDs busy)
+            using C64 = Cfg<64, 128, 1, 4, false>;
             dim3 grid64(g.nblk_n, p.nz / zb);
-            hipLaunchKernelGGL((gemm_zloop_kernel<64, 128, 1, 2, 2>), grid64, dim3(C64::NT), C64::MAIN_BYTES, s, g);
+            hipLaunchKernelGGL((gemm_zloop_kernel<64, 128, 1, 4, 2>), grid64, dim3(C64::NT), C64::MAIN_BYTES, s, g);
             IRSDE_HIP_CHECK(hipGetLastError());
             return;
         }
