@@ -750,6 +750,11 @@ int zloop_1x1_rows(const ConvParams& p) {
     return mb;
 }
 
+// few rows (single image, deep levels): 64 x 128 tiles — a 128-row tile would be half empty or the grid under-filled
+bool zloop_small_m(const ConvParams& p) {
+    return p.Wo <= 64 || (long long)((p.Wo + 127) / 128) * ((p.Cout + 127) / 128) * p.nz < 512;
+}
+
 // components per block for gemm_zloop_kernel, or 0 = use one block per (component, tile)
 int zloop_batch(const ConvParams& p) {
     if (p.nz <= 1 || p.w_bf || p.KH != 1 || p.KW != 1 || p.C1 || p.bias || p.film || p.silu || p.res || p.splits != 1 ||
@@ -763,7 +768,7 @@ int zloop_batch(const ConvParams& p) {
     const int nk = p.C0 / 32;
     const long long tiles = (long long)((p.Wo + 127) / 128) * ((p.Cout + 127) / 128);
     if (force > 0) return p.nz % force == 0 ? force : 0;
-    if (p.Wo <= 64) return nk >= 4 ? 1 : 0;  // single-image deep levels: 64-row tiles (a 128-row tile would be half empty)
+    if (zloop_small_m(p)) return nk >= 4 ? 1 : 0;  // single-image deep levels: 64-row tiles, one component per block
     static const int max_nk = getenv("IRSDE_ZLOOP_MAXNK") ? atoi(getenv("IRSDE_ZLOOP_MAXNK")) : 32;
     static const int min_blocks = getenv("IRSDE_ZLOOP_MINBLK") ? atoi(getenv("IRSDE_ZLOOP_MINBLK")) : 1024;
     if (nk > max_nk) return 0;  // long K: the per-block overhead is already amortised (measured: 12 / 32 / 48 -> 2.82 / 2.87 / 2.83 img/s)
@@ -839,9 +844,9 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
         g.M = p.Wo; g.N = p.Cout; g.K = p.C0; g.ldc = p.Cout;
         g.n_inner = zb; g.n_outer = 1; g.pA = p.z_in; g.pB = p.z_w; g.pO = p.z_out; g.col_step = 0; g.row_step = 0;
         g.nblk_n = (p.Cout + 127) / 128;
-        if (p.Wo <= 64) {  // 64 x 128 tiles, 4 waves of 64 x 32 (all four SIMDs busy)
+        if (zloop_small_m(p)) {  // 64 x 128 tiles, 4 waves of 64 x 32 (all four SIMDs busy)
             using C64 = Cfg<64, 128, 1, 4, false>;
-            dim3 grid64(g.nblk_n, p.nz / zb);
+            dim3 grid64(((p.Wo + 63) / 64) * g.nblk_n, p.nz / zb);
             hipLaunchKernelGGL((gemm_zloop_kernel<64, 128, 1, 4, 2>), grid64, dim3(C64::NT), C64::MAIN_BYTES, s, g);
             IRSDE_HIP_CHECK(hipGetLastError());
             return;
