@@ -791,6 +791,8 @@ void conv_global_init() {
     conv_halo_global_init();
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<128, 128, 2, 2, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<128, 64, 2, 2, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<64, 128, 1, 4, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     init_cfg<128, 128, 2, 2, 2, false>();
@@ -851,6 +853,14 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
             IRSDE_HIP_CHECK(hipGetLastError());
             return;
         }
+        if (p.Cout <= 64) {  // 128 x 64 tiles: a 128-wide tile would be half padding (the 64-channel full-resolution layers)
+            using C64n = Cfg<128, 64, 2, 2, false>;
+            g.nblk_n = 1;
+            dim3 grid_n((p.Wo + 127) / 128, p.nz / zb);
+            hipLaunchKernelGGL((gemm_zloop_kernel<128, 64, 2, 2, 2>), grid_n, dim3(C64n::NT), C64n::MAIN_BYTES, s, g);
+            IRSDE_HIP_CHECK(hipGetLastError());
+            return;
+        }
         dim3 grid(((p.Wo + 127) / 128) * g.nblk_n, p.nz / zb);
         hipLaunchKernelGGL((gemm_zloop_kernel<128, 128, 2, 2, 2>), grid, dim3(C::NT), C::MAIN_BYTES, s, g);
         IRSDE_HIP_CHECK(hipGetLastError());
@@ -867,6 +877,14 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
         g.nblk_n = 1;
         const int mtiles = (M + 127) / 128;
         dim3 grid((mtiles + mb - 1) / mb, 1);
+        if (p.Cout <= 64) {  // one 64-wide column tile
+            using C64n = Cfg<128, 64, 2, 2, false>;
+            g.col_step = 64;
+            hipLaunchKernelGGL((gemm_zloop_kernel<128, 64, 2, 2, 2>), grid, dim3(C64n::NT),
+                               C64n::MAIN_BYTES + (p.bias ? 64 * 4 : 0), s, g);
+            IRSDE_HIP_CHECK(hipGetLastError());
+            return;
+        }
         const int lds = C::MAIN_BYTES + (p.bias ? g.n_inner * 128 * 4 : 0);  // + the block's bias columns
         hipLaunchKernelGGL((gemm_zloop_kernel<128, 128, 2, 2, 2>), grid, dim3(C::NT), lds, s, g);
         IRSDE_HIP_CHECK(hipGetLastError());

@@ -111,6 +111,7 @@ CONV_CASES = {
     "1x1_concat_res_conv": (1, 128, 64, 16, 16, 128, 1, 1, 0, 0, False, False, False, False),
     "1x1_qkv_384": (2, 64, 0, 12, 12, 384, 1, 1, 0, 0, False, False, False, False),
     "1x1_to_out_bias": (2, 128, 0, 12, 12, 256, 1, 1, 0, 0, True, False, False, False),
+    "1x1_narrow_64_bias": (2, 128, 0, 12, 12, 64, 1, 1, 0, 0, True, False, False, False),
     "4x4_s2_down": (2, 64, 0, 16, 24, 128, 4, 2, 1, 0, True, False, False, False),
     "3x3_upsample_fused": (2, 128, 0, 8, 12, 64, 3, 1, 1, 1, True, False, False, False),
     "3x3_final_cout3": (2, 64, 0, 24, 20, 3, 3, 1, 1, 0, True, False, False, False),
