@@ -353,7 +353,61 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
                     }
         }
         __syncthreads();
-        if (n < p.Cout) {
+        if (p.ln_g) {
+            // bias -> channel LayerNorm -> +res (LinearAttention.to_out + Residual): four rows per iteration, so that the ten
+            // dependent cross-lane steps (ds_bpermute, ~100 cycles each) of the four rows overlap instead of queueing up
+            constexpr int U = 4;
+            const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + n);
+            for (int rb = tid / NV; rb < C::EPI_ROWS; rb += U * RSTEP) {
+                float v[U][4], sum[U], sq[U];
+                long long mrow[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int row = rb + u * RSTEP;
+                    const int m = m0 + pass * C::EPI_ROWS + row;
+                    mrow[u] = (row < C::EPI_ROWS && m < M) ? m : -1;
+                    const float4 cv = *reinterpret_cast<const float4*>(Cs + (row < C::EPI_ROWS ? row : 0) * C::LDS_C + c4 * 4);
+                    v[u][0] = cv.x + bias[0]; v[u][1] = cv.y + bias[1]; v[u][2] = cv.z + bias[2]; v[u][3] = cv.w + bias[3];
+                    sum[u] = (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+                }
+#pragma unroll
+                for (int o = NV / 2; o > 0; o >>= 1)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) sum[u] += __shfl_xor(sum[u], o, 64);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float mean = sum[u] * (1.0f / (float)BN);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] -= mean;
+                    sq[u] = (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]);
+                }
+#pragma unroll
+                for (int o = NV / 2; o > 0; o >>= 1)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) sq[u] += __shfl_xor(sq[u], o, 64);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (mrow[u] < 0) continue;
+                    const float rstd = 1.0f / sqrtf(sq[u] * (1.0f / (float)BN) + p.ln_eps);
+                    float o4[4] = {v[u][0] * rstd * g4.x, v[u][1] * rstd * g4.y, v[u][2] * rstd * g4.z, v[u][3] * rstd * g4.w};
+                    const size_t off = (size_t)mrow[u];
+                    if (BF16 && p.out_bf16) {
+                        if (p.res) {
+                            const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.res) + off * p.res_stride + n);
+                            o4[0] += (float)t4[0]; o4[1] += (float)t4[1]; o4[2] += (float)t4[2]; o4[3] += (float)t4[3];
+                        }
+                        const floatx4 fv = {o4[0], o4[1], o4[2], o4[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + off * p.out_stride + n) = __builtin_convertvector(fv, bf16x4);
+                    } else {
+                        if (p.res) {
+                            const float4 t4 = *reinterpret_cast<const float4*>(p.res + off * p.res_stride + n);
+                            o4[0] += t4.x; o4[1] += t4.y; o4[2] += t4.z; o4[3] += t4.w;
+                        }
+                        *reinterpret_cast<float4*>(p.out + off * p.out_stride + n) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                    }
+                }
+            }
+        } else if (n < p.Cout) {
         for (int row = tid / NV; row < C::EPI_ROWS; row += RSTEP) {
             const int m = m0 + pass * C::EPI_ROWS + row;
             if (m >= M) break;
@@ -403,19 +457,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
                 if (p.film) t = t * sc[e] + sh[e];
                 if (p.silu) t = silu_f(t);
                 v[e] = t * cs[e];
-            }
-            if (p.ln_g) {  // fused channel LayerNorm: the NV lanes of this row group hold the whole row (Cout == BN)
-                float sum = (v[0] + v[1]) + (v[2] + v[3]);
-#pragma unroll
-                for (int o = NV / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-                const float mean = sum * (1.0f / (float)BN);
-                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-                float sq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-#pragma unroll
-                for (int o = NV / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-                const float rstd = 1.0f / sqrtf(sq * (1.0f / (float)BN) + p.ln_eps);
-                const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + n);
-                v[0] = d0 * rstd * g4.x; v[1] = d1 * rstd * g4.y; v[2] = d2 * rstd * g4.z; v[3] = d3 * rstd * g4.w;
             }
             if (p.gate) {  // SimpleGate: pairs are adjacent by construction of the packed weights
                 float* dst = p.out + opix * p.out_stride + ocol;
@@ -835,7 +876,7 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
         throw HipError("launch_conv: channel counts must be multiples of 32 (got " + std::to_string(p.C0) + "+" +
                        std::to_string(p.C1) + ")");
     if (p.splits > 1 && !p.partial) throw HipError("launch_conv: split-K needs a partial buffer");
-    if (p.ln_g && (p.splits != 1 || (p.Cout != 64 && p.Cout != 128) || p.nz != 1 || (p.out_stride & 3)))
+    if (p.ln_g && (p.splits != 1 || (p.Cout != 64 && p.Cout != 128) || p.nz != 1 || (p.out_stride & 3) || (p.res && (p.res_stride & 3))))
         throw HipError("launch_conv: fused LayerNorm needs Cout == 64 or 128 in one tile, no split-K");
     if (!p.zeros) throw HipError("launch_conv: ConvParams::zeros (zero page for out-of-image taps) is not set");
     if (const int zb = zloop_batch(p)) {  // short-K Winograd component GEMMs: component loop inside the block
