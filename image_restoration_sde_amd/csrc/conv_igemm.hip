@@ -695,6 +695,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
     flush(fl_i, fl_o);
 }
 
+// final_conv (DenoisingUNet_arch.py:76, 64 -> 3 channels): with Cout <= 4 an MFMA tile is > 90 % padding (8 TFLOP/s, 0.44 ms).
+// Vector pipe instead: 16 lanes share a pixel, lane l owns channels 4l..4l+3 (one coalesced 256-byte row per tap), keeps its
+// 27 weight float4s in registers, walks 8 consecutive pixels, and the 16 partial sums are reduced once per pixel.
+// (One thread per pixel with its own 256-byte rows was 5x SLOWER than the MFMA kernel: 64 cache lines per load instruction.)
+constexpr int kNarrowPPG = 8;  // pixels per 16-lane group
+__global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const ConvParams p, const int M) {
+    const int l = threadIdx.x & 15;
+    const int group = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int C = p.C0;  // == 64
+    float4 w[3][9];
+#pragma unroll
+    for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            w[co][t] = co < p.Cout ? *reinterpret_cast<const float4*>(p.w + ((size_t)co * 9 + t) * C + l * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < kNarrowPPG; ++i) {
+        const int m = group * kNarrowPPG + i;
+        const bool ok = m < M;  // all 16 lanes of a group agree; the shuffles below need every lane
+        const int mm = ok ? m : 0;
+        const int ox = mm % p.Wo, t1 = mm / p.Wo, oy = t1 % p.Ho, b = t1 / p.Ho;
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy - 1 + ky, ix = ox - 1 + kx;
+                const bool in = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                const float* g = in ? p.in0 + ((size_t)(b * p.Hin + iy) * p.Win + ix) * p.pix0 + l * 4 : p.zeros;
+                const float4 v = *reinterpret_cast<const float4*>(g);
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    const float4 wv = w[co][ky * 3 + kx];
+                    acc[co] = fmaf(v.x, wv.x, acc[co]);
+                    acc[co] = fmaf(v.y, wv.y, acc[co]);
+                    acc[co] = fmaf(v.z, wv.z, acc[co]);
+                    acc[co] = fmaf(v.w, wv.w, acc[co]);
+                }
+            }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int co = 0; co < 3; ++co) acc[co] += __shfl_xor(acc[co], o, 64);
+        if (ok && l < p.Cout) p.out[(size_t)m * p.out_stride + l] = (l == 0 ? acc[0] : l == 1 ? acc[1] : acc[2]) + (p.bias ? p.bias[l] : 0.f);
+    }
+}
+
 // split-K second stage: sum partials, run the epilogue (memory-bound, tiny layers only)
 __global__ void conv_splitk_reduce(const ConvParams p, const int M) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -879,6 +925,13 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.ln_g && (p.splits != 1 || (p.Cout != 64 && p.Cout != 128) || p.nz != 1 || (p.out_stride & 3) || (p.res && (p.res_stride & 3))))
         throw HipError("launch_conv: fused LayerNorm needs Cout == 64 or 128 in one tile, no split-K");
     if (!p.zeros) throw HipError("launch_conv: ConvParams::zeros (zero page for out-of-image taps) is not set");
+    if (!p.w_bf && g_variant == 0 && p.Cout <= 3 && p.C0 == 64 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 &&
+        !p.in_shift && !p.C1 && !p.film && !p.silu && !p.res && p.splits == 1 && p.nz == 1 && !p.gate && !p.shuffle &&
+        !p.ch_scale && !p.in_scale && !p.ln_g && M >= 65536) {  // final_conv: vector-pipe kernel (big feature maps only)
+        hipLaunchKernelGGL(conv3x3_narrow_kernel, dim3((M + 16 * kNarrowPPG - 1) / (16 * kNarrowPPG)), dim3(256), 0, s, p, M);
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (const int zb = zloop_batch(p)) {  // short-K Winograd component GEMMs: component loop inside the block
         using C = Cfg<128, 128, 2, 2, false>;
         ZLoopArgs g{};

@@ -115,6 +115,7 @@ CONV_CASES = {
     "4x4_s2_down": (2, 64, 0, 16, 24, 128, 4, 2, 1, 0, True, False, False, False),
     "3x3_upsample_fused": (2, 128, 0, 8, 12, 64, 3, 1, 1, 1, True, False, False, False),
     "3x3_final_cout3": (2, 64, 0, 24, 20, 3, 3, 1, 1, 0, True, False, False, False),
+    "3x3_final_cout3_large": (1, 64, 0, 256, 256, 3, 3, 1, 1, 0, True, False, False, False),   # >= 65536 pixels: vector-pipe kernel
     "3x3_m_tail_odd": (1, 32, 0, 7, 9, 96, 3, 1, 1, 0, False, False, True, False),
     "3x3_deep_k_1536": (1, 1024, 512, 4, 4, 256, 3, 1, 1, 0, False, True, True, False),
     "3x3_wino_res_bias": (2, 256, 0, 12, 20, 256, 3, 1, 1, 0, True, False, True, True),
