@@ -55,7 +55,7 @@ struct ConvParams {
     // epilogue runs in conv_splitk_reduce.
     int splits = 1;
     float* partial = nullptr;
-    const float* zeros = nullptr;  // >= 16 zero bytes (source of out-of-image taps for LDS-DMA staging)
+    const float* zeros = nullptr;  // >= 16 zero bytes: out-of-image taps are loaded from here (address select, no branch)
     // --- NAFNet (Refusion) fusions -------------------------------------------------------------------------
     const float* ch_scale = nullptr;  // [Cout]: v *= ch_scale[n] after the activation, before +res  (beta / gamma)
     const float* in_scale = nullptr;  // [B][C0]: input element (b, k) is multiplied by in_scale[b][k] while staged (SCA)

@@ -243,7 +243,7 @@ struct irsde_engine {
     StepState* step = nullptr;
     SampleCtl* ctl = nullptr;
 
-    float* zeros = nullptr;        // zero page for LDS-DMA staging of out-of-image taps
+    float* zeros = nullptr;        // zero page: the branch-free source of out-of-image conv taps
     hipStream_t stream = nullptr;  // engine stream (graph capture needs a non-default stream)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::vector<std::unique_ptr<Plan>> plans;

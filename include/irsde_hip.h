@@ -197,16 +197,22 @@ int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buf
 
 /* Kernel-level test hook: one implicit-GEMM convolution (csrc/conv_igemm.hip) on NHWC device tensors.
  * in0/in1: [B][Hin][Win][C0|C1] (channel concat, in1 may be NULL); w_oihw/bias: HOST, reference layout;
- * film: device [rows][2*Cout] or NULL; res/out: device [B][Ho][Wo][Cout].  naive != 0 runs the VALU
- * cross-check kernel, naive == 2 / 3 the Winograd F(2x2,3x3) / F(4x4,3x3) path (3x3 s1 p1 only), naive >= 100 an experimental
- * tile variant; splits > 1 forces split-K.  Synchronises `stream`. */
+ * film: device [rows][2*Cout] or NULL; res/out: device [B][Ho][Wo][Cout].  `naive` selects the code path under test:
+ *   0 production dispatch      1 VALU cross-check kernel
+ *   2 / 3 Winograd F(2x2,3x3) / F(4x4,3x3) (3x3 s1 p1 only); 12 / 13 and 22 / 23: the same with the component GEMMs forced
+ *         onto the tile-loop kernel (all / 2 components per block)
+ *   4 bf16-MFMA mode (halo kernel for eligible 3x3 layers); 160 / 161 its generic 256 / 128 tile
+ *   204 / 260 / 261 the same three with bf16 activation storage (inputs / residual are rounded, the result widened back)
+ *   100 + v: tile variant v of the fp32 kernel (3 = 256x128, 50 = 256x256, 73 = tile-loop kernel for 1x1 layers)
+ * splits > 1 forces split-K.  Synchronises `stream`. */
 int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int in_shift,
                      const float* w_oihw, int Cout, int KH, int KW, int stride, int pad, const float* bias,
                      const float* film, int film_bstride, int silu, const float* res, float* out, int naive,
                      int splits, void* stream);
 
 /* Kernel tuning hook: average ms of one KxK convolution (pad K/2, or 4x4 s2 p1) on random NHWC data.
- * variant selects an experimental tile configuration (0 = production); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
+ * variant: 0 production dispatch, 3 / 50 fp32 256x128 / 256x256 tiles, 60 / 61 / 62 bf16 mode (256 tile / 128 tile / automatic
+ * incl. the halo kernel); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out);
 
