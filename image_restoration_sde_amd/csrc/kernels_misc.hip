@@ -43,7 +43,10 @@ __device__ __forceinline__ float wave_xor_sum(float v, int width) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kLnMaxVec = 8;  // float4 vectors per lane -> C <= 2048
 
-template <typename T>
+// KV = float4 vectors per lane (1, 2, 4, 8), U = independent pixel groups per iteration: all U x KV loads are issued before the
+// first reduction and the U cross-lane reductions interleave — with one pixel group per iteration a wave had a single load
+// in flight and the kernel sat at ~2.5 TB/s, latency-bound.
+template <typename T, int KV, int U>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ g,
                                                         const T* __restrict__ res, T* __restrict__ out,
                                                         const long long M, const int C, const int L, const float eps,
@@ -58,48 +61,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
     const float invC = 1.0f / (float)C;
-    for (long long base = wave_id * ppw; base < M; base += nwaves * ppw) {
-        const long long pix = base + sub;
-        const bool ok = pix < M;
-        const T* xp = x + (ok ? pix : 0) * C;
-        float4 v[kLnMaxVec];
-        float s = 0.f;
+    for (long long base = wave_id * ppw * U; base < M; base += nwaves * ppw * U) {
+        float4 v[U][KV];
+        float s[U], q[U];
+        long long pix[U];
 #pragma unroll
-        for (int k = 0; k < kLnMaxVec; ++k) {
-            const int vi = li + k * L;
-            if (vi < nvec) {
-                v[k] = ld4(xp + 4 * vi);
-                s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        for (int u = 0; u < U; ++u) {
+            pix[u] = base + (long long)u * ppw + sub;
+            const T* xp = x + (pix[u] < M ? pix[u] : 0) * C;
+            s[u] = 0.f;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int vi = li + k * L;
+                const float4 t = ld4(xp + 4 * (vi < nvec ? vi : 0));  // unconditional load from a clamped index, then select
+                v[u][k] = vi < nvec ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                s[u] += (v[u][k].x + v[u][k].y) + (v[u][k].z + v[u][k].w);
             }
         }
-        s = wave_xor_sum(s, L);
-        const float mean = s * invC;
-        float q = 0.f;
+        for (int o = L >> 1; o > 0; o >>= 1)
 #pragma unroll
-        for (int k = 0; k < kLnMaxVec; ++k) {
-            const int vi = li + k * L;
-            if (vi < nvec) {
-                const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
-                q += (a * a + b * b) + (c * c + d * d);
+            for (int u = 0; u < U; ++u) s[u] += __shfl_xor(s[u], o, 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float mean = s[u] * invC;
+            q[u] = 0.f;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int vi = li + k * L;
+                if (vi < nvec) {
+                    v[u][k].x -= mean; v[u][k].y -= mean; v[u][k].z -= mean; v[u][k].w -= mean;
+                    q[u] += (v[u][k].x * v[u][k].x + v[u][k].y * v[u][k].y) + (v[u][k].z * v[u][k].z + v[u][k].w * v[u][k].w);
+                }
             }
         }
-        q = wave_xor_sum(q, L);
-        const float rstd = 1.0f / sqrtf(q * invC + eps);
-        if (ok) {
-            T* op = out + pix * C;
+        for (int o = L >> 1; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < U; ++u) q[u] += __shfl_xor(q[u], o, 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pix[u] >= M) continue;
+            const float rstd = 1.0f / sqrtf(q[u] * invC + eps);
+            T* op = out + pix[u] * C;
             const float4* gp = reinterpret_cast<const float4*>(g);
-            const T* rp = res ? res + pix * C : nullptr;
-            const size_t frow = fscale ? (size_t)(film_bstride ? pix / ppi : 0) * film_bstride : 0;
+            const T* rp = res ? res + pix[u] * C : nullptr;
+            const size_t frow = fscale ? (size_t)(film_bstride ? pix[u] / ppi : 0) * film_bstride : 0;
 #pragma unroll
-            for (int k = 0; k < kLnMaxVec; ++k) {
+            for (int k = 0; k < KV; ++k) {
                 const int vi = li + k * L;
                 if (vi < nvec) {
                     const float4 gg = gp[vi];
                     float4 o;
-                    o.x = (v[k].x - mean) * rstd * gg.x;
-                    o.y = (v[k].y - mean) * rstd * gg.y;
-                    o.z = (v[k].z - mean) * rstd * gg.z;
-                    o.w = (v[k].w - mean) * rstd * gg.w;
+                    o.x = v[u][k].x * rstd * gg.x;
+                    o.y = v[u][k].y * rstd * gg.y;
+                    o.z = v[u][k].z * rstd * gg.z;
+                    o.w = v[u][k].w * rstd * gg.w;
                     if (fscale) {  // NAFNet: x * (scale + 1) + shift  (DenoisingNAFNet_arch.py:64,75)
                         const float4 s4 = reinterpret_cast<const float4*>(fscale + frow)[vi];
                         const float4 h4 = reinterpret_cast<const float4*>(fshift + frow)[vi];
@@ -115,6 +130,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
             }
         }
     }
+}
+
+template <typename T>
+static void launch_ln_t(const T* x, const float* g, const T* res, T* out, int64_t M, int C, float eps, const float* fscale,
+                        const float* fshift, int film_bstride, int64_t ppi, hipStream_t s) {
+    if (C % 4 || C > 4 * 64 * kLnMaxVec) throw HipError("layernorm: unsupported channel count " + std::to_string(C));
+    int L = 1;
+    while (L * 2 <= 64 && L * 2 <= C / 4) L *= 2;
+    const int need = (C / 4 + L - 1) / L;
+    if (need > kLnMaxVec) throw HipError("layernorm: channel count too large");
+    const int ppw = 64 / L;
+    const int U = need <= 2 ? 4 : (need <= 4 ? 2 : 1);
+    const int64_t waves = (M + (int64_t)ppw * U - 1) / ((int64_t)ppw * U);
+    int64_t blocks = (waves + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), blk(256);
+#define IRSDE_LN(KV, UU) hipLaunchKernelGGL((layernorm_kernel<T, KV, UU>), grid, blk, 0, s, x, g, res, out, (long long)M, C, L, eps, fscale, fshift, film_bstride, (long long)ppi)
+    if (need <= 1) IRSDE_LN(1, 4);
+    else if (need <= 2) IRSDE_LN(2, 4);
+    else if (need <= 4) IRSDE_LN(4, 2);
+    else IRSDE_LN(8, 1);
+#undef IRSDE_LN
+    IRSDE_HIP_CHECK(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -747,39 +786,16 @@ __global__ void philox_normal_kernel(float* out, const int CHW, const int t, con
 // ---------------------------------------------------------------------------------------------
 void launch_layernorm(const float* x, const float* g, const float* res, float* out, int64_t M, int C, float eps,
                       hipStream_t s, bool bf16) {
-    if (C % 4 || C > 4 * 64 * kLnMaxVec) throw HipError("layernorm: unsupported channel count " + std::to_string(C));
-    int L = 1;
-    while (L * 2 <= 64 && L * 2 <= C / 4) L *= 2;
-    if ((C / 4 + L - 1) / L > kLnMaxVec) throw HipError("layernorm: channel count too large");
-    const int ppw = 64 / L;
-    const int64_t waves = (M + ppw - 1) / ppw;
-    int64_t blocks = (waves + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    if (blocks < 1) blocks = 1;
     if (bf16)
-        hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(x), g,
-                           reinterpret_cast<const bf16_t*>(res), reinterpret_cast<bf16_t*>(out), (long long)M, C, L, eps,
-                           (const float*)nullptr, (const float*)nullptr, 0, (long long)1);
+        launch_ln_t(reinterpret_cast<const bf16_t*>(x), g, reinterpret_cast<const bf16_t*>(res), reinterpret_cast<bf16_t*>(out), M,
+                    C, eps, nullptr, nullptr, 0, 1, s);
     else
-        hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, g, res, out, (long long)M, C, L,
-                           eps, (const float*)nullptr, (const float*)nullptr, 0, (long long)1);
-    IRSDE_HIP_CHECK(hipGetLastError());
+        launch_ln_t(x, g, res, out, M, C, eps, nullptr, nullptr, 0, 1, s);
 }
 
 void launch_layernorm_film(const float* x, const float* g, const float* scale, const float* shift, int film_bstride,
                            int64_t pixels_per_image, float* out, int64_t M, int C, float eps, hipStream_t s) {
-    if (C % 4 || C > 4 * 64 * kLnMaxVec) throw HipError("layernorm: unsupported channel count " + std::to_string(C));
-    int L = 1;
-    while (L * 2 <= 64 && L * 2 <= C / 4) L *= 2;
-    if ((C / 4 + L - 1) / L > kLnMaxVec) throw HipError("layernorm: channel count too large");
-    const int ppw = 64 / L;
-    const int64_t waves = (M + ppw - 1) / ppw;
-    int64_t blocks = (waves + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, g, (const float*)nullptr, out,
-                       (long long)M, C, L, eps, scale, shift, film_bstride, (long long)pixels_per_image);
-    IRSDE_HIP_CHECK(hipGetLastError());
+    launch_ln_t(x, g, (const float*)nullptr, out, M, C, eps, scale, shift, film_bstride, pixels_per_image, s);
 }
 
 int dwgate_tiles(int HW) { return (HW + kDwTile - 1) / kDwTile; }
