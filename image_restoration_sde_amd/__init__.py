@@ -14,7 +14,7 @@ csrc/ -> libirsde_hip.so) with the reference's own Python interface on top:
     metrics            codes/utils/img_utils.py:136-234 + codes/data/util.py:177-198 (tensor2img / PSNR / SSIM / Y channel)
 """
 from ._lib import IrsdeError, IrsdeLibraryError, build_library  # noqa: F401
-from .denoising_model import DenoisingModel, create_model, define_G  # noqa: F401
+from .denoising_model import DenoisingModel, ReverseSDEDenoisingModel, create_model, define_G  # noqa: F401
 from .dist import gather_batch, sample_sharded, shard_bounds  # noqa: F401
 from .sde import IRSDE  # noqa: F401
 from .unet import ConditionalUNet  # noqa: F401
@@ -26,5 +26,5 @@ from . import latent  # noqa: F401
 from . import latent_bokeh  # noqa: F401
 from .latent import LatentDenoisingModel  # noqa: F401
 
-__all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "metrics", "latent", "latent_bokeh", "LatentDenoisingModel", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "create_model", "define_G", "build_library",
+__all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "metrics", "latent", "latent_bokeh", "LatentDenoisingModel", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "ReverseSDEDenoisingModel", "create_model", "define_G", "build_library",
            "IrsdeError", "IrsdeLibraryError", "shard_bounds", "gather_batch", "sample_sharded"]

@@ -26,10 +26,14 @@ def define_G(opt):
     return cls(**opt_net["setting"])
 
 
-def create_model(opt):
-    """models.create_model (deraining/models/__init__.py:6-15)."""
+def create_model(opt, task="deraining"):
+    """models.create_model (deraining/models/__init__.py:6-15).  `task`: the reference keeps one copy of the wrapper per
+    task directory; deblurring / deshadow / inpainting / sisr differ from deraining only in `test()` (hard-coded
+    reverse_sde, deblurring/models/denoising_model.py:150-157) -> `ReverseSDEDenoisingModel`."""
     if opt["model"] != "denoising":
         raise NotImplementedError("Model [{:s}] not recognized.".format(opt["model"]))
+    if task in ("deblurring", "deshadow", "inpainting", "sisr"):
+        return ReverseSDEDenoisingModel(opt)
     return DenoisingModel(opt)
 
 
@@ -87,3 +91,11 @@ class DenoisingModel:
         for k, v in load_net.items():  # strip DataParallel/DDP "module." prefixes
             clean[k[7:] if k.startswith("module.") else k] = v
         network.load_state_dict(clean, strict=strict)
+
+
+class ReverseSDEDenoisingModel(DenoisingModel):
+    """The wrapper of the deblurring / deshadow / inpainting / sisr task directories: `test(sde, save_states)` always runs
+    `sde.reverse_sde` (deblurring/models/denoising_model.py:150-157); everything else is the deraining wrapper."""
+
+    def test(self, sde=None, save_states=False):
+        return DenoisingModel.test(self, sde, mode="sde", save_states=save_states)

@@ -598,6 +598,14 @@ def test_denoising_model_boundary(tmp_path):
                    sigma_bars=c[:, 2], x0_gain=c[:, 5], post_term1=c[:, 6], post_term2=c[:, 7], post_std=c[:, 8])
         want = O.sample(params, sch, xT, lq, mode, noise=z, depth=depth, dtype=np.float64)
         assert relerr(vis["Output"].numpy()[None], want) < 1e-3
+    # the deblurring / deshadow / inpainting / sisr copies of the wrapper: test(sde, save_states) == reverse_sde
+    mdl2 = P.create_model(opt, task="deblurring")
+    assert isinstance(mdl2, P.ReverseSDEDenoisingModel)
+    sde.set_model(mdl2.model)
+    mdl2.feed_data(torch.from_numpy(xT), torch.from_numpy(lq))
+    mdl2.test(sde, save_states=False)
+    assert relerr(mdl2.get_current_visuals(need_GT=False)["Output"].numpy(), vis["Output"].numpy()) < 1e-6  # vis: mode "sde"
+    sde.set_model(mdl.model)
     # save_states dumps PNGs every T//100 (>=1) steps like sde_utils.py:260-264 and gives the same result
     out_a = sde.reverse_sde(mdl.state)
     out_b = sde.reverse_sde(mdl.state, save_states=True, save_dir=str(tmp_path / "sde_state"))
