@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restri
     float ssum = 0.f;
     float mrun = -INFINITY;  // running max of k[d = l31] over this wave's pixels (same value in both lane halves)
     // wave w takes pixel pairs w, w+4, ...; lane half h takes pixel 2*pair + h
-    constexpr int U = 4;
+    constexpr int U = 8;  // 16 scalar loads (k, v of 8 pixel pairs) in flight per wave
     for (int pr = wave; 2 * pr < n1 - n0; pr += 4 * U) {
         float kx[U], vv[U];
         float mit = -INFINITY;
@@ -286,18 +286,26 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int s = 0; s < 16; ++s) cb[s] = cp[s * 32];
 
-    for (int t = 0; t < kOutTilesPerBlock; ++t) {
-        const int nbase = (blockIdx.x * kOutTilesPerBlock + t) * 32;
-        if (nbase >= N) break;
-        const int n = nbase + l31;
-        const bool ok = n < N;
-        const T* qp = qkv + ((size_t)b * N + (ok ? n : nbase)) * kQkv + head * kDh + 16 * h;
-        float q[16];
+    // the q rows of tile t+1 are loaded before the softmax / MFMAs of tile t (one tile of loads always in flight)
+    auto load_q = [&](int t, float* dst) {
+        const int nb = (blockIdx.x * kOutTilesPerBlock + t) * 32;
+        const int nn = nb + l31;
+        const T* qp = qkv + ((size_t)b * N + (nn < N ? nn : (nb < N ? nb : 0))) * kQkv + head * kDh + 16 * h;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const float4 t4 = ld4(qp + 4 * v);
-            q[4 * v + 0] = t4.x; q[4 * v + 1] = t4.y; q[4 * v + 2] = t4.z; q[4 * v + 3] = t4.w;
+            dst[4 * v + 0] = t4.x; dst[4 * v + 1] = t4.y; dst[4 * v + 2] = t4.z; dst[4 * v + 3] = t4.w;
         }
+    };
+    float qn[16];
+    load_q(0, qn);
+    for (int t = 0; t < kOutTilesPerBlock; ++t) {
+        const int nbase = (blockIdx.x * kOutTilesPerBlock + t) * 32;
+        if (nbase >= N) break;
+        float q[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) q[s] = qn[s];
+        if (t + 1 < kOutTilesPerBlock) load_q(t + 1, qn);
         float m = q[0];
 #pragma unroll
         for (int s = 1; s < 16; ++s) m = fmaxf(m, q[s]);
