@@ -7,14 +7,24 @@ updates) on a synthetic batch of 16 x 3 x 256 x 256 per GPU (BASELINE.json confi
 rank samples its own 16 images (global image index keyed RNG), the only collective is the final all_gather
 of the restored images (RCCL over xGMI), which is inside the timed region.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = conv_igemm on the fp32 MFMA pipe, timed live
-with hipEvents on the engine's stream during the timed steps) and `cpu_baseline` (the torch-CPU port of the
-reference timed on this box's host cores on a bounded sample).
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches itself: it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU).
+
+`value` is timed on the production path: one captured hipGraph per step replayed T times (`sde.use_graph`), no
+per-kernel events.  After the timed region rank 0 runs ONE more, untimed, event-instrumented pass (eager launches
+with a hipEvent pair around every kernel on the engine's stream) to fill `roofline`:
+    roofline.frac = FLOPs the MFMA pipe executed (Winograd layers counted at their reduced multiply count)
+                    / (time of the MFMA kernels + the Winograd transform kernels that belong to them) / peak   (<= 1)
+`mfma_kernel_frac` is the same over the MFMA kernels alone; the direct-convolution-equivalent rate (which exceeds the
+fp32 peak because Winograd skips multiplies) is reported as `algorithmic_equiv_TFLOPs`, never as a fraction.
+`cpu_baseline`: the torch-CPU port of the reference timed on this box's host cores on a bounded sample.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -92,8 +102,11 @@ def cpu_baseline(size, T, budget_s=20.0):
     per_step = (time.time() - t0) / n
     return {"value": 1.0 / (per_step * T), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "B=1 %dx%d, %d of T=%d reverse_sde steps timed (%.2f s/step), extrapolated x%d; torch %s CPU, "
-                      "%d threads (affinity/cgroup quota; host has %d logical CPUs)" % (size, size, n, T, per_step, T,
-                                                                                       torch.__version__, cores, os.cpu_count() or 0)}
+                      "%d threads (affinity/cgroup quota; host has %d logical CPUs). kind=port: oracle/torch_cpu_port.py, the "
+                      "reference's algorithm restated in torch-CPU functional ops and golden-checked against the reference "
+                      "(tests/test_oracle_golden.py) - /root/reference itself does not exist on the GPU box.  The unmodified "
+                      "reference classes measured in the build container (SURVEY.md 8d): 0.034 images/s at 1x128x128, T=100, 8 vCPU"
+                      % (size, size, n, T, per_step, T, torch.__version__, cores, os.cpu_count() or 0)}
 
 
 def main():
@@ -111,8 +124,22 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16_act"],
                     help="bf16 = BASELINE configs[2] (conv operands bf16, fp32 accumulate); the headline metric is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="time graph replay instead of the event-instrumented loop")
+    ap.add_argument("--no-profile", action="store_true", help="skip the untimed event-instrumented pass (no `roofline` object)")
     a = ap.parse_args()
+
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: launch one rank per GPU ourselves (the driver may call `python bench.py --gpus 8` directly)
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     import numpy as np
     import torch
@@ -123,12 +150,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        sys.exit("bench.py: --gpus %d does not match WORLD_SIZE=%d of the launcher" % (a.gpus, world))
+    # test hook (tests/test_gpu_parity.py on a 1-GPU box): IRSDE_BENCH_OVERSUBSCRIBE=1 lets several ranks share the visible
+    # GPUs; RCCL refuses two ranks on one device, so the final gather then goes through gloo (host staging)
+    oversub = os.environ.get("IRSDE_BENCH_OVERSUBSCRIBE") == "1" and torch.cuda.device_count() >= 1
+    if torch.cuda.device_count() <= local_rank and not oversub:
+        sys.exit("bench.py: rank %d needs GPU %d but only %d device(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
+    dev_index = local_rank % torch.cuda.device_count() if oversub else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if oversub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     latent_model = None
     if a.model == "latent":  # latent-bokeh/options/bokeh/test/refusion.yml: UNet ch 64 [1,2,4] embed 4 (256^2 -> 64x64x4) + NAFNet
@@ -155,8 +190,9 @@ def main():
         sde = P.IRSDE(max_sigma=max_sigma, T=a.T, schedule="cosine", eps=0.005, device=dev)
     sde.set_model(model)
     sde.seed = 7
-    sde.profile = (not a.no_profile) and a.model not in ("dsde", "latent")
+    sde.profile = False    # the timed region runs the production path: hipGraph replay, no per-kernel events
     sde.use_graph = True
+    want_profile = (not a.no_profile) and a.model not in ("dsde", "latent")
 
     nglobal = a.batch * world
     # every rank materialises only its shard of the synthetic global batch (same generator => same images)
@@ -182,15 +218,15 @@ def main():
             return latent_model.decode(sample(sde.noise_state(latent_LQ), lens_info=lens_info), hidden)
     else:
         sde.set_mu(mu)
-        fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[a.mode]
+        fn = None
 
     def one_step():
-        out = fn(x_T)
-        if world > 1:
-            parts = [torch.empty_like(out) for _ in range(world)]
-            dist.all_gather(parts, out)  # the final gather: the only collective of the path
-            out = torch.cat(parts, 0)
-        return out
+        if fn is not None:
+            out = fn(x_T)
+            return P.gather_batch(out, nglobal) if world > 1 else out
+        # the product's N>1 path: sample this rank's shard, then the final all_gather (the only collective)
+        sde.image_offset = 0
+        return P.sample_shard(sde, a.mode, x_T, mu, rank * a.batch, nglobal)
 
     def fence():
         torch.cuda.synchronize()
@@ -200,16 +236,10 @@ def main():
 
     for _ in range(a.warmup):
         out = one_step()
-    prof = dict(conv_ms=0.0, conv_flops=0.0, conv_launches=0.0, conv_bytes=0.0, ln_ms=0.0, attn_ms=0.0, other_ms=0.0,
-                wall_ms=0.0, net_evals=0.0, wino_ms=0.0, conv_exec_flops=0.0, reserved=0.0)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = one_step()
-        if sde.profile:
-            torch.cuda.synchronize()
-            for k, v in sde.last_profile().items():
-                prof[k] += v
     fence()
     dt = time.perf_counter() - t0
     assert out.shape[0] == nglobal and bool(torch.isfinite(out).all())
@@ -217,6 +247,17 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    prof = None
+    if want_profile and rank == 0:
+        # untimed: the same sampling call once more with a hipEvent pair around every kernel (eager launches)
+        sde.profile = True
+        sde.image_offset = 0
+        sde.set_mu(mu)
+        {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[a.mode](x_T)
+        torch.cuda.synchronize()
+        prof = sde.last_profile()
+        sde.profile = False
 
     if rank == 0:
         imgs = nglobal * a.steps
@@ -235,35 +276,40 @@ def main():
                                     "(BASELINE.json configs[3] network)" if a.model == "nafnet" else
                                     "IR-SDE deraining ConditionalUNet nf=64 depth=4, reverse_%s, batch=%d/GPU %dx%d, "
                                     "T=%d, fp32 (BASELINE.json configs[1])") % (a.mode, a.batch, a.size, a.size, a.T),
-                       "compute_dtype": a.dtype, "global_batch": nglobal, "parallelism": "batch-shard x%d (no collective in the T loop; final all_gather)" % world},
+                       "compute_dtype": a.dtype, "global_batch": nglobal, "parallelism": "batch-shard x%d (no collective in the T loop; final all_gather over %s)"
+                                      % (world, "gloo, ranks sharing GPUs: TEST HOOK, not a scaling number" if (world > 1 and oversub) else "RCCL")},
         }
-        if sde.profile and prof["conv_ms"] > 0:
-            # `achieved` = ALGORITHMIC FLOPs (direct-convolution count) / time of the convolution kernels
-            # (conv_igemm + the Winograd transform kernels that belong to it).  Winograd F(4x4,3x3)/F(2x2,3x3) layers
-            # issue 4x / 2.25x fewer multiplies than that count, so the fraction can exceed 1; `executed_*` is what the
-            # MFMA pipe actually ran inside conv_igemm_kernel alone.
-            ach = prof["conv_flops"] / ((prof["conv_ms"] + prof["wino_ms"]) * 1e-3) / 1e12
+        if prof is not None and prof["conv_ms"] > 0:
+            # `achieved` = FLOPs the MFMA pipe EXECUTED (Winograd F(4x4,3x3) / F(2x2,3x3) layers issue 4x / 2.25x fewer
+            # multiplies than the direct-convolution count of SURVEY.md 8d) / time of the MFMA kernels plus the Winograd
+            # transform kernels that exist only to serve them: a true fraction of the fp32 MFMA roof (<= 1).
+            conv_t = (prof["conv_ms"] + prof["wino_ms"]) * 1e-3
+            ach = prof["conv_exec_flops"] / conv_t / 1e12
             exe = prof["conv_exec_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
-            traffic = None  # HBM bytes per conv launch from the PMC passes (cannot be collected live here)
+            alg = prof["conv_flops"] / conv_t / 1e12
+            # HBM bytes per conv launch: rocprofv3 PMC passes cannot run inside this process; the figure comes from the
+            # builder's PMC run of this same command, committed under profiles/ (source named next to it)
+            traffic, traffic_src = None, None
             try:
-                if a.batch == 16 and a.size == 256:
+                if a.batch == 16 and a.size == 256 and a.dtype == "fp32" and a.model == "unet":
                     pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc_hbm.json"))
                     traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"]
+                    traffic_src = "profiles/%s (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)" % pm[-1]
             except (OSError, IndexError, KeyError, ValueError):
-                traffic = None
-            if a.dtype != "fp32":
-                traffic = None
+                traffic, traffic_src = None, None
             peak = PEAK_FP32_TFLOPS if a.dtype == "fp32" else PEAK_BF16_TFLOPS
             res["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": traffic,
+                "frac": ach / peak, "mfma_kernel_frac": exe / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_unit": "bytes per conv launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes, profiles/*_bench_pmc_hbm.txt)",
+                "algorithmic_equiv_TFLOPs": alg,
+                "timing": "separate untimed pass after the timed region: eager launches, hipEvent pair around every kernel on the engine stream",
                 "algorithmic_bytes_per_launch": prof["conv_bytes"] / max(prof["conv_launches"], 1),
                 "kernel": "conv_igemm_kernel + gemm_zloop_kernel (fp32 v_mfma_f32_32x32x2_f32: direct 1x1/4x4/7x7 layers as implicit GEMM, the 3x3 layers as Winograd F(4x4,3x3)/F(2x2,3x3) component GEMMs; %d launches per network evaluation) + wino_input/wino_output transform kernels"
                           % int(round(prof["conv_launches"] / max(prof["net_evals"], 1))),
                 "avg_launch_ms": (prof["conv_ms"] + prof["wino_ms"]) / max(prof["conv_launches"], 1),
                 "flops_per_launch": prof["conv_flops"] / max(prof["conv_launches"], 1),
-                "executed_TFLOPs": exe, "executed_frac": exe / peak,
+                "executed_TFLOPs_mfma_kernels_only": exe,
                 "executed_flops_per_launch": prof["conv_exec_flops"] / max(prof["conv_launches"], 1),
                 "kernel_time_share": {"conv": prof["conv_ms"] / prof["wall_ms"], "layernorm": prof["ln_ms"] / prof["wall_ms"],
                                       "attention": prof["attn_ms"] / prof["wall_ms"], "winograd_transforms": prof["wino_ms"] / prof["wall_ms"],
@@ -278,7 +324,7 @@ def main():
                 r = res["roofline"]
                 gbps = prof["conv_bytes"] / (prof["conv_ms"] * 1e-3) / 1e9
                 r.update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                          "mfma_TFLOPs": ach, "mfma_frac": ach / PEAK_BF16_TFLOPS,
+                          "mfma_TFLOPs": alg, "mfma_frac": alg / PEAK_BF16_TFLOPS,
                           "kernel": "conv_igemm_kernel<bf16> (v_mfma_f32_32x32x16_bf16 implicit GEMM, fp32 activations rounded while staged; "
                                     "achieved = ideal-fusion conv bytes / conv kernel time)"})
         if not a.no_cpu_baseline and world == 1 and a.model == "unet":

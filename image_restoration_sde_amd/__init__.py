@@ -15,7 +15,7 @@ csrc/ -> libirsde_hip.so) with the reference's own Python interface on top:
 """
 from ._lib import IrsdeError, IrsdeLibraryError, build_library  # noqa: F401
 from .denoising_model import DenoisingModel, ReverseSDEDenoisingModel, create_model, define_G  # noqa: F401
-from .dist import gather_batch, sample_sharded, shard_bounds  # noqa: F401
+from .dist import gather_batch, sample_shard, sample_sharded, shard_bounds  # noqa: F401
 from .sde import IRSDE  # noqa: F401
 from .unet import ConditionalUNet  # noqa: F401
 from .nafnet import ConditionalNAFNet  # noqa: F401
@@ -27,4 +27,4 @@ from . import latent_bokeh  # noqa: F401
 from .latent import LatentDenoisingModel  # noqa: F401
 
 __all__ = ["IRSDE", "DenoisingSDE", "denoising_sde", "metrics", "latent", "latent_bokeh", "LatentDenoisingModel", "ConditionalUNet", "ConditionalNAFNet", "DenoisingModel", "ReverseSDEDenoisingModel", "create_model", "define_G", "build_library",
-           "IrsdeError", "IrsdeLibraryError", "shard_bounds", "gather_batch", "sample_sharded"]
+           "IrsdeError", "IrsdeLibraryError", "shard_bounds", "gather_batch", "sample_shard", "sample_sharded"]

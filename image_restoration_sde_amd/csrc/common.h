@@ -14,6 +14,16 @@ struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
+// Tuning knobs (A/B experiments logged under profiles/) are honoured only when IRSDE_TUNING=1 is set: a stray
+// environment variable must not change the launch plan the parity tests validated.  Returns the integer value of
+// `name`, or `dflt` when tuning is off or the variable is unset.
+inline int tuning_env_int(const char* name, int dflt) {
+    static const bool on = [] { const char* t = getenv("IRSDE_TUNING"); return t && atoi(t) == 1; }();
+    if (!on) return dflt;
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 #define IRSDE_HIP_CHECK(expr)                                                                  \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \

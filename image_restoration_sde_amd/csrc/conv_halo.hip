@@ -306,7 +306,7 @@ template <int BN, bool ABF>
 void launch_halo(const ConvParams& p, hipStream_t s) {
     const int tiles_x = (p.Wo + TS - 1) / TS, tiles_y = (p.Ho + TS - 1) / TS;
     const int nblk_n = (p.Cout + BN - 1) / BN;
-    static const int env = getenv("IRSDE_HALO_NSLOW") ? atoi(getenv("IRSDE_HALO_NSLOW")) : -1;
+    static const int env = tuning_env_int("IRSDE_HALO_NSLOW", -1);
     const double wbytes = 2.0 * p.Cout * 9.0 * (p.C0 + p.C1);
     const int n_slow = env >= 0 ? (env && nblk_n > 1) : (nblk_n >= 2 && wbytes > 4.0e6);  // one XCD L2 = 4 MiB
     hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, ABF>), dim3((unsigned)(p.B * tiles_y * tiles_x * nblk_n)), dim3(NT),

@@ -825,7 +825,7 @@ int zloop_1x1_rows(const ConvParams& p) {
     if (p.nz != 1 || p.w_bf || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_y || p.pad_x || p.in_shift || p.film || p.silu ||
         p.res || p.splits != 1 || p.gate || p.shuffle || p.ch_scale || p.in_scale || p.ln_g || p.in_bf16 || p.out_bf16)
         return 0;
-    static const int env = getenv("IRSDE_ZLOOP_1X1") ? atoi(getenv("IRSDE_ZLOOP_1X1")) : -1;  // tuning: 0 = off, n = rows tiles
+    static const int env = tuning_env_int("IRSDE_ZLOOP_1X1", -1);  // tuning: 0 = off, n = rows tiles
     if (g_variant == 70 || env == 0) return 0;
     const int M = p.B * p.Ho * p.Wo, K = p.C0 + p.C1;
     const int mtiles = (M + 127) / 128, ntiles = (p.Cout + 127) / 128, nk = K / 32;
@@ -848,7 +848,7 @@ int zloop_batch(const ConvParams& p) {
         p.gate || p.shuffle || p.ch_scale || p.in_scale || p.stride != 1 || p.out_stride != p.Cout || p.pix0 != p.C0 ||
         p.B != 1 || p.Ho != 1)
         return 0;
-    static const int env_force = getenv("IRSDE_ZLOOP") ? atoi(getenv("IRSDE_ZLOOP")) : -1;  // tuning: 0 = off, n = fixed batch
+    static const int env_force = tuning_env_int("IRSDE_ZLOOP", -1);  // tuning: 0 = off, n = fixed batch
     // test hooks: variant 71 = all components in one block, 72 = batches of 2 (F2: 16, F4: 36 components), 70 = off
     const int force = g_variant == 70 ? 0 : g_variant == 71 ? p.nz : g_variant == 72 ? 2 : env_force;
     if (force == 0) return 0;
@@ -856,10 +856,10 @@ int zloop_batch(const ConvParams& p) {
     const long long tiles = (long long)((p.Wo + 127) / 128) * ((p.Cout + 127) / 128);
     if (force > 0) return p.nz % force == 0 ? force : 0;
     if (zloop_small_m(p)) return nk >= 4 ? 1 : 0;  // single-image deep levels: 64-row tiles, one component per block
-    static const int max_nk = getenv("IRSDE_ZLOOP_MAXNK") ? atoi(getenv("IRSDE_ZLOOP_MAXNK")) : 32;
-    static const int min_blocks = getenv("IRSDE_ZLOOP_MINBLK") ? atoi(getenv("IRSDE_ZLOOP_MINBLK")) : 1024;
+    static const int max_nk = tuning_env_int("IRSDE_ZLOOP_MAXNK", 32);
+    static const int min_blocks = tuning_env_int("IRSDE_ZLOOP_MINBLK", 1024);
     if (nk > max_nk) return 0;  // long K: the per-block overhead is already amortised (measured: 12 / 32 / 48 -> 2.82 / 2.87 / 2.83 img/s)
-    static const int deep_rule = getenv("IRSDE_ZLOOP_DEEP") ? atoi(getenv("IRSDE_ZLOOP_DEEP")) : 1;
+    static const int deep_rule = tuning_env_int("IRSDE_ZLOOP_DEEP", 1);
     if (deep_rule && nk > 16 && (p.Wo + 127) / 128 < 32) return 0;  // few row tiles + long K (32x32 level): generic kernel is ahead
     int best = 0;
     for (int zb = p.nz; zb >= 2; --zb) {  // largest batch that still fills the 2 x 256 block slots evenly

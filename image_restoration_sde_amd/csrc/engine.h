@@ -26,11 +26,26 @@ namespace irsde {
 // Winograd only where the transforms' extra HBM traffic is small next to the GEMM: F(2x2) moves 4x the input and
 // 4x the output through HBM and pays from 256 channels, F(4x4) 2.25x and pays from 128 — from 64 (+1.6 %) since the
 // component GEMMs run on the batch-loop kernel (measured, profiles/).
-// IRSDE_WINO2_MINC / IRSDE_WINO4_MINC override the thresholds (tuning experiments).
+// IRSDE_WINO2_MINC / IRSDE_WINO4_MINC override the thresholds (tuning experiments, only with IRSDE_TUNING=1).
 inline int wino_min_c(int tile) {
-    const char* v = getenv(tile == 4 ? "IRSDE_WINO4_MINC" : "IRSDE_WINO2_MINC");
-    return v ? atoi(v) : (tile == 4 ? 64 : 256);
+    return tuning_env_int(tile == 4 ? "IRSDE_WINO4_MINC" : "IRSDE_WINO2_MINC", tile == 4 ? 64 : 256);
 }
+
+// Selects the engine's device for the scope of one C-ABI call and restores the caller's current device afterwards
+// (a multi-GPU host process — and PyTorch inside it — must not see its current device change under its feet).
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) IRSDE_HIP_CHECK(hipSetDevice(dev));
+        else prev = -1;
+    }
+    ~DeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
 
 struct HostTensor {
     std::vector<int64_t> shape;

@@ -8,6 +8,7 @@
 //               eager or as one captured hipGraph replayed T times; the step index lives in device
 //               memory (StepState) so the graph is t-invariant.
 #include "engine.h"
+#include "../../include/irsde_hip_debug.h"
 
 using namespace irsde;
 
@@ -44,6 +45,13 @@ void one_step(irsde_engine* e, Plan* pl, hipStream_t s) {
     run_net(pl, s);
     launch_sde_update(make_update(e, pl), s);
 }
+
+// irsde_debug_conv / irsde_bench_conv only: selects a kernel variant for the launches of ONE call and always returns to
+// the production dispatch (also when a launch throws).
+struct VariantScope {
+    explicit VariantScope(int v) { conv_set_variant(v); }
+    ~VariantScope() { conv_set_variant(0); }
+};
 
 int guard(const std::function<void()>& f) {
     try {
@@ -125,6 +133,8 @@ int irsde_create_nafnet(const irsde_nafnet_config* cfg, irsde_engine** out) {
 
 void irsde_destroy(irsde_engine* e) {
     if (!e) return;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     e->plans.clear();
@@ -137,6 +147,7 @@ void irsde_destroy(irsde_engine* e) {
     for (auto& kv : e->bf16_copies) (void)hipFree(kv.second);
     if (e->coef_table) (void)hipFree(e->coef_table);
     if (e->film_table) (void)hipFree(e->film_table);
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);  // destroy runs from a Python finaliser: leave the current device alone
     delete e;
 }
 
@@ -184,7 +195,7 @@ int irsde_set_schedule(irsde_engine* e, int T, const float* coef) {
     return guard([&] {
         if (!e || !coef || T < 1) throw HipError("bad schedule arguments");
         if (!e->finalized) throw HipError("set_schedule: weights not finalized");
-        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        DeviceScope dev_scope(e->cfg.device);
         IRSDE_HIP_CHECK(hipDeviceSynchronize());
         std::lock_guard<std::mutex> lk(e->mu);
         // captured graphs bake the table pointers into their kernel nodes: drop them with the old tables
@@ -220,7 +231,7 @@ int irsde_unet_forward(irsde_engine* e, const float* xt, const float* cond, cons
         if (nt != 1 && nt != B) throw HipError("unet_forward: need 1 or B timesteps");
         if (B < 1 || H < 2 || W < 2) throw HipError("unet_forward: bad shape");
         std::lock_guard<std::mutex> lk(e->mu);
-        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        DeviceScope dev_scope(e->cfg.device);
         hipStream_t user = reinterpret_cast<hipStream_t>(stream);
         const bool per_sample = nt > 1;
         Plan* pl = get_plan(e, B, H, W, per_sample);
@@ -260,13 +271,22 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
         const bool uncond_e = e->arch == 0 && (e->cfg.flags & IRSDE_FLAG_UNCOND_FULLATTN);
         if ((mode >= 3) != uncond_e) throw HipError("sample: DenoisingSDE modes (3,4) go with the unconditional network and vice versa");
         if (!mu && !uncond_e) throw HipError("null argument");
-        if (T <= 0) T = e->T;
+        if (T < 0) T = e->T;
         if (T > e->T) throw HipError("sample: T exceeds the schedule length");
+        if (B < 1 || H < 2 || W < 2) throw HipError("sample: bad shape");
+        if (T == 0) {
+            // the reference's `for t in reversed(range(1, T + 1))` runs zero steps and returns the clone of xt
+            // (e.g. reverse_ode(x, T=sde.get_optimal_timestep(sigma)) when the argmin is index 0)
+            if (t_stop != 0) throw HipError("sample: t_stop must be in [0, T)");
+            DeviceScope dev0(e->cfg.device);
+            hipStream_t user0 = reinterpret_cast<hipStream_t>(stream);
+            IRSDE_HIP_CHECK(hipMemcpyAsync(out, xT, (size_t)B * e->cfg.in_nc * H * W * 4, hipMemcpyDeviceToDevice, user0));
+            return;
+        }
         if (t_stop < 0 || t_stop >= T) throw HipError("sample: t_stop must be in [0, T)");
         const int nsteps = T - t_stop;
-        if (B < 1 || H < 2 || W < 2) throw HipError("sample: bad shape");
         std::lock_guard<std::mutex> lk(e->mu);
-        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        DeviceScope dev_scope(e->cfg.device);
         hipStream_t user = reinterpret_cast<hipStream_t>(stream);
         Plan* pl = get_plan(e, B, H, W, false);
         hipStream_t s = e->stream;
@@ -399,7 +419,7 @@ int irsde_debug_tap(irsde_engine* e, const char* name, float* dst, int64_t dims[
         const Tensor& t = it->second;
         dims[0] = t.B; dims[1] = t.C; dims[2] = t.H; dims[3] = t.W;
         if (!dst) return;
-        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        DeviceScope dev_scope(e->cfg.device);
         IRSDE_HIP_CHECK(hipDeviceSynchronize());
         float* tmp = nullptr;
         IRSDE_HIP_CHECK(hipMalloc(&tmp, t.numel() * 4));
@@ -429,7 +449,7 @@ int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buf
         if (!e || !buf || buflen < 1) throw HipError("null argument");
         if (!e->finalized) throw HipError("plan_describe: weights not finalized");
         std::lock_guard<std::mutex> lk(e->mu);
-        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        DeviceScope dev_scope(e->cfg.device);
         Plan* pl = get_plan(e, B, H, W, false);
         std::string out;
         for (auto& op : pl->net_ops) out += op.desc + "\n";
@@ -443,7 +463,7 @@ int irsde_work_model(irsde_engine* e, int B, int H, int W, double out[2]) {
         if (!e || !out) throw HipError("null argument");
         if (!e->finalized) throw HipError("work_model: weights not finalized");
         std::lock_guard<std::mutex> lk(e->mu);
-        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        DeviceScope dev_scope(e->cfg.device);
         Plan* pl = get_plan(e, B, H, W, false);
         out[0] = pl->conv_flops;
         out[1] = pl->conv_bytes;
@@ -504,9 +524,10 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)ncomp * T * Cout * 4));
             const WinoPlan wp = make_wino(p, dU, dV, dM, tile);
             launch_wino_input(wp.in, s);
-            conv_set_variant(naive >= 20 ? 72 : naive >= 10 ? 71 : 0);
-            launch_conv(wp.gemm, s);
-            conv_set_variant(0);
+            {
+                VariantScope vs(naive >= 20 ? 72 : naive >= 10 ? 71 : 0);
+                launch_conv(wp.gemm, s);
+            }
             launch_wino_output(wp.out, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dU); (void)hipFree(dV); (void)hipFree(dM);
@@ -536,9 +557,10 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
                 p.out = reinterpret_cast<float*>(ao);
                 p.in_bf16 = p.out_bf16 = 1;
             }
-            conv_set_variant(act ? (naive == 204 ? 0 : naive - 200) : (naive >= 100 ? naive - 100 : 0));  // tile variants
-            launch_conv(p, s);
-            conv_set_variant(0);
+            {
+                VariantScope vs(act ? (naive == 204 ? 0 : naive - 200) : (naive >= 100 ? naive - 100 : 0));  // tile variants
+                launch_conv(p, s);
+            }
             if (act) launch_bf16_to_f32(ao, out, nout, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             for (unsigned short* q : {dbf, a0, a1, ar, ao})
@@ -589,7 +611,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         }
         if (epi == 1) { p.film = dfilm; p.silu = 1; }
         if (epi == 2) { p.silu = 1; p.res = dres; p.res_stride = Cout; }
-        conv_set_variant(variant);
+        VariantScope vs(variant);
         hipEvent_t e0, e1;
         IRSDE_HIP_CHECK(hipEventCreate(&e0));
         IRSDE_HIP_CHECK(hipEventCreate(&e1));
@@ -601,7 +623,6 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         float ms = 0;
         IRSDE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
         *ms_out = ms / iters;
-        conv_set_variant(0);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
         if (dbf) (void)hipFree(dbf);
@@ -654,7 +675,7 @@ int irsde_latent_encode(irsde_engine* e, const float* x, int B, int H, int W, fl
         if (!e->finalized) throw HipError("latent_encode: weights not finalized");
         if (B < 1 || H < 2 || W < 2) throw HipError("latent_encode: bad shape");
         std::lock_guard<std::mutex> lk(e->mu);
-        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        DeviceScope dev_scope(e->cfg.device);
         hipStream_t user = reinterpret_cast<hipStream_t>(stream), s = e->stream;
         LatentPlan* lp = get_latent_plan(e, B, H, W, false);
         Plan* pl = lp->plan.get();
@@ -680,7 +701,7 @@ int irsde_latent_decode(irsde_engine* e, const float* latent, const float* const
         if (!e || e->arch != 2 || !latent || !hidden || !out) throw HipError("latent_decode: not a latent UNet engine / null argument");
         if (!e->finalized) throw HipError("latent_decode: weights not finalized");
         std::lock_guard<std::mutex> lk(e->mu);
-        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        DeviceScope dev_scope(e->cfg.device);
         hipStream_t user = reinterpret_cast<hipStream_t>(stream), s = e->stream;
         LatentPlan* lp = get_latent_plan(e, B, H, W, true);
         Plan* pl = lp->plan.get();
@@ -706,7 +727,7 @@ int irsde_set_lens_info(irsde_engine* e, const float* info, int B) {
         if (e->arch != 1 || !naf_lens(e)) throw HipError("set_lens_info: not a latent-bokeh ConditionalNAFNet engine");
         if (!e->finalized) throw HipError("set_lens_info: weights not finalized");
         std::lock_guard<std::mutex> lk(e->mu);
-        IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+        DeviceScope dev_scope(e->cfg.device);
         hipStream_t s = e->stream;
         if (e->cam_rows < B) {  // plans bake the table pointer: drop them when it moves
             IRSDE_HIP_CHECK(hipDeviceSynchronize());

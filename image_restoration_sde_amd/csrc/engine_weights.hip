@@ -468,7 +468,7 @@ void finalize_latent(irsde_engine* e) {
 }
 
 void finalize(irsde_engine* e) {
-    IRSDE_HIP_CHECK(hipSetDevice(e->cfg.device));
+    DeviceScope dev_scope(e->cfg.device);
     for (auto& n : e->names)
         if (!e->host[n].loaded) throw HipError("missing weight: " + n);
     if (e->arch == 2) {
@@ -603,7 +603,9 @@ void ensure_film_cur(irsde_engine* e, int rows) {
     if (rows <= e->film_cur_rows) return;
     e->film_cur = e->dmalloc((size_t)rows * e->film_row);
     e->film_cur_rows = rows;
-    // plans bake the film_cur pointer: drop them
+    // plans bake the film_cur pointer: drop them — after everything queued on the engine stream (a previous asynchronous
+    // irsde_sample / forward may still be replaying their graphs and reading their arenas) has finished
+    if (e->stream) IRSDE_HIP_CHECK(hipStreamSynchronize(e->stream));
     e->plans.clear();
 }
 

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
 
 // IRSDE_WINO_VEC=1 (experiment): one channel per thread instead of four
 static int wino_vec() {
-    static const int v = getenv("IRSDE_WINO_VEC") ? atoi(getenv("IRSDE_WINO_VEC")) : 4;
+    static const int v = tuning_env_int("IRSDE_WINO_VEC", 4);
     return v;
 }
 

@@ -148,6 +148,8 @@ class DenoisingSDE:
         if not torch.is_tensor(xt) or xt.device.type != "cuda":
             raise _lib.IrsdeError("the DenoisingSDE sampler runs only on an AMD GPU through libirsde_hip.so (no CPU fallback)")
         x_in = xt.detach().to(torch.float32).contiguous()
+        if T == 0:  # range(1, 1) is empty in the reference: the clone of xt comes back unchanged
+            return x_in.clone()
         out = torch.empty_like(x_in)
         z = None
         if not ode and self.injected_noise is not None:
@@ -162,7 +164,9 @@ class DenoisingSDE:
         interval = max(self.T // 100, 1)
         with torch.cuda.device(xt.device):
             stream = _lib.stream_ptr()
-            if x0 is None and isinstance(m, ConditionalUNet) and not save_states:
+            # x0 replaces the model score only in reverse_sde (:489-493); reverse_ode always calls the model and uses x0
+            # for nothing but the dumped [x, score, real_score] state image (:510-525)
+            if (x0 is None or ode) and isinstance(m, ConditionalUNet) and not save_states:
                 eng = m.engine(xt.device)
                 key = ("dsde", self.T, self.schedule, self.max_sigma)
                 if eng.schedule_key != key:
@@ -175,16 +179,21 @@ class DenoisingSDE:
                 return out
             out.copy_(x_in)
             for t in reversed(range(1, T + 1)):
-                if x0 is not None:  # oracle score from the clean image (training / debugging aid, :492-493)
+                if x0 is not None and not ode:  # oracle score from the clean image (training / debugging aid, :492-493)
                     eps_hat = ((out - x0) / self.sigma_bars[t]).to(torch.float32).contiguous()
                 else:
                     eps_hat = self.model(out, t).detach().to(torch.float32).contiguous()
+                if save_states and ode and x0 is not None:
+                    x_prev = out.clone()
                 zt = ctypes.c_void_p(z[t].data_ptr()) if z is not None else None
                 _lib.check(L.irsde_sde_step(mode, t, ctypes.c_void_p(self._coef[t].data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                             None, ctypes.c_void_p(eps_hat.data_ptr()), zt, self.seed, self.image_offset,
                                             B, C, H, W, stream))
                 if save_states and t % interval == 0:
-                    _save_state(out, save_dir, t // interval)
+                    state = out
+                    if ode and x0 is not None:  # :519-521 (score / real_score are those of the state BEFORE this step)
+                        state = torch.cat([out, -eps_hat / self.sigma_bars[t], -(x_prev - x0) / self.sigma_bars[t] ** 2], dim=0)
+                    _save_state(state, save_dir, t // interval)
         return out
 
     def reverse_sde(self, xt, x0=None, T=-1, save_states=False, save_dir="sde_state"):

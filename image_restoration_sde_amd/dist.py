@@ -27,11 +27,31 @@ def gather_batch(local, n_items, group=None):
     world = dist.get_world_size(group)
     sizes = [shard_bounds(n_items, world, r) for r in range(world)]
     nmax = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    # gloo (CPU tests, or ranks sharing one GPU) gathers host tensors; nccl (= RCCL) gathers in place over xGMI
+    stage = local.device if dist.get_backend(group) != "gloo" else torch.device("cpu")
+    pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
     pad[: local.shape[0]] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0).to(local.device)
+
+
+def sample_shard(sde, mode, x_local, mu_local, lo, n_items, group=None, **kwargs):
+    """Run `sde.reverse_<mode>` on THIS rank's shard (images [lo, lo + len(x_local)) of a global batch of `n_items`)
+    and all_gather the restored global batch.  Only the shard has to be resident on the rank.  The noise streams are
+    keyed by the global image index (`sde.image_offset` is set to its current value + lo for the call), so the result
+    equals one single-GPU call on the whole batch.  This is the one N>1 code path: `sample_sharded`, `bench.py --gpus N`
+    and `tools/eval_folder.py` all go through it."""
+    fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[mode]
+    old_off, old_mu = sde.image_offset, getattr(sde, "mu", None)
+    try:
+        sde.image_offset = old_off + lo
+        sde.set_mu(mu_local)
+        local = fn(x_local, **kwargs) if x_local.shape[0] > 0 else x_local.clone()
+    finally:
+        sde.image_offset = old_off
+        sde.set_mu(old_mu)
+    return gather_batch(local, n_items, group)
 
 
 def sample_sharded(sde, mode, x_T, mu, group=None):
@@ -45,15 +65,11 @@ def sample_sharded(sde, mode, x_T, mu, group=None):
     else:
         world, rank = 1, 0
     lo, hi = shard_bounds(n, world, rank)
-    fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[mode]
-    old_off, old_noise = sde.image_offset, sde.injected_noise
+    old_noise = sde.injected_noise
     try:
-        sde.image_offset = old_off + lo
         if old_noise is not None:
             sde.injected_noise = old_noise[:, lo:hi].contiguous()
-        sde.set_mu(mu[lo:hi])
-        local = fn(x_T[lo:hi]) if hi > lo else x_T[lo:hi].clone()
+        sde.set_mu(mu)  # what sample_shard restores afterwards
+        return sample_shard(sde, mode, x_T[lo:hi], mu[lo:hi], lo, n, group)
     finally:
-        sde.image_offset, sde.injected_noise = old_off, old_noise
-        sde.set_mu(mu)
-    return gather_batch(local, n, group)
+        sde.injected_noise = old_noise

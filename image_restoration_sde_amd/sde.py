@@ -153,6 +153,8 @@ class IRSDE:
         T = self.T if T < 0 else T
         self._check_inputs(xt)
         x_in = xt.detach().to(torch.float32).contiguous()
+        if int(T) == 0:  # range(1, 1) is empty in the reference: the clone of xt comes back unchanged
+            return x_in.clone()
         mu = self.mu.detach().to(device=xt.device, dtype=torch.float32).contiguous()
         out = torch.empty_like(x_in)
         z, _ = self._noise_ptr(x_in, mode != "ode")

@@ -153,7 +153,8 @@ int irsde_unet_forward(irsde_engine* e, const float* xt, const float* cond, cons
  *   xT, mu, out : device NCHW [B][C][H][W]; xT is not modified (the reference clones it, :254).
  *   noise       : device [T_sched+1][B][C][H][W] injected N(0,1) draws indexed by t (parity runs), or
  *                 NULL => Philox4x32-10 keyed by (seed, image_offset + b, t, element).
- *   T           : first step (<= the T given to irsde_set_schedule; <= 0 means that T), like the
+ *   T           : first step (<= the T given to irsde_set_schedule; < 0 means that T; 0 runs no step and copies
+ *                 xT to out, as the reference's empty range(1, 1) does), like the
  *                 reference's `T` argument; t_stop: last step NOT taken (0 = run down to t = 1); running
  *                 T..t_stop+1 and then t_stop..1 equals one T..1 call (used for save_states dumps).
  *   flags       : IRSDE_SAMPLE_* */
@@ -194,27 +195,6 @@ int irsde_op_profile(irsde_engine* e, char* buf, int buflen);
 
 /* Text description (one line per launch group) of the network-evaluation plan at (B,H,W): debugging/analysis. */
 int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buflen);
-
-/* Kernel-level test hook: one implicit-GEMM convolution (csrc/conv_igemm.hip) on NHWC device tensors.
- * in0/in1: [B][Hin][Win][C0|C1] (channel concat, in1 may be NULL); w_oihw/bias: HOST, reference layout;
- * film: device [rows][2*Cout] or NULL; res/out: device [B][Ho][Wo][Cout].  `naive` selects the code path under test:
- *   0 production dispatch      1 VALU cross-check kernel
- *   2 / 3 Winograd F(2x2,3x3) / F(4x4,3x3) (3x3 s1 p1 only); 12 / 13 and 22 / 23: the same with the component GEMMs forced
- *         onto the tile-loop kernel (all / 2 components per block)
- *   4 bf16-MFMA mode (halo kernel for eligible 3x3 layers); 160 / 161 its generic 256 / 128 tile
- *   204 / 260 / 261 the same three with bf16 activation storage (inputs / residual are rounded, the result widened back)
- *   100 + v: tile variant v of the fp32 kernel (3 = 256x128, 50 = 256x256, 73 = tile-loop kernel for 1x1 layers)
- * splits > 1 forces split-K.  Synchronises `stream`. */
-int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int in_shift,
-                     const float* w_oihw, int Cout, int KH, int KW, int stride, int pad, const float* bias,
-                     const float* film, int film_bstride, int silu, const float* res, float* out, int naive,
-                     int splits, void* stream);
-
-/* Kernel tuning hook: average ms of one KxK convolution (pad K/2, or 4x4 s2 p1) on random NHWC data.
- * variant: 0 production dispatch, 3 / 50 fp32 256x128 / 256x256 tiles, 60 / 61 / 62 bf16 mode (256 tile / 128 tile / automatic
- * incl. the halo kernel); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
-int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
-                     double* ms_out);
 
 /* Latent wrapper.  irsde_create_latent_unet replaces UNet.__init__ (UNet_arch.py:18-50); weights load
  * through irsde_load_weight / irsde_finalize_weights with the reference's state_dict names (69 tensors for nasde.yml).

@@ -1,0 +1,41 @@
+/* irsde_hip_debug.h — kernel-level TEST and TUNING hooks of libirsde_hip.so.
+ *
+ * Not part of the drop-in boundary (include/irsde_hip.h): nothing here replaces a reference interface.  The parity
+ * tests use irsde_debug_conv to exercise one convolution code path at a time; tools/ uses irsde_bench_conv for the
+ * A/B measurements logged under profiles/.  Neither changes the launch plan of an engine: the `naive` / `variant`
+ * selector is scoped to the one call (reset to the production dispatch before returning).
+ */
+#ifndef IRSDE_HIP_DEBUG_H
+#define IRSDE_HIP_DEBUG_H
+
+#include "irsde_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Kernel-level test hook: one implicit-GEMM convolution (csrc/conv_igemm.hip) on NHWC device tensors.
+ * in0/in1: [B][Hin][Win][C0|C1] (channel concat, in1 may be NULL); w_oihw/bias: HOST, reference layout;
+ * film: device [rows][2*Cout] or NULL; res/out: device [B][Ho][Wo][Cout].  `naive` selects the code path under test:
+ *   0 production dispatch      1 VALU cross-check kernel
+ *   2 / 3 Winograd F(2x2,3x3) / F(4x4,3x3) (3x3 s1 p1 only); 12 / 13 and 22 / 23: the same with the component GEMMs forced
+ *         onto the tile-loop kernel (all / 2 components per block)
+ *   4 bf16-MFMA mode (halo kernel for eligible 3x3 layers); 160 / 161 its generic 256 / 128 tile
+ *   204 / 260 / 261 the same three with bf16 activation storage (inputs / residual are rounded, the result widened back)
+ *   100 + v: tile variant v of the fp32 kernel (3 = 256x128, 50 = 256x256, 73 = tile-loop kernel for 1x1 layers)
+ * splits > 1 forces split-K.  Synchronises `stream`. */
+int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int in_shift,
+                     const float* w_oihw, int Cout, int KH, int KW, int stride, int pad, const float* bias,
+                     const float* film, int film_bstride, int silu, const float* res, float* out, int naive,
+                     int splits, void* stream);
+
+/* Kernel tuning hook: average ms of one KxK convolution (pad K/2, or 4x4 s2 p1) on random NHWC data.
+ * variant: 0 production dispatch, 3 / 50 fp32 256x128 / 256x256 tiles, 60 / 61 / 62 bf16 mode (256 tile / 128 tile / automatic
+ * incl. the halo kernel); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
+int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
+                     double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRSDE_HIP_DEBUG_H */

@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/irsde_hip.h declares (no GPU needed)."""
+"""The C-ABI library loads and exports every symbol include/*.h declares (no GPU needed)."""
 import ctypes
 import os
 import re
@@ -12,9 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    src = open(os.path.join(ROOT, "include", "irsde_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(irsde_[a-z0-9_]+)\s*\(", src)))
+    import glob
+    syms = set()
+    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        syms |= set(re.findall(r"\b(irsde_[a-z0-9_]+)\s*\(", src))
+    return sorted(syms)
 
 
 def test_library_exports_every_declared_symbol():
