@@ -121,8 +121,9 @@ def main():
     ap.add_argument("--model", default="unet", choices=["unet", "nafnet", "dsde", "latent"],
                     help="unet: IR-SDE ConditionalUNet (BASELINE configs[1]); nafnet: Refusion ConditionalNAFNet (configs[3])")
     ap.add_argument("--max-sigma", type=float, default=None)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16_act"],
-                    help="bf16 = BASELINE configs[2] (conv operands bf16, fp32 accumulate); the headline metric is fp32")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16_act", "fp16"],
+                    help="bf16 = BASELINE configs[2] (conv operands bf16, fp32 accumulate); fp16 = configs[4] (IEEE fp16 operands); "
+                         "the headline metric is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the untimed event-instrumented pass (no `roofline` object)")
     a = ap.parse_args()
@@ -267,7 +268,8 @@ def main():
             "value": imgs / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate+state",
-                                          "bf16_act": "bf16 operands + bf16 activation storage / f32 accumulate+state"}[a.dtype], "data": "synthetic",
+                                          "bf16_act": "bf16 operands + bf16 activation storage / f32 accumulate+state",
+                                          "fp16": "f16 operands / f32 accumulate+state"}[a.dtype], "data": "synthetic",
             "config": {"workload": ("denoising-sde unconditional UNet nf=64 depth=4 (full attention at the bottleneck), DenoisingSDE reverse_%s from the "
                                     "optimal timestep of sigma=25 (" + str(n_evals) + " network evaluations), batch=%d/GPU %dx%d, schedule T=%d, fp32"
                                     if a.model == "dsde" else "Latent-Refusion (latent-bokeh): latent UNet ch=64 [1,2,4] embed 4 (encode + decode once per image) + lens-conditioned ConditionalNAFNet "

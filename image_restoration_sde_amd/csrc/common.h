@@ -50,6 +50,7 @@ struct ConvParams {
     int in_shift = 0;            // 1: fused nearest x2 upsample
     const float* w = nullptr;    // [Cout][KH*KW][C0+C1]
     const unsigned short* w_bf = nullptr;  // same layout rounded to bf16: selects the bf16-MFMA kernel (fp32 accumulate)
+    int f16 = 0;                 // 1: w_bf holds IEEE fp16 (IRSDE_FLAG_FP16): operands rounded to fp16, v_mfma_f32_32x32x16_f16
     int Cout = 0;
     int KH = 1, KW = 1, stride = 1, pad_y = 0, pad_x = 0;
     int B = 0, Ho = 0, Wo = 0;
@@ -121,6 +122,7 @@ void launch_conv_halo(const ConvParams& p, hipStream_t s);
 void conv_set_variant(int v);  // tuning experiments (irsde_bench_conv)
 void launch_fill_random(float* p, size_t n, unsigned seed, float scale, hipStream_t s);  // sets the dynamic-LDS attribute of every tile configuration (call before graph capture)
 void launch_f32_to_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);  // round-to-nearest-even
+void launch_f32_to_f16(const float* in, unsigned short* out, size_t n, hipStream_t s);   // IEEE binary16, round-to-nearest-even
 void launch_bf16_to_f32(const unsigned short* in, float* out, size_t n, hipStream_t s);
 // naive direct convolution on VALU (one thread per output) — debug / cross-check path only
 void launch_conv_naive(const ConvParams& p, hipStream_t s);

@@ -20,8 +20,24 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// 16-bit operand type: bf16 (IRSDE_FLAG_BF16) or IEEE fp16 (IRSDE_FLAG_FP16, fp32 activation storage only)
+template <bool F16>
+struct HOp16 {
+    using x8 = bf16x8;
+    using x4 = bf16x4;
+    static __device__ __forceinline__ floatx16 mfma(x8 a, x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct HOp16<true> {
+    using x8 = f16x8;
+    using x4 = f16x4;
+    static __device__ __forceinline__ floatx16 mfma(x8 a, x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 constexpr int TS = 16;                 // output tile edge (pixels)
 constexpr int HW_ = TS + 2;            // halo edge
@@ -43,10 +59,12 @@ struct HCfg {
 };
 
 // ABF: the activations are bf16 in HBM (IRSDE_FLAG_BF16_ACT): 4 instead of 8 16-byte pieces per halo pixel, no conversion.
-template <int BN, bool ABF>
+template <int BN, bool ABF, bool F16 = false>
 __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvParams p, const int tiles_x, const int tiles_y,
                                                                   const int nblk_n, const int n_slow) {
     using C = HCfg<BN>;
+    using H16 = HOp16<F16>;
+    static_assert(!F16 || !ABF, "fp16 operands go with fp32 activation storage");
     constexpr int PPP = ABF ? 4 : 8;                            // 16-byte pieces per halo pixel (32 channels)
     constexpr int PSH = ABF ? 2 : 3;
     constexpr int NPIECE = HALO_PIX * PPP;
@@ -131,7 +149,7 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
             *reinterpret_cast<float4*>(Ah + buf * HALO_BYTES + off) = v;
         } else {
             const floatx4 fv = {v.x, v.y, v.z, v.w};
-            *reinterpret_cast<bf16x4*>(Ah + buf * HALO_BYTES + off) = __builtin_convertvector(fv, bf16x4);
+            *reinterpret_cast<typename H16::x4*>(Ah + buf * HALO_BYTES + off) = __builtin_convertvector(fv, typename H16::x4);
         }
     };
     const int last_step = nch * 9 - 1;
@@ -183,16 +201,16 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
             const char* bs = Bs + (tap % 3) * C::B_BYTES + b_base;
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
-                bf16x8 fa[2], fb[C::TN];
+                typename H16::x8 fa[2], fb[C::TN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + a_base[i] + toff + sb * 32);
+                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const typename H16::x8*>(ah + a_base[i] + toff + sb * 32);
 #pragma unroll
-                for (int j = 0; j < C::TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * ROWB + sb * 32);
+                for (int j = 0; j < C::TN; ++j) fb[j] = *reinterpret_cast<const typename H16::x8*>(bs + j * 32 * ROWB + sb * 32);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = H16::mfma(fa[i], fb[j], acc[i][j]);
             }
             // pass q is loaded at tap q and written one tap later (ra[q % 2] is free again before pass q + 2 loads)
             if (more_chunks && tap >= 1 && tap - 1 < A_PASSES) a_store(tap - 1, (ci + 1) & 1);
@@ -302,14 +320,14 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
     }
 }
 
-template <int BN, bool ABF>
+template <int BN, bool ABF, bool F16 = false>
 void launch_halo(const ConvParams& p, hipStream_t s) {
     const int tiles_x = (p.Wo + TS - 1) / TS, tiles_y = (p.Ho + TS - 1) / TS;
     const int nblk_n = (p.Cout + BN - 1) / BN;
     static const int env = tuning_env_int("IRSDE_HALO_NSLOW", -1);
     const double wbytes = 2.0 * p.Cout * 9.0 * (p.C0 + p.C1);
     const int n_slow = env >= 0 ? (env && nblk_n > 1) : (nblk_n >= 2 && wbytes > 4.0e6);  // one XCD L2 = 4 MiB
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, ABF>), dim3((unsigned)(p.B * tiles_y * tiles_x * nblk_n)), dim3(NT),
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, ABF, F16>), dim3((unsigned)(p.B * tiles_y * tiles_x * nblk_n)), dim3(NT),
                        HCfg<BN>::LDS_BYTES, s, p, tiles_x, tiles_y, nblk_n, n_slow);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
@@ -325,6 +343,10 @@ void conv_halo_global_init() {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<64, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<128, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_bf16_kernel<64, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
 bool conv_halo_eligible(const ConvParams& p) {
@@ -335,7 +357,10 @@ bool conv_halo_eligible(const ConvParams& p) {
 
 void launch_conv_halo(const ConvParams& p, hipStream_t s) {
     if (!conv_halo_eligible(p)) throw HipError("launch_conv_halo: layer not eligible");
-    if (p.in_bf16) {
+    if (p.f16) {
+        if (p.in_bf16) throw HipError("launch_conv_halo: fp16 operands go with fp32 activation storage");
+        if (p.Cout >= 128) launch_halo<128, false, true>(p, s); else launch_halo<64, false, true>(p, s);
+    } else if (p.in_bf16) {
         if (p.Cout >= 128) launch_halo<128, true>(p, s); else launch_halo<64, true>(p, s);
     } else {
         if (p.Cout >= 128) launch_halo<128, false>(p, s); else launch_halo<64, false>(p, s);

@@ -36,8 +36,25 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// The 16-bit operand type of the reduced-precision modes: bf16 (IRSDE_FLAG_BF16) or IEEE fp16 (IRSDE_FLAG_FP16) — the same
+// 32x32x16 MFMA shape, the same fragment layout, fp32 accumulation; only the rounding (8 vs 11 significand bits) differs.
+template <bool F16>
+struct Op16 {
+    using x8 = bf16x8;
+    using x4 = bf16x4;
+    static __device__ __forceinline__ floatx16 mfma(x8 a, x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Op16<true> {
+    using x8 = f16x8;
+    using x4 = f16x4;
+    static __device__ __forceinline__ floatx16 mfma(x8 a, x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 constexpr int BK = 32;  // k per K-step (channels of one tap)
 
@@ -82,11 +99,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // INSCALE: per-(batch, input channel) scale applied while staging (NAFNet SCA).  A template parameter, not a runtime
 // test: a branch inside the staging code makes the compiler wait for every load where the paths join, which
 // serialises the loads of a K-step and pulls the vmcnt(0) in front of the MFMAs.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD, bool BF16, bool INSCALE, bool ABF = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD, bool BF16, bool INSCALE, bool ABF = false, bool F16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void conv_igemm_kernel(
     const ConvParams pin, const int nblk_n, const int M, const int nk_total) {
     using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16, ABF>;
+    using H16 = Op16<F16>;
     static_assert(!ABF || (BF16 && !INSCALE), "bf16 activation storage belongs to the bf16-MFMA mode");
+    static_assert(!F16 || (BF16 && !ABF), "fp16 operands: the 16-bit MFMA mode with fp32 activation storage");
     ConvParams p = pin;  // batched launch: component blockIdx.z works on its own slice of in0 / w / out
     if (pin.nz > 1) {
         const long long z = blockIdx.z;
@@ -229,7 +248,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
             if (ABF) {
                 *reinterpret_cast<floatx4*>(dst + chunk * 16) = rs[q];  // already bf16: 8 k per piece
             } else if (BF16) {
-                *reinterpret_cast<bf16x4*>(dst + chunk * 8) = __builtin_convertvector(rs[q], bf16x4);  // v_cvt_pk_bf16_f32, RNE
+                *reinterpret_cast<typename H16::x4*>(dst + chunk * 8) = __builtin_convertvector(rs[q], typename H16::x4);  // v_cvt_pk_bf16_f32 / v_cvt_f16_f32, RNE
             } else {
                 *reinterpret_cast<floatx4*>(dst + chunk * 16) = rs[q];
             }
@@ -273,18 +292,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
             if (BF16) {
-                bf16x8 fa[C::TM], fb[C::TN];
+                typename H16::x8 fa[C::TM], fb[C::TN];
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
-                    fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * C::ROW_BYTES + sb * 32);
+                    fa[i] = *reinterpret_cast<const typename H16::x8*>(a + i * 32 * C::ROW_BYTES + sb * 32);
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j)
-                    fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * C::ROW_BYTES + sb * 32);
+                    fb[j] = *reinterpret_cast<const typename H16::x8*>(b + j * 32 * C::ROW_BYTES + sb * 32);
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = H16::mfma(fa[i], fb[j], acc[i][j]);
             } else {
                 float4 fa[C::TM], fb[C::TN];
 #pragma unroll
@@ -800,10 +819,13 @@ __global__ void conv_naive_kernel(const ConvParams p, const int M) {
     p.out[(size_t)m * p.out_stride + n] = v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false, bool ABF = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false, bool ABF = false, bool F16 = false>
 void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds_override = 0) {
     using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16, ABF>;
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE, ABF>;
+    if constexpr (BF16 && !ABF && !F16) {
+        if (p.f16) return launch_cfg<BM, BN, WAVES_M, WAVES_N, MINW, true, INSCALE, false, true>(p, M, nk_total, s, lds_override);
+    }
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE, ABF, F16>;
     const int nblk_m = (M + BM - 1) / BM;
     const int nblk_n = (p.Cout + BN - 1) / BN;
     dim3 grid(nblk_m * nblk_n, p.splits, p.nz);
@@ -816,6 +838,10 @@ void init_cfg() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE, ABF>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if constexpr (BF16 && !ABF)  // the fp16 twin of every bf16-operand kernel
+        IRSDE_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, true, INSCALE, false, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
 int g_variant = 0;  // tuning experiments only (irsde_bench_conv)
@@ -986,6 +1012,7 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     }
     const int nk_total = p.KH * p.KW * (Ctot / 32);
     if ((p.in_bf16 || p.out_bf16) && !p.w_bf) throw HipError("launch_conv: bf16 activation storage needs the bf16-MFMA mode");
+    if (p.f16 && (!p.w_bf || p.in_bf16 || p.out_bf16)) throw HipError("launch_conv: fp16 operands go with fp32 activation storage");
     if (p.in_bf16 && (p.in_scale || p.gate || p.shuffle)) throw HipError("launch_conv: NAFNet fusions are fp32-storage only");
     if (p.in_scale) {  // NAFNet SCA fused into the staging (128-row tiles only)
         if (p.C1) throw HipError("launch_conv: in_scale needs a single source");

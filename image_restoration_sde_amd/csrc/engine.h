@@ -276,14 +276,15 @@ struct irsde_engine {
         dev_allocs.push_back(p);
         return p;
     }
-    // bf16 (RNE) copy of a packed fp32 weight tensor, made once per tensor (IRSDE_FLAG_BF16)
+    // bf16 / fp16 (RNE) copy of a packed fp32 weight tensor, made once per tensor (IRSDE_FLAG_BF16 / IRSDE_FLAG_FP16)
     std::map<const float*, unsigned short*> bf16_copies;
     const unsigned short* bf16_copy(const float* w, size_t n) {
         auto it = bf16_copies.find(w);
         if (it != bf16_copies.end()) return it->second;
         unsigned short* d = nullptr;
         IRSDE_HIP_CHECK(hipMalloc(&d, n * sizeof(unsigned short)));
-        launch_f32_to_bf16(w, d, n, stream);
+        if (cfg.flags & IRSDE_FLAG_FP16) launch_f32_to_f16(w, d, n, stream);  // IEEE fp16 operands (RNE)
+        else launch_f32_to_bf16(w, d, n, stream);
         IRSDE_HIP_CHECK(hipStreamSynchronize(stream));
         bf16_copies[w] = d;
         return d;

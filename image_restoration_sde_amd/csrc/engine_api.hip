@@ -53,6 +53,16 @@ struct VariantScope {
     ~VariantScope() { conv_set_variant(0); }
 };
 
+// IRSDE_FLAG_FP16 = the 16-bit operand mode (IRSDE_FLAG_BF16's kernels, plans and weight copies) with IEEE fp16 rounding
+void apply_fp16_flag(irsde_engine* e) {
+    if (!(e->cfg.flags & IRSDE_FLAG_FP16)) return;
+    if (e->cfg.flags & IRSDE_FLAG_BF16_ACT) {
+        delete e;
+        throw HipError("IRSDE_FLAG_FP16 keeps fp32 activation storage: it cannot be combined with IRSDE_FLAG_BF16_ACT");
+    }
+    e->cfg.flags |= IRSDE_FLAG_BF16;
+}
+
 int guard(const std::function<void()>& f) {
     try {
         f();
@@ -98,6 +108,7 @@ int irsde_create(const irsde_config* cfg, irsde_engine** out) {
             }
             e->cfg.flags |= IRSDE_FLAG_BF16;
         }
+        apply_fp16_flag(e);
         e->time_dim = cfg->nf * 4;
         build_inventory(e);
         *out = e;
@@ -119,6 +130,7 @@ int irsde_create_nafnet(const irsde_nafnet_config* cfg, irsde_engine** out) {
         e->cfg.depth = cfg->n_enc;  // pad multiple 2^stages (padder_size, DenoisingNAFNet_arch.py:147)
         e->cfg.device = cfg->device;
         e->cfg.flags = cfg->flags;
+        apply_fp16_flag(e);
         e->time_dim = cfg->width * 4;
         for (int i = 0; i < cfg->n_enc; ++i) {
             if (cfg->enc_blk_nums[i] < 0 || cfg->dec_blk_nums[i] < 0) throw HipError("negative block count");
@@ -541,6 +553,13 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
                 launch_f32_to_bf16(dw, dbf, pk.size(), s);
                 p.w_bf = dbf;
             }
+            const bool f16 = naive == 5 || naive == 165;  // fp16-MFMA mode: production dispatch / generic 128-row tile
+            if (f16) {
+                IRSDE_HIP_CHECK(hipMalloc(&dbf, pk.size() * 2));
+                launch_f32_to_f16(dw, dbf, pk.size(), s);
+                p.w_bf = dbf;
+                p.f16 = 1;
+            }
             const size_t npix_in = (size_t)B * Hin * Win, nout = (size_t)B * p.Ho * p.Wo * Cout;
             if (act) {  // the caller's fp32 tensors are rounded into bf16 copies; the bf16 result is widened back
                 auto to_bf = [&](const float* src, size_t n) {
@@ -558,7 +577,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
                 p.in_bf16 = p.out_bf16 = 1;
             }
             {
-                VariantScope vs(act ? (naive == 204 ? 0 : naive - 200) : (naive >= 100 ? naive - 100 : 0));  // tile variants
+                VariantScope vs(f16 ? (naive == 165 ? 61 : 0) : act ? (naive == 204 ? 0 : naive - 200) : (naive >= 100 ? naive - 100 : 0));  // tile variants
                 launch_conv(p, s);
             }
             if (act) launch_bf16_to_f32(ao, out, nout, s);
@@ -641,6 +660,7 @@ int irsde_create_latent_unet(const irsde_latent_unet_config* cfg, irsde_engine**
         e->arch = 2;
         e->cfg.in_nc = cfg->in_ch; e->cfg.out_nc = cfg->out_ch; e->cfg.nf = cfg->ch; e->cfg.depth = cfg->n_mult;
         e->cfg.device = cfg->device; e->cfg.flags = cfg->flags;
+        apply_fp16_flag(e);
         e->lat_in = cfg->in_ch; e->lat_out = cfg->out_ch; e->lat_ch = cfg->ch; e->lat_embed = cfg->embed_dim;
         for (int i = 0; i < cfg->n_mult; ++i) {
             if (cfg->ch_mult[i] < 1 || cfg->ch * cfg->ch_mult[i] > 2048) throw HipError("ch * ch_mult out of range");

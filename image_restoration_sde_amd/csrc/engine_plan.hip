@@ -46,8 +46,10 @@ struct Builder {
             p.partial = pl->alloc((size_t)splits * M * p.Cout, true);
         }
         p.zeros = e->zeros;
-        if (!naive && (e->cfg.flags & IRSDE_FLAG_BF16))
+        if (!naive && (e->cfg.flags & IRSDE_FLAG_BF16)) {
             p.w_bf = e->bf16_copy(p.w, (size_t)p.Cout * p.KH * p.KW * (p.C0 + p.C1));
+            p.f16 = (e->cfg.flags & IRSDE_FLAG_FP16) ? 1 : 0;
+        }
         Op op;
         op.kind = OP_CONV;
         op.flops = conv_flops(p);
@@ -61,7 +63,7 @@ struct Builder {
         {
             char buf[256];
             snprintf(buf, sizeof buf, "conv%s M=%d Cout=%d Cin=%d k=%dx%d s=%d up=%d splits=%d blocks=%d flops=%.4g",
-                     p.w_bf ? "(bf16)" : "", M, p.Cout, p.C0 + p.C1, p.KH, p.KW, p.stride, p.in_shift, splits, blocks, op.flops);
+                     p.w_bf ? (p.f16 ? "(fp16)" : "(bf16)") : "", M, p.Cout, p.C0 + p.C1, p.KH, p.KW, p.stride, p.in_shift, splits, blocks, op.flops);
             op.desc = buf;
         }
         const bool nv = naive;

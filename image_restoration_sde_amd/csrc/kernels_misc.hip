@@ -1006,4 +1006,16 @@ void launch_f32_to_bf16(const float* in, unsigned short* out, size_t n, hipStrea
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
+// fp32 -> IEEE fp16 (round to nearest even) copy of packed conv weights for the fp16-MFMA mode (IRSDE_FLAG_FP16)
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const _Float16 b = (_Float16)in[i];
+    out[i] = __builtin_bit_cast(unsigned short, b);
+}
+void launch_f32_to_f16(const float* in, unsigned short* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace irsde

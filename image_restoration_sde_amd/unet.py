@@ -146,17 +146,20 @@ class ConditionalUNet(nn.Module):
         return self._engine
 
     def set_compute_dtype(self, dtype):
-        """'fp32' (default: exact-fp32 MFMA + Winograd) or 'bf16' (BASELINE configs[2]: conv operands rounded to bf16,
-        fp32 accumulation, everything else fp32).  New behaviour — the reference is fp32 only."""
-        self.engine_flags &= ~(_lib.FLAG_BF16 | _lib.FLAG_BF16_ACT)
+        """'fp32' (default: exact-fp32 MFMA + Winograd), 'bf16' (BASELINE configs[2]: conv operands rounded to bf16,
+        fp32 accumulation, everything else fp32), 'bf16_act' (+ bf16 activation storage) or 'fp16' (BASELINE configs[4]:
+        the 'bf16' mode with IEEE fp16 operands).  New behaviour — the reference is fp32 only."""
+        self.engine_flags &= ~(_lib.FLAG_BF16 | _lib.FLAG_BF16_ACT | _lib.FLAG_FP16)
         if dtype in ("fp32", "f32", torch.float32):
             pass
         elif dtype in ("bf16", torch.bfloat16):
             self.engine_flags |= _lib.FLAG_BF16
         elif dtype == "bf16_act":  # + bf16 storage of the activation tensors (conditional UNet only)
             self.engine_flags |= _lib.FLAG_BF16 | _lib.FLAG_BF16_ACT
+        elif dtype in ("fp16", "f16", torch.float16):
+            self.engine_flags |= _lib.FLAG_FP16
         else:
-            raise _lib.IrsdeError("compute dtype must be 'fp32', 'bf16' or 'bf16_act'")
+            raise _lib.IrsdeError("compute dtype must be 'fp32', 'bf16', 'bf16_act' or 'fp16'")
         return self
 
     # ---- reference interface -----------------------------------------------------------------

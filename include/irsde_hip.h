@@ -59,6 +59,12 @@ enum {
                                         per-block FiLM on the gated FFN activation; needs irsde_set_lens_info before forward/sample */
     IRSDE_FLAG_NAF_INTRO_SKIP = 64,  /* ConditionalNAFNet of the latent tasks (codes/config/latent-dehazing/models/modules/
                                         DenoisingNAFNet_arch.py:162-176): ending(x + intro(x)) instead of ending(x) */
+    IRSDE_FLAG_FP16 = 1024,          /* IRSDE_FLAG_BF16's mode with IEEE fp16 operands instead (BASELINE configs[4] names fp16; the reference is
+                                        fp32 only): every convolution runs on v_mfma_f32_32x32x16_f16 with activations and weights
+                                        rounded to binary16 (RNE, 11 significand bits vs 8 for bf16) and fp32 accumulation;
+                                        activation storage, LayerNorm, attention, FiLM and the update step stay fp32.  Not
+                                        combinable with IRSDE_FLAG_BF16_ACT.  Operands beyond +-65504 would overflow: the score
+                                        networks' activations are O(1..100) */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };

@@ -21,6 +21,7 @@ extern "C" {
  *   2 / 3 Winograd F(2x2,3x3) / F(4x4,3x3) (3x3 s1 p1 only); 12 / 13 and 22 / 23: the same with the component GEMMs forced
  *         onto the tile-loop kernel (all / 2 components per block)
  *   4 bf16-MFMA mode (halo kernel for eligible 3x3 layers); 160 / 161 its generic 256 / 128 tile
+ *   5 fp16-MFMA mode (IRSDE_FLAG_FP16; halo kernel for eligible 3x3 layers); 165 its generic 128 tile
  *   204 / 260 / 261 the same three with bf16 activation storage (inputs / residual are rounded, the result widened back)
  *   100 + v: tile variant v of the fp32 kernel (3 = 256x128, 50 = 256x256, 73 = tile-loop kernel for 1x1 layers)
  * splits > 1 forces split-K.  Synchronises `stream`. */

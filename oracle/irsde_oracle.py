@@ -138,6 +138,14 @@ def round_bf16(a):
     return u.view(np.float32).astype(a.dtype)
 
 
+def round_f16(a):
+    """Round to the nearest IEEE binary16 (ties to even; the engine's IRSDE_FLAG_FP16 operand rounding), returned in the
+    dtype of `a`."""
+    a = np.asarray(a)
+    return np.ascontiguousarray(a, dtype=np.float32).astype(np.float16).astype(a.dtype)
+
+
+CONV_OPERANDS_F16 = False   # restatement of the engine's IRSDE_FLAG_FP16 mode: conv operands rounded to fp16, fp32+ accumulation
 CONV_OPERANDS_BF16 = False  # restatement of the engine's IRSDE_FLAG_BF16 mode: conv operands rounded, fp32+ accumulation
 
 
@@ -163,6 +171,20 @@ class bf16_convs:
         CONV_OPERANDS_BF16, ACT_STORAGE_BF16 = self.prev
 
 
+class f16_convs:
+    """Context manager: every conv2d inside rounds activations and weights to IEEE fp16 first (IRSDE_FLAG_FP16); everything
+    else stays in full precision, as in the engine."""
+
+    def __enter__(self):
+        global CONV_OPERANDS_F16
+        self.prev = CONV_OPERANDS_F16
+        CONV_OPERANDS_F16 = True
+
+    def __exit__(self, *a):
+        global CONV_OPERANDS_F16
+        CONV_OPERANDS_F16 = self.prev
+
+
 def _st(x):
     """A tensor the engine writes to HBM (identity unless the bf16 storage mode is being restated)."""
     return round_bf16(x) if ACT_STORAGE_BF16 else x
@@ -172,6 +194,8 @@ def conv2d(x, w, b=None, stride=1, pad=0):
     """nn.Conv2d forward (cross-correlation), NCHW / OIHW, zero padding."""
     if CONV_OPERANDS_BF16:
         x, w = round_bf16(x), round_bf16(w)
+    elif CONV_OPERANDS_F16:
+        x, w = round_f16(x), round_f16(w)
     B, C, H, W = x.shape
     O, C2, kh, kw = w.shape
     assert C == C2

@@ -192,6 +192,68 @@ def test_conv_kernel_bf16(name):
         assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=160), ref) < 2e-5  # 256x256 tile
 
 
+@pytest.mark.parametrize("name", ["3x3_64_64_film_silu", "3x3_concat_192_128", "1x1_qkv_384", "4x4_s2_down", "3x3_upsample_fused",
+                                  "3x3_m_tail_odd", "3x3_deep_k_1536", "3x3_wino_res_bias"])
+def test_conv_kernel_fp16(name):
+    """IRSDE_FLAG_FP16 kernels (v_mfma_f32_32x32x16_f16; BASELINE configs[4] names fp16): same operands as the oracle once
+    both round to IEEE binary16 (RNE); products are exact in fp32, so only the fp32 accumulation order differs.  fp16
+    keeps 11 significand bits: 8x closer to the fp32 result than the bf16 mode."""
+    B, C0, C1, H, W, Cout, K, stride, pad, in_shift, has_bias, has_film, silu, has_res = CONV_CASES[name]
+    rs = np.random.RandomState(hash(name) % 2 ** 31)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, K, K)) / np.sqrt((C0 + C1) * K * K)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32) if has_bias else None
+    film = (0.3 * rs.standard_normal((1, 2 * Cout))).astype(np.float32) if has_film else None
+    Ho = ((H << in_shift) + 2 * pad - K) // stride + 1
+    Wo = ((W << in_shift) + 2 * pad - K) // stride + 1
+    res = rs.standard_normal((B, Cout, Ho, Wo)).astype(np.float32) if has_res else None
+    with O.f16_convs():
+        ref = oracle_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res)
+    full = oracle_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res)
+    got = run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=5)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert relerr(got, ref) < 2e-5, name
+    assert 1e-5 < relerr(got, full) < 3e-3, name  # and it really is the fp16-operand product (bf16 would be ~8x further off)
+    assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=165), ref) < 2e-5  # generic 128 tile
+
+
+def test_unet_fp16_mode(golden):
+    """IRSDE_FLAG_FP16 on the whole network: follows the oracle's restatement of the mode (conv operands rounded to fp16,
+    everything else full precision) to 3e-3 of max|ref| and the fp32 reference to 5e-3; the plan is the bf16 mode's (no
+    Winograd); a 20-step reverse_ode stays within 1e-2 of the fp32 engine."""
+    params = O.synth_params(seed=0, nf=64, depth=4)
+    m = P.ConditionalUNet(3, 3, 64, depth=4)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.set_compute_dtype("fp16")
+    assert m.engine_flags == _lib.FLAG_FP16
+    lq, xT = O.synth_inputs(1234, 1, 64, 64)
+    y = m(torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV), 50).cpu().numpy()
+    with O.f16_convs():
+        ref16 = O.unet_forward(params, xT, lq, 50, depth=4, dtype=np.float64)
+    e_oracle, e_fp32 = relerr(y, ref16), relerr(y, golden.forward["nf64d4_1x64x64/t50"])
+    print("fp16 forward: vs fp16 oracle %.3g, vs fp32 reference %.3g" % (e_oracle, e_fp32))
+    assert e_oracle < 3e-3 and 1e-6 < e_fp32 < 5e-3
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 1, 64, 64, buf, len(buf)))
+    assert b"conv(fp16)" in buf.value and b"winograd" not in buf.value and b"conv(bf16)" not in buf.value
+    m32, _ = model(64, 4)
+    outs = {}
+    for name, mm in (("fp16", m), ("fp32", m32)):
+        sde = P.IRSDE(10, 100, "cosine", 0.005, device=DEV)
+        sde.set_model(mm)
+        sde.set_mu(torch.from_numpy(lq).to(DEV))
+        outs[name] = sde.reverse_ode(torch.from_numpy(xT).to(DEV), T=20).cpu().numpy()
+    e_ode = relerr(outs["fp16"], outs["fp32"])
+    print("fp16 reverse_ode T=20 vs fp32: %.3g" % e_ode)
+    assert e_ode < 1e-2
+    # the flag cannot be combined with bf16 activation storage
+    cfg = _lib.Config(3, 3, 64, 4, 0, _lib.FLAG_FP16 | _lib.FLAG_BF16_ACT)
+    h = ctypes.c_void_p()
+    assert _lib.lib().irsde_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+
+
 @pytest.mark.parametrize("name", ["3x3_64_64_film_silu", "3x3_64_64_silu_res", "3x3_concat_192_128", "1x1_qkv_384", "4x4_s2_down",
                                   "3x3_upsample_fused", "3x3_m_tail_odd", "3x3_deep_k_1536", "3x3_wino_res_bias"])
 def test_conv_kernel_bf16_storage(name):

@@ -192,3 +192,62 @@ def test_compute_dtype_flags_and_metrics_fail_loudly_on_cpu():
         P.metrics.evaluate_batch(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
     with pytest.raises(P.IrsdeError):
         P.metrics.tensor2img(torch.zeros(3, 16, 16))
+
+
+def _load_tool(name):
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", name + ".py")
+    spec = importlib.util.spec_from_file_location("tool_" + name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_eval_folder_host_helpers(tmp_path):
+    """tools/eval_folder.py: folder walk / LQ-GT pairing / image I/O / equal-size batching (the parts of the reference's
+    test loop, deraining/test.py:93-217, that run on the host)."""
+    import os
+    from PIL import Image
+    ef = _load_tool("eval_folder")
+    rs = np.random.RandomState(0)
+    lq, gt = tmp_path / "LQ", tmp_path / "GT" / "sub"
+    lq.mkdir()
+    gt.mkdir(parents=True)
+    imgs = {}
+    for i, (h, w) in enumerate([(20, 24), (20, 24), (16, 24), (20, 24)]):
+        a = rs.randint(0, 256, size=(h, w, 3), dtype=np.uint8)
+        imgs["im%d" % i] = a
+        Image.fromarray(a).save(str(lq / ("im%d.png" % i)))
+        Image.fromarray(255 - a).save(str(gt / ("im%d.PNG" % i)))
+    (lq / "notes.txt").write_text("not an image")
+    pairs = ef.pair_paths(str(lq), str(gt))
+    assert [os.path.basename(p[0]) for p in pairs] == ["im0.png", "im1.png", "im2.png", "im3.png"]
+    assert all(os.path.basename(p[1]).lower() == os.path.basename(p[0]) for p in pairs)
+    x = ef.read_img(pairs[2][0])
+    assert x.dtype == np.float32 and x.shape == (3, 16, 24)
+    assert np.array_equal(x, imgs["im2"].transpose(2, 0, 1).astype(np.float32) / np.float32(255))   # RGB, CHW, [0, 1]
+    sizes = [ef.read_img(p[0]).shape for p in pairs]
+    assert ef.batches_of_equal_size(pairs, sizes, 16) == [[0, 1], [2], [3]]
+    assert ef.batches_of_equal_size(pairs[:2], sizes[:2], 1) == [[0], [1]]
+    # save_img takes the BGR uint8 image tensor2img produces and writes it as RGB
+    ef.save_img(imgs["im0"][..., ::-1], str(tmp_path / "out" / "o.png"))
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "out" / "o.png"))), imgs["im0"])
+    (gt / "extra.png").write_bytes((gt / "im0.PNG").read_bytes())
+    with pytest.raises(ValueError):
+        ef.pair_paths(str(lq), str(gt))
+    with pytest.raises(FileNotFoundError):
+        ef.list_images(str(tmp_path / "no_such_dir"))
+
+
+def test_tuning_env_knobs_are_inert_without_IRSDE_TUNING():
+    """A stray IRSDE_* tuning variable must not change the validated launch plan: the library reads them only through
+    tuning_env_int(), which returns the default unless IRSDE_TUNING=1 (csrc/common.h)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(P.__file__), "csrc")
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(root, f)).read()
+            for m in re.finditer(r"getenv\(\"(\w+)\"\)", src):
+                assert f == "common.h" and m.group(1) == "IRSDE_TUNING", (f, m.group(0))

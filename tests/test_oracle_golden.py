@@ -154,6 +154,45 @@ def test_torch_cpu_port_matches_reference(golden, tag):
         assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-5
 
 
+def test_torch_cpu_port_matches_reference_at_256(golden):
+    """The cpu_baseline port at the benchmarked image size (1x3x256x256) and at the Rain100H size (reflect pad 321 -> 336,
+    481 -> 496) vs the REAL reference (tests/golden/fullres.npz; `sub3` = every third pixel, oracle/gen_golden.py)."""
+    import torch
+    from oracle import torch_cpu_port as TP
+    g = golden.fullres
+    params = {k: torch.from_numpy(v) for k, v in O.synth_params(seed=0, nf=64, depth=4).items()}
+    lq, xT = O.synth_inputs(1234, 1, 256, 256)
+    with torch.no_grad():
+        y = TP.unet_forward(params, torch.from_numpy(xT), torch.from_numpy(lq), 50, 4).numpy()
+    ref = g["unet_1x256x256/t50"]
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-5
+    lq, xT = O.synth_inputs(1234, 2, 321, 481)
+    with torch.no_grad():
+        y = TP.unet_forward(params, torch.from_numpy(xT[:1]), torch.from_numpy(lq[:1]), 37, 4).numpy()
+    ref = g["unet_2x321x481/t37_bottom"][:1]
+    assert np.abs(y[:, :, -20:, :] - ref).max() / np.abs(ref).max() < 1e-5
+    ref = g["unet_2x321x481/t37_sub3"][:1]
+    assert np.abs(y[..., 1::3, 2::3] - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def test_f16_restatement_rounds_like_ieee_binary16():
+    """O.round_f16 / O.f16_convs (the checker of IRSDE_FLAG_FP16): RNE to 11 significand bits, ties to even, and the
+    conv oracle applies it to both operands."""
+    a = np.array([1.0, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 1.0 + 2.0 ** -10, 65504.0, 1e-8, -0.1], dtype=np.float32)
+    r = O.round_f16(a)
+    assert r.dtype == np.float32
+    assert r[0] == 1.0 and r[1] == 1.0 and r[2] == np.float32(1.0 + 2.0 ** -9) and r[3] == np.float32(1.0 + 2.0 ** -10)
+    assert r[4] == 65504.0 and r[5] == np.float32(np.float16(1e-8)) and r[6] == np.float32(np.float16(-0.1))
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((1, 8, 6, 6)).astype(np.float32)
+    w = rs.standard_normal((4, 8, 3, 3)).astype(np.float32)
+    with O.f16_convs():
+        y16 = O.conv2d(x, w, pad=1)
+    assert np.allclose(y16, O.conv2d(O.round_f16(x), O.round_f16(w), pad=1), rtol=0, atol=0)
+    assert 1e-5 < np.abs(y16 - O.conv2d(x, w, pad=1)).max() < 5e-2
+    assert not O.CONV_OPERANDS_F16
+
+
 def test_torch_cpu_port_sampler_steps(golden):
     import torch
     from oracle import torch_cpu_port as TP
