@@ -111,6 +111,12 @@ struct WinoParams {
 void launch_wino_input(const WinoParams& p, hipStream_t s);
 void launch_wino_output(const WinoParams& p, hipStream_t s);
 void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U, int tile);  // host
+// Fused Winograd F(4x4,3x3) convolution (wino_fused.hip): transforms and the 36 component GEMMs in one kernel.  `p` is the
+// plain 3x3 s1 p1 convolution (as for launch_conv), Uf the weights from wino_fused_pack_weights.
+bool wino_fused_eligible(const ConvParams& p);
+void wino_fused_pack_weights(const float* U, int Cout, int Cin, float* Uf);  // host: U[36][Cout][Cin] -> fragment order
+void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s);
+void wino_fused_global_init();
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)
 void launch_conv(const ConvParams& p, hipStream_t s);

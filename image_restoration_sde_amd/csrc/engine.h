@@ -27,6 +27,11 @@ namespace irsde {
 // 4x the output through HBM and pays from 256 channels, F(4x4) 2.25x and pays from 128 — from 64 (+1.6 %) since the
 // component GEMMs run on the batch-loop kernel (measured, profiles/).
 // IRSDE_WINO2_MINC / IRSDE_WINO4_MINC override the thresholds (tuning experiments, only with IRSDE_TUNING=1).
+// The fused Winograd kernel (wino_fused.hip) streams a layer's whole U slice per block: it pays where the feature map is
+// large (many tiles) and the channel counts are moderate; beyond these limits the three-launch path keeps the layer.
+constexpr int kWinoFusedMaxCin = 512, kWinoFusedMaxCout = 256;
+inline long long wino_fused_min_tiles() { return tuning_env_int("IRSDE_WINO_FUSED_MINT", 4096); }
+
 inline int wino_min_c(int tile) {
     return tuning_env_int(tile == 4 ? "IRSDE_WINO4_MINC" : "IRSDE_WINO2_MINC", tile == 4 ? 64 : 256);
 }
@@ -59,6 +64,7 @@ struct ConvW {
     int Cout = 0, Cin = 0, KH = 1, KW = 1;
     float* wino_u2 = nullptr;  // device [16][Cout][Cin] = G g G^T of F(2x2,3x3)  (3x3 layers with Cin,Cout >= 256)
     float* wino_u4 = nullptr;  // device [36][Cout][Cin]              F(4x4,3x3)  (3x3 layers with Cin,Cout >= 128)
+    float* wino_uf = nullptr;  // the same F(4x4,3x3) weights in the fused kernel's fragment order (wino_fused.hip)
 };
 struct ResW {
     ConvW b1, b2, res;

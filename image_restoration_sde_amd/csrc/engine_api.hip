@@ -523,7 +523,18 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
             p.partial = dp;
         }
-        if (wino_tile) {  // naive / 10: 0 = production dispatch, 1 / 2 = force the batch-loop GEMM kernel (all / 2 components per block)
+        if (naive == 33) {  // fused Winograd F(4x4,3x3) kernel (wino_fused.hip)
+            if (!wino_fused_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
+            std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
+            wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
+            wino_fused_pack_weights(U.data(), Cout, Cin, Uf.data());
+            float* dUf = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dUf, Uf.size() * 4));
+            IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
+            launch_wino_fused(p, dUf, s);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(dUf);
+        } else if (wino_tile) {  // naive / 10: 0 = production dispatch, 1 / 2 = force the batch-loop GEMM kernel (all / 2 components per block)
             const int tile = wino_tile, ncomp = (tile + 2) * (tile + 2);
             if (!wino_shape_ok(p, tile)) throw HipError("debug_conv: shape not eligible for Winograd");
             std::vector<float> U((size_t)ncomp * Cout * Cin);
@@ -630,13 +641,40 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         }
         if (epi == 1) { p.film = dfilm; p.silu = 1; }
         if (epi == 2) { p.silu = 1; p.res = dres; p.res_stride = Cout; }
-        VariantScope vs(variant);
+        // 80: fused Winograd F(4x4,3x3) kernel; 81: the three-launch Winograd F(4x4,3x3) path (random U: timing only)
+        float *dU = nullptr, *dV = nullptr, *dM = nullptr;
+        WinoPlan wp{};
+        if (variant == 80 || variant == 81) {
+            if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
+            IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
+            launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
+            if (variant == 80 && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
+            if (variant == 81) {
+                if (!wino_shape_ok(p, 4)) throw HipError("bench_conv: shape not eligible for Winograd F(4x4,3x3)");
+                const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
+                IRSDE_HIP_CHECK(hipMalloc(&dV, (size_t)36 * T * Cin * 4));
+                IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)36 * T * Cout * 4));
+                wp = make_wino(p, dU, dV, dM, 4);
+            }
+        }
+        auto run = [&] {
+            if (variant == 80) {
+                launch_wino_fused(p, dU, s);
+            } else if (variant == 81) {
+                launch_wino_input(wp.in, s);
+                launch_conv(wp.gemm, s);
+                launch_wino_output(wp.out, s);
+            } else {
+                launch_conv(p, s);
+            }
+        };
+        VariantScope vs(variant >= 80 ? 0 : variant);
         hipEvent_t e0, e1;
         IRSDE_HIP_CHECK(hipEventCreate(&e0));
         IRSDE_HIP_CHECK(hipEventCreate(&e1));
-        for (int i = 0; i < 2; ++i) launch_conv(p, s);
+        for (int i = 0; i < 2; ++i) run();
         IRSDE_HIP_CHECK(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) launch_conv(p, s);
+        for (int i = 0; i < iters; ++i) run();
         IRSDE_HIP_CHECK(hipEventRecord(e1, s));
         IRSDE_HIP_CHECK(hipStreamSynchronize(s));
         float ms = 0;
@@ -645,6 +683,8 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
         if (dbf) (void)hipFree(dbf);
+        for (float* q : {dU, dV, dM})
+            if (q) (void)hipFree(q);
         (void)hipStreamDestroy(s);
     });
 }

@@ -102,11 +102,38 @@ struct Builder {
         p.silu = silu;
         if (res) { p.res = res->p; p.res_stride = res->C; }
         if (!naive) {  // prefer F(4x4,3x3), then F(2x2,3x3), then the direct implicit GEMM
+            if (w.wino_uf && push_wino_fused(p, w.wino_uf)) return out;
             if (w.wino_u4 && wino_shape_ok(p, 4) && push_wino(p, w.wino_u4, 4)) return out;
             if (w.wino_u2 && wino_shape_ok(p, 2) && push_wino(p, w.wino_u2, 2)) return out;
         }
         push_conv(p);
         return out;
+    }
+
+    // Winograd F(4x4,3x3) with both transforms inside the GEMM kernel (wino_fused.hip): the big feature maps
+    bool push_wino_fused(const ConvParams& d, const float* Uf) {
+        ConvParams dd = d;
+        dd.zeros = e->zeros;
+        if (!wino_fused_eligible(dd)) return false;
+        const int Ctot = d.C0 + d.C1;
+        const long long T = (long long)d.B * (d.Ho / 4) * (d.Wo / 4);
+        const long long blocks = (long long)d.B * ((d.Ho / 4 + 3) / 4) * ((d.Wo / 4 + 7) / 8) * (d.Cout / 32);
+        if (T < wino_fused_min_tiles() || blocks < 256) return false;
+        Op op;
+        op.kind = OP_CONV;
+        op.flops = conv_flops(d);
+        op.exec_flops = 36 * 2.0 * (double)T * Ctot * d.Cout;
+        op.bytes = 4.0 * (double)d.B * d.Hin * d.Win * Ctot + 4.0 * (double)d.B * d.Ho * d.Wo * d.Cout + 4.0 * 9.0 * (double)d.Cout * Ctot;
+        pl->conv_flops += op.flops;
+        pl->conv_exec_flops += op.exec_flops;
+        pl->conv_bytes += op.bytes;
+        char buf[256];
+        snprintf(buf, sizeof buf, "conv(winograd F4 fused) T=%lld Cout=%d Cin=%d up=%d blocks=%lld flops=%.4g exec=%.4g", T, d.Cout, Ctot,
+                 d.in_shift, blocks, op.flops, op.exec_flops);
+        op.desc = buf;
+        op.fn = [dd, Uf](hipStream_t s) { launch_wino_fused(dd, Uf, s); };
+        pl->net_ops.push_back(std::move(op));
+        return true;
     }
 
     // Winograd F(2x2,3x3): input transform -> 16 batched GEMMs on the MFMA kernel -> output transform + epilogue

@@ -105,6 +105,12 @@ ConvW pack_conv(irsde_engine* e, const std::string& wname, const std::string& bn
             std::vector<float> U((size_t)(tile + 2) * (tile + 2) * O * I);
             wino_transform_weights(p.data(), O, I, U.data(), tile);
             (tile == 4 ? c.wino_u4 : c.wino_u2) = e->upload(U);
+            if (tile == 4 && !(e->cfg.flags & IRSDE_FLAG_NO_WINOGRAD_FUSED) && O % 32 == 0 && I % 16 == 0 && I <= kWinoFusedMaxCin &&
+                O <= kWinoFusedMaxCout) {
+                std::vector<float> Uf(U.size());
+                wino_fused_pack_weights(U.data(), O, I, Uf.data());
+                c.wino_uf = e->upload(Uf);
+            }
         }
     }
     return c;

@@ -1,0 +1,326 @@
+// Fused Winograd F(4x4,3x3) convolution for the big feature maps: input transform, the 36 component GEMMs and the output
+// transform + epilogue in ONE kernel, so the transformed tensors V (2.25x the input) and M (2.25x the output) never reach
+// HBM.  Replaces, for the layers where the transforms cost as much as the GEMM they serve (64..256 channels on the
+// 256^2 / 128^2 levels: Block.proj, module_util.py:108-122, and the fused-upsample default_conv, DenoisingUNet_arch.py:67),
+// the three-launch path of wino.hip (wino_input -> gemm_zloop -> wino_output: 24 % of the r01 step, 69 GB per evaluation).
+//
+// Block = 32 tiles (8 wide x 4 tall = 32 x 16 output pixels of one image) x 32 output channels x all 36 components;
+// K loop over the input channels in chunks of 16.  512 threads, specialised by wave (1 MFMA wave + 1 producer wave per SIMD):
+//   waves 0-3  MFMA: wave z-group zg owns components 9zg .. 9zg+8: 9 accumulator tiles M_z[32 tiles][32 couts] of
+//              v_mfma_f32_32x32x2_f32 (144 registers).  A = V_z[tile][k] from LDS (one ds_read_b128 = 4 k per lane),
+//              B = U_z[cout][k] straight from L2 into registers (the weight slice of a (component, 32 couts) pair is
+//              private to one wave, so LDS staging would buy nothing): U is stored pre-swizzled so that a wave's
+//              fragment of one K sub-step is 1 KB contiguous (buffer_load_dwordx4, refilled in place right after use).
+//   waves 4-7  producers: lane = (tile, channel pair): 36 buffer_load_dwordx2 of the 6x6 input patch (out-of-image taps,
+//              tiles past the edge: out-of-range offset -> hardware returns 0; concat sources and the fused nearest x2
+//              upsample are resolved in the offset table), B^T d B in registers, 36 ds_write_b64 into the V buffer of
+//              the NEXT chunk (double buffer, one barrier per chunk).
+// The matrix pipe runs the MFMA wave of each SIMD while the producer wave of the same SIMD uses the vector / LDS / memory
+// pipes.  Epilogue (all 8 waves): accumulators -> LDS in two passes of 16 tiles, thread = (tile, cout): A^T M A,
+// bias -> FiLM -> SiLU -> +residual, 16 output pixels.
+//
+// Arithmetic is exact fp32 (f32 MFMA = fmaf chain); the result differs from wino.hip's only in summation order.
+#include "common.h"
+
+namespace irsde {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int WF_NT = 512;
+constexpr int WF_KC = 16;                  // input channels per chunk (two K sub-steps of 8)
+constexpr int WF_HS = 136;                 // LDS floats between the two k-halves (32 tiles x 4 k + 8 pad)
+constexpr int WF_SS = 2 * WF_HS;           // ... between the two sub-steps of a chunk (272 = 16 mod 32: conflict-free b64 writes)
+constexpr int WF_ZS = 2 * WF_SS;           // ... between components (544)
+constexpr int WF_VBUF = 36 * WF_ZS;        // floats per V buffer (78 336 B)
+constexpr int WF_LDS_BYTES = 2 * WF_VBUF * 4;
+constexpr unsigned WF_OOB = 0x80000000u;   // voffset of a tap that must read 0 (tensors are < 2 GiB, checked at launch)
+
+__device__ __forceinline__ float silu_w(float v) { return v / (1.0f + expf(-v)); }
+
+// B^T of F(4x4,3x3) along one axis (same matrix as wino.hip)
+__device__ __forceinline__ void bt6(const floatx2* d, floatx2* t) {
+    t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+    t[1] = (d[3] + d[4]) - 4.0f * (d[1] + d[2]);
+    t[2] = 4.0f * (d[1] - d[2]) + (d[4] - d[3]);
+    t[3] = 2.0f * (d[3] - d[1]) + (d[4] - d[2]);
+    t[4] = 2.0f * (d[1] - d[3]) + (d[4] - d[2]);
+    t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+}
+// A^T of F(4x4,3x3) along one axis
+__device__ __forceinline__ void at6(const float* m, float* y) {
+    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = m[0] + s12 + s34;
+    y[1] = d12 + 2.0f * d34;
+    y[2] = s12 + 4.0f * s34;
+    y[3] = d12 + 8.0f * d34 + m[5];
+}
+
+// Output transform + epilogue of one pass (16 tiles x 32 couts, one (tile, cout) pair per thread); every wave runs it.
+__device__ __forceinline__ void wf_epilogue_pass(const ConvParams& p, const float* Ms, const int pass, const int tid, const int b,
+                                                 const int gy, const int gx, const int TH, const int TW, const int n,
+                                                 const float bias, const float sc, const float sh) {
+    const int etl = tid >> 5, ec = tid & 31;
+    const int t = 16 * pass + etl;
+    const int tyy = gy * 4 + (t >> 3), txx = gx * 8 + (t & 7);
+    if (tyy >= TH || txx >= TW || n >= p.Cout) return;
+    const size_t pix0 = ((size_t)b * p.Ho + 4 * tyy) * p.Wo + 4 * txx;  // top-left output pixel of the tile
+    // residual: all 16 loads in flight before the LDS reads / arithmetic (one wait, not one per pixel)
+    float rv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rv[i][j] = 0.f;
+    if (p.res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[i][j] = p.res[(pix0 + (size_t)i * p.Wo + j) * p.res_stride + n];
+    }
+    float u[4][6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        float col[6], yc[4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = Ms[((r * 6 + s) * 16 + etl) * 32 + ec];
+        at6(col, yc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i][s] = yc[i];
+    }
+    const float fsc = p.film ? sc : 1.0f, fsh = p.film ? sh : 0.0f;  // v * 1 + 0 is exact: no per-pixel branch
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float y[4];
+        at6(u[i], y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = (y[j] + bias) * fsc + fsh;
+            if (p.silu) v = silu_w(v);
+            p.out[(pix0 + (size_t)i * p.Wo + j) * p.out_stride + n] = v + rv[i][j];
+        }
+    }
+}
+
+// The two wave roles run separate code paths (their register sets do not add up: accumulators on one side, the input
+// patch / offset table / transform temporaries on the other); both execute the same sequence of s_barrier instructions:
+// nch + 1 in the K loop, 3 in the epilogue.
+__global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX,
+                                                                const int GY, const int NB, const unsigned in0_bytes,
+                                                                const unsigned in1_bytes, const unsigned uf_bytes) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the role branch
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    // XCD-aware bijective block remap: an XCD walks a contiguous range of (tile group, cout group) pairs, cout groups
+    // fastest, so the NB blocks that read the same input patch share one L2
+    int wgid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int nblk = wgid % NB;
+    int g = wgid / NB;
+    const int gx = g % GX; g /= GX;
+    const int gy = g % GY;
+    const int b = g / GY;
+    const int TH = p.Ho >> 2, TW = p.Wo >> 2;
+    const int Ctot = p.C0 + p.C1;
+    const int nch = Ctot / WF_KC;
+    const int nsub = Ctot / 8;
+
+    // epilogue constants of this thread's output channel
+    float* Ms = smem;  // [36][16 tiles][32 couts], aliases the V buffers after the K loop
+    const int n = nblk * 32 + (tid & 31);
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (n < p.Cout) {
+        if (p.bias) bias = p.bias[n];
+        if (p.film) {
+            const float* f = p.film + (size_t)b * p.film_bstride;
+            sc = f[n] + 1.0f;
+            sh = f[p.Cout + n];
+        }
+    }
+
+    if (wave < 4) {
+        // =============================== MFMA waves ===============================
+        const int zg = wave;
+        const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Uf), 0, uf_bytes, 0x00020000);
+        floatx16 acc[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        floatx4 breg[9];
+        int uvoff[9];
+#pragma unroll
+        for (int zi = 0; zi < 9; ++zi) {
+            uvoff[zi] = ((((zg * 9 + zi) * NB + nblk) * nsub) * 64 + h * 32 + l31) * 16;
+            breg[zi] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uvoff[zi], 0, 0));
+        }
+        __syncthreads();  // iteration 0: the producers fill V[0]
+        for (int c = 0; c < nch; ++c) {
+            const float* vb = smem + (c & 1) * WF_VBUF + zg * 9 * WF_ZS + h * WF_HS + l31 * 4;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int ss = 2 * c + sub;
+                const int nxt = (ss + 1 < nsub ? ss + 1 : ss) * 1024;  // byte offset of the next sub-step's fragments
+#pragma unroll
+                for (int zi = 0; zi < 9; ++zi) {
+                    const floatx4 a = *reinterpret_cast<const floatx4*>(vb + zi * WF_ZS + sub * WF_SS);
+                    const floatx4 bb = breg[zi];
+                    acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, acc[zi], 0, 0, 0);
+                    acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, acc[zi], 0, 0, 0);
+                    acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb.z, acc[zi], 0, 0, 0);
+                    acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb.w, acc[zi], 0, 0, 0);
+                    // refill in place: the MFMAs above have read breg[zi] (in-order issue); the data is needed again
+                    // 36 MFMAs from now
+                    breg[zi] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uvoff[zi], nxt, 0));
+                }
+            }
+            __syncthreads();
+        }
+        // epilogue: accumulators -> LDS in two passes of 16 tiles (accumulator register r holds tile (r&3) + 8 (r>>2) + 4h)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int zi = 0; zi < 9; ++zi)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = (2 * pass + (rr >> 2)) * 4 + (rr & 3);
+                    const int tl = (rr & 3) + 8 * (rr >> 2) + 4 * h;  // tile inside this pass
+                    Ms[((zg * 9 + zi) * 16 + tl) * 32 + l31] = acc[zi][r];
+                }
+            __syncthreads();
+            wf_epilogue_pass(p, Ms, pass, tid, b, gy, gx, TH, TW, n, bias, sc, sh);
+            if (pass == 0) __syncthreads();
+        }
+    } else {
+        // =============================== producer waves ===============================
+        const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc1 =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1 ? p.in1 : p.in0), 0, p.in1 ? in1_bytes : 0u, 0x00020000);
+        const int cp = lane & 7;                           // channel pair of the chunk: channels 2cp, 2cp+1
+        const int trow = wave - 4, tcol = lane >> 3;       // this lane's tile inside the group
+        // LDS float offset of (tile, channel pair): [sub = c>>3][hh = (c>>2)&1][tile][kk = c&3]
+        const int vw_base = (cp >> 2) * WF_SS + ((cp >> 1) & 1) * WF_HS + (trow * 8 + tcol) * 4 + 2 * (cp & 1);
+        const int tyy = gy * 4 + trow, txx = gx * 8 + tcol;
+        const bool tile_ok = tyy < TH && txx < TW;
+        const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
+        int rowpix[6], colpix[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int y = 4 * tyy - 1 + r, x = 4 * txx - 1 + r;
+            rowpix[r] = (tile_ok && (unsigned)y < (unsigned)Hv) ? (b * p.Hin + (y >> p.in_shift)) * p.Win : -1;
+            colpix[r] = (tile_ok && (unsigned)x < (unsigned)Wv) ? (x >> p.in_shift) : -1;
+        }
+        unsigned voff[36];
+        floatx2 raw[36];
+#define WF_BUILD_VOFF(PIXF)                                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 6; ++r) _Pragma("unroll") for (int s = 0; s < 6; ++s) voff[r * 6 + s] =            \
+        (rowpix[r] >= 0 && colpix[s] >= 0) ? (unsigned)(rowpix[r] + colpix[s]) * (unsigned)((PIXF)*4) + (unsigned)(cp * 8) : WF_OOB;
+#define WF_LOAD_RAW(CI)                                                                                                      \
+    {                                                                                                                        \
+        const int cc_ = (CI)*WF_KC;                                                                                          \
+        const bool second_ = cc_ >= p.C0;                                                                                    \
+        const int soff_ = (second_ ? cc_ - p.C0 : cc_) * 4;                                                                  \
+        const __amdgpu_buffer_rsrc_t rs_ = second_ ? rsrc1 : rsrc0;                                                          \
+        _Pragma("unroll") for (int e = 0; e < 36; ++e) raw[e] =                                                              \
+            __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[e], soff_, 0));                 \
+    }
+        WF_BUILD_VOFF(p.pix0)
+        WF_LOAD_RAW(0)
+        for (int it = 0; it < nch; ++it) {
+            // column pass (consumes raw[]), then the next chunk's loads into the same registers, then the row pass
+            floatx2 w[6][6];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                floatx2 col[6], tc[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) col[r] = raw[r * 6 + s];
+                bt6(col, tc);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) w[r][s] = tc[r];
+            }
+            if (it + 1 < nch) {
+                if ((it + 1) * WF_KC == p.C0) {  // the next chunk starts the second concat source
+                    WF_BUILD_VOFF(p.pix1)
+                }
+                WF_LOAD_RAW(it + 1)
+            }
+            float* vw = smem + (it & 1) * WF_VBUF + vw_base;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                floatx2 o[6];
+                bt6(w[r], o);
+#pragma unroll
+                for (int s = 0; s < 6; ++s) *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * WF_ZS) = o[s];
+            }
+            __syncthreads();
+        }
+#undef WF_BUILD_VOFF
+#undef WF_LOAD_RAW
+        __syncthreads();  // the MFMA waves' last chunk
+        __syncthreads();  // pass 0 accumulators are in LDS
+        wf_epilogue_pass(p, Ms, 0, tid, b, gy, gx, TH, TW, n, bias, sc, sh);
+        __syncthreads();
+        __syncthreads();  // pass 1 accumulators are in LDS
+        wf_epilogue_pass(p, Ms, 1, tid, b, gy, gx, TH, TW, n, bias, sc, sh);
+    }
+}
+
+}  // namespace
+
+void wino_fused_global_init() {
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024));
+}
+
+// Geometry / feature check only (the plan decides where the fused kernel pays)
+bool wino_fused_eligible(const ConvParams& p) {
+    if (p.w_bf || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_y != 1 || p.pad_x != 1 || p.splits != 1 || p.nz != 1) return false;
+    if (p.gate || p.shuffle || p.ch_scale || p.in_scale || p.ln_g || p.in_bf16 || p.out_bf16) return false;
+    if (p.in_shift != 0 && p.in_shift != 1) return false;
+    if (p.Ho != (p.Hin << p.in_shift) || p.Wo != (p.Win << p.in_shift) || (p.Ho & 3) || (p.Wo & 3)) return false;
+    if (p.C0 % WF_KC || p.C1 % WF_KC || p.C0 + p.C1 == 0 || p.Cout % 32) return false;
+    if (p.C1 && !p.in1) return false;
+    const double lim = 2147483648.0 - 65536.0;  // buffer offsets are 32-bit; 0x80000000 is the "reads zero" offset
+    if (4.0 * p.B * p.Hin * p.Win * (double)p.pix0 >= lim || (p.C1 && 4.0 * p.B * p.Hin * p.Win * (double)p.pix1 >= lim)) return false;
+    if (36.0 * 4.0 * p.Cout * (double)(p.C0 + p.C1) >= lim) return false;
+    return true;
+}
+
+// U[z][n][c] (wino_transform_weights, tile 4) -> the fused kernel's fragment order
+//   Uf[z][n >> 5][c >> 3][(c >> 2) & 1][n & 31][c & 3]
+// so that the B fragments of one (component, 32 couts, K sub-step of 8) are 1 KB contiguous: lane (cout = l & 31, h = l >> 5)
+// reads the 16 bytes k = 4h .. 4h+3, the same k assignment as the A fragments in LDS.
+void wino_fused_pack_weights(const float* U, int Cout, int Cin, float* Uf) {
+    const int NB = Cout / 32, nsub = Cin / 8;
+    for (int z = 0; z < 36; ++z)
+        for (int n = 0; n < Cout; ++n)
+            for (int c = 0; c < Cin; ++c) {
+                const size_t dst = ((((size_t)(z * NB + (n >> 5)) * nsub + (c >> 3)) * 2 + ((c >> 2) & 1)) * 32 + (n & 31)) * 4 + (c & 3);
+                Uf[dst] = U[((size_t)z * Cout + n) * Cin + c];
+            }
+}
+
+void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s) {
+    if (!wino_fused_eligible(p)) throw HipError("launch_wino_fused: layer not eligible");
+    if (!Uf) throw HipError("launch_wino_fused: fused weights missing");
+    const int TH = p.Ho / 4, TW = p.Wo / 4;
+    const int GX = (TW + 7) / 8, GY = (TH + 3) / 4, NB = p.Cout / 32;
+    const unsigned in0_bytes = (unsigned)((size_t)p.B * p.Hin * p.Win * p.pix0 * 4);
+    const unsigned in1_bytes = p.C1 ? (unsigned)((size_t)p.B * p.Hin * p.Win * p.pix1 * 4) : 0u;
+    const unsigned uf_bytes = (unsigned)((size_t)36 * p.Cout * (p.C0 + p.C1) * 4);
+    hipLaunchKernelGGL(wino4_fused_kernel, dim3((unsigned)(p.B * GY * GX * NB)), dim3(WF_NT), WF_LDS_BYTES, s, p, Uf, GX, GY, NB,
+                       in0_bytes, in1_bytes, uf_bytes);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace irsde

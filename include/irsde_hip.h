@@ -65,6 +65,9 @@ enum {
                                         activation storage, LayerNorm, attention, FiLM and the update step stay fp32.  Not
                                         combinable with IRSDE_FLAG_BF16_ACT.  Operands beyond +-65504 would overflow: the score
                                         networks' activations are O(1..100) */
+    IRSDE_FLAG_NO_WINOGRAD_FUSED = 2048, /* keep every Winograd layer on the three-launch path (input transform, component GEMMs, output
+                                        transform); default: the big feature maps (>= 4096 tiles, Cin <= 512, Cout <= 256) run the
+                                        fused kernel of csrc/wino_fused.hip, whose transformed tensors never reach HBM */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };

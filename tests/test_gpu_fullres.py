@@ -211,6 +211,28 @@ def test_batch16_256_equals_single_images():
     assert relerr(m(xx, cc, 50).cpu().numpy()[5:6], g["unet_1x256x256/t50"]) < 1e-4
 
 
+def test_fused_winograd_plan_vs_three_launch_plan():
+    """The production plan at 2 x 256 x 256 runs the big feature maps on the fused Winograd kernel (csrc/wino_fused.hip);
+    IRSDE_FLAG_NO_WINOGRAD_FUSED keeps them on the three-launch path.  Same arithmetic, different summation order."""
+    m = unet64()
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 2, 256, 256, buf, len(buf)))
+    assert b"winograd F4 fused" in buf.value
+    params = O.synth_params(seed=0, nf=64, depth=4)
+    m3 = P.ConditionalUNet(3, 3, 64, depth=4)
+    m3.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m3.engine_flags = _lib.FLAG_NO_WINOGRAD_FUSED
+    m3 = m3.to(DEV).eval()
+    _lib.check(_lib.lib().irsde_plan_describe(m3.engine().h, 2, 256, 256, buf, len(buf)))
+    assert b"fused" not in buf.value and b"winograd F4 gemm" in buf.value
+    lq, xT = O.synth_inputs(31, 2, 256, 256)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    ya, yb = m(x, c, 42).cpu().numpy(), m3(x, c, 42).cpu().numpy()
+    e = relerr(ya, yb)
+    print("fused vs three-launch Winograd plan, 2x256x256: %.3g" % e)
+    assert 0 < e < 5e-5
+
+
 @pytest.mark.parametrize("dtype,tol", [("bf16_act", 2e-2), ("bf16", 2e-2), ("fp16", 3e-3)])
 def test_reduced_precision_ode_256_vs_fp32(dtype, tol):
     """BASELINE configs[2]: reverse_ode at 256x256 in the reduced-precision modes vs the fp32 engine, 20 steps, same weights.

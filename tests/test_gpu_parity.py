@@ -153,6 +153,30 @@ def test_conv_kernel(name):
         assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=3), ref) < 5e-5
         assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=13), ref) < 5e-5
         assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=23), ref) < 5e-5
+        if C0 % 16 == 0 and C1 % 16 == 0 and Cout % 32 == 0:
+            # the fused Winograd F(4x4,3x3) kernel (wino_fused.hip): transforms inside the GEMM kernel
+            assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=33), ref) < 5e-5
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 0, 36, 44, 96, 0), (2, 16, 48, 8, 12, 32, 1), (1, 64, 0, 64, 96, 64, 0), (5, 48, 16, 4, 4, 160, 0)])
+def test_conv_wino_fused_edges(shape):
+    """The fused Winograd kernel on ragged tile groups (tile rows / columns that do not fill a 4 x 8 group), concat sources
+    of 16-channel granularity, the fused upsample, per-sample FiLM rows, bias + SiLU + residual together."""
+    B, C0, C1, H, W, Cout, up = shape
+    rs = np.random.RandomState(B * 1000 + H)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, 3, 3)) / np.sqrt((C0 + C1) * 9)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32)
+    film = (0.3 * rs.standard_normal((B, 2 * Cout))).astype(np.float32)
+    res = rs.standard_normal((B, Cout, H << up, W << up)).astype(np.float32)
+    ref = oracle_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, film_bstride=2 * Cout)
+    got = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=33, film_bstride=2 * Cout)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert relerr(got, ref) < 5e-5, shape
+    # no epilogue at all
+    ref = oracle_conv(x0, x1, w, None, 1, 1, up, None, 0, None)
+    assert relerr(run_conv(x0, x1, w, None, 1, 1, up, None, 0, None, naive=33), ref) < 5e-5, shape
 
 
 def test_conv_per_sample_film():

@@ -1,0 +1,35 @@
+"""Fused Winograd kernel vs the three-launch Winograd path (GPU box): ms per layer for every 3x3 stride-1 layer class of
+the 16 x 256^2 plan that is eligible for csrc/wino_fused.hip (variant 80 = fused, 81 = wino_input + component GEMMs +
+wino_output, 0 = direct implicit GEMM).  usage: python tools/wino_fused_sweep.py [B] [filter]"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from image_restoration_sde_amd import _lib
+L = _lib.lib()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+flt = sys.argv[2] if len(sys.argv) > 2 else ""
+# (name, H, W, Cin, Cout, up, epi)
+cases = [
+    ("L0  64->64  film", 256, 256, 64, 64, 0, 1),
+    ("L0  64->64  res", 256, 256, 64, 64, 0, 2),
+    ("L0 128->64  film", 256, 256, 128, 64, 0, 1),
+    ("L0 128->128 res", 256, 256, 128, 128, 0, 2),
+    ("L0 192->128 film", 256, 256, 192, 128, 0, 1),
+    ("L0 up 256->128", 128, 128, 256, 128, 1, 0),
+    ("L1 128->128 film", 128, 128, 128, 128, 0, 1),
+    ("L1 256->256 res", 128, 128, 256, 256, 0, 2),
+    ("L1 384->256 film", 128, 128, 384, 256, 0, 1),
+    ("L1 up 512->256", 64, 64, 512, 256, 1, 0),
+    ("L2 256->256 film", 64, 64, 256, 256, 0, 1),
+]
+cases = [c for c in cases if flt in c[0]]
+print("B=%d  %-20s %10s %10s %10s   %s" % (B, "layer", "fused ms", "3-launch", "direct", "fused: TF/s executed (of 157.3)"))
+for name, H, W, Cin, Cout, up, epi in cases:
+    Ho, Wo = H << up, W << up
+    exec_flops = 36 * 2.0 * B * (Ho // 4) * (Wo // 4) * Cin * Cout
+    res = []
+    for v in (80, 81, 0):
+        ms = ctypes.c_double()
+        rc = L.irsde_bench_conv(v, B, H, W, Cin, Cout, 3, 1, up, epi, 10, ctypes.byref(ms))
+        res.append(ms.value if rc == 0 else float("nan"))
+    print("      %-20s %10.4f %10.4f %10.4f   %.1f" % (name, res[0], res[1], res[2], exec_flops / res[0] / 1e9), flush=True)
