@@ -115,7 +115,8 @@ void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U, 
 // plain 3x3 s1 p1 convolution (as for launch_conv), Uf the weights from wino_fused_pack_weights.
 bool wino_fused_eligible(const ConvParams& p);
 void wino_fused_pack_weights(const float* U, int Cout, int Cin, float* Uf);  // host: U[36][Cout][Cin] -> fragment order
-void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s);
+void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s, unsigned long long* dbg = nullptr, int dflags = 0);
+int wino_fused_num_blocks(const ConvParams& p);
 void wino_fused_global_init();
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)

@@ -29,7 +29,7 @@ namespace irsde {
 // IRSDE_WINO2_MINC / IRSDE_WINO4_MINC override the thresholds (tuning experiments, only with IRSDE_TUNING=1).
 // The fused Winograd kernel (wino_fused.hip) streams a layer's whole U slice per block: it pays where the feature map is
 // large (many tiles) and the channel counts are moderate; beyond these limits the three-launch path keeps the layer.
-constexpr int kWinoFusedMaxCin = 512, kWinoFusedMaxCout = 256;
+constexpr int kWinoFusedMaxCin = 256, kWinoFusedMaxCout = 256;  // measured crossover (profiles/r02_wino_fused_sweep.txt): Cin 384+ is faster on the three-launch path
 inline long long wino_fused_min_tiles() { return tuning_env_int("IRSDE_WINO_FUSED_MINT", 4096); }
 
 inline int wino_min_c(int tile) {

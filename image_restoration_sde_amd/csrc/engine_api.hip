@@ -644,11 +644,11 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         // 80: fused Winograd F(4x4,3x3) kernel; 81: the three-launch Winograd F(4x4,3x3) path (random U: timing only)
         float *dU = nullptr, *dV = nullptr, *dM = nullptr;
         WinoPlan wp{};
-        if (variant == 80 || variant == 81) {
+        if (variant == 80 || variant == 81 || (variant >= 83 && variant <= 82 + 255)) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
-            if (variant == 80 && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
+            if (variant != 81 && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
             if (variant == 81) {
                 if (!wino_shape_ok(p, 4)) throw HipError("bench_conv: shape not eligible for Winograd F(4x4,3x3)");
                 const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
@@ -657,9 +657,48 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
                 wp = make_wino(p, dU, dV, dM, 4);
             }
         }
+        if (variant == 82) {  // fused Winograd kernel once, with per-wave phase stamps: prints the averaged timeline
+            IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
+            launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
+            const int nb = wino_fused_num_blocks(p);
+            unsigned long long* dd = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dd, (size_t)nb * 128 * 8));
+            launch_wino_fused(p, dU, s);  // warm
+            IRSDE_HIP_CHECK(hipMemsetAsync(dd, 0, (size_t)nb * 128 * 8, s));
+            launch_wino_fused(p, dU, s, dd);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            std::vector<unsigned long long> hd((size_t)nb * 128);
+            IRSDE_HIP_CHECK(hipMemcpy(hd.data(), dd, hd.size() * 8, hipMemcpyDeviceToHost));
+            double ph[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            unsigned long long rt_min = ~0ull, rt_max = 0;
+            for (int bi = 0; bi < nb; ++bi)
+                for (int w = 0; w < 8; ++w) {
+                    const unsigned long long* t = &hd[((size_t)bi * 8 + w) * 16];
+                    for (int k = 0; k < 4; ++k) ph[w >= 4][k] += (double)(t[k + 1] - t[k]) / ((double)nb * 4);
+                    rt_min = std::min(rt_min, t[7]);
+                    rt_max = std::max(rt_max, t[7]);
+                }
+            // block start times (100 MHz realtime counter) -> how long the launch kept dispatching new blocks
+            printf("wino_fused timeline B=%d %dx%d Cin=%d Cout=%d: %d blocks, block starts span %.1f us\n", B, p.Ho, p.Wo, Cin, Cout, nb,
+                   (double)(rt_max - rt_min) / 100.0);
+            printf("  MFMA waves     (shader cycles): start->V[0] ready %.0f | K loop %.0f | acc->LDS+barrier %.0f | epilogue %.0f\n", ph[0][0],
+                   ph[0][1], ph[0][2], ph[0][3]);
+            printf("  producer waves (shader cycles): start->chunk 0 done %.0f | K loop rest %.0f | wait MFMA+acc %.0f | epilogue %.0f\n",
+                   ph[1][0], ph[1][1], ph[1][2], ph[1][3]);
+            fflush(stdout);
+            (void)hipFree(dd);
+            (void)hipFree(dU);
+            dU = nullptr;
+            *ms_out = 0.0;
+            (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
+            (void)hipStreamDestroy(s);
+            return;
+        }
         auto run = [&] {
             if (variant == 80) {
                 launch_wino_fused(p, dU, s);
+            } else if (variant >= 83 && variant <= 82 + 255) {  // tuning aids: dflags = variant - 82 (1 no patch traffic, 2 no weight traffic, 4 / 8 producer / MFMA waves at s_setprio 2)
+                launch_wino_fused(p, dU, s, nullptr, variant - 82);
             } else if (variant == 81) {
                 launch_wino_input(wp.in, s);
                 launch_conv(wp.gemm, s);

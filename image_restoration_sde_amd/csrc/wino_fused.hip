@@ -11,10 +11,10 @@
 //              B = U_z[cout][k] straight from L2 into registers (the weight slice of a (component, 32 couts) pair is
 //              private to one wave, so LDS staging would buy nothing): U is stored pre-swizzled so that a wave's
 //              fragment of one K sub-step is 1 KB contiguous (buffer_load_dwordx4, refilled in place right after use).
-//   waves 4-7  producers: lane = (tile, channel pair): 36 buffer_load_dwordx2 of the 6x6 input patch (out-of-image taps,
-//              tiles past the edge: out-of-range offset -> hardware returns 0; concat sources and the fused nearest x2
-//              upsample are resolved in the offset table), B^T d B in registers, 36 ds_write_b64 into the V buffer of
-//              the NEXT chunk (double buffer, one barrier per chunk).
+//   waves 4-7  producers: lane = (tile, channel pair of the 16-channel chunk): 36 buffer_load_dwordx2 of the 6x6 input patch
+//              (out-of-image taps, tiles past the edge: out-of-range offset -> hardware returns 0;
+//              concat sources and the fused nearest x2 upsample are resolved in the row / column offsets), B^T d B in
+//              registers, ds_write_b64 into the V buffer of the NEXT chunk (double buffer, one barrier per chunk).
 // The matrix pipe runs the MFMA wave of each SIMD while the producer wave of the same SIMD uses the vector / LDS / memory
 // pipes.  Epilogue (all 8 waves): accumulators -> LDS in two passes of 16 tiles, thread = (tile, cout): A^T M A,
 // bias -> FiLM -> SiLU -> +residual, 16 output pixels.
@@ -59,61 +59,88 @@ __device__ __forceinline__ void at6(const float* m, float* y) {
     y[3] = d12 + 8.0f * d34 + m[5];
 }
 
-// Output transform + epilogue of one pass (16 tiles x 32 couts, one (tile, cout) pair per thread); every wave runs it.
-__device__ __forceinline__ void wf_epilogue_pass(const ConvParams& p, const float* Ms, const int pass, const int tid, const int b,
-                                                 const int gy, const int gx, const int TH, const int TW, const int n,
-                                                 const float bias, const float sc, const float sh) {
-    const int etl = tid >> 5, ec = tid & 31;
-    const int t = 16 * pass + etl;
+// Output transform + epilogue (every wave runs it): thread = (tile, 4 consecutive couts, row pair), 512 threads = 32 tiles x
+// 8 cout quads x 2 row pairs.  16-byte LDS reads, residual loads and output stores: a wave-level store covers 8 x 128
+// contiguous bytes (4-byte-per-lane stores made the epilogue cost more than a K=64 main loop: the store tail is issue-bound).
+__device__ __forceinline__ void wf_epilogue(const ConvParams& p, const float* Ms, const int tid, const int b, const int gy,
+                                            const int gx, const int TH, const int TW, const int n0) {
+    const int quad = tid & 7, half = (tid >> 3) & 1, t = tid >> 4;
     const int tyy = gy * 4 + (t >> 3), txx = gx * 8 + (t & 7);
-    if (tyy >= TH || txx >= TW || n >= p.Cout) return;
-    const size_t pix0 = ((size_t)b * p.Ho + 4 * tyy) * p.Wo + 4 * txx;  // top-left output pixel of the tile
-    // residual: all 16 loads in flight before the LDS reads / arithmetic (one wait, not one per pixel)
-    float rv[4][4];
+    const int n = n0 + 4 * quad;
+    if (tyy >= TH || txx >= TW) return;
+    floatx4 bias = {0.f, 0.f, 0.f, 0.f}, fsc = {1.f, 1.f, 1.f, 1.f}, fsh = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias = *reinterpret_cast<const floatx4*>(p.bias + n);
+    if (p.film) {
+        const float* f = p.film + (size_t)b * p.film_bstride;
+        fsc = *reinterpret_cast<const floatx4*>(f + n) + 1.0f;
+        fsh = *reinterpret_cast<const floatx4*>(f + p.Cout + n);
+    }
+    // this thread's two output rows: 2 half, 2 half + 1
+    const size_t pix0 = ((size_t)b * p.Ho + 4 * tyy + 2 * half) * p.Wo + 4 * txx;
+    floatx4 rv[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rv[i][j] = 0.f;
+        for (int j = 0; j < 4; ++j) rv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     if (p.res) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rv[i][j] = p.res[(pix0 + (size_t)i * p.Wo + j) * p.res_stride + n];
+            for (int j = 0; j < 4; ++j) rv[i][j] = *reinterpret_cast<const floatx4*>(p.res + (pix0 + (size_t)i * p.Wo + j) * p.res_stride + n);
     }
-    float u[4][6];
+    // A^T rows (2 half, 2 half + 1): half 0: [1 1 1 1 1 0], [0 1 -1 2 -2 0];  half 1: [0 1 1 4 4 0], [0 1 -1 8 -8 1]
+    // (multiplying by the constants 0 / 1 is exact)
+    const float c0 = half ? 0.f : 1.f, ka = half ? 4.f : 1.f, kb = half ? 8.f : 2.f, c5 = half ? 1.f : 0.f;
+    floatx4 u[2][6];
+    const float* mp = Ms + t * 32 + 4 * quad;
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-        float col[6], yc[4];
+        floatx4 m[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) col[r] = Ms[((r * 6 + s) * 16 + etl) * 32 + ec];
-        at6(col, yc);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) u[i][s] = yc[i];
+        for (int r = 0; r < 6; ++r) m[r] = *reinterpret_cast<const floatx4*>(mp + (r * 6 + s) * 1024);
+        const floatx4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        u[0][s] = c0 * m[0] + s12 + ka * s34;
+        u[1][s] = d12 + kb * d34 + c5 * m[5];
     }
-    const float fsc = p.film ? sc : 1.0f, fsh = p.film ? sh : 0.0f;  // v * 1 + 0 is exact: no per-pixel branch
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float y[4];
-        at6(u[i], y);
+    for (int i = 0; i < 2; ++i) {
+        const floatx4 s12 = u[i][1] + u[i][2], d12 = u[i][1] - u[i][2], s34 = u[i][3] + u[i][4], d34 = u[i][3] - u[i][4];
+        floatx4 y[4];
+        y[0] = u[i][0] + s12 + s34;
+        y[1] = d12 + 2.0f * d34;
+        y[2] = s12 + 4.0f * s34;
+        y[3] = d12 + 8.0f * d34 + u[i][5];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float v = (y[j] + bias) * fsc + fsh;
-            if (p.silu) v = silu_w(v);
-            p.out[(pix0 + (size_t)i * p.Wo + j) * p.out_stride + n] = v + rv[i][j];
+            floatx4 v = (y[j] + bias) * fsc + fsh;
+            if (p.silu) {
+                v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w);
+            }
+            *reinterpret_cast<floatx4*>(p.out + (pix0 + (size_t)i * p.Wo + j) * p.out_stride + n) = v + rv[i][j];
         }
     }
 }
 
 // The two wave roles run separate code paths (their register sets do not add up: accumulators on one side, the input
 // patch / offset table / transform temporaries on the other); both execute the same sequence of s_barrier instructions:
-// nch + 1 in the K loop, 3 in the epilogue.
+// nch + 1 in the K loop, 1 in the epilogue.
+template <bool STAMPS>
 __global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX,
                                                                 const int GY, const int NB, const unsigned in0_bytes,
-                                                                const unsigned in1_bytes, const unsigned uf_bytes) {
+                                                                const unsigned in1_bytes, const unsigned uf_bytes,
+                                                                unsigned long long* __restrict__ dbg, const int dflags) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the role branch
+    // tuning aid (irsde_bench_conv variant 82): per-wave shader-clock stamps at the phase boundaries; dbg == nullptr otherwise
+#define WF_STAMP(K)                                                                                                  \
+    if (STAMPS && dbg) {                                                                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                  \
+        if (lane == 0) dbg[((size_t)blockIdx.x * 8 + wave) * 16 + (K)] = t_;                                          \
+    }
+    WF_STAMP(0)
+    if (STAMPS && dbg && lane == 0) dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 7] = __builtin_amdgcn_s_memrealtime();
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
@@ -135,74 +162,76 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams 
     const int nch = Ctot / WF_KC;
     const int nsub = Ctot / 8;
 
-    // epilogue constants of this thread's output channel
-    float* Ms = smem;  // [36][16 tiles][32 couts], aliases the V buffers after the K loop
-    const int n = nblk * 32 + (tid & 31);
-    float bias = 0.f, sc = 1.f, sh = 0.f;
-    if (n < p.Cout) {
-        if (p.bias) bias = p.bias[n];
-        if (p.film) {
-            const float* f = p.film + (size_t)b * p.film_bstride;
-            sc = f[n] + 1.0f;
-            sh = f[p.Cout + n];
-        }
-    }
+    float* Ms = smem;  // [36][32 tiles][32 couts] (147 456 B), aliases the V buffers after the K loop
+    const int n0 = nblk * 32;
 
     if (wave < 4) {
         // =============================== MFMA waves ===============================
         const int zg = wave;
+        if (dflags & 8) __builtin_amdgcn_s_setprio(2);
         const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Uf), 0, uf_bytes, 0x00020000);
         floatx16 acc[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        floatx4 breg[9];
+        floatx4 breg[9];  // B fragments: breg[zi] is refilled in place for the next K sub-step right after its 4 MFMAs
         int uvoff[9];
 #pragma unroll
         for (int zi = 0; zi < 9; ++zi) {
             uvoff[zi] = ((((zg * 9 + zi) * NB + nblk) * nsub) * 64 + h * 32 + l31) * 16;
+            if (dflags & 2) uvoff[zi] = (int)WF_OOB;  // tuning aid: weight fragments read as zeros without touching memory
             breg[zi] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uvoff[zi], 0, 0));
         }
         __syncthreads();  // iteration 0: the producers fill V[0]
+        WF_STAMP(1)
         for (int c = 0; c < nch; ++c) {
             const float* vb = smem + (c & 1) * WF_VBUF + zg * 9 * WF_ZS + h * WF_HS + l31 * 4;
+            floatx4 a_cur = *reinterpret_cast<const floatx4*>(vb);
+            // 18 groups (2 K sub-steps x 9 components) of { A fragment of the next group, 4 MFMAs, refill of this group's
+            // B fragment for the next sub-step }.  The scheduling barrier pins that order: left alone, the compiler sinks
+            // the refills to a few MFMAs before their use (it runs out of registers for 18 A fragments held up front),
+            // which exposes the L2 latency; here every refill has 36 MFMAs (2304 cycles) of cover.
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
+            for (int gi = 0; gi < 18; ++gi) {
+                const int sub = gi / 9, zi = gi % 9;
                 const int ss = 2 * c + sub;
                 const int nxt = (ss + 1 < nsub ? ss + 1 : ss) * 1024;  // byte offset of the next sub-step's fragments
-#pragma unroll
-                for (int zi = 0; zi < 9; ++zi) {
-                    const floatx4 a = *reinterpret_cast<const floatx4*>(vb + zi * WF_ZS + sub * WF_SS);
-                    const floatx4 bb = breg[zi];
-                    acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, acc[zi], 0, 0, 0);
-                    acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, acc[zi], 0, 0, 0);
-                    acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb.z, acc[zi], 0, 0, 0);
-                    acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb.w, acc[zi], 0, 0, 0);
-                    // refill in place: the MFMAs above have read breg[zi] (in-order issue); the data is needed again
-                    // 36 MFMAs from now
-                    breg[zi] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uvoff[zi], nxt, 0));
+                floatx4 a_next = a_cur;
+                if (gi + 1 < 18) a_next = *reinterpret_cast<const floatx4*>(vb + ((gi + 1) % 9) * WF_ZS + ((gi + 1) / 9) * WF_SS);
+                const floatx4 bb = breg[zi];
+                if (!(dflags & 128)) {  // (tuning aid: no MFMAs)
+                acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, bb.x, acc[zi], 0, 0, 0);
+                acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, bb.y, acc[zi], 0, 0, 0);
+                acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, bb.z, acc[zi], 0, 0, 0);
+                acc[zi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, bb.w, acc[zi], 0, 0, 0);
                 }
+                breg[zi] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uvoff[zi], nxt, 0));
+                a_cur = a_next;
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
         }
-        // epilogue: accumulators -> LDS in two passes of 16 tiles (accumulator register r holds tile (r&3) + 8 (r>>2) + 4h)
+        WF_STAMP(2)
+        // epilogue: accumulators -> LDS (accumulator register r of lane (l31, h) holds tile (r&3) + 8 (r>>2) + 4h, cout l31)
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int zi = 0; zi < 9; ++zi)
 #pragma unroll
-            for (int zi = 0; zi < 9; ++zi)
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = (2 * pass + (rr >> 2)) * 4 + (rr & 3);
-                    const int tl = (rr & 3) + 8 * (rr >> 2) + 4 * h;  // tile inside this pass
-                    Ms[((zg * 9 + zi) * 16 + tl) * 32 + l31] = acc[zi][r];
-                }
-            __syncthreads();
-            wf_epilogue_pass(p, Ms, pass, tid, b, gy, gx, TH, TW, n, bias, sc, sh);
-            if (pass == 0) __syncthreads();
-        }
+            for (int r = 0; r < 16; ++r)
+                Ms[((zg * 9 + zi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[zi][r];
+        __syncthreads();
+        WF_STAMP(3)
+        wf_epilogue(p, Ms, tid, b, gy, gx, TH, TW, n0);
+        WF_STAMP(4)
     } else {
         // =============================== producer waves ===============================
+        // lane = (tile column, channel pair of the 16-channel chunk).  Per chunk: column pass of the 6x6 patch (consumes the
+        // patch registers), the 36 loads of the NEXT chunk into the same registers, row pass + 36 ds_write_b64.
+        // (Measured alternatives, profiles/r02_wino_fused_notes.md: two chunks of loads in flight, full-line dwordx4 loads,
+        // scalar per-channel transforms, wave priorities — none faster: every VMEM / DS-write instruction issued on a SIMD
+        // costs its MFMA wave ~50 cycles of matrix-pipe time, whichever wave issues it, and their count per chunk is fixed by
+        // the 36-pixel patch.)
+        if (dflags & 4) __builtin_amdgcn_s_setprio(2);  // tuning aid
         const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc1 =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1 ? p.in1 : p.in0), 0, p.in1 ? in1_bytes : 0u, 0x00020000);
@@ -211,7 +240,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams 
         // LDS float offset of (tile, channel pair): [sub = c>>3][hh = (c>>2)&1][tile][kk = c&3]
         const int vw_base = (cp >> 2) * WF_SS + ((cp >> 1) & 1) * WF_HS + (trow * 8 + tcol) * 4 + 2 * (cp & 1);
         const int tyy = gy * 4 + trow, txx = gx * 8 + tcol;
-        const bool tile_ok = tyy < TH && txx < TW;
+        const bool tile_ok = tyy < TH && txx < TW && !(dflags & 1);  // (dflags & 1, tuning aid: every patch load reads zeros, no memory traffic)
         const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
         int rowpix[6], colpix[6];
 #pragma unroll
@@ -237,6 +266,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams 
         WF_BUILD_VOFF(p.pix0)
         WF_LOAD_RAW(0)
         for (int it = 0; it < nch; ++it) {
+            if (it == 1) { WF_STAMP(1) }
             // column pass (consumes raw[]), then the next chunk's loads into the same registers, then the row pass
             floatx2 w[6][6];
 #pragma unroll
@@ -266,19 +296,28 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams 
         }
 #undef WF_BUILD_VOFF
 #undef WF_LOAD_RAW
+        WF_STAMP(2)
         __syncthreads();  // the MFMA waves' last chunk
-        __syncthreads();  // pass 0 accumulators are in LDS
-        wf_epilogue_pass(p, Ms, 0, tid, b, gy, gx, TH, TW, n, bias, sc, sh);
-        __syncthreads();
-        __syncthreads();  // pass 1 accumulators are in LDS
-        wf_epilogue_pass(p, Ms, 1, tid, b, gy, gx, TH, TW, n, bias, sc, sh);
+        __syncthreads();  // the accumulators are in LDS
+        WF_STAMP(3)
+        wf_epilogue(p, Ms, tid, b, gy, gx, TH, TW, n0);
+        WF_STAMP(4)
     }
 }
 
+#undef WF_STAMP
+
 }  // namespace
 
+// Blocks the launch of launch_wino_fused(p, ...) creates (the size of the variant-82 stamp buffer: 64 stamps per block)
+int wino_fused_num_blocks(const ConvParams& p) {
+    return p.B * ((p.Ho / 4 + 3) / 4) * ((p.Wo / 4 + 7) / 8) * (p.Cout / 32);
+}
+
 void wino_fused_global_init() {
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         160 * 1024));
 }
 
@@ -288,8 +327,9 @@ bool wino_fused_eligible(const ConvParams& p) {
     if (p.gate || p.shuffle || p.ch_scale || p.in_scale || p.ln_g || p.in_bf16 || p.out_bf16) return false;
     if (p.in_shift != 0 && p.in_shift != 1) return false;
     if (p.Ho != (p.Hin << p.in_shift) || p.Wo != (p.Win << p.in_shift) || (p.Ho & 3) || (p.Wo & 3)) return false;
-    if (p.C0 % WF_KC || p.C1 % WF_KC || p.C0 + p.C1 == 0 || p.Cout % 32) return false;
+    if (p.C0 % 32 || p.C1 % 32 || p.C0 + p.C1 == 0 || p.Cout % 32) return false;  // chunk pairs (2 x 16 channels) never straddle the sources
     if (p.C1 && !p.in1) return false;
+    if ((p.out_stride & 3) || (p.res && (p.res_stride & 3))) return false;  // 16-byte epilogue accesses
     const double lim = 2147483648.0 - 65536.0;  // buffer offsets are 32-bit; 0x80000000 is the "reads zero" offset
     if (4.0 * p.B * p.Hin * p.Win * (double)p.pix0 >= lim || (p.C1 && 4.0 * p.B * p.Hin * p.Win * (double)p.pix1 >= lim)) return false;
     if (36.0 * 4.0 * p.Cout * (double)(p.C0 + p.C1) >= lim) return false;
@@ -310,7 +350,7 @@ void wino_fused_pack_weights(const float* U, int Cout, int Cin, float* Uf) {
             }
 }
 
-void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s) {
+void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s, unsigned long long* dbg, int dflags) {
     if (!wino_fused_eligible(p)) throw HipError("launch_wino_fused: layer not eligible");
     if (!Uf) throw HipError("launch_wino_fused: fused weights missing");
     const int TH = p.Ho / 4, TW = p.Wo / 4;
@@ -318,8 +358,12 @@ void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s) {
     const unsigned in0_bytes = (unsigned)((size_t)p.B * p.Hin * p.Win * p.pix0 * 4);
     const unsigned in1_bytes = p.C1 ? (unsigned)((size_t)p.B * p.Hin * p.Win * p.pix1 * 4) : 0u;
     const unsigned uf_bytes = (unsigned)((size_t)36 * p.Cout * (p.C0 + p.C1) * 4);
-    hipLaunchKernelGGL(wino4_fused_kernel, dim3((unsigned)(p.B * GY * GX * NB)), dim3(WF_NT), WF_LDS_BYTES, s, p, Uf, GX, GY, NB,
-                       in0_bytes, in1_bytes, uf_bytes);
+    if (dbg)  // tuning aid: the instrumented twin (the stamps cost ~10 % even when they are branched over)
+        hipLaunchKernelGGL(wino4_fused_kernel<true>, dim3((unsigned)(p.B * GY * GX * NB)), dim3(WF_NT), WF_LDS_BYTES, s, p, Uf, GX, GY, NB,
+                           in0_bytes, in1_bytes, uf_bytes, dbg, dflags);
+    else
+        hipLaunchKernelGGL(wino4_fused_kernel<false>, dim3((unsigned)(p.B * GY * GX * NB)), dim3(WF_NT), WF_LDS_BYTES, s, p, Uf, GX, GY, NB,
+                           in0_bytes, in1_bytes, uf_bytes, dbg, dflags);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

@@ -20,7 +20,7 @@ extern "C" {
  *   0 production dispatch      1 VALU cross-check kernel
  *   2 / 3 Winograd F(2x2,3x3) / F(4x4,3x3) (3x3 s1 p1 only); 12 / 13 and 22 / 23: the same with the component GEMMs forced
  *         onto the tile-loop kernel (all / 2 components per block)
- *   33 the fused Winograd F(4x4,3x3) kernel (csrc/wino_fused.hip; 3x3 s1 p1, H and W multiples of 4, Cin % 16 == 0, Cout % 32 == 0)
+ *   33 the fused Winograd F(4x4,3x3) kernel (csrc/wino_fused.hip; 3x3 s1 p1, H and W multiples of 4, C0, C1 and Cout multiples of 32)
  *   4 bf16-MFMA mode (halo kernel for eligible 3x3 layers); 160 / 161 its generic 256 / 128 tile
  *   5 fp16-MFMA mode (IRSDE_FLAG_FP16; halo kernel for eligible 3x3 layers); 165 its generic 128 tile
  *   204 / 260 / 261 the same three with bf16 activation storage (inputs / residual are rounded, the result widened back)
@@ -33,7 +33,8 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
 
 /* Kernel tuning hook: average ms of one KxK convolution (pad K/2, or 4x4 s2 p1) on random NHWC data.
  * variant: 0 production dispatch, 3 / 50 fp32 256x128 / 256x256 tiles, 60 / 61 / 62 bf16 mode (256 tile / 128 tile / automatic
- * incl. the halo kernel), 80 / 81 Winograd F(4x4,3x3) fused kernel / three-launch path (3x3 s1 only); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
+ * incl. the halo kernel), 80 / 81 Winograd F(4x4,3x3) fused kernel / three-launch path (3x3 s1 only), 82 the fused kernel once with its
+ * phase timeline printed to stdout; epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out);
 
