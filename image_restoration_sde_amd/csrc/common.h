@@ -167,6 +167,11 @@ int attn_num_chunks(int N);
 void launch_linear_attention(const float* qkv, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s,
                              bool bf16 = false);
 
+// fp32 fused form of the same block: k, v and their softmax / context from the LayerNorm output and the k | v rows of
+// to_qkv.weight ([256][C]) without a k / v tensor in HBM; q is a separate [B][N][128] tensor (its own 1x1 convolution).
+void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s);
+void launch_attention_q_out(const float* q, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s);
+
 // Full softmax attention over N tokens (denoising-sde bottleneck): qkv [B][N][384] -> out [B][N][128].
 void launch_full_attention(const float* qkv, float* out, int B, int N, hipStream_t s);
 

@@ -305,9 +305,38 @@ struct Builder {
             const bool bf = x.bf16;
             push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(xp, g, nullptr, o, M, C, 1e-5f, s, bf); });
         }
+        Tensor a = talloc(x.B, x.H, x.W, 128);
+        if (w.g2 && !naive && !x.bf16 && !(e->cfg.flags & (IRSDE_FLAG_BF16 | IRSDE_FLAG_NO_FUSED_ATTN)) && x.C % 32 == 0 && x.C <= 256) {
+            // fp32 fused form: the k and v thirds of to_qkv never reach HBM — their projection, the softmax over the pixels and
+            // the context run in one kernel on the LayerNorm output; only q (rows 0..127 of to_qkv.weight) is a convolution
+            AttnWorkspace ws;
+            ws.nch = attn_num_chunks(N);
+            ws.pmax = pl->alloc((size_t)x.B * ws.nch * 128, false);
+            ws.pctx = pl->alloc((size_t)x.B * 4 * ws.nch * 1024, false);
+            ws.psum = pl->alloc((size_t)x.B * 4 * ws.nch * 32, false);
+            ws.ctx = pl->alloc((size_t)x.B * 4 * 1024, false);
+            {
+                const float *xp = xn.p, *wkv = w.qkv.w + (size_t)128 * x.C;
+                const int B = x.B, C = x.C;
+                push_other(OP_ATTN, [=](hipStream_t s) { launch_attention_kv_context(xp, wkv, B, N, C, ws, s); });
+                pl->net_ops.back().desc = "linear_attention k,v projection + context (fused) C=" + std::to_string(C);
+            }
+            ConvW wq = w.qkv;  // rows 0..127 = q
+            wq.Cout = 128;
+            Tensor q = conv(wq, xn, nullptr, 1, 0, 0, nullptr, 0, nullptr);
+            tfree(xn);
+            {
+                const float* qp = q.p;
+                float* o = a.p;
+                const int B = x.B;
+                push_other(OP_ATTN, [=](hipStream_t s) { launch_attention_q_out(qp, o, B, N, ws, s); });
+                pl->net_ops.back().desc = "linear_attention softmax(q) . context";
+            }
+            tfree(q);
+            return attn_tail(w, x, a, M);
+        }
         Tensor qkv = conv(w.qkv, xn, nullptr, 1, 0, 0, nullptr, 0, nullptr);
         tfree(xn);
-        Tensor a = talloc(x.B, x.H, x.W, 128);
         if (!w.g2) {
             // Residual(PreNorm(dim, Attention(dim))): full softmax attention, to_out without LayerNorm, + x
             const float* q = qkv.p;
@@ -333,6 +362,11 @@ struct Builder {
             push_other(OP_ATTN, [=](hipStream_t s) { launch_linear_attention(q, o, B, N, ws, s, bf); });
         }
         tfree(qkv);
+        return attn_tail(w, x, a, M);
+    }
+
+    // to_out (1x1 conv + bias) -> LayerNorm -> + x   (module_util.py:158-161, Residual)
+    Tensor attn_tail(const AttnW& w, const Tensor& x, const Tensor& a, int64_t M) {
         if (!naive && (x.C == 64 || x.C == 128) && !(e->cfg.flags & IRSDE_FLAG_NO_FUSED_LN)) {
             // to_out conv + LayerNorm + residual in one kernel: the conv tile holds the whole channel row
             fused_ln_g = w.g2;

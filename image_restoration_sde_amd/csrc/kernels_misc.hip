@@ -252,6 +252,109 @@ __global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restri
     }
 }
 
+// k, v projection + context in one kernel (fp32): the k and v thirds of to_qkv never reach HBM.
+//   per 128-pixel tile of one image:  [k | v](128 px x 64) = xn(128 x C) . W_{k,v}^T   for each head (wave = head)
+//   then straight from the accumulator registers: online softmax of k over the pixels and ctx[d][e] += exp(k - m)[px][d] v[px][e].
+// The accumulator layout of v_mfma_f32_32x32x2_f32 (lane = column, registers = rows) is exactly the operand layout of the
+// second product (A[i = d][k = pixel], B[k = pixel][j = e]: both indexed by the lane's column and a pixel pair picked by
+// the register index and the lane half), so nothing is transposed or staged between the two GEMMs.
+// xn tile in LDS ([128][C + 4]: odd number of 16-byte slots per row => conflict-free ds_read_b128), weight fragments
+// straight from L2 (a wave's 64 weight rows x 8 k = two 16-byte loads per lane, one K step ahead).
+// Output = the (max, sum, context) partials of attn_ctx_partial_kernel, merged by attn_ctx_finalize_kernel.
+constexpr int kKvTile = 128;
+__global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __restrict__ xn, const float* __restrict__ wkv,
+                                                             float* __restrict__ pmax, float* __restrict__ pctx,
+                                                             float* __restrict__ psum, const int N, const int chunk_len,
+                                                             const int nch, const int C) {
+    extern __shared__ __attribute__((aligned(16))) float kv_smem[];
+    const int ch = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int LDA = C + 4;
+    const int n0 = ch * chunk_len;
+    const int n1 = min(N, n0 + chunk_len);
+    const float* wk = wkv + (size_t)(head * kDh + l31) * C + 4 * h;          // k rows of this head (to_qkv rows 128..255)
+    const float* wv = wkv + (size_t)(kHid + head * kDh + l31) * C + 4 * h;   // v rows (256..383)
+    const int c4n = C >> 2;
+    floatx16 ctx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+    float ssum = 0.f, mrun = -INFINITY;
+    for (int t0 = n0; t0 < n1; t0 += kKvTile) {
+        // stage the tile (rows past the chunk repeat its last pixel; they are masked below)
+        for (int i = tid; i < kKvTile * c4n; i += 256) {
+            const int row = i / c4n, c4 = i - row * c4n;
+            const int n = min(t0 + row, n1 - 1);
+            *reinterpret_cast<floatx4*>(kv_smem + row * LDA + 4 * c4) =
+                *reinterpret_cast<const floatx4*>(xn + ((size_t)b * N + n) * C + 4 * c4);
+        }
+        __syncthreads();
+        floatx16 ak[4], av[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ak[rt][r] = 0.f; av[rt][r] = 0.f; }
+        floatx4 bk = *reinterpret_cast<const floatx4*>(wk), bv = *reinterpret_cast<const floatx4*>(wv);
+        const float* arow = kv_smem + l31 * LDA + 4 * h;
+        for (int k8 = 0; k8 < C; k8 += 8) {
+            const int kn = k8 + 8 < C ? k8 + 8 : k8;
+            const floatx4 bkn = *reinterpret_cast<const floatx4*>(wk + kn), bvn = *reinterpret_cast<const floatx4*>(wv + kn);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const floatx4 a = *reinterpret_cast<const floatx4*>(arow + rt * 32 * LDA + k8);
+                ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bk.x, ak[rt], 0, 0, 0);
+                av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, av[rt], 0, 0, 0);
+                ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bk.y, ak[rt], 0, 0, 0);
+                av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, av[rt], 0, 0, 0);
+                ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bk.z, ak[rt], 0, 0, 0);
+                av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, av[rt], 0, 0, 0);
+                ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bk.w, ak[rt], 0, 0, 0);
+                av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, av[rt], 0, 0, 0);
+            }
+            bk = bkn;
+            bv = bvn;
+        }
+        // accumulator register r of row tile rt: pixel t0 + 32 rt + (r&3) + 8 (r>>2) + 4h, column d (k) / e (v) = l31
+        float mit = -INFINITY;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = t0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n >= n1) { ak[rt][r] = -INFINITY; av[rt][r] = 0.f; }
+                mit = fmaxf(mit, ak[rt][r]);
+            }
+        mit = fmaxf(mit, __shfl_xor(mit, 32, 64));
+        if (__any(mit > mrun)) {  // wave-uniform; the tile's first pixel exists, so mnew is finite
+            const float mnew = fmaxf(mrun, mit);
+            const float alpha = expf(mrun - mnew);  // 0 on the first tile (mrun = -inf)
+            mrun = mnew;
+            ssum *= alpha;
+            // context row d = (r&3) + 8(r>>2) + 4h needs the factor of channel d, which lives in lane d of either half
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ctx[r] *= __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(ak[rt][r] - mrun);  // exp(-inf) = 0 for the masked pixels
+                ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(e, av[rt][r], ctx, 0, 0, 0);
+                ssum += e;
+            }
+        __syncthreads();  // every wave is done with the tile in LDS
+    }
+    ssum += __shfl_xor(ssum, 32, 64);
+    const int bh = b * kHeads + head;
+    float* oc = pctx + ((size_t)bh * nch + ch) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oc[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = ctx[r];
+    if (h == 0) {
+        psum[((size_t)bh * nch + ch) * 32 + l31] = ssum;
+        pmax[((size_t)b * nch + ch) * kHid + head * kDh + l31] = mrun;
+    }
+}
+
 __global__ __launch_bounds__(1024) void attn_ctx_finalize_kernel(const float* __restrict__ pctx,
                                                                  const float* __restrict__ psum,
                                                                  const float* __restrict__ pmax,
@@ -276,7 +379,7 @@ constexpr int kOutTilesPerBlock = 8;  // 256 pixels per block
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_out_kernel(const T* __restrict__ qkv, const float* __restrict__ ctx,
-                                                       T* __restrict__ out, const int N) {
+                                                       T* __restrict__ out, const int N, const int qstride) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, head = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -290,7 +393,7 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const T* __restrict__ qkv
     auto load_q = [&](int t, float* dst) {
         const int nb = (blockIdx.x * kOutTilesPerBlock + t) * 32;
         const int nn = nb + l31;
-        const T* qp = qkv + ((size_t)b * N + (nn < N ? nn : (nb < N ? nb : 0))) * kQkv + head * kDh + 16 * h;
+        const T* qp = qkv + ((size_t)b * N + (nn < N ? nn : (nb < N ? nb : 0))) * qstride + head * kDh + 16 * h;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const float4 t4 = ld4(qp + 4 * v);
@@ -850,9 +953,34 @@ static void linear_attention_t(const T* qkv, T* out, int B, int N, const AttnWor
                        1.0f / (float)N, 1.0f / sqrtf((float)kDh));
     const int tiles = (N + 31) / 32;
     hipLaunchKernelGGL(attn_out_kernel<T>, dim3((tiles + kOutTilesPerBlock - 1) / kOutTilesPerBlock, B), dim3(256), 0, s,
-                       qkv, ws.ctx, out, N);
+                       qkv, ws.ctx, out, N, kQkv);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
+// fp32 fused form: context from xn and the k / v weight rows (attn_kv_ctx_kernel), then q (its own [B][N][128] tensor) -> out
+void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s) {
+    if (C % 8 || C > 256) throw HipError("attention_kv_context: C must be a multiple of 8, <= 256");
+    const int len = attn_chunk_len(N);
+    const int nch = attn_num_chunks(N);
+    if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
+    static bool attr_set = false;
+    if (!attr_set) {
+        IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_kv_ctx_kernel, dim3(nch, B), dim3(256), (size_t)kKvTile * (C + 4) * sizeof(float), s, xn, wkv, ws.pmax,
+                       ws.pctx, ws.psum, N, len, nch, C);
+    hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
+                       1.0f / (float)N, 1.0f / sqrtf((float)kDh));
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+void launch_attention_q_out(const float* q, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s) {
+    const int tiles = (N + 31) / 32;
+    hipLaunchKernelGGL(attn_out_kernel<float>, dim3((tiles + kOutTilesPerBlock - 1) / kOutTilesPerBlock, B), dim3(256), 0, s, q, ws.ctx,
+                       out, N, kHid);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
 void launch_linear_attention(const float* qkv, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s, bool bf16) {
     if (bf16)
         linear_attention_t(reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(out), B, N, ws, s);

@@ -68,6 +68,8 @@ enum {
     IRSDE_FLAG_NO_WINOGRAD_FUSED = 2048, /* keep every Winograd layer on the three-launch path (input transform, component GEMMs, output
                                         transform); default: the big feature maps (>= 4096 tiles, Cin <= 512, Cout <= 256) run the
                                         fused kernel of csrc/wino_fused.hip, whose transformed tensors never reach HBM */
+    IRSDE_FLAG_NO_FUSED_ATTN = 4096, /* LinearAttention with the whole to_qkv convolution and a q | k | v tensor in HBM (default for fp32, C <= 256:
+                                        k / v projection + softmax over the pixels + context in one kernel, only q is a convolution) */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };

@@ -224,12 +224,35 @@ def test_fused_winograd_plan_vs_three_launch_plan():
     m3.engine_flags = _lib.FLAG_NO_WINOGRAD_FUSED
     m3 = m3.to(DEV).eval()
     _lib.check(_lib.lib().irsde_plan_describe(m3.engine().h, 2, 256, 256, buf, len(buf)))
-    assert b"fused" not in buf.value and b"winograd F4 gemm" in buf.value
+    assert b"winograd F4 fused" not in buf.value and b"winograd F4 gemm" in buf.value
     lq, xT = O.synth_inputs(31, 2, 256, 256)
     x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
     ya, yb = m(x, c, 42).cpu().numpy(), m3(x, c, 42).cpu().numpy()
     e = relerr(ya, yb)
     print("fused vs three-launch Winograd plan, 2x256x256: %.3g" % e)
+    assert 0 < e < 5e-5
+
+
+def test_fused_attention_plan_vs_qkv_tensor_plan():
+    """Default fp32 plan: LinearAttention's k / v projection, softmax over the pixels and context run in one kernel (no k / v
+    tensor in HBM); IRSDE_FLAG_NO_FUSED_ATTN keeps the to_qkv convolution + q|k|v tensor.  Same arithmetic up to summation
+    order (odd sizes: 2 x 136 x 200 -> N = 27200 pixels at level 0, ragged chunk tails; attention at C = 64 .. 1024)."""
+    m = unet64()
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 2, 136, 200, buf, len(buf)))
+    assert b"k,v projection + context (fused)" in buf.value
+    params = O.synth_params(seed=0, nf=64, depth=4)
+    m3 = P.ConditionalUNet(3, 3, 64, depth=4)
+    m3.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m3.engine_flags = _lib.FLAG_NO_FUSED_ATTN
+    m3 = m3.to(DEV).eval()
+    _lib.check(_lib.lib().irsde_plan_describe(m3.engine().h, 2, 136, 200, buf, len(buf)))
+    assert b"(fused)" not in buf.value.replace(b"winograd F4 fused", b"")
+    lq, xT = O.synth_inputs(32, 2, 136, 200)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    ya, yb = m(x, c, 17).cpu().numpy(), m3(x, c, 17).cpu().numpy()
+    e = relerr(ya, yb)
+    print("fused attention vs qkv-tensor plan, 2x136x200: %.3g" % e)
     assert 0 < e < 5e-5
 
 
