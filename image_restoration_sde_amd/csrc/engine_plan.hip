@@ -297,6 +297,29 @@ struct Builder {
     Tensor attn(const AttnW& w, const Tensor& x) {
         const int64_t M = (int64_t)x.B * x.H * x.W;
         const int N = x.H * x.W;
+        const bool fused_kv = w.g2 && !naive && !x.bf16 && !(e->cfg.flags & (IRSDE_FLAG_BF16 | IRSDE_FLAG_NO_FUSED_ATTN)) &&
+                              x.C % 32 == 0 && x.C <= 256;
+        const bool fused_all = fused_kv && (x.C == 64 || x.C == 128) && !(e->cfg.flags & IRSDE_FLAG_NO_FUSED_LN);
+        if (fused_all) {
+            // whole Residual(PreNorm(LinearAttention)) block in two kernels + the context merge: PreNorm's LayerNorm runs on
+            // the tiles both kernels stage, so no normalised copy of x, no q / k / v, no attention output reach HBM
+            AttnWorkspace ws;
+            ws.nch = attn_num_chunks(N);
+            ws.pmax = pl->alloc((size_t)x.B * ws.nch * 128, false);
+            ws.pctx = pl->alloc((size_t)x.B * 4 * ws.nch * 1024, false);
+            ws.psum = pl->alloc((size_t)x.B * 4 * ws.nch * 32, false);
+            ws.ctx = pl->alloc((size_t)x.B * 4 * 1024, false);
+            Tensor y = talloc(x.B, x.H, x.W, x.C);
+            const float *xp = x.p, *wq = w.qkv.w, *wkv = w.qkv.w + (size_t)128 * x.C, *wo = w.out.w, *bo = w.out.bias, *g1 = w.g1, *g2 = w.g2;
+            float* yp = y.p;
+            const int B = x.B, C = x.C;
+            if (!bo) throw HipError("attention: to_out.0.bias missing");
+            push_other(OP_ATTN, [=](hipStream_t s) { launch_attention_kv_context(xp, wkv, B, N, C, ws, s, g1, 1e-5f); });
+            pl->net_ops.back().desc = "linear_attention LayerNorm + k,v projection + context (fused) C=" + std::to_string(C);
+            push_other(OP_ATTN, [=](hipStream_t s) { launch_attention_q_out_fused(xp, xp, wq, wo, bo, g2, yp, B, N, C, 1e-5f, ws, s, g1); });
+            pl->net_ops.back().desc = "linear_attention LayerNorm + q projection + softmax + context + to_out + LayerNorm + residual (fused) C=" + std::to_string(C);
+            return y;
+        }
         Tensor xn = talloc(x.B, x.H, x.W, x.C);
         {
             const float *xp = x.p, *g = w.g1;
@@ -306,7 +329,7 @@ struct Builder {
             push_other(OP_LN, [=](hipStream_t s) { launch_layernorm(xp, g, nullptr, o, M, C, 1e-5f, s, bf); });
         }
         Tensor a = talloc(x.B, x.H, x.W, 128);
-        if (w.g2 && !naive && !x.bf16 && !(e->cfg.flags & (IRSDE_FLAG_BF16 | IRSDE_FLAG_NO_FUSED_ATTN)) && x.C % 32 == 0 && x.C <= 256) {
+        if (fused_kv) {
             // fp32 fused form: the k and v thirds of to_qkv never reach HBM — their projection, the softmax over the pixels and
             // the context run in one kernel on the LayerNorm output; only q (rows 0..127 of to_qkv.weight) is a convolution
             AttnWorkspace ws;

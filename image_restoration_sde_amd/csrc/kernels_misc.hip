@@ -252,6 +252,22 @@ __global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restri
     }
 }
 
+// LayerNorm of a row whose C/4 16-byte pieces sit in C/4 consecutive (aligned) lanes: two-pass mean / centred variance like
+// layernorm_kernel (and torch.var / torch.mean), then * g.  C4 = C/4 is a power of two <= 64.
+template <int C4>
+__device__ __forceinline__ floatx4 ln_piece(floatx4 v, const floatx4 g, const float eps) {
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = C4 >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / (float)(4 * C4));
+    v -= mean;
+    float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+    for (int o = C4 >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / (float)(4 * C4)) + eps);
+    return v * rstd * g;
+}
+
 // k, v projection + context in one kernel (fp32): the k and v thirds of to_qkv never reach HBM.
 //   per 128-pixel tile of one image:  [k | v](128 px x 64) = xn(128 x C) . W_{k,v}^T   for each head (wave = head)
 //   then straight from the accumulator registers: online softmax of k over the pixels and ctx[d][e] += exp(k - m)[px][d] v[px][e].
@@ -262,31 +278,49 @@ __global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restri
 // straight from L2 (a wave's 64 weight rows x 8 k = two 16-byte loads per lane, one K step ahead).
 // Output = the (max, sum, context) partials of attn_ctx_partial_kernel, merged by attn_ctx_finalize_kernel.
 constexpr int kKvTile = 128;
+template <int C>
 __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __restrict__ xn, const float* __restrict__ wkv,
                                                              float* __restrict__ pmax, float* __restrict__ pctx,
                                                              float* __restrict__ psum, const int N, const int chunk_len,
-                                                             const int nch, const int C) {
+                                                             const int nch, const float* __restrict__ ln_g, const float ln_eps) {
     extern __shared__ __attribute__((aligned(16))) float kv_smem[];
     const int ch = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int LDA = C + 4;
+    constexpr int LDA = C + 4;
     const int n0 = ch * chunk_len;
     const int n1 = min(N, n0 + chunk_len);
     const float* wk = wkv + (size_t)(head * kDh + l31) * C + 4 * h;          // k rows of this head (to_qkv rows 128..255)
     const float* wv = wkv + (size_t)(kHid + head * kDh + l31) * C + 4 * h;   // v rows (256..383)
-    const int c4n = C >> 2;
+    constexpr int c4n = C >> 2;
     floatx16 ctx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
     float ssum = 0.f, mrun = -INFINITY;
     for (int t0 = n0; t0 < n1; t0 += kKvTile) {
         // stage the tile (rows past the chunk repeat its last pixel; they are masked below)
-        for (int i = tid; i < kKvTile * c4n; i += 256) {
-            const int row = i / c4n, c4 = i - row * c4n;
-            const int n = min(t0 + row, n1 - 1);
-            *reinterpret_cast<floatx4*>(kv_smem + row * LDA + 4 * c4) =
-                *reinterpret_cast<const floatx4*>(xn + ((size_t)b * N + n) * C + 4 * c4);
+        {
+            // 4 loads in flight before the first LDS write of a pass (a rolled loop waits for every load in turn; more than 4
+            // do not fit next to the 144 accumulator registers)
+            constexpr int NP = kKvTile * c4n / 256;
+#pragma unroll 1
+            for (int j0 = 0; j0 < NP; j0 += 4) {
+                floatx4 st[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = tid + 256 * (j0 + j), row = i / c4n, c4 = i - row * c4n;
+                    st[j] = *reinterpret_cast<const floatx4*>(xn + ((size_t)b * N + min(t0 + row, n1 - 1)) * C + 4 * c4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = tid + 256 * (j0 + j), row = i / c4n, c4 = i - row * c4n;
+                    // ln_g != nullptr: the input is the block's x and PreNorm's LayerNorm (module_util.py:82-90) runs here,
+                    // on the staged pieces (power-of-two C only: a row = C/4 consecutive lanes)
+                    if constexpr ((c4n & (c4n - 1)) == 0)
+                        if (ln_g) st[j] = ln_piece<c4n>(st[j], *reinterpret_cast<const floatx4*>(ln_g + 4 * c4), ln_eps);
+                    *reinterpret_cast<floatx4*>(kv_smem + row * LDA + 4 * c4) = st[j];
+                }
+            }
         }
         __syncthreads();
         floatx16 ak[4], av[4];
@@ -294,11 +328,27 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { ak[rt][r] = 0.f; av[rt][r] = 0.f; }
-        floatx4 bk = *reinterpret_cast<const floatx4*>(wk), bv = *reinterpret_cast<const floatx4*>(wv);
         const float* arow = kv_smem + l31 * LDA + 4 * h;
-        for (int k8 = 0; k8 < C; k8 += 8) {
-            const int kn = k8 + 8 < C ? k8 + 8 : k8;
-            const floatx4 bkn = *reinterpret_cast<const floatx4*>(wk + kn), bvn = *reinterpret_cast<const floatx4*>(wv + kn);
+        // weight fragments (from L2) one K step = 32 MFMAs (2048 cycles) ahead of their use: two register slots, K loop
+        // unrolled by two only (a full unroll of up to 32 steps x 32 MFMAs spills)
+        constexpr int NK = C / 8;
+        static_assert(NK % 2 == 0, "C must be a multiple of 16");
+        floatx4 wkr[2], wvr[2];
+        wkr[0] = *reinterpret_cast<const floatx4*>(wk);
+        wvr[0] = *reinterpret_cast<const floatx4*>(wv);
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < NK; ks0 += 2)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ks = ks0 + u;
+            const int k8 = 8 * ks;
+            {
+                const int kp = ks + 1 < NK ? k8 + 8 : k8;  // past the end: a harmless reload
+                wkr[u ^ 1] = *reinterpret_cast<const floatx4*>(wk + kp);
+                wvr[u ^ 1] = *reinterpret_cast<const floatx4*>(wv + kp);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of this step's MFMAs
+            const floatx4 bk = wkr[u], bv = wvr[u];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 const floatx4 a = *reinterpret_cast<const floatx4*>(arow + rt * 32 * LDA + k8);
@@ -311,8 +361,6 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
                 ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bk.w, ak[rt], 0, 0, 0);
                 av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, av[rt], 0, 0, 0);
             }
-            bk = bkn;
-            bv = bvn;
         }
         // accumulator register r of row tile rt: pixel t0 + 32 rt + (r&3) + 8 (r>>2) + 4h, column d (k) / e (v) = l31
         float mit = -INFINITY;
@@ -431,6 +479,210 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const T* __restrict__ qkv
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int nn = nbase + row;
             if (nn < N) st1(out + ((size_t)b * N + nn) * kHid + head * kDh + l31, acc[r]);
+        }
+    }
+}
+
+// q projection + softmax over d + context product + to_out + bias + LayerNorm + residual in one kernel (fp32, C = 64 / 128):
+// neither q nor the attention output nor the to_out result reach HBM — the second half of the fused LinearAttention block
+// (module_util.py:163-178: q.softmax(dim=-2) * scale, einsum with the context, to_out = Conv2d + LayerNorm, Residual).
+// One block = 128 pixels of one image, 4 waves:
+//   A  xn tile -> LDS Xs[128][C+4]
+//   B  wave = head: Q^T[d][px] = Wq_h . xn^T   (A operand = weight rows straight from L2, B operand = Xs rows): 4 pixel tiles
+//   C  softmax over d in registers: the lane's 16 rows + the other lane half (the 1/sqrt(32) scale is folded into ctx)
+//   D  out^T[e][px] = ctx^T . softmax(q): A = 16 preloaded context registers, B = the lane's own q registers (the accumulator
+//      layout of B is the operand layout of D: no transposition)
+//   E  out tile -> LDS Os[128][128+4] (row = pixel, column = head*32 + e)
+//   F  wave = 32-pixel tile: y^T[c][px] = Wout . out^T  (A = to_out rows from L2, B = Os rows), + bias
+//   G  LayerNorm over c in registers (C/32 x 16 values + the other lane half), * g, -> LDS (the wave's own rows), then
+//      coalesced 16-byte passes: + x (residual), store y.
+template <int C>
+__global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* __restrict__ xn, const float* __restrict__ xres,
+                                                               const float* __restrict__ wq, const float* __restrict__ ctx,
+                                                               const float* __restrict__ wout, const float* __restrict__ bias,
+                                                               const float* __restrict__ g2, float* __restrict__ y, const int N,
+                                                               const float eps, const float* __restrict__ ln_g) {
+    constexpr int TP = 128, LDA = C + 4, LDO = kHid + 4, RT = C / 32;
+    extern __shared__ __attribute__((aligned(16))) float qo_smem[];
+    // one LDS region (67.6 KB -> two blocks per CU, whose phases overlap): the xn tile (phases A, B), then — behind a barrier —
+    // the attention output tile (E, F), then, wave-locally, the normalised rows (G)
+    float* Xs = qo_smem;  // [128][C+4]
+    float* Os = qo_smem;  // [128][132]
+    const int b = blockIdx.y, t0 = blockIdx.x * TP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const size_t img = (size_t)b * N;
+
+    // ---- A: stage the xn tile (rows past N repeat the last pixel; their results are never stored)
+    constexpr int C4 = C / 4;
+    {
+        // all loads of the tile in flight before the first LDS write (a rolled loop waits for every load in turn)
+        constexpr int NP = TP * C4 / 256;
+        floatx4 st[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = tid + 256 * j, row = i / C4, c4 = i - row * C4;
+            st[j] = *reinterpret_cast<const floatx4*>(xn + (img + min(t0 + row, N - 1)) * C + 4 * c4);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = tid + 256 * j, row = i / C4, c4 = i - row * C4;
+            // ln_g != nullptr: xn == the block's x and PreNorm's LayerNorm runs here on the staged pieces
+            if (ln_g) st[j] = ln_piece<C4>(st[j], *reinterpret_cast<const floatx4*>(ln_g + 4 * c4), eps);
+            *reinterpret_cast<floatx4*>(Xs + row * LDA + 4 * c4) = st[j];
+        }
+    }
+    // context operand of phase D: ctx[d = (s&3) + 8(s>>2) + 4h][e = l31] of head = wave
+    float cb[16];
+    {
+        const float* cp = ctx + ((size_t)(b * kHeads + wave)) * 1024 + l31;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) cb[s2] = cp[((s2 & 3) + 8 * (s2 >> 2) + 4 * h) * 32];
+    }
+    __syncthreads();
+
+    // ---- B: Q^T of head = wave
+    floatx16 q[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[ct][r] = 0.f;
+    {
+        const float* wrow = wq + (size_t)(wave * kDh + l31) * C + 4 * h;
+        const float* brow = Xs + l31 * LDA + 4 * h;
+        // weight fragments two K steps (32 MFMAs) ahead of their use: they come from L2
+        constexpr int NK = C / 8;
+        floatx4 wa[3];
+        wa[0] = *reinterpret_cast<const floatx4*>(wrow);
+        wa[1] = *reinterpret_cast<const floatx4*>(wrow + 8);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            if (ks + 2 < NK) wa[(ks + 2) % 3] = *reinterpret_cast<const floatx4*>(wrow + 8 * (ks + 2));
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of this step's MFMAs (the scheduler sinks it to its use)
+            const floatx4 a = wa[ks % 3];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const floatx4 bb = *reinterpret_cast<const floatx4*>(brow + ct * 32 * LDA + 8 * ks);
+                q[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, q[ct], 0, 0, 0);
+                q[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, q[ct], 0, 0, 0);
+                q[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb.z, q[ct], 0, 0, 0);
+                q[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb.w, q[ct], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // every wave is done reading Xs: the region becomes Os
+    // ---- C + D + E per pixel tile: q[ct][r] = Q[d = (r&3) + 8(r>>2) + 4h][pixel 32 ct + l31]
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float m = q[ct][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, q[ct][r]);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float z = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            q[ct][r] = expf(q[ct][r] - m);
+            z += q[ct][r];
+        }
+        z += __shfl_xor(z, 32, 64);
+        const float iz = 1.0f / z;
+        floatx16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) o = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[s2], q[ct][s2] * iz, o, 0, 0, 0);
+        // o[r] = out[pixel 32 ct + l31][e = (r&3) + 8(r>>2) + 4h]: four 16-byte groups per lane
+        float* orow = Os + (ct * 32 + l31) * LDO + wave * kDh + 4 * h;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<floatx4*>(orow + 8 * gq) = floatx4{o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]};
+    }
+    __syncthreads();  // Os complete
+
+    // ---- F: y^T[c][px] of the 32-pixel tile = wave
+    floatx16 yv[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[rt][r] = 0.f;
+    {
+        const float* wrow = wout + (size_t)l31 * kHid + 4 * h;
+        const float* brow = Os + (wave * 32 + l31) * LDO + 4 * h;
+        // to_out weight fragments (RT per K step, from L2) two K steps ahead of their use
+        constexpr int NK = kHid / 8;
+        floatx4 wa[3][RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            wa[0][rt] = *reinterpret_cast<const floatx4*>(wrow + (size_t)rt * 32 * kHid);
+            wa[1][rt] = *reinterpret_cast<const floatx4*>(wrow + (size_t)rt * 32 * kHid + 8);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            if (ks + 2 < NK) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    wa[(ks + 2) % 3][rt] = *reinterpret_cast<const floatx4*>(wrow + (size_t)rt * 32 * kHid + 8 * (ks + 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const floatx4 bb = *reinterpret_cast<const floatx4*>(brow + 8 * ks);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const floatx4 a = wa[ks % 3][rt];
+                yv[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, yv[rt], 0, 0, 0);
+                yv[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, yv[rt], 0, 0, 0);
+                yv[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb.z, yv[rt], 0, 0, 0);
+                yv[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb.w, yv[rt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- G: bias, LayerNorm over the C channels of pixel 32 wave + l31 (this lane holds c = 32 rt + (r&3) + 8(r>>2) + 4h)
+    float sum = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            yv[rt][r] += bias[32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h];
+            sum += yv[rt][r];
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / (float)C);
+    float sq = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            yv[rt][r] -= mean;
+            sq += yv[rt][r] * yv[rt][r];
+        }
+    sq += __shfl_xor(sq, 32, 64);
+    const float rstd = 1.0f / sqrtf(sq * (1.0f / (float)C) + eps);
+    // Ys = this wave's own 32 rows of Os (row stride LDO >= C + 4): only this wave read them in phase F and reads them below
+    float* yrow = Os + (wave * 32 + l31) * LDO + 4 * h;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const floatx4 g4 = *reinterpret_cast<const floatx4*>(g2 + 32 * rt + 8 * gq + 4 * h);
+            *reinterpret_cast<floatx4*>(yrow + 32 * rt + 8 * gq) =
+                floatx4{yv[rt][4 * gq] * rstd * g4.x, yv[rt][4 * gq + 1] * rstd * g4.y, yv[rt][4 * gq + 2] * rstd * g4.z,
+                        yv[rt][4 * gq + 3] * rstd * g4.w};
+        }
+    // the wave re-reads only its own rows: LDS operations of one wave complete in order, no block barrier needed
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    {
+        constexpr int NQ = 32 * C4 / 64;
+        floatx4 xr[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {  // residual loads first, all in flight
+            const int i = lane + 64 * j, row = i / C4, c4 = i - row * C4;
+            xr[j] = *reinterpret_cast<const floatx4*>(xres + (img + min(t0 + wave * 32 + row, N - 1)) * C + 4 * c4);
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i = lane + 64 * j, row = i / C4, c4 = i - row * C4;
+            const int n = t0 + wave * 32 + row;
+            const floatx4 v = *reinterpret_cast<const floatx4*>(Os + (wave * 32 + row) * LDO + 4 * c4);
+            if (n < N) *reinterpret_cast<floatx4*>(y + (img + n) * C + 4 * c4) = v + xr[j];
         }
     }
 }
@@ -957,19 +1209,34 @@ static void linear_attention_t(const T* qkv, T* out, int B, int N, const AttnWor
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 // fp32 fused form: context from xn and the k / v weight rows (attn_kv_ctx_kernel), then q (its own [B][N][128] tensor) -> out
-void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s) {
-    if (C % 8 || C > 256) throw HipError("attention_kv_context: C must be a multiple of 8, <= 256");
+void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s,
+                                 const float* ln_g, float ln_eps) {
+    if (ln_g && (C & (C - 1))) throw HipError("attention_kv_context: the fused LayerNorm needs a power-of-two channel count");
+    if (C % 32 || C > 256 || C < 32) throw HipError("attention_kv_context: C must be a multiple of 32, <= 256");
     const int len = attn_chunk_len(N);
     const int nch = attn_num_chunks(N);
     if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
     static bool attr_set = false;
     if (!attr_set) {
-        IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            160 * 1024));
+#define IRSDE_KV_ATTR(CC) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        IRSDE_KV_ATTR(32); IRSDE_KV_ATTR(64); IRSDE_KV_ATTR(96); IRSDE_KV_ATTR(128); IRSDE_KV_ATTR(160); IRSDE_KV_ATTR(192); IRSDE_KV_ATTR(224); IRSDE_KV_ATTR(256);
+#undef IRSDE_KV_ATTR
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_kv_ctx_kernel, dim3(nch, B), dim3(256), (size_t)kKvTile * (C + 4) * sizeof(float), s, xn, wkv, ws.pmax,
-                       ws.pctx, ws.psum, N, len, nch, C);
+    const size_t lds = (size_t)kKvTile * (C + 4) * sizeof(float);
+#define IRSDE_KV_LAUNCH(CC) hipLaunchKernelGGL(attn_kv_ctx_kernel<CC>, dim3(nch, B), dim3(256), lds, s, xn, wkv, ws.pmax, ws.pctx, ws.psum, N, len, nch, ln_g, ln_eps)
+    switch (C) {
+        case 32: IRSDE_KV_LAUNCH(32); break;
+        case 64: IRSDE_KV_LAUNCH(64); break;
+        case 96: IRSDE_KV_LAUNCH(96); break;
+        case 128: IRSDE_KV_LAUNCH(128); break;
+        case 160: IRSDE_KV_LAUNCH(160); break;
+        case 192: IRSDE_KV_LAUNCH(192); break;
+        case 224: IRSDE_KV_LAUNCH(224); break;
+        case 256: IRSDE_KV_LAUNCH(256); break;
+        default: throw HipError("attention_kv_context: unsupported channel count");
+    }
+#undef IRSDE_KV_LAUNCH
     hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
                        1.0f / (float)N, 1.0f / sqrtf((float)kDh));
     IRSDE_HIP_CHECK(hipGetLastError());
@@ -978,6 +1245,28 @@ void launch_attention_q_out(const float* q, float* out, int B, int N, const Attn
     const int tiles = (N + 31) / 32;
     hipLaunchKernelGGL(attn_out_kernel<float>, dim3((tiles + kOutTilesPerBlock - 1) / kOutTilesPerBlock, B), dim3(256), 0, s, q, ws.ctx,
                        out, N, kHid);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+// y = LayerNorm(to_out(softmax(q) . ctx)) * g + x with q = Wq . xn computed in the kernel (C = 64 or 128)
+void launch_attention_q_out_fused(const float* xn, const float* x, const float* wq, const float* wout, const float* bias,
+                                  const float* g2, float* y, int B, int N, int C, float eps, const AttnWorkspace& ws, hipStream_t s,
+                                  const float* ln_g) {
+    if (C != 64 && C != 128) throw HipError("attention_q_out_fused: C must be 64 or 128");
+    const size_t lds = (size_t)128 * (kHid + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<64>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<128>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const dim3 grid((N + 127) / 128, B);
+    if (C == 64)
+        hipLaunchKernelGGL(attn_q_out_fused_kernel<64>, grid, dim3(256), lds, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g);
+    else
+        hipLaunchKernelGGL(attn_q_out_fused_kernel<128>, grid, dim3(256), lds, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
