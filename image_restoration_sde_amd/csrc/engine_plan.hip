@@ -299,7 +299,7 @@ struct Builder {
         const int N = x.H * x.W;
         const bool fused_kv = w.g2 && !naive && !x.bf16 && !(e->cfg.flags & (IRSDE_FLAG_BF16 | IRSDE_FLAG_NO_FUSED_ATTN)) &&
                               x.C % 32 == 0 && x.C <= 256;
-        const bool fused_all = fused_kv && (x.C == 64 || x.C == 128) && !(e->cfg.flags & IRSDE_FLAG_NO_FUSED_LN);
+        const bool fused_all = fused_kv && (x.C == 64 || x.C == 128 || x.C == 256) && !(e->cfg.flags & IRSDE_FLAG_NO_FUSED_LN);
         if (fused_all) {
             // whole Residual(PreNorm(LinearAttention)) block in two kernels + the context merge: PreNorm's LayerNorm runs on
             // the tiles both kernels stage, so no normalised copy of x, no q / k / v, no attention output reach HBM

@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
                                                                const float* __restrict__ g2, float* __restrict__ y, const int N,
                                                                const float eps, const float* __restrict__ ln_g) {
     constexpr int TP = 128, LDA = C + 4, LDO = kHid + 4, RT = C / 32;
+    constexpr int LDY = C > kHid ? C + 4 : LDO;  // row stride of the normalised rows (phase G): they must not overlap the next wave's rows
     extern __shared__ __attribute__((aligned(16))) float qo_smem[];
     // one LDS region (67.6 KB -> two blocks per CU, whose phases overlap): the xn tile (phases A, B), then — behind a barrier —
     // the attention output tile (E, F), then, wave-locally, the normalised rows (G)
@@ -516,20 +517,23 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
     // ---- A: stage the xn tile (rows past N repeat the last pixel; their results are never stored)
     constexpr int C4 = C / 4;
     {
-        // all loads of the tile in flight before the first LDS write (a rolled loop waits for every load in turn)
+        // 8 loads in flight before the first LDS write of a pass (a rolled loop waits for every load in turn)
         constexpr int NP = TP * C4 / 256;
-        floatx4 st[NP];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int i = tid + 256 * j, row = i / C4, c4 = i - row * C4;
-            st[j] = *reinterpret_cast<const floatx4*>(xn + (img + min(t0 + row, N - 1)) * C + 4 * c4);
-        }
+        for (int j0 = 0; j0 < NP; j0 += 8) {
+            floatx4 st[8];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int i = tid + 256 * j, row = i / C4, c4 = i - row * C4;
-            // ln_g != nullptr: xn == the block's x and PreNorm's LayerNorm runs here on the staged pieces
-            if (ln_g) st[j] = ln_piece<C4>(st[j], *reinterpret_cast<const floatx4*>(ln_g + 4 * c4), eps);
-            *reinterpret_cast<floatx4*>(Xs + row * LDA + 4 * c4) = st[j];
+            for (int j = 0; j < 8; ++j) {
+                const int i = tid + 256 * (j0 + j), row = i / C4, c4 = i - row * C4;
+                st[j] = *reinterpret_cast<const floatx4*>(xn + (img + min(t0 + row, N - 1)) * C + 4 * c4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = tid + 256 * (j0 + j), row = i / C4, c4 = i - row * C4;
+                // ln_g != nullptr: xn == the block's x and PreNorm's LayerNorm runs here on the staged pieces
+                if (ln_g) st[j] = ln_piece<C4>(st[j], *reinterpret_cast<const floatx4*>(ln_g + 4 * c4), eps);
+                *reinterpret_cast<floatx4*>(Xs + row * LDA + 4 * c4) = st[j];
+            }
         }
     }
     // context operand of phase D: ctx[d = (s&3) + 8(s>>2) + 4h][e = l31] of head = wave
@@ -608,26 +612,27 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
     {
         const float* wrow = wout + (size_t)l31 * kHid + 4 * h;
         const float* brow = Os + (wave * 32 + l31) * LDO + 4 * h;
-        // to_out weight fragments (RT per K step, from L2) two K steps ahead of their use
+        // to_out weight fragments (RT per K step, from L2) PF K steps ahead of their use (C = 256: one step = 32 MFMAs already,
+        // and eight fragments per step leave no registers for a deeper ring)
         constexpr int NK = kHid / 8;
-        floatx4 wa[3][RT];
+        constexpr int PF = RT > 4 ? 1 : 2, RING = PF + 1;
+        floatx4 wa[RING][RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            wa[0][rt] = *reinterpret_cast<const floatx4*>(wrow + (size_t)rt * 32 * kHid);
-            wa[1][rt] = *reinterpret_cast<const floatx4*>(wrow + (size_t)rt * 32 * kHid + 8);
-        }
+        for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) wa[pf][rt] = *reinterpret_cast<const floatx4*>(wrow + (size_t)rt * 32 * kHid + 8 * pf);
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-            if (ks + 2 < NK) {
+            if (ks + PF < NK) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    wa[(ks + 2) % 3][rt] = *reinterpret_cast<const floatx4*>(wrow + (size_t)rt * 32 * kHid + 8 * (ks + 2));
+                    wa[(ks + PF) % RING][rt] = *reinterpret_cast<const floatx4*>(wrow + (size_t)rt * 32 * kHid + 8 * (ks + PF));
             }
             __builtin_amdgcn_sched_barrier(0);
             const floatx4 bb = *reinterpret_cast<const floatx4*>(brow + 8 * ks);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const floatx4 a = wa[ks % 3][rt];
+                const floatx4 a = wa[ks % RING][rt];
                 yv[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, yv[rt], 0, 0, 0);
                 yv[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, yv[rt], 0, 0, 0);
                 yv[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb.z, yv[rt], 0, 0, 0);
@@ -656,8 +661,10 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
         }
     sq += __shfl_xor(sq, 32, 64);
     const float rstd = 1.0f / sqrtf(sq * (1.0f / (float)C) + eps);
-    // Ys = this wave's own 32 rows of Os (row stride LDO >= C + 4): only this wave read them in phase F and reads them below
-    float* yrow = Os + (wave * 32 + l31) * LDO + 4 * h;
+    // Ys = this wave's own 32 rows of the region.  C <= 128: row stride LDO, exactly the Os rows only this wave read in phase F.
+    // C = 256: the rows are wider than an Os row, so they overlap other waves' Os rows -> wait until every wave has left phase F.
+    if constexpr (C > kHid) __syncthreads();
+    float* yrow = Os + (wave * 32 + l31) * LDY + 4 * h;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -681,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
         for (int j = 0; j < NQ; ++j) {
             const int i = lane + 64 * j, row = i / C4, c4 = i - row * C4;
             const int n = t0 + wave * 32 + row;
-            const floatx4 v = *reinterpret_cast<const floatx4*>(Os + (wave * 32 + row) * LDO + 4 * c4);
+            const floatx4 v = *reinterpret_cast<const floatx4*>(Os + (wave * 32 + row) * LDY + 4 * c4);
             if (n < N) *reinterpret_cast<floatx4*>(y + (img + n) * C + 4 * c4) = v + xr[j];
         }
     }
@@ -1252,21 +1259,25 @@ void launch_attention_q_out(const float* q, float* out, int B, int N, const Attn
 void launch_attention_q_out_fused(const float* xn, const float* x, const float* wq, const float* wout, const float* bias,
                                   const float* g2, float* y, int B, int N, int C, float eps, const AttnWorkspace& ws, hipStream_t s,
                                   const float* ln_g) {
-    if (C != 64 && C != 128) throw HipError("attention_q_out_fused: C must be 64 or 128");
-    const size_t lds = (size_t)128 * (kHid + 4) * sizeof(float);
+    if (C != 64 && C != 128 && C != 256) throw HipError("attention_q_out_fused: C must be 64, 128 or 256");
+    const size_t lds = (size_t)128 * ((C > kHid ? C : kHid) + 4) * sizeof(float);  // one region: max(xn tile, out tile)
     static bool attr_set = false;
     if (!attr_set) {
         IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<64>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<128>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<256>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const dim3 grid((N + 127) / 128, B);
     if (C == 64)
         hipLaunchKernelGGL(attn_q_out_fused_kernel<64>, grid, dim3(256), lds, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g);
-    else
+    else if (C == 128)
         hipLaunchKernelGGL(attn_q_out_fused_kernel<128>, grid, dim3(256), lds, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g);
+    else
+        hipLaunchKernelGGL(attn_q_out_fused_kernel<256>, grid, dim3(256), lds, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
