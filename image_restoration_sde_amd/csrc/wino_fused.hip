@@ -41,14 +41,20 @@ constexpr unsigned WF_OOB = 0x80000000u;   // voffset of a tap that must read 0 
 
 __device__ __forceinline__ float silu_w(float v) { return v / (1.0f + expf(-v)); }
 
-// B^T of F(4x4,3x3) along one axis (same matrix as wino.hip)
+// B^T of F(4x4,3x3) along one axis (same matrix as wino.hip), 14 packed operations with explicit FMAs: the producer's vector
+// instructions compete with the f32 MFMAs of the wave that shares its SIMD (the f32 matrix rate IS the vector FMA rate), so
+// every operation saved here is matrix-pipe time (profiles/r02_wino_fused_notes.md).
+__device__ __forceinline__ floatx2 fma2(const float a, const floatx2 b, const floatx2 c) {
+    return __builtin_elementwise_fma(floatx2{a, a}, b, c);
+}
 __device__ __forceinline__ void bt6(const floatx2* d, floatx2* t) {
-    t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
-    t[1] = (d[3] + d[4]) - 4.0f * (d[1] + d[2]);
-    t[2] = 4.0f * (d[1] - d[2]) + (d[4] - d[3]);
-    t[3] = 2.0f * (d[3] - d[1]) + (d[4] - d[2]);
-    t[4] = 2.0f * (d[1] - d[3]) + (d[4] - d[2]);
-    t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+    t[0] = fma2(-5.0f, d[2], fma2(4.0f, d[0], d[4]));          // 4 d0 - 5 d2 + d4
+    t[1] = fma2(-4.0f, d[1] + d[2], d[3] + d[4]);              // (d3 + d4) - 4 (d1 + d2)
+    t[2] = fma2(4.0f, d[1] - d[2], d[4] - d[3]);               // 4 (d1 - d2) + (d4 - d3)
+    const floatx2 a = d[3] - d[1], b = d[4] - d[2];
+    t[3] = fma2(2.0f, a, b);                                   // 2 (d3 - d1) + (d4 - d2)
+    t[4] = fma2(-2.0f, a, b);                                  // 2 (d1 - d3) + (d4 - d2)
+    t[5] = fma2(-5.0f, d[3], fma2(4.0f, d[1], d[5]));          // 4 d1 - 5 d3 + d5
 }
 // A^T of F(4x4,3x3) along one axis
 __device__ __forceinline__ void at6(const float* m, float* y) {
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams 
         const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc1 =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1 ? p.in1 : p.in0), 0, p.in1 ? in1_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, 0u, 0x00020000);
         const int cp = lane & 7;                           // channel pair of the chunk: channels 2cp, 2cp+1
         const int trow = wave - 4, tcol = lane >> 3;       // this lane's tile inside the group
         // LDS float offset of (tile, channel pair): [sub = c>>3][hh = (c>>2)&1][tile][kk = c&3]
@@ -250,50 +257,52 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams 
             colpix[r] = (tile_ok && (unsigned)x < (unsigned)Wv) ? (x >> p.in_shift) : -1;
         }
         unsigned voff[36];
-        floatx2 raw[36];
+        floatx2 rawA[36], rawB[36];
 #define WF_BUILD_VOFF(PIXF)                                                                                                  \
     _Pragma("unroll") for (int r = 0; r < 6; ++r) _Pragma("unroll") for (int s = 0; s < 6; ++s) voff[r * 6 + s] =            \
         (rowpix[r] >= 0 && colpix[s] >= 0) ? (unsigned)(rowpix[r] + colpix[s]) * (unsigned)((PIXF)*4) + (unsigned)(cp * 8) : WF_OOB;
-#define WF_LOAD_RAW(CI)                                                                                                      \
+        // ONE unconditional load site per register set (a load under `if (ci < nch)` turns the patch registers into a phi
+        // and costs 36 register-pair copies per chunk); past the last chunk the descriptor has zero bytes: zeros, no traffic.
+#define WF_LOAD_RAW(RAW, CI)                                                                                                 \
     {                                                                                                                        \
         const int cc_ = (CI)*WF_KC;                                                                                          \
         const bool second_ = cc_ >= p.C0;                                                                                    \
         const int soff_ = (second_ ? cc_ - p.C0 : cc_) * 4;                                                                  \
-        const __amdgpu_buffer_rsrc_t rs_ = second_ ? rsrc1 : rsrc0;                                                          \
-        _Pragma("unroll") for (int e = 0; e < 36; ++e) raw[e] =                                                              \
+        const __amdgpu_buffer_rsrc_t rs_ = (CI) >= nch ? rsrc_none : second_ ? rsrc1 : rsrc0;                                \
+        _Pragma("unroll") for (int e = 0; e < 36; ++e) RAW[e] =                                                              \
             __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[e], soff_, 0));                 \
     }
+        // one chunk: the NEXT chunk's 36 loads into the other register set first (they have the whole transform of this
+        // chunk to land), column pass, row pass + 36 ds_write_b64.  The chunk loop is unrolled by two so that the two
+        // register sets swap roles without copies (C0 and C1 are multiples of 32: the chunk count is even).
+#define WF_CHUNK(CUR, NXT, IT)                                                                                               \
+    {                                                                                                                        \
+        if (((IT) + 1) * WF_KC == p.C0) { WF_BUILD_VOFF(p.pix1) }                                                            \
+        WF_LOAD_RAW(NXT, (IT) + 1)                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        floatx2 w[6][6];                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 6; ++s) {                                                                      \
+            floatx2 col[6], tc[6];                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) col[r] = CUR[r * 6 + s];                                           \
+            bt6(col, tc);                                                                                                    \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) w[r][s] = tc[r];                                                   \
+        }                                                                                                                    \
+        float* vw = smem + ((IT)&1) * WF_VBUF + vw_base;                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                                      \
+            floatx2 o[6];                                                                                                    \
+            bt6(w[r], o);                                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < 6; ++s) *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * WF_ZS) = o[s];      \
+        }                                                                                                                    \
+        __syncthreads();                                                                                                     \
+    }
         WF_BUILD_VOFF(p.pix0)
-        WF_LOAD_RAW(0)
-        for (int it = 0; it < nch; ++it) {
-            if (it == 1) { WF_STAMP(1) }
-            // column pass (consumes raw[]), then the next chunk's loads into the same registers, then the row pass
-            floatx2 w[6][6];
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                floatx2 col[6], tc[6];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) col[r] = raw[r * 6 + s];
-                bt6(col, tc);
-#pragma unroll
-                for (int r = 0; r < 6; ++r) w[r][s] = tc[r];
-            }
-            if (it + 1 < nch) {
-                if ((it + 1) * WF_KC == p.C0) {  // the next chunk starts the second concat source
-                    WF_BUILD_VOFF(p.pix1)
-                }
-                WF_LOAD_RAW(it + 1)
-            }
-            float* vw = smem + (it & 1) * WF_VBUF + vw_base;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                floatx2 o[6];
-                bt6(w[r], o);
-#pragma unroll
-                for (int s = 0; s < 6; ++s) *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * WF_ZS) = o[s];
-            }
-            __syncthreads();
+        WF_LOAD_RAW(rawA, 0)
+        for (int it = 0; it < nch; it += 2) {
+            if (it == 2) { WF_STAMP(1) }
+            WF_CHUNK(rawA, rawB, it)
+            WF_CHUNK(rawB, rawA, it + 1)
         }
+#undef WF_CHUNK
 #undef WF_BUILD_VOFF
 #undef WF_LOAD_RAW
         WF_STAMP(2)
