@@ -10,8 +10,10 @@
 // LDS rows are 32 bf16 + 16 B pad (80 B: an odd number of 16-byte slots => conflict-free ds_read_b128, as in
 // conv_igemm.hip); lane half h owns the second 16 bytes of each 32-byte group for A and B alike.
 // Pipeline: the weight slice of K-step s+2 and one sixth of the next chunk's halo are loaded before the MFMAs of step s
-// and written to LDS (ring of 3 slices, 2 halo buffers) after the MFMAs of step s+1: a full K-step of cover for the
-// loads; one barrier per tap.
+// and written to LDS (2 slice buffers, 2 halo buffers) after the MFMAs of step s+1: a full K-step of cover for the
+// loads; one barrier per tap.  The slice of step s+2 goes to the buffer step s read: every wave is past the barrier that
+// ended step s by then.  Two slice buffers (not three) keep BN = 128 at 72,320 B of LDS: two blocks per CU, so one
+// block's barrier stalls are covered by the other's MFMAs.
 #include "common.h"
 
 namespace irsde {
@@ -52,7 +54,7 @@ template <int BN>
 struct HCfg {
     static constexpr int TN = BN / 2 / 32;  // MFMA tiles per wave along N (wave tile 64 x BN/2)
     static constexpr int B_BYTES = BN * ROWB;
-    static constexpr int MAIN_BYTES = 2 * HALO_BYTES + 3 * B_BYTES;
+    static constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * B_BYTES;
     static constexpr int LDS_C = BN + 4;
     static constexpr int EPI_BYTES = 64 * LDS_C * 4;
     static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
     char* Ah = lds;                    // 2 halo buffers
-    char* Bs = lds + 2 * HALO_BYTES;   // ring of 3 weight-slice buffers
+    char* Bs = lds + 2 * HALO_BYTES;   // 2 weight-slice buffers (K-step parity)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
             b_load(tap % 2, ci * 9 + tap + 2);
             if (more_chunks && tap < A_PASSES) a_load(tap, ci + 1);
             const int toff = ((tap / 3) * HW_ + (tap % 3)) * ROWB;
-            const char* bs = Bs + (tap % 3) * C::B_BYTES + b_base;
+            const char* bs = Bs + ((ci + tap) & 1) * C::B_BYTES + b_base;  // step = 9 ci + tap: parity (ci + tap) & 1
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
                 typename H16::x8 fa[2], fb[C::TN];
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
             }
             // pass q is loaded at tap q and written one tap later (ra[q % 2] is free again before pass q + 2 loads)
             if (more_chunks && tap >= 1 && tap - 1 < A_PASSES) a_store(tap - 1, (ci + 1) & 1);
-            b_store((tap + 1) % 3, (tap + 1) % 2);  // ring slot = step % 3 (9 taps per chunk keep it aligned)
+            b_store((ci + tap + 1) & 1, (tap + 1) % 2);  // slice of step + 1 -> the buffer step - 1 read
             __syncthreads();
         }
         const float4 tsw = rb[0];

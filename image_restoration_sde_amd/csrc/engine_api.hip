@@ -634,13 +634,21 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         launch_fill_random(dfilm, (size_t)2 * Cout, 4, 0.3f, s);
         p.in0 = din; p.w = dw; p.out = dout; p.out_stride = Cout;
         unsigned short* dbf = nullptr;
-        if (variant >= 60 && variant <= 62) {  // bf16-MFMA mode: 60 = 256x256 tile, 61 = 128x128, 62 = automatic
+        if (variant >= 60 && variant <= 63) {  // bf16-MFMA mode: 60 = 256x256 tile, 61 = 128x128, 62 = automatic, 63 = automatic + bf16 activations
             IRSDE_HIP_CHECK(hipMalloc(&dbf, nw * 2));
             launch_f32_to_bf16(dw, dbf, nw, s);
             p.w_bf = dbf;
         }
         if (epi == 1) { p.film = dfilm; p.silu = 1; }
         if (epi == 2) { p.silu = 1; p.res = dres; p.res_stride = Cout; }
+        unsigned short* dabf = nullptr;
+        if (variant == 63) {  // bf16 activation storage (the output / residual buffers are simply twice the size needed)
+            IRSDE_HIP_CHECK(hipMalloc(&dabf, nin * 2));
+            launch_f32_to_bf16(din, dabf, nin, s);
+            launch_f32_to_bf16(dout, reinterpret_cast<unsigned short*>(dres), nout / 2, s);
+            p.in0 = reinterpret_cast<const float*>(dabf);
+            p.in_bf16 = 1; p.out_bf16 = 1;
+        }
         // 80: fused Winograd F(4x4,3x3) kernel; 81: the three-launch Winograd F(4x4,3x3) path (random U: timing only)
         float *dU = nullptr, *dV = nullptr, *dM = nullptr;
         WinoPlan wp{};
@@ -707,7 +715,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
                 launch_conv(p, s);
             }
         };
-        VariantScope vs(variant >= 80 ? 0 : variant);
+        VariantScope vs(variant >= 80 || variant == 63 ? 0 : variant);
         hipEvent_t e0, e1;
         IRSDE_HIP_CHECK(hipEventCreate(&e0));
         IRSDE_HIP_CHECK(hipEventCreate(&e1));
@@ -722,6 +730,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
         if (dbf) (void)hipFree(dbf);
+        if (dabf) (void)hipFree(dabf);
         for (float* q : {dU, dV, dM})
             if (q) (void)hipFree(q);
         (void)hipStreamDestroy(s);
