@@ -137,8 +137,8 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
     const int b_lds = brow * ROWB + bchunk * 16;
 
     float4 ra[2];  // halo pieces in flight (pass q lives in ra[q % 2])
-    float4 rb[2];  // weight slices in flight: the slice of K-step s+2 is loaded during step s (register slot = tap parity),
-                   // written during step s+1; 9 taps per chunk flip the parity, so the two slots are swapped per chunk
+    float4 rb0, rb1, rb2;  // weight slices in flight: the slice of K-step s+3 is loaded during step s (register slot = tap % 3; 9 taps
+                   // per chunk keep it aligned), written to LDS during step s+2: two K-steps of cover for an L2 round trip
     auto a_load = [&](int q, int chunk) {
         const int cc = chunk * 32;
         const float* src;
@@ -163,9 +163,9 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
     auto b_load = [&](int slot, int step) {  // step = chunk * 9 + tap; steps past the end re-read the last slice (unused)
         const int st = step < last_step ? step : last_step;
         const int chunk = st / 9, tap = st - chunk * 9;
-        rb[slot] = *reinterpret_cast<const float4*>(wrow + ((size_t)tap * Ctot + chunk * 32) * 2);
+        (slot == 0 ? rb0 : slot == 1 ? rb1 : rb2) = *reinterpret_cast<const float4*>(wrow + ((size_t)tap * Ctot + chunk * 32) * 2);
     };
-    auto b_store = [&](int ring, int slot) { *reinterpret_cast<float4*>(Bs + ring * C::B_BYTES + b_lds) = rb[slot]; };
+    auto b_store = [&](int ring, int slot) { *reinterpret_cast<float4*>(Bs + ring * C::B_BYTES + b_lds) = (slot == 0 ? rb0 : slot == 1 ? rb1 : rb2); };
 
     floatx16 acc[2][C::TN];
 #pragma unroll
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
     }
     b_load(0, 0);
     b_store(0, 0);
-    b_load(1, 1);  // slice of step 1: written to the ring during step 0
+    b_load(1, 1);  // slices of steps 1 and 2: written to LDS during steps 0 and 1
+    b_load(2, 2);
     __syncthreads();
 
     for (int ci = 0; ci < nch; ++ci) {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
         const char* ah = Ah + (ci & 1) * HALO_BYTES;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            b_load(tap % 2, ci * 9 + tap + 2);
+            b_load(tap % 3, ci * 9 + tap + 3);
             if (more_chunks && tap < A_PASSES) a_load(tap, ci + 1);
             const int toff = ((tap / 3) * HW_ + (tap % 3)) * ROWB;
             const char* bs = Bs + ((ci + tap) & 1) * C::B_BYTES + b_base;  // step = 9 ci + tap: parity (ci + tap) & 1
@@ -226,12 +227,9 @@ __global__ __launch_bounds__(NT, 4) void conv3x3_halo_bf16_kernel(const ConvPara
             }
             // pass q is loaded at tap q and written one tap later (ra[q % 2] is free again before pass q + 2 loads)
             if (more_chunks && tap >= 1 && tap - 1 < A_PASSES) a_store(tap - 1, (ci + 1) & 1);
-            b_store((ci + tap + 1) & 1, (tap + 1) % 2);  // slice of step + 1 -> the buffer step - 1 read
+            b_store((ci + tap + 1) & 1, (tap + 1) % 3);  // slice of step + 1 -> the buffer step - 1 read
             __syncthreads();
         }
-        const float4 tsw = rb[0];
-        rb[0] = rb[1];
-        rb[1] = tsw;
     }
 
     // ---- epilogue: 4 passes of 64 tile rows through LDS; bias -> FiLM -> SiLU -> +res, 16-byte stores ----
