@@ -146,7 +146,7 @@ void launch_layernorm_film(const float* x, const float* g, const float* scale, c
                            int64_t pixels_per_image, float* out, int64_t M, int C, float eps, hipStream_t s);
 // NAFNet: depthwise 3x3 (pad 1, bias) over u [B][H][W][2c] fused with SimpleGate -> out [B][H][W][c], plus per-tile
 // channel sums partial[b][tile][c] (deterministic two-stage global average pool).  w: [9][2c], bias: [2c].
-int dwgate_tiles(int HW);
+int dwgate_tiles(int H, int W, int c);  // tiles of launch_dwconv_gate = rows of its `partial` buffer per image
 void launch_dwconv_gate(const float* u, const float* w, const float* bias, float* out, float* partial, int B, int H, int W,
                         int c, hipStream_t s);
 // NAFNet SCA: s[b][o] = bias[o] + sum_k W[o][k] * mean_hw(gated)[b][k]

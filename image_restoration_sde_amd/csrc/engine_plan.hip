@@ -238,7 +238,7 @@ struct Builder {
         Tensor u = conv_naf(w.conv1, t1, ConvOpts());
         tfree(t1);
         Tensor gt = talloc(x.B, x.H, x.W, c);
-        const int nt = dwgate_tiles(x.H * x.W);
+        const int nt = dwgate_tiles(x.H, x.W, c);
         float* partial = pl->alloc((size_t)x.B * nt * c, true);
         float* sca = pl->alloc((size_t)x.B * c, true);
         float* mean = pl->alloc((size_t)x.B * c, true);

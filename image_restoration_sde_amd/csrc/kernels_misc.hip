@@ -1001,29 +1001,48 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // NAFNet (Refusion) — DenoisingNAFNet_arch.py:15-82
 // depthwise 3x3 (+bias) -> SimpleGate, with per-tile channel sums for the SCA global average pool.
-// Block = one tile of kDwTile pixels of one image; thread = (pixel lane, 4-channel group).
+// Tile = kDwRows image rows x (pixel lanes x kDwRun) columns of one image; thread = (pixel lane, 4-channel group): the
+// 2 x 9 depthwise weights of its channels live in registers, and the lane walks kDwRun columns to the right keeping a
+// (kDwRows + 2) x 3 register window per gate half: one new window column = 6 rows x 2 halves of 16-byte loads yields
+// kDwRows = 4 outputs, so every input row passes through the CU's L1 1.5 times (a one-row walk re-read it 3 times, and the
+// kernel ran at the ~13 B/clk a CU can pull from L2, not at HBM speed).  Consecutive lanes = consecutive channel groups:
+// each load instruction covers whole 128-byte lines.
 // ---------------------------------------------------------------------------------------------
-constexpr int kDwTile = 64;
+constexpr int kDwRows = 4;
+constexpr int kDwRun = 16;
 
-// Thread = (4-channel group g, pixel lane): the 2 x 9 depthwise weights of its channels live in registers; the lane walks
-// a run of CONSECUTIVE pixels keeping a 3x3 (x 2 halves) register window, so each new pixel costs 6 float4 loads.
+struct DwGeom {
+    int gpp, PP, tiles_x, tiles_y;
+};
+static inline DwGeom dw_geom(int H, int W, int c) {
+    DwGeom g;
+    const int G = c >> 2;
+    g.gpp = G < 256 ? G : 256;
+    g.PP = 256 / g.gpp;
+    g.tiles_x = (W + g.PP * kDwRun - 1) / (g.PP * kDwRun);
+    g.tiles_y = (H + kDwRows - 1) / kDwRows;
+    return g;
+}
+
 __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restrict__ u, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           float* __restrict__ partial, const int H, const int W,
-                                                          const int c, const int ntiles) {
+                                                          const int c, const int tiles_x, const int ntiles) {
     __shared__ float4 red[256];
+    constexpr int R = kDwRows;
     const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int HW = H * W;
     const int G = c >> 2;                        // float4 groups of gated channels
     const int gpp = G < 256 ? G : 256;           // groups handled per pass
     const int PP = 256 / gpp;                    // pixel lanes per pass
-    const int run = (kDwTile + PP - 1) / PP;     // consecutive pixels per lane
     const int C2 = 2 * c;
     for (int gc = 0; gc < G; gc += gpp) {
         const int g = gc + (int)(threadIdx.x % gpp);
         const int pl = threadIdx.x / gpp;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < G && pl < PP) {
+        const int y0 = ty * R, x0 = (tx * PP + pl) * kDwRun;
+        if (g < G && pl < PP && x0 < W) {
             const int ch = g * 4;
             const float4 b1 = *reinterpret_cast<const float4*>(bias + ch);
             const float4 b2 = *reinterpret_cast<const float4*>(bias + c + ch);
@@ -1039,43 +1058,51 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restric
                 if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return zero;
                 return *reinterpret_cast<const float4*>(ub + ((size_t)iy * W + ix) * C2 + half * c);
             };
-            float4 win1[3][3], win2[3][3];  // [ky][kx] window of the two gate halves
-            int wy = -2, wx = -2;           // pixel the window is centred on
-            const int p0 = tile * kDwTile + pl * run;
-            for (int pi = 0; pi < run; ++pi) {
-                const int pix = p0 + pi;
-                if (pix >= HW || pix >= (tile + 1) * kDwTile) break;
-                const int y = pix / W, x = pix - y * W;
-                if (y == wy && x == wx + 1) {  // slide right: reuse two columns
+            float4 win1[R + 2][3], win2[R + 2][3];  // [row y0 - 1 + r][column slot] of the two gate halves
+            // one step: the new column x + 1 goes to slot CN (the oldest), the outputs of column x use slots (CL, CM, CN)
+            auto step = [&](const int x, auto cl, auto cm, auto cn) {
+                constexpr int CL = decltype(cl)::value, CM = decltype(cm)::value, CN = decltype(cn)::value;
+#pragma unroll
+                for (int r = 0; r < R + 2; ++r) {
+                    win1[r][CN] = ld(y0 - 1 + r, x + 1, 0);
+                    win2[r][CN] = ld(y0 - 1 + r, x + 1, 1);
+                }
+#pragma unroll
+                for (int ro = 0; ro < R; ++ro) {
+                    const int y = y0 + ro;
+                    if (y >= H) break;
+                    float4 a1 = b1, a2 = b2;
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
-                        win1[ky][0] = win1[ky][1]; win1[ky][1] = win1[ky][2]; win1[ky][2] = ld(y + ky - 1, x + 1, 0);
-                        win2[ky][0] = win2[ky][1]; win2[ky][1] = win2[ky][2]; win2[ky][2] = ld(y + ky - 1, x + 1, 1);
-                    }
-                } else {
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                        const int slot[3] = {CL, CM, CN};
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
-                            win1[ky][kx] = ld(y + ky - 1, x + kx - 1, 0);
-                            win2[ky][kx] = ld(y + ky - 1, x + kx - 1, 1);
+                            const float4 v1 = win1[ro + ky][slot[kx]], v2 = win2[ro + ky][slot[kx]];
+                            const float4 q1 = w1[ky * 3 + kx], q2 = w2[ky * 3 + kx];
+                            a1.x = fmaf(v1.x, q1.x, a1.x); a1.y = fmaf(v1.y, q1.y, a1.y);
+                            a1.z = fmaf(v1.z, q1.z, a1.z); a1.w = fmaf(v1.w, q1.w, a1.w);
+                            a2.x = fmaf(v2.x, q2.x, a2.x); a2.y = fmaf(v2.y, q2.y, a2.y);
+                            a2.z = fmaf(v2.z, q2.z, a2.z); a2.w = fmaf(v2.w, q2.w, a2.w);
                         }
-                }
-                wy = y; wx = x;
-                float4 a1 = b1, a2 = b2;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float4 v1 = win1[ky][kx], v2 = win2[ky][kx], q1 = w1[ky * 3 + kx], q2 = w2[ky * 3 + kx];
-                        a1.x = fmaf(v1.x, q1.x, a1.x); a1.y = fmaf(v1.y, q1.y, a1.y);
-                        a1.z = fmaf(v1.z, q1.z, a1.z); a1.w = fmaf(v1.w, q1.w, a1.w);
-                        a2.x = fmaf(v2.x, q2.x, a2.x); a2.y = fmaf(v2.y, q2.y, a2.y);
-                        a2.z = fmaf(v2.z, q2.z, a2.z); a2.w = fmaf(v2.w, q2.w, a2.w);
                     }
-                const float4 o = make_float4(a1.x * a2.x, a1.y * a2.y, a1.z * a2.z, a1.w * a2.w);
-                *reinterpret_cast<float4*>(out + ((size_t)b * HW + pix) * c + ch) = o;
-                sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+                    const float4 o = make_float4(a1.x * a2.x, a1.y * a2.y, a1.z * a2.z, a1.w * a2.w);
+                    *reinterpret_cast<float4*>(out + ((size_t)b * HW + (size_t)y * W + x) * c + ch) = o;
+                    sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+                }
+            };
+#pragma unroll
+            for (int r = 0; r < R + 2; ++r) {  // columns x0 - 1 and x0 into slots 0 and 1: the first step loads slot 2
+                win1[r][0] = ld(y0 - 1 + r, x0 - 1, 0); win2[r][0] = ld(y0 - 1 + r, x0 - 1, 1);
+                win1[r][1] = ld(y0 - 1 + r, x0, 0);     win2[r][1] = ld(y0 - 1 + r, x0, 1);
+            }
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            const int xe = x0 + kDwRun < W ? x0 + kDwRun : W;
+            for (int x = x0; x < xe; x += 3) {  // three steps per iteration: the slot roles rotate at compile time
+                step(x, I0{}, I1{}, I2{});
+                if (x + 1 < xe) step(x + 1, I1{}, I2{}, I0{});
+                if (x + 2 < xe) step(x + 2, I2{}, I0{}, I1{});
             }
         }
         red[threadIdx.x] = sum;
@@ -1168,13 +1195,17 @@ void launch_layernorm_film(const float* x, const float* g, const float* scale, c
     launch_ln_t(x, g, (const float*)nullptr, out, M, C, eps, scale, shift, film_bstride, pixels_per_image, s);
 }
 
-int dwgate_tiles(int HW) { return (HW + kDwTile - 1) / kDwTile; }
+int dwgate_tiles(int H, int W, int c) {
+    const DwGeom g = dw_geom(H, W, c);
+    return g.tiles_x * g.tiles_y;
+}
 
 void launch_dwconv_gate(const float* u, const float* w, const float* bias, float* out, float* partial, int B, int H, int W,
                         int c, hipStream_t s) {
     if (c % 4) throw HipError("dwconv_gate: channel count must be a multiple of 4");
-    const int nt = dwgate_tiles(H * W);
-    hipLaunchKernelGGL(dwconv_gate_kernel, dim3(nt, B), dim3(256), 0, s, u, w, bias, out, partial, H, W, c, nt);
+    const DwGeom g = dw_geom(H, W, c);
+    const int nt = g.tiles_x * g.tiles_y;
+    hipLaunchKernelGGL(dwconv_gate_kernel, dim3(nt, B), dim3(256), 0, s, u, w, bias, out, partial, H, W, c, g.tiles_x, nt);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
