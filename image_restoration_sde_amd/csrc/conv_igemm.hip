@@ -615,6 +615,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
             set_tile_ptrs();
         }
     };
+    auto load_piece = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const bool first = kk < g.C0;  // wave-uniform: which concatenated source this K-step reads
+        if constexpr (q < C::A_PASSES)
+            rs[q] = *reinterpret_cast<const floatx4*>((first ? arow0[q] : arow1[q]) + kk);
+        else
+            rs[q] = *reinterpret_cast<const floatx4*>(brow[q - C::A_PASSES] + kk);
+    };
+    auto store_piece = [&](auto qc, int buf) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q < C::A_PASSES)
+            *reinterpret_cast<floatx4*>(As + (buf * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES + chunk * 16) = rs[q];
+        else
+            *reinterpret_cast<floatx4*>(Bs + (buf * BN + row0 + (q - C::A_PASSES) * C::B_ROWS) * C::ROW_BYTES + chunk * 16) = rs[q];
+    };
     auto load_all = [&]() {
         const bool first = kk < g.C0;  // wave-uniform: which concatenated source this K-step reads
         static_for<C::A_PASSES>([&](auto q) { rs[q()] = *reinterpret_cast<const floatx4*>((first ? arow0[q()] : arow1[q()]) + kk); });
@@ -675,34 +690,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
         const bool more = st + 1 < steps;
-        if (more) {
-            advance();
-            load_all();
-        }
+        if (more) advance();
         if (pending) {
             flush(fl_i, fl_o);
             pending = false;
         }
         const char* a = As + (buf * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
         const char* b = Bs + (buf * BN + wn * C::TN * 32 + l31) * C::ROW_BYTES + h * 16;
+        // Pinned schedule: 16 groups of TM x TN MFMAs (one k pair each); the fragments of the next 8-k sub-step are read
+        // while the current one multiplies, and ONE staging instruction rides behind each group — the loads of the next
+        // K-step behind groups 0..NP-1, their LDS writes behind groups 16-NP..15 (>= 8 groups = 2k MFMA cycles later).
+        // Left to itself hipcc puts all loads in front of the 64 MFMAs and all LDS writes behind them: the wave then spends
+        // ~3k of every ~7k cycles outside the matrix pipe (1 wave/SIMD: 0.55 MFMA-busy, profiles/r02_pmc_gemm_*.txt).
+        float4 fa[2][C::TM], fb[2][C::TN];
+        auto read_frags = [&](auto sbc) {
+            constexpr int sb = decltype(sbc)::value;
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
-            float4 fa[C::TM], fb[C::TN];
+            for (int i = 0; i < C::TM; ++i) fa[sb & 1][i] = *reinterpret_cast<const float4*>(a + i * 32 * C::ROW_BYTES + sb * 32);
 #pragma unroll
-            for (int i = 0; i < C::TM; ++i) fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * C::ROW_BYTES + sb * 32);
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j) fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * C::ROW_BYTES + sb * 32);
+            for (int j = 0; j < C::TN; ++j) fb[sb & 1][j] = *reinterpret_cast<const float4*>(b + j * 32 * C::ROW_BYTES + sb * 32);
+        };
+        read_frags(std::integral_constant<int, 0>{});
+        static_for<16>([&](auto gic) {
+            constexpr int gi = decltype(gic)::value, sb = gi >> 2, q = gi & 3, cur = sb & 1;
+            if constexpr (q == 0 && sb < 3) read_frags(std::integral_constant<int, sb + 1>{});
 #pragma unroll
             for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    const float av = q == 0 ? fa[cur][i].x : q == 1 ? fa[cur][i].y : q == 2 ? fa[cur][i].z : fa[cur][i].w;
+                    const float bv = q == 0 ? fb[cur][j].x : q == 1 ? fb[cur][j].y : q == 2 ? fb[cur][j].z : fb[cur][j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                 }
-        }
-        if (more) store_all(buf ^ 1);
+            // (unconditional: a branch around the staging instructions splits the K-step into basic blocks, and the wait
+            //  insertion then drains every load before the next one is issued.  The last K-step re-stages its own operands
+            //  into the buffer nobody reads any more.)
+            if constexpr (gi < NP) load_piece(std::integral_constant<int, gi>{});
+            if constexpr (gi >= 16 - NP) store_piece(std::integral_constant<int, gi - (16 - NP)>{}, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
         if (++kdone == nk) {  // tile finished
             kdone = 0;
             fl_i = cu_i; fl_o = cu_o;
