@@ -214,6 +214,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     // ---- staging pieces: A rows (A_PASSES) then B rows (B_PASSES), one 16-byte load each ----
     constexpr int NP = C::A_PASSES + C::B_PASSES;
     floatx4 rs[NP];  // (ext_vector: HIP's float4 struct copies become memcpys that can pin the array to scratch)
+    floatx4 rscale[INSCALE ? C::A_PASSES : 1];  // NAFNet SCA: the per-(image, channel) scales of the A pieces in flight
     constexpr int AESZ = ABF ? 2 : 4;        // bytes per activation element in HBM
     constexpr int ACE = 16 / AESZ;           // elements per 16-byte chunk
     const char* cur_src = nullptr;  // source pointer (+channel +chunk) of the K-step being staged
@@ -234,10 +235,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         if (q < C::A_PASSES) {
             // branch-free: out-of-image taps (zero padding, rows past M) read the zero page instead
             const char* g = a_poff[q] >= 0 ? cur_src + (size_t)a_poff[q] * cur_pix : reinterpret_cast<const char*>(p.zeros);
-            floatx4 v = *reinterpret_cast<const floatx4*>(g);
-            if (INSCALE)  // single source (C1 == 0)
-                v *= *reinterpret_cast<const floatx4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + chunk * 4);
-            rs[q] = v;
+            rs[q] = *reinterpret_cast<const floatx4*>(g);
+            if constexpr (INSCALE)  // single source (C1 == 0); multiplied when the piece is written to LDS (store_piece)
+                rscale[q < C::A_PASSES ? q : 0] = *reinterpret_cast<const floatx4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + chunk * 4);
         } else {
             rs[q] = *reinterpret_cast<const floatx4*>(wrow[q - C::A_PASSES] + cur_wk);
         }
@@ -248,9 +248,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
             if (ABF) {
                 *reinterpret_cast<floatx4*>(dst + chunk * 16) = rs[q];  // already bf16: 8 k per piece
             } else if (BF16) {
-                *reinterpret_cast<typename H16::x4*>(dst + chunk * 8) = __builtin_convertvector(rs[q], typename H16::x4);  // v_cvt_pk_bf16_f32 / v_cvt_f16_f32, RNE
+                floatx4 v = rs[q];
+                if constexpr (INSCALE) v *= rscale[q < C::A_PASSES ? q : 0];
+                *reinterpret_cast<typename H16::x4*>(dst + chunk * 8) = __builtin_convertvector(v, typename H16::x4);  // v_cvt_pk_bf16_f32 / v_cvt_f16_f32, RNE
             } else {
-                *reinterpret_cast<floatx4*>(dst + chunk * 16) = rs[q];
+                if constexpr (INSCALE)
+                    *reinterpret_cast<floatx4*>(dst + chunk * 16) = rs[q] * rscale[q < C::A_PASSES ? q : 0];
+                else
+                    *reinterpret_cast<floatx4*>(dst + chunk * 16) = rs[q];
             }
         } else {
             const int ps = q - C::A_PASSES;
@@ -284,14 +289,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         if (more) {
             advance();
             stage_setup();
-#pragma unroll
-            for (int q = 0; q < NP; ++q) load_piece(q);
         }
         const char* a = As + (buf * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
         const char* b = Bs + (buf * BN + wn * C::TN * 32 + l31) * C::ROW_BYTES + h * 16;
+        if constexpr (BF16) {
+            if (more) {
 #pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
-            if (BF16) {
+                for (int q = 0; q < NP; ++q) load_piece(q);
+            }
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) {
                 typename H16::x8 fa[C::TM], fb[C::TN];
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
@@ -304,28 +311,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j)
                         acc[i][j] = H16::mfma(fa[i], fb[j], acc[i][j]);
-            } else {
-                float4 fa[C::TM], fb[C::TN];
+            }
+            if (more) {
 #pragma unroll
-                for (int i = 0; i < C::TM; ++i)
-                    fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * C::ROW_BYTES + sb * 32);
+                for (int q = 0; q < NP; ++q) store_piece(q, buf ^ 1);
+            }
+        } else {
+            // f32: pinned schedule, as in gemm_zloop_kernel — 16 groups of TM x TN MFMAs (one k pair each), the next 8-k
+            // sub-step's fragments read while the current one multiplies, ONE staging instruction behind each group (the
+            // next K-step's loads behind groups 0..NP-1, their LDS writes behind groups 16-NP..15).  The staging is
+            // unconditional — a branch around it splits the K-step into basic blocks and the wait insertion then drains
+            // every load before the next is issued; the last K-step re-stages its own operands into the dead buffer.
+            static_assert(NP <= 8, "one staging slot per MFMA group");
+            float4 fa[2][C::TM], fb[2][C::TN];
+            auto read_frags = [&](auto sbc) {
+                constexpr int sb = decltype(sbc)::value;
 #pragma unroll
-                for (int j = 0; j < C::TN; ++j)
-                    fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * C::ROW_BYTES + sb * 32);
+                for (int i = 0; i < C::TM; ++i) fa[sb & 1][i] = *reinterpret_cast<const float4*>(a + i * 32 * C::ROW_BYTES + sb * 32);
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) fb[sb & 1][j] = *reinterpret_cast<const float4*>(b + j * 32 * C::ROW_BYTES + sb * 32);
+            };
+            read_frags(std::integral_constant<int, 0>{});
+            static_for<16>([&](auto gic) {
+                constexpr int gi = decltype(gic)::value, sb = gi >> 2, q = gi & 3, cur = sb & 1;
+                if constexpr (q == 0 && sb < 3) read_frags(std::integral_constant<int, sb + 1>{});
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                        const float av = q == 0 ? fa[cur][i].x : q == 1 ? fa[cur][i].y : q == 2 ? fa[cur][i].z : fa[cur][i].w;
+                        const float bv = q == 0 ? fb[cur][j].x : q == 1 ? fb[cur][j].y : q == 2 ? fb[cur][j].z : fb[cur][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                     }
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < NP; ++q) store_piece(q, buf ^ 1);
+                if constexpr (gi < NP) load_piece(gi);
+                if constexpr (gi >= 16 - NP) store_piece(gi - (16 - NP), buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
     };
 
