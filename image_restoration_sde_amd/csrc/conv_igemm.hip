@@ -99,7 +99,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // INSCALE: per-(batch, input channel) scale applied while staging (NAFNet SCA).  A template parameter, not a runtime
 // test: a branch inside the staging code makes the compiler wait for every load where the paths join, which
 // serialises the loads of a K-step and pulls the vmcnt(0) in front of the MFMAs.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD, bool BF16, bool INSCALE, bool ABF = false, bool F16 = false>
+// BUFA (f32 kernels): activations, weights and the SCA scale are read through buffer descriptors — per-thread 32-bit
+// offsets that change only with the tap / concat source, the K-step's channel offset in an SGPR — so a K-step's loads cost
+// no vector instruction.  On gfx950 the f32 MFMA shares the SIMD's vector ALU: vector instructions between MFMAs are paid
+// in full (4+ cycles each) plus ~16 cycles per MFMA they follow (tools/probe/mfma_valu_samewave.hip), and the pointer
+// arithmetic of the generic path was ~100 of them per K-step.  Needs every operand tensor < 2 GiB (launch_cfg checks).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD, bool BF16, bool INSCALE, bool ABF = false, bool F16 = false,
+          bool BUFA = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void conv_igemm_kernel(
     const ConvParams pin, const int nblk_n, const int M, const int nk_total) {
     using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16, ABF>;
@@ -183,6 +189,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         wrow[ps] = wbase + ((size_t)(n < p.Cout ? n : p.Cout - 1) * taps * Ctot) * WESZ + bchunk * 16;
     }
 
+    // BUFA: descriptors + per-thread offsets
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rA0, rA1, rW, rS;
+    [[maybe_unused]] unsigned a_voff[C::A_PASSES], b_voff[C::B_PASSES], s_voff[C::A_PASSES];
+    constexpr unsigned kOOB = 0x80000000u;
+    if constexpr (BUFA) {
+        const unsigned in0_bytes = (unsigned)((((long long)p.B * p.Hin * p.Win - 1) * p.pix0 + p.C0) * 4);
+        const unsigned in1_bytes = p.C1 ? (unsigned)((((long long)p.B * p.Hin * p.Win - 1) * p.pix1 + p.C1) * 4) : 0u;
+        rA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
+        rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.C1 ? p.in1 : p.in0), 0, in1_bytes, 0x00020000);
+        rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase), 0, (unsigned)((long long)p.Cout * taps * Ctot * WESZ), 0x00020000);
+        rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(INSCALE ? p.in_scale : p.in0), 0,
+                                               INSCALE ? (unsigned)((long long)p.B * p.C0 * 4) : 0u, 0x00020000);
+#pragma unroll
+        for (int ps = 0; ps < C::B_PASSES; ++ps) {
+            const int n = n0 + brow0 + ps * C::B_ROWS;
+            b_voff[ps] = (unsigned)(n < p.Cout ? n : p.Cout - 1) * (unsigned)(taps * Ctot * WESZ) + bchunk * 16;
+        }
+#pragma unroll
+        for (int ps = 0; ps < C::A_PASSES; ++ps) s_voff[ps] = (unsigned)(a_b[ps] * p.C0 + chunk * 4) * 4u;
+    }
+
     // ---- K-loop state: (tap, channel offset); per-tap pixel offsets of the staged rows ----
     int tap = kt_begin / steps_per_tap;
     int cc = (kt_begin - tap * steps_per_tap) * BK;
@@ -220,7 +247,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     const char* cur_src = nullptr;  // source pointer (+channel +chunk) of the K-step being staged
     int cur_pix = 0;                // bytes between consecutive pixels of that source
     size_t cur_wk = 0;  // byte offset of the K-step inside a weight row
-    auto stage_setup = [&]() {
+    [[maybe_unused]] int cur_c = 0;  // BUFA: byte offset of the K-step's channels inside a pixel of the current source
+    auto stage_setup = [&](const bool force_voff = false) {
         const float* src;
         int c;
         if (cc < p.C0) {
@@ -230,9 +258,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         }
         cur_src = reinterpret_cast<const char*>(src) + (size_t)(c + chunk * ACE) * AESZ;
         cur_wk = ((size_t)tap * Ctot + cc) * WESZ;
+        if constexpr (BUFA) {
+            cur_c = c * AESZ;
+            if (c == 0 || force_voff) {  // first K-step of a (tap, source): one burst of vector instructions, then none until the next one
+#pragma unroll
+                for (int ps = 0; ps < C::A_PASSES; ++ps)
+                    a_voff[ps] = a_poff[ps] >= 0 ? (unsigned)a_poff[ps] * (unsigned)cur_pix + (unsigned)(chunk * 16) : kOOB;
+            }
+        }
     };
     auto load_piece = [&](int q) {
-        if (q < C::A_PASSES) {
+        if constexpr (BUFA) {
+            if (q < C::A_PASSES) {  // out-of-image taps and rows past M: offset out of range, the descriptor returns zeros
+                rs[q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(cc < p.C0 ? rA0 : rA1, (int)a_voff[q < C::A_PASSES ? q : 0], cur_c, 0));
+                if constexpr (INSCALE)
+                    rscale[q < C::A_PASSES ? q : 0] =
+                        __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rS, (int)s_voff[q < C::A_PASSES ? q : 0], cc * 4, 0));
+            } else {
+                rs[q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)b_voff[q >= C::A_PASSES ? q - C::A_PASSES : 0], (int)cur_wk, 0));
+            }
+        } else if (q < C::A_PASSES) {
             // branch-free: out-of-image taps (zero padding, rows past M) read the zero page instead
             const char* g = a_poff[q] >= 0 ? cur_src + (size_t)a_poff[q] * cur_pix : reinterpret_cast<const char*>(p.zeros);
             rs[q] = *reinterpret_cast<const floatx4*>(g);
@@ -274,7 +319,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
 
     if (kt_begin < kt_end) {
         set_tap();
-        stage_setup();
+        stage_setup(true);  // (a split-K range may start in the middle of a tap)
 #pragma unroll
         for (int q = 0; q < NP; ++q) load_piece(q);
 #pragma unroll
@@ -323,6 +368,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
             // unconditional — a branch around it splits the K-step into basic blocks and the wait insertion then drains
             // every load before the next is issued; the last K-step re-stages its own operands into the dead buffer.
             static_assert(NP <= 8, "one staging slot per MFMA group");
+            // LDS write addresses of this K-step's pieces: formed here, in the vector-instruction burst in front of the
+            // first MFMA; the stores behind the MFMA groups then only add immediates
+            char* const st_a = As + ((buf ^ 1) * BM + row0) * C::ROW_BYTES + chunk * 16;
+            char* const st_b = Bs + ((buf ^ 1) * BN + brow0) * C::ROW_BYTES + bchunk * 16;
+            auto store_piece_f32 = [&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                if constexpr (q < C::A_PASSES) {
+                    if constexpr (INSCALE)
+                        *reinterpret_cast<floatx4*>(st_a + q * C::A_ROWS * C::ROW_BYTES) = rs[q] * rscale[q < C::A_PASSES ? q : 0];
+                    else
+                        *reinterpret_cast<floatx4*>(st_a + q * C::A_ROWS * C::ROW_BYTES) = rs[q];
+                } else {
+                    constexpr int ps = q - C::A_PASSES;
+                    if (C::B_PASSES * C::B_ROWS == BN || brow0 + ps * C::B_ROWS < BN)
+                        *reinterpret_cast<floatx4*>(st_b + ps * C::B_ROWS * C::ROW_BYTES) = rs[q];
+                }
+            };
             float4 fa[2][C::TM], fb[2][C::TN];
             auto read_frags = [&](auto sbc) {
                 constexpr int sb = decltype(sbc)::value;
@@ -344,7 +406,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                     }
                 if constexpr (gi < NP) load_piece(gi);
-                if constexpr (gi >= 16 - NP) store_piece(gi - (16 - NP), buf ^ 1);
+                if constexpr (gi >= 16 - NP) store_piece_f32(std::integral_constant<int, gi - (16 - NP)>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -644,13 +706,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
         else
             rs[q] = *reinterpret_cast<const floatx4*>(brow[q - C::A_PASSES] + kk);
     };
-    auto store_piece = [&](auto qc, int buf) {
-        constexpr int q = decltype(qc)::value;
-        if constexpr (q < C::A_PASSES)
-            *reinterpret_cast<floatx4*>(As + (buf * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES + chunk * 16) = rs[q];
-        else
-            *reinterpret_cast<floatx4*>(Bs + (buf * BN + row0 + (q - C::A_PASSES) * C::B_ROWS) * C::ROW_BYTES + chunk * 16) = rs[q];
-    };
     auto load_all = [&]() {
         const bool first = kk < g.C0;  // wave-uniform: which concatenated source this K-step reads
         static_for<C::A_PASSES>([&](auto q) { rs[q()] = *reinterpret_cast<const floatx4*>((first ? arow0[q()] : arow1[q()]) + kk); });
@@ -723,6 +778,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
         // K-step behind groups 0..NP-1, their LDS writes behind groups 16-NP..15 (>= 8 groups = 2k MFMA cycles later).
         // Left to itself hipcc puts all loads in front of the 64 MFMAs and all LDS writes behind them: the wave then spends
         // ~3k of every ~7k cycles outside the matrix pipe (1 wave/SIMD: 0.55 MFMA-busy, profiles/r02_pmc_gemm_*.txt).
+        char* const st_a = As + ((buf ^ 1) * BM + row0) * C::ROW_BYTES + chunk * 16;  // LDS write addresses, formed once per K-step
+        char* const st_b = Bs + ((buf ^ 1) * BN + row0) * C::ROW_BYTES + chunk * 16;
+        auto store_piece_at = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q < C::A_PASSES)
+                *reinterpret_cast<floatx4*>(st_a + q * C::A_ROWS * C::ROW_BYTES) = rs[q];
+            else
+                *reinterpret_cast<floatx4*>(st_b + (q - C::A_PASSES) * C::B_ROWS * C::ROW_BYTES) = rs[q];
+        };
         float4 fa[2][C::TM], fb[2][C::TN];
         auto read_frags = [&](auto sbc) {
             constexpr int sb = decltype(sbc)::value;
@@ -747,7 +811,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
             //  insertion then drains every load before the next one is issued.  The last K-step re-stages its own operands
             //  into the buffer nobody reads any more.)
             if constexpr (gi < NP) load_piece(std::integral_constant<int, gi>{});
-            if constexpr (gi >= 16 - NP) store_piece(std::integral_constant<int, gi - (16 - NP)>{}, buf ^ 1);
+            if constexpr (gi >= 16 - NP) store_piece_at(std::integral_constant<int, gi - (16 - NP)>{});
             __builtin_amdgcn_sched_barrier(0);
         });
         if (++kdone == nk) {  // tile finished
@@ -866,6 +930,8 @@ __global__ void conv_naive_kernel(const ConvParams p, const int M) {
     p.out[(size_t)m * p.out_stride + n] = v;
 }
 
+int g_variant = 0;  // tuning experiments only (irsde_bench_conv); 6 = generic pointer staging instead of buffer descriptors
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false, bool ABF = false, bool F16 = false>
 void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds_override = 0) {
     using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16, ABF>;
@@ -873,6 +939,14 @@ void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds
         if (p.f16) return launch_cfg<BM, BN, WAVES_M, WAVES_N, MINW, true, INSCALE, false, true>(p, M, nk_total, s, lds_override);
     }
     auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE, ABF, F16>;
+    if constexpr (!BF16) {  // f32: the buffer-descriptor staging when every operand tensor is below 2 GiB
+        const long long npix = (long long)p.B * p.Hin * p.Win;
+        const long long e0 = ((npix - 1) * p.pix0 + p.C0) * 4, e1 = p.C1 ? ((npix - 1) * p.pix1 + p.C1) * 4 : 0;
+        const long long ew = (long long)p.Cout * p.KH * p.KW * (p.C0 + p.C1) * 4;
+        static const int nobuf = tuning_env_int("IRSDE_NO_BUFA", 0);
+        if (!nobuf && e0 < (1ll << 31) && e1 < (1ll << 31) && ew < (1ll << 31) && g_variant != 6)
+            kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, BF16, INSCALE, ABF, F16, true>;
+    }
     const int nblk_m = (M + BM - 1) / BM;
     const int nblk_n = (p.Cout + BN - 1) / BN;
     dim3 grid(nblk_m * nblk_n, p.splits, p.nz);
@@ -889,9 +963,12 @@ void init_cfg() {
         IRSDE_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, true, INSCALE, false, true>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if constexpr (!BF16)  // the buffer-descriptor twin of every f32 kernel
+        IRSDE_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, false, INSCALE, false, false, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
-int g_variant = 0;  // tuning experiments only (irsde_bench_conv)
 
 // 1x1 convolutions with a short K on the tile-loop kernel: row tiles per block, or 0 = generic kernel.
 int zloop_1x1_rows(const ConvParams& p) {
