@@ -83,7 +83,7 @@ struct Cfg {
     static_assert(BN % B_ROWS == 0 || BN < B_ROWS, "tile/pass mismatch");
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return silu_hw(v); }
 
 // compile-time loop: the index is a constant already in the front end, so register arrays indexed by it are promoted to
 // registers no matter when the optimiser unrolls (a `#pragma unroll` loop over a staging array inside a lambda was

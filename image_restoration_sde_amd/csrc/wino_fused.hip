@@ -39,7 +39,7 @@ constexpr int WF_VBUF = 36 * WF_ZS;        // floats per V buffer (78 336 B)
 constexpr int WF_LDS_BYTES = 2 * WF_VBUF * 4;
 constexpr unsigned WF_OOB = 0x80000000u;   // voffset of a tap that must read 0 (tensors are < 2 GiB, checked at launch)
 
-__device__ __forceinline__ float silu_w(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_w(float v) { return silu_hw(v); }
 
 // B^T of F(4x4,3x3) along one axis (same matrix as wino.hip), 14 packed operations with explicit FMAs: the producer's vector
 // instructions compete with the f32 MFMAs of the wave that shares its SIMD (the f32 matrix rate IS the vector FMA rate), so
