@@ -128,17 +128,13 @@ bool conv_halo_eligible(const ConvParams& p);
 void launch_conv_halo(const ConvParams& p, hipStream_t s);
 void conv_set_variant(int v);  // tuning experiments (irsde_bench_conv)
 void launch_fill_random(float* p, size_t n, unsigned seed, float scale, hipStream_t s);  // sets the dynamic-LDS attribute of every tile configuration (call before graph capture)
-// SiLU for the epilogues of the f32 MFMA kernels: v_exp_f32 + v_rcp_f32 + one Newton step — 8 vector instructions instead
-// of the ~25 of expf() + IEEE division.  On gfx950 the vector instructions of an f32-MFMA kernel are paid in matrix-pipe time
+// SiLU for the epilogues of the f32 MFMA kernels: v_exp_f32 + v_rcp_f32 (1 ulp each) — 5 vector instructions instead of the
+// ~25 of expf() + IEEE division.  On gfx950 the vector instructions of an f32-MFMA kernel are paid in matrix-pipe time
 // (tools/probe/mfma_valu_*.hip); the epilogue SiLU was a third of the fused Winograd kernel's vector instructions.
 // |result - v / (1 + exp(-v))| <= ~3e-7 |result| (the exponent product adds |v| 2^-24 relative to e^-v, which only matters
-// where SiLU itself is ~0); the clamp keeps 1 + e^-v finite so the Newton step never sees inf * 0.
+// where SiLU itself is ~0); e^-v = inf gives v * 0.
 __device__ __forceinline__ float silu_hw(const float v) {
-    const float e = __builtin_amdgcn_exp2f(fminf(v * -1.44269504088896341f, 126.0f));
-    const float d = 1.0f + e;
-    float r = __builtin_amdgcn_rcpf(d);
-    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    return v * r;
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 }
 
 void launch_f32_to_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);  // round-to-nearest-even
