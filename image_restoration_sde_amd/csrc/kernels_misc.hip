@@ -382,14 +382,26 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) ctx[r] *= __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
         }
+        // exp(k - m) for the whole tile FIRST (one fma + v_exp_f32 per element, in place), then the 64 MFMAs back to back:
+        // a vector instruction between two f32 MFMAs costs its own time plus ~16 cycles (tools/probe/mfma_valu_samewave.hip),
+        // and expf() in front of every MFMA (~17 instructions) made each of them cost ~150 cycles instead of 64.  The common
+        // factor 2^(-m log2e) carries one rounding of m log2e; it is the same for every pixel of channel d and cancels
+        // against ssum.  exp2(-inf) = 0 for the masked pixels.
+        {
+            const float ml = mrun * 1.44269504088896341f;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    ak[rt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(ak[rt][r], 1.44269504088896341f, -ml));
+                    ssum += ak[rt][r];
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = expf(ak[rt][r] - mrun);  // exp(-inf) = 0 for the masked pixels
-                ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(e, av[rt][r], ctx, 0, 0, 0);
-                ssum += e;
-            }
+            for (int r = 0; r < 16; ++r) ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rt][r], av[rt][r], ctx, 0, 0, 0);
         __syncthreads();  // every wave is done with the tile in LDS
     }
     ssum += __shfl_xor(ssum, 32, 64);
@@ -583,9 +595,10 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
         for (int r = 1; r < 16; ++r) m = fmaxf(m, q[ct][r]);
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float z = 0.f;
+        const float ml = m * 1.44269504088896341f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            q[ct][r] = expf(q[ct][r] - m);
+            q[ct][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(q[ct][r], 1.44269504088896341f, -ml));  // (the factor of m's rounding cancels in / z)
             z += q[ct][r];
         }
         z += __shfl_xor(z, 32, 64);
