@@ -742,21 +742,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
         const int ncols = g.col_step ? g.n_inner * g.col_step : BN;
         for (int c = tid; c < ncols; c += C::NT) bias_s[c] = (n0 + c < g.N) ? g.bias[n0 + c] : 0.f;
     }
+    // Tile write-back: buffer stores with per-thread offsets formed ONCE (row pattern of the MFMA accumulator x ldc) and
+    // the (i, j) sub-tile position in an SGPR; rows past M fall outside the descriptor and are dropped by the hardware.
+    // (With 64-bit index arithmetic and two compares per element the 64 stores of a tile cost ~300 vector instructions —
+    // more than the K loop of a short-K tile, and vector instructions are paid in f32-MFMA time.)
+    const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
+    unsigned o_voff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_voff[r] = (unsigned)(((r & 3) + 8 * (r >> 2) + 4 * h) * g.ldc + l31) * 4u;
     auto flush = [&](int fi, int fo) {
-        const int rowb = m0 + fo * g.row_step, colb = n0 + fi * g.col_step;
-        float* oz = g.out + (long long)(plane0 + (g.col_step ? 0 : fi)) * g.pO;
+        const int rowb = m0 + fo * g.row_step + wm_s * C::TM * 32, colb = n0 + fi * g.col_step + wn_s * C::TN * 32;
+        float* ob = g.out + (long long)(plane0 + (g.col_step ? 0 : fi)) * g.pO + (long long)rowb * g.ldc;
+        const int rows = g.M - rowb;  // valid rows of this wave's C::TM * 32
+        const unsigned nrec = rows <= 0 ? 0u : (unsigned)(rows < C::TM * 32 ? rows : C::TM * 32) * (unsigned)g.ldc * 4u;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, nrec, 0x00020000);
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
 #pragma unroll
             for (int j = 0; j < C::TN; ++j) {
-                const int col = colb + wn * C::TN * 32 + j * 32 + l31;
-                const float bvj = g.bias ? bias_s[col - n0] : 0.f;
+                const int colu = colb + j * 32;
+                const float bvj = g.bias ? bias_s[colu + l31 - n0] : 0.f;
+                if (colu + l31 < g.N) {
+                    const int soff = (i * 32 * g.ldc + colu) * 4;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rowb + wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < g.M && col < g.N) oz[(size_t)row * g.ldc + col] = acc[i][j][r] + bvj;
-                    acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r] + bvj), ro, (int)o_voff[r], soff, 0);
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
     };
     int kdone = 0;          // K-steps finished inside the current tile
