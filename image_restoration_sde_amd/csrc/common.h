@@ -79,6 +79,7 @@ struct ConvParams {
     // batched launch (Winograd: 16 independent GEMMs): blockIdx.z = k offsets the three tensors (floats)
     int nz = 1;
     long long z_in = 0, z_w = 0, z_out = 0;
+    int no_direct_epi = 0;  // tuning (irsde_bench_conv variant 7 / IRSDE_NO_DIRECT_EPI): LDS-transposed epilogue in the f32 BUFA kernels too
     // bf16 activation storage (IRSDE_FLAG_BF16_ACT, bf16-MFMA kernels only): in0/in1 resp. out/res point at bf16 tensors
     // (strides in elements); accumulation and the epilogue arithmetic stay fp32
     int in_bf16 = 0, out_bf16 = 0;

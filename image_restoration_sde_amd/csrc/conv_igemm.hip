@@ -417,6 +417,64 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         __syncthreads();
     }
 
+    // ---- direct epilogue (BUFA kernels, plain output layouts): straight from the accumulator registers through buffer
+    // descriptors, like gemm_zloop_kernel's write-back.  An MFMA register holds 2 rows x 32 consecutive columns: a store
+    // (and a residual load) covers two full 128-byte lines; the per-thread offsets are formed once, the sub-tile position
+    // goes in an SGPR, rows past M fall outside the descriptor.  bias -> FiLM (one row for the batch) -> SiLU -> channel
+    // scale -> + residual, per column = per lane.  No LDS round trip, no per-row index arithmetic: ~4 vector instructions
+    // per output instead of ~10 (vector instructions are paid in f32-MFMA time on gfx950).
+    if constexpr (BUFA) {
+        if (p.splits == 1 && !p.ln_g && !p.gate && !p.shuffle && !(p.film && p.film_bstride != 0) && !p.out_bf16 && !p.no_direct_epi) {
+            const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
+            const int rowb = m0 + wm_s * C::TM * 32, colb = n0 + wn_s * C::TN * 32;
+            const int rows = M - rowb;
+            const unsigned nrows = rows <= 0 ? 0u : (unsigned)(rows < C::TM * 32 ? rows : C::TM * 32);
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out + (long long)rowb * p.out_stride, 0,
+                                                                                nrows * (unsigned)p.out_stride * 4u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.res ? p.res + (long long)rowb * p.res_stride : p.out), 0,
+                p.res ? nrows * (unsigned)p.res_stride * 4u : 0u, 0x00020000);
+            unsigned o_voff[16], r_voff[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro_ = (r & 3) + 8 * (r >> 2) + 4 * h;
+                o_voff[r] = (unsigned)(ro_ * p.out_stride + l31) * 4u;
+                r_voff[r] = (unsigned)(ro_ * p.res_stride + l31) * 4u;
+            }
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) {
+                const int colu = colb + j * 32, col = colu + l31;
+                const bool ok = col < p.Cout;
+                const int cc_ = ok ? col : 0;
+                const float bj = p.bias ? p.bias[cc_] : 0.f;
+                const float scj = p.film ? p.film[cc_] + 1.0f : 1.0f, shj = p.film ? p.film[p.Cout + cc_] : 0.f;
+                const float csj = p.ch_scale ? p.ch_scale[cc_] : 1.0f;
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) {
+                    float rv[16];
+                    if (p.res) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)r_voff[r], (i * 32 * p.res_stride + colu) * 4, 0));
+                    }
+                    if (ok) {
+                        const int soff = (i * 32 * p.out_stride + colu) * 4;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float t = acc[i][j][r] + bj;
+                            if (p.film) t = t * scj + shj;
+                            if (p.silu) t = silu_f(t);
+                            if (p.ch_scale) t *= csj;
+                            if (p.res) t += rv[r];
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), ro, (int)o_voff[r], soff, 0);
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+
     // ---- epilogue: transpose the accumulators through LDS (A/B buffers are dead after the last barrier) ----
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cs = smem;
@@ -963,7 +1021,10 @@ void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds
     const int nblk_m = (M + BM - 1) / BM;
     const int nblk_n = (p.Cout + BN - 1) / BN;
     dim3 grid(nblk_m * nblk_n, p.splits, p.nz);
-    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds_override ? lds_override : C::LDS_BYTES, s, p, nblk_n, M, nk_total);
+    ConvParams pk = p;
+    static const int no_direct = tuning_env_int("IRSDE_NO_DIRECT_EPI", 0);
+    if (no_direct || g_variant == 7) pk.no_direct_epi = 1;
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds_override ? lds_override : C::LDS_BYTES, s, pk, nblk_n, M, nk_total);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
