@@ -15,9 +15,11 @@
 //              (out-of-image taps, tiles past the edge: out-of-range offset -> hardware returns 0;
 //              concat sources and the fused nearest x2 upsample are resolved in the row / column offsets), B^T d B in
 //              registers, ds_write_b64 into the V buffer of the NEXT chunk (double buffer, one barrier per chunk).
-// The matrix pipe runs the MFMA wave of each SIMD while the producer wave of the same SIMD uses the vector / LDS / memory
-// pipes.  Epilogue (all 8 waves): accumulators -> LDS in two passes of 16 tiles, thread = (tile, cout): A^T M A,
-// bias -> FiLM -> SiLU -> +residual, 16 output pixels.
+// The MFMA wave of each SIMD has no vector instruction in its K loop; the producer wave of the same SIMD overlaps its loads,
+// LDS writes and waits with the MFMAs, but NOT its transform arithmetic: on gfx950 an f32 MFMA and the vector instructions of
+// the other wave on the SIMD serialise (tools/probe/mfma_valu_overlap.hip), which is what holds the kernel at ~0.5 MFMA-busy.
+// Epilogue (all 8 waves): accumulators -> LDS (one pass), thread = (tile, 4 couts, row pair): A^T M A,
+// bias -> FiLM -> SiLU -> +residual, 16-byte stores.
 //
 // Arithmetic is exact fp32 (f32 MFMA = fmaf chain); the result differs from wino.hip's only in summation order.
 #include "common.h"
@@ -233,10 +235,11 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams 
         // =============================== producer waves ===============================
         // lane = (tile column, channel pair of the 16-channel chunk).  Per chunk: column pass of the 6x6 patch (consumes the
         // patch registers), the 36 loads of the NEXT chunk into the same registers, row pass + 36 ds_write_b64.
-        // (Measured alternatives, profiles/r02_wino_fused_notes.md: two chunks of loads in flight, full-line dwordx4 loads,
-        // scalar per-channel transforms, wave priorities — none faster: every VMEM / DS-write instruction issued on a SIMD
-        // costs its MFMA wave ~50 cycles of matrix-pipe time, whichever wave issues it, and their count per chunk is fixed by
-        // the 36-pixel patch.)
+        // (Measured alternatives, profiles/r02_wino_fused_notes.md: two chunks of loads in flight, full-line / quad-channel
+        // dwordx4 loads, 16 loads for the fused-upsample layers, scalar per-channel transforms, wave priorities, a second
+        // barrier separating the transform from the MFMA phase — none faster.  What bounds the period: this wave's ~200 vector
+        // instructions per chunk and the 72 f32 MFMAs of the wave it shares the SIMD with do not overlap
+        // (tools/probe/mfma_valu_overlap.hip), so every instruction below is matrix-pipe time.)
         if (dflags & 4) __builtin_amdgcn_s_setprio(2);  // tuning aid
         const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc1 =
