@@ -119,6 +119,7 @@ void wino_fused_pack_weights(const float* U, int Cout, int Cin, float* Uf);  // 
 void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s, unsigned long long* dbg = nullptr, int dflags = 0);
 int wino_fused_num_blocks(const ConvParams& p);
 void wino_fused_global_init();
+void attention_global_init();
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)
 void launch_conv(const ConvParams& p, hipStream_t s);
@@ -183,7 +184,7 @@ void launch_linear_attention(const float* qkv, float* out, int B, int N, const A
 void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s,
                                  const float* ln_g = nullptr, float ln_eps = 1e-5f);
 void launch_attention_q_out(const float* q, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s);
-// C = 64 / 128: q projection, softmax over d, context product, to_out (+ bias), LayerNorm (* g2) and the residual in one
+// C = 64 / 128 / 256: q projection, softmax over d, context product, to_out (+ bias), LayerNorm (* g2) and the residual in one
 // kernel: y = LayerNorm(Wout . (ctx^T softmax(Wq . xn)) + bias) * g2 + x.  wq = rows 0..127 of to_qkv.weight ([128][C]),
 // wout = to_out.0.weight ([C][128]); needs ws.ctx from launch_attention_kv_context.
 void launch_attention_q_out_fused(const float* xn, const float* x, const float* wq, const float* wout, const float* bias,

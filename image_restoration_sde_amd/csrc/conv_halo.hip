@@ -9,11 +9,11 @@
 // 8 waves = 4 (pixel rows of 64) x 2 (BN/2 channels), each 2 x TN tiles of v_mfma_f32_32x32x16_bf16, fp32 accumulate.
 // LDS rows are 32 bf16 + 16 B pad (80 B: an odd number of 16-byte slots => conflict-free ds_read_b128, as in
 // conv_igemm.hip); lane half h owns the second 16 bytes of each 32-byte group for A and B alike.
-// Pipeline: the weight slice of K-step s+2 and one sixth of the next chunk's halo are loaded before the MFMAs of step s
-// and written to LDS (2 slice buffers, 2 halo buffers) after the MFMAs of step s+1: a full K-step of cover for the
-// loads; one barrier per tap.  The slice of step s+2 goes to the buffer step s read: every wave is past the barrier that
-// ended step s by then.  Two slice buffers (not three) keep BN = 128 at 72,320 B of LDS: two blocks per CU, so one
-// block's barrier stalls are covered by the other's MFMAs.
+// Pipeline: three weight slices in flight — the slice of K-step s+3 and one sixth of the next chunk's halo are loaded
+// before the MFMAs of step s and written to LDS (2 slice buffers, 2 halo buffers) after the MFMAs of step s+2; one barrier
+// per tap.  The slice stored at step s+2 goes to the buffer step s+1 read: every wave is past the barrier that ended that
+// step by then.  Two slice buffers (not three) keep BN = 128 at 72,320 B of LDS: two blocks per CU, so one block's
+// barrier stalls are covered by the other's MFMAs.
 #include "common.h"
 
 namespace irsde {

@@ -88,7 +88,7 @@ int guard(const std::function<void()>& f) {
 extern "C" {
 
 const char* irsde_last_error(void) { return g_last_error.c_str(); }
-int irsde_version(void) { return 100; }
+int irsde_version(void) { return 102; }  // changelog: include/irsde_hip.h
 
 int irsde_create(const irsde_config* cfg, irsde_engine** out) {
     return guard([&] {
@@ -286,20 +286,17 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
         if (T < 0) T = e->T;
         if (T > e->T) throw HipError("sample: T exceeds the schedule length");
         if (B < 1 || H < 2 || W < 2) throw HipError("sample: bad shape");
-        if (T == 0) {
-            // the reference's `for t in reversed(range(1, T + 1))` runs zero steps and returns the clone of xt
-            // (e.g. reverse_ode(x, T=sde.get_optimal_timestep(sigma)) when the argmin is index 0)
-            if (t_stop != 0) throw HipError("sample: t_stop must be in [0, T)");
-            DeviceScope dev0(e->cfg.device);
-            hipStream_t user0 = reinterpret_cast<hipStream_t>(stream);
-            IRSDE_HIP_CHECK(hipMemcpyAsync(out, xT, (size_t)B * e->cfg.in_nc * H * W * 4, hipMemcpyDeviceToDevice, user0));
-            return;
-        }
-        if (t_stop < 0 || t_stop >= T) throw HipError("sample: t_stop must be in [0, T)");
+        if (t_stop < 0 || (T > 0 && t_stop >= T) || (T == 0 && t_stop != 0)) throw HipError("sample: t_stop must be in [0, T)");
         const int nsteps = T - t_stop;
         std::lock_guard<std::mutex> lk(e->mu);
         DeviceScope dev_scope(e->cfg.device);
         hipStream_t user = reinterpret_cast<hipStream_t>(stream);
+        if (T == 0) {
+            // the reference's `for t in reversed(range(1, T + 1))` runs zero steps and returns the clone of xt
+            // (e.g. reverse_ode(x, T=sde.get_optimal_timestep(sigma)) when the argmin is index 0)
+            IRSDE_HIP_CHECK(hipMemcpyAsync(out, xT, (size_t)B * e->cfg.in_nc * H * W * 4, hipMemcpyDeviceToDevice, user));
+            return;
+        }
         Plan* pl = get_plan(e, B, H, W, false);
         hipStream_t s = e->stream;
         const bool profile = (flags & IRSDE_SAMPLE_PROFILE) != 0;

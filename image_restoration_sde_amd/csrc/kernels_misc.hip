@@ -1259,6 +1259,19 @@ static void linear_attention_t(const T* qkv, T* out, int B, int N, const AttnWor
                        qkv, ws.ctx, out, N, kQkv);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
+// > 64 KB of dynamic LDS needs the attribute on the CURRENT device: called from conv_global_init() (engine finalize, per
+// engine and so per device, outside any stream capture) like every other kernel of the library
+void attention_global_init() {
+#define IRSDE_KV_ATTR(CC) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    IRSDE_KV_ATTR(32); IRSDE_KV_ATTR(64); IRSDE_KV_ATTR(96); IRSDE_KV_ATTR(128); IRSDE_KV_ATTR(160); IRSDE_KV_ATTR(192); IRSDE_KV_ATTR(224); IRSDE_KV_ATTR(256);
+#undef IRSDE_KV_ATTR
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<64>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<128>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<256>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
 // fp32 fused form: context from xn and the k / v weight rows (attn_kv_ctx_kernel), then q (its own [B][N][128] tensor) -> out
 void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s,
                                  const float* ln_g, float ln_eps) {
@@ -1267,13 +1280,6 @@ void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N
     const int len = attn_chunk_len(N);
     const int nch = attn_num_chunks(N);
     if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
-    static bool attr_set = false;
-    if (!attr_set) {
-#define IRSDE_KV_ATTR(CC) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        IRSDE_KV_ATTR(32); IRSDE_KV_ATTR(64); IRSDE_KV_ATTR(96); IRSDE_KV_ATTR(128); IRSDE_KV_ATTR(160); IRSDE_KV_ATTR(192); IRSDE_KV_ATTR(224); IRSDE_KV_ATTR(256);
-#undef IRSDE_KV_ATTR
-        attr_set = true;
-    }
     const size_t lds = (size_t)kKvTile * (C + 4) * sizeof(float);
 #define IRSDE_KV_LAUNCH(CC) hipLaunchKernelGGL(attn_kv_ctx_kernel<CC>, dim3(nch, B), dim3(256), lds, s, xn, wkv, ws.pmax, ws.pctx, ws.psum, N, len, nch, ln_g, ln_eps)
     switch (C) {
@@ -1299,22 +1305,12 @@ void launch_attention_q_out(const float* q, float* out, int B, int N, const Attn
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-// y = LayerNorm(to_out(softmax(q) . ctx)) * g + x with q = Wq . xn computed in the kernel (C = 64 or 128)
+// y = LayerNorm(to_out(softmax(q) . ctx)) * g + x with q = Wq . xn computed in the kernel (C = 64, 128 or 256)
 void launch_attention_q_out_fused(const float* xn, const float* x, const float* wq, const float* wout, const float* bias,
                                   const float* g2, float* y, int B, int N, int C, float eps, const AttnWorkspace& ws, hipStream_t s,
                                   const float* ln_g) {
     if (C != 64 && C != 128 && C != 256) throw HipError("attention_q_out_fused: C must be 64, 128 or 256");
     const size_t lds = (size_t)128 * ((C > kHid ? C : kHid) + 4) * sizeof(float);  // one region: max(xn tile, out tile)
-    static bool attr_set = false;
-    if (!attr_set) {
-        IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<64>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<128>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<256>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     const dim3 grid((N + 127) / 128, B);
     if (C == 64)
         hipLaunchKernelGGL(attn_q_out_fused_kernel<64>, grid, dim3(256), lds, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g);

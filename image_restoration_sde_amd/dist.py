@@ -40,8 +40,9 @@ def sample_shard(sde, mode, x_local, mu_local, lo, n_items, group=None, **kwargs
     """Run `sde.reverse_<mode>` on THIS rank's shard (images [lo, lo + len(x_local)) of a global batch of `n_items`)
     and all_gather the restored global batch.  Only the shard has to be resident on the rank.  The noise streams are
     keyed by the global image index (`sde.image_offset` is set to its current value + lo for the call), so the result
-    equals one single-GPU call on the whole batch.  This is the one N>1 code path: `sample_sharded`, `bench.py --gpus N`
-    and `tools/eval_folder.py` all go through it."""
+    equals one single-GPU call on the whole batch.  This is the one N>1 sampling path: `sample_sharded` and
+    `bench.py --gpus N` go through it (`tools/eval_folder.py --gpus N` shards its FILE LIST over the ranks instead and only
+    all_reduces the metric sums)."""
     fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[mode]
     old_off, old_mu = sde.image_offset, getattr(sde, "mu", None)
     try:

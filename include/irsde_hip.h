@@ -13,6 +13,12 @@
  * call is stream-ordered with respect to it and does not synchronise the device unless stated.
  *
  * Return value: 0 on success, negative IRSDE_ERR_* otherwise; irsde_last_error() gives the text.
+ *
+ * ABI changelog (irsde_version()):
+ *   100  round 1.
+ *   101  irsde_sample: T == 0 runs NO step and copies xT to out (the reference's `range(1, T + 1)` is empty); only T < 0
+ *        selects the full schedule.  (Version 100 treated T <= 0 as "full schedule".)
+ *   102  IRSDE_FLAG_SPLIT_BF16 / IRSDE_FLAG_SPLIT_BF16X2 (fp32-equivalent split-operand GEMMs on the bf16 MFMA pipe).
  */
 #ifndef IRSDE_HIP_H
 #define IRSDE_HIP_H
@@ -66,7 +72,7 @@ enum {
                                         combinable with IRSDE_FLAG_BF16_ACT.  Operands beyond +-65504 would overflow: the score
                                         networks' activations are O(1..100) */
     IRSDE_FLAG_NO_WINOGRAD_FUSED = 2048, /* keep every Winograd layer on the three-launch path (input transform, component GEMMs, output
-                                        transform); default: the big feature maps (>= 4096 tiles, Cin <= 512, Cout <= 256) run the
+                                        transform); default: the big feature maps (>= 4096 tiles, Cin <= 256, Cout <= 256) run the
                                         fused kernel of csrc/wino_fused.hip, whose transformed tensors never reach HBM */
     IRSDE_FLAG_NO_FUSED_ATTN = 4096, /* LinearAttention with the whole to_qkv convolution and a q | k | v tensor in HBM (default for fp32, C <= 256:
                                         k / v projection + softmax over the pixels + context in one kernel, only q is a convolution) */

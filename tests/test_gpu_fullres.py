@@ -256,30 +256,112 @@ def test_fused_attention_plan_vs_qkv_tensor_plan():
     assert 0 < e < 5e-5
 
 
-@pytest.mark.parametrize("dtype,tol", [("bf16_act", 2e-2), ("bf16", 2e-2), ("fp16", 3e-3)])
-def test_reduced_precision_ode_256_vs_fp32(dtype, tol):
-    """BASELINE configs[2]: reverse_ode at 256x256 in the reduced-precision modes vs the fp32 engine, 20 steps, same weights.
-    Stated tolerance: 2e-2 of max|x0| for the bf16 modes (8 significand bits), 3e-3 for fp16 (11 bits)."""
-    B, T = 2, 20
-    lq, xT = O.synth_inputs(9, B, 256, 256)
+def _fresh_unet64(dtype):
+    params = O.synth_params(seed=0, nf=64, depth=4)
+    mm = P.ConditionalUNet(3, 3, 64, depth=4)
+    mm.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    mm = mm.to(DEV).eval()
+    mm.set_compute_dtype(dtype)
+    return mm
+
+
+def test_ode_256_T100_vs_reference_golden(golden):
+    """Full T=100 `reverse_ode` (sde_utils.py:268-282) at 1x3x256x256 in fp32 vs the REAL reference (fullres2.npz):
+    the sampler BASELINE configs[2] names, at the shape it names."""
+    m = unet64()
+    lq, xT = O.synth_inputs(1234, 1, 256, 256)
+    sde = P.IRSDE(10, 100, "cosine", 0.005, device=DEV)
+    sde.set_model(m)
+    sde.set_mu(torch.from_numpy(lq).to(DEV))
+    y = sde.reverse_ode(torch.from_numpy(xT).to(DEV)).cpu().numpy()
+    ref = golden.fullres2["unet_1x256x256/sampler_ode"]
+    e = relerr(y, ref)
+    print("sampler 256x256 ode T=100 fp32 vs reference: %.3g (max-abs %.3g)" % (e, float(np.abs(y - ref).max())))
+    assert e < 2e-3 and float(np.abs(y - ref).max()) < 1e-3   # north_star: 1e-3 max-abs in fp32
+    _CACHE["ode256_fp32"] = y
+
+
+# Stated tolerances for the reduced-precision T=100 trajectory (relative to max|x0| of the fp32 result).  The reverse
+# drift expands a per-evaluation perturbation ~200x over the high-theta steps t > 50 (SURVEY.md 7), so these are ~200x the
+# 20-step figures r02 quoted (bf16 1.9e-5, fp16 2.4e-6): measured values are printed and recorded in DESIGN.md.
+_ODE_T100_TOL = {"bf16_act": 5e-2, "bf16": 5e-2, "fp16": 1e-2}
+
+
+@pytest.mark.parametrize("dtype", ["bf16_act", "bf16", "fp16"])
+def test_reduced_precision_ode_256_T100(golden, dtype):
+    """BASELINE configs[2] as stated: `reverse_ode`, T=100, 256x256, reduced-precision operands — the WHOLE trajectory
+    (r02 checked only the last 20 steps) vs the fp32 engine on the same weights and vs the reference's fp32 ODE golden."""
+    lq, xT = O.synth_inputs(1234, 1, 256, 256)
     x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
-    outs = {}
-    for name in ("fp32", dtype):
-        if name == "fp32":
-            mm = unet64()
-        else:
-            params = O.synth_params(seed=0, nf=64, depth=4)
-            mm = P.ConditionalUNet(3, 3, 64, depth=4)
-            mm.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
-            mm = mm.to(DEV).eval()
-            mm.set_compute_dtype(name)
+    if "ode256_fp32" not in _CACHE:
         sde = P.IRSDE(10, 100, "cosine", 0.005, device=DEV)
-        sde.set_model(mm)
+        sde.set_model(unet64())
         sde.set_mu(c)
-        outs[name] = sde.reverse_ode(x, T=T).cpu().numpy()
-    e = relerr(outs[dtype], outs["fp32"])
-    print("%s reverse_ode 256x256 T=%d vs fp32: %.3g" % (dtype, T, e))
-    assert np.isfinite(outs[dtype]).all() and 0 < e < tol
+        _CACHE["ode256_fp32"] = sde.reverse_ode(x).cpu().numpy()
+    sde = P.IRSDE(10, 100, "cosine", 0.005, device=DEV)
+    sde.set_model(_fresh_unet64(dtype))
+    sde.set_mu(c)
+    y = sde.reverse_ode(x).cpu().numpy()
+    e32 = relerr(y, _CACHE["ode256_fp32"])
+    ref = golden.fullres2["unet_1x256x256/sampler_ode"]
+    eref = relerr(y, ref)
+    print("%s reverse_ode 256x256 T=100: vs fp32 engine %.3g, vs reference golden %.3g (max-abs %.3g)"
+          % (dtype, e32, eref, float(np.abs(y - ref).max())))
+    tol = _ODE_T100_TOL[dtype]
+    assert np.isfinite(y).all() and 0 < e32 < tol and eref < tol
+    _CACHE["ode_err_" + dtype] = e32
+    if "ode_err_fp16" in _CACHE and "ode_err_bf16" in _CACHE:
+        assert _CACHE["ode_err_fp16"] < _CACHE["ode_err_bf16"]   # 11 vs 8 significand bits
+
+
+def test_unet_forward_512_vs_reference_golden_and_batch_plan(golden):
+    """ConditionalUNet.forward at 512x512 (north_star: "256x256 and 512x512 batches"): the single-image plan vs the REAL
+    reference, then the 4 x 512 x 512 batch plan (1M-pixel level 0, 262 144 Winograd tiles per layer: other tile-loop /
+    components-per-block choices than 16 x 256 x 256) vs four single-image evaluations and vs the golden through one slot."""
+    g = golden.fullres2
+    m = unet64()
+    lq1, xT1 = O.synth_inputs(1234, 1, 512, 512)
+    x1, c1 = torch.from_numpy(xT1).to(DEV), torch.from_numpy(lq1).to(DEV)
+    for t in (100, 23):
+        y = m(x1, c1, t).cpu().numpy()
+        scale = np.abs(g["unet_1x512x512/t%d_sub3" % t]).max()
+        e1 = float(np.abs(sub3(y) - g["unet_1x512x512/t%d_sub3" % t]).max() / scale)
+        e2 = float(np.abs(y[:, :, -48:, -48:] - g["unet_1x512x512/t%d_corner" % t]).max() / scale)
+        print("unet 512x512 t=%d: %.3g %.3g" % (t, e1, e2))
+        assert e1 < 1e-4 and e2 < 1e-4
+    lq, xT = O.synth_inputs(78, 4, 512, 512)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    x[2], c[2] = x1[0], c1[0]
+    yb = m(x, c, 23).cpu().numpy()
+    scale = np.abs(yb).max()
+    worst = 0.0
+    for b in range(4):
+        yy = m(x[b:b + 1], c[b:b + 1], 23).cpu().numpy()
+        worst = max(worst, float(np.abs(yy - yb[b:b + 1]).max() / scale))
+    print("B=4 vs 4 x B=1 at 512x512: %.3g" % worst)
+    assert worst < 5e-5
+    assert float(np.abs(sub3(yb[2:3]) - g["unet_1x512x512/t23_sub3"]).max() / np.abs(g["unet_1x512x512/t23_sub3"]).max()) < 1e-4
+
+
+def test_nafnet_batch8_512_equals_single_images(golden):
+    """BASELINE configs[3] plan: Refusion NAFNet at 8 x 512 x 512 vs eight single-image evaluations (deterministic pooled
+    sums of the SCA branch are per image; the batch plan picks other GEMM tilings), and vs the reference golden through
+    one slot of the batch."""
+    g = golden.fullres
+    m = refusion_net()
+    lq1, xT1 = O.synth_inputs(1234, 1, 512, 512, max_sigma=50)
+    lq, xT = O.synth_inputs(79, 8, 512, 512, max_sigma=50)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    x[6], c[6] = torch.from_numpy(xT1[0]).to(DEV), torch.from_numpy(lq1[0]).to(DEV)
+    yb = m(x, c, 60).cpu().numpy()
+    scale = np.abs(yb).max()
+    worst = 0.0
+    for b in range(8):
+        yy = m(x[b:b + 1], c[b:b + 1], 60).cpu().numpy()
+        worst = max(worst, float(np.abs(yy - yb[b:b + 1]).max() / scale))
+    print("NAFNet B=8 vs 8 x B=1 at 512x512: %.3g" % worst)
+    assert worst < 5e-5
+    assert float(np.abs(sub3(yb[6:7]) - g["naf_1x512x512/t60_sub3"]).max() / np.abs(g["naf_1x512x512/t60_sub3"]).max()) < 1e-4
 
 
 # ---------------------------------------------------------------------------------------------
@@ -573,8 +655,9 @@ def test_eval_folder_on_a_synthetic_dataset(tmp_path):
         o = np.asarray(Image.open(str(out_dir / (n + ".png"))), dtype=np.float64)[..., ::-1]       # BGR like cv2.imread
         gtv = np.asarray(Image.open(str(gt_dir / (n + ".png"))), dtype=np.float64)[..., ::-1]
         assert np.array_equal(np.asarray(Image.open(str(out_dir / (n + "_HQ.png")))), np.asarray(Image.open(str(gt_dir / (n + ".png")))))
-        psnr.append(O.calculate_psnr(o, gtv))
-        ssim.append(O.calculate_ssim(o, gtv))
+        # the reference protocol: crop `crop_border or scale` = 4 px before the metrics (deraining/test.py:134, ir-sde.yml scale 4)
+        psnr.append(O.calculate_psnr(o[4:-4, 4:-4], gtv[4:-4, 4:-4]))
+        ssim.append(O.calculate_ssim(o[4:-4, 4:-4], gtv[4:-4, 4:-4]))
     assert abs(summary["psnr"] - float(np.mean(psnr))) < 1e-9
     assert abs(summary["ssim"] - float(np.mean(ssim))) < 1e-8
     # batching must not change a result: --batch 1 gives the same images

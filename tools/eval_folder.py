@@ -7,7 +7,9 @@ dataset averages.  This is the one command for the Rain100H gate of BASELINE.jso
 reference's 31.65 dB, /root/reference/README.md:42-46) once `rain100h_sde.pth` and the dataset are supplied:
 
     python tools/eval_folder.py --lq Rain100H/LQ --gt Rain100H/GT --weights rain100h_sde.pth \
-        --max-sigma 10 --T 100 --mode posterior --out results/Rain100H [--gpus 8]
+        --max-sigma 10 --T 100 --mode posterior --scale 4 --out results/Rain100H [--gpus 8]
+
+(`--scale 4` is the default: the reference crops `crop_border or scale` = 4 pixels before PSNR / SSIM, test.py:134.)
 
 Differences from the reference loop, all stated: images of equal size are sampled as one batch (`--batch`); with
 `--gpus N` the image list is sharded over N ranks (one process per GPU, no collective except the final metric
@@ -110,12 +112,15 @@ def main(argv=None):
     ap.add_argument("--schedule", default="cosine")
     ap.add_argument("--eps", type=float, default=0.005)
     ap.add_argument("--mode", default="posterior", choices=["sde", "ode", "posterior"])
-    ap.add_argument("--crop-border", type=int, default=0, help="opt['crop_border'] (falls back to the degradation scale in test.py:139)")
+    ap.add_argument("--crop-border", type=int, default=None, help="opt['crop_border']; unset / 0 falls back to --scale exactly as test.py:134 does")
+    ap.add_argument("--scale", type=int, default=4, help="opt['degradation']['scale'] (deraining options/test/ir-sde.yml:20 sets 4 and no crop_border, "
+                    "so the published Rain100H PSNR / SSIM are computed on images cropped by 4 px)")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16_act", "fp16"])
     a = ap.parse_args(argv)
+    crop_border = a.crop_border if a.crop_border else a.scale   # test.py:134: `opt["crop_border"] if opt["crop_border"] else scale`
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sk = socket.socket()
@@ -173,7 +178,7 @@ def main(argv=None):
         GT = None
         if a.gt is not None:
             GT = torch.from_numpy(np.stack([read_img(pairs[mine[j]][1]) for j in grp])).to(dev)
-            m = P.metrics.evaluate_batch(out, GT, crop_border=a.crop_border)
+            m = P.metrics.evaluate_batch(out, GT, crop_border=crop_border)
             for k in res:
                 res[k].extend(m[k].tolist())
             for n, name in enumerate(names):
