@@ -118,6 +118,11 @@ bool wino_fused_eligible(const ConvParams& p);
 void wino_fused_pack_weights(const float* U, int Cout, int Cin, float* Uf);  // host: U[36][Cout][Cin] -> fragment order
 void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s, unsigned long long* dbg = nullptr, int dflags = 0);
 int wino_fused_num_blocks(const ConvParams& p);
+// r03: 16 tiles x 64 couts per block (Cout and Cin multiples of 64); its own weight fragment order
+bool wino_fused64_eligible(const ConvParams& p);
+void wino_fused64_pack_weights(const float* U, int Cout, int Cin, float* Uf);
+void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, int variant = 0);
+int wino_fused64_num_blocks(const ConvParams& p);
 void wino_fused_global_init();
 void attention_global_init();
 

@@ -31,6 +31,12 @@ namespace irsde {
 // large (many tiles) and the channel counts are moderate; beyond these limits the three-launch path keeps the layer.
 constexpr int kWinoFusedMaxCin = 256, kWinoFusedMaxCout = 256;  // measured crossover (profiles/r02_wino_fused_sweep.txt): Cin 384+ is faster on the three-launch path
 inline long long wino_fused_min_tiles() { return tuning_env_int("IRSDE_WINO_FUSED_MINT", 4096); }
+// r03: the 64-cout fused kernel (16 tiles x 64 couts per block) takes the layers whose channel counts are multiples of 64;
+// IRSDE_WINO_FUSED64=0 keeps them on the 32-cout kernel, IRSDE_WINO_FUSED64_MAXCIN / _MAXCOUT move its crossover (tuning only)
+inline bool wino_fused64_enabled() { return tuning_env_int("IRSDE_WINO_FUSED64", 1) != 0; }
+inline int wino_fused64_max_cin() { return tuning_env_int("IRSDE_WINO_FUSED64_MAXCIN", 512); }
+inline int wino_fused64_max_cout() { return tuning_env_int("IRSDE_WINO_FUSED64_MAXCOUT", 512); }
+inline long long wino_fused64_min_tiles() { return tuning_env_int("IRSDE_WINO_FUSED64_MINT", 1024); }
 
 inline int wino_min_c(int tile) {
     return tuning_env_int(tile == 4 ? "IRSDE_WINO4_MINC" : "IRSDE_WINO2_MINC", tile == 4 ? 64 : 256);
@@ -65,6 +71,7 @@ struct ConvW {
     float* wino_u2 = nullptr;  // device [16][Cout][Cin] = G g G^T of F(2x2,3x3)  (3x3 layers with Cin,Cout >= 256)
     float* wino_u4 = nullptr;  // device [36][Cout][Cin]              F(4x4,3x3)  (3x3 layers with Cin,Cout >= 128)
     float* wino_uf = nullptr;  // the same F(4x4,3x3) weights in the fused kernel's fragment order (wino_fused.hip)
+    float* wino_uf64 = nullptr;  // ... in the 64-cout fused kernel's fragment order (Cout, Cin multiples of 64)
 };
 struct ResW {
     ConvW b1, b2, res;

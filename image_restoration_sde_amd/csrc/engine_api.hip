@@ -520,15 +520,17 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
             p.partial = dp;
         }
-        if (naive == 33) {  // fused Winograd F(4x4,3x3) kernel (wino_fused.hip)
-            if (!wino_fused_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
+        if (naive == 33 || naive == 34) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
+            if (naive == 33 ? !wino_fused_eligible(p) : !wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
-            wino_fused_pack_weights(U.data(), Cout, Cin, Uf.data());
+            if (naive == 33) wino_fused_pack_weights(U.data(), Cout, Cin, Uf.data());
+            else wino_fused64_pack_weights(U.data(), Cout, Cin, Uf.data());
             float* dUf = nullptr;
             IRSDE_HIP_CHECK(hipMalloc(&dUf, Uf.size() * 4));
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
-            launch_wino_fused(p, dUf, s);
+            if (naive == 33) launch_wino_fused(p, dUf, s);
+            else launch_wino_fused64(p, dUf, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf);
         } else if (wino_tile) {  // naive / 10: 0 = production dispatch, 1 / 2 = force the batch-loop GEMM kernel (all / 2 components per block)
@@ -649,11 +651,12 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         // 80: fused Winograd F(4x4,3x3) kernel; 81: the three-launch Winograd F(4x4,3x3) path (random U: timing only)
         float *dU = nullptr, *dV = nullptr, *dM = nullptr;
         WinoPlan wp{};
-        if (variant == 80 || variant == 81 || (variant >= 83 && variant <= 82 + 255)) {
+        if (variant == 80 || variant == 81 || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 403)) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
             if (variant != 81 && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
+            if (variant >= 400 && !wino_fused64_eligible(p)) throw HipError("bench_conv: shape not eligible for the 64-cout fused Winograd kernel");
             if (variant == 81) {
                 if (!wino_shape_ok(p, 4)) throw HipError("bench_conv: shape not eligible for Winograd F(4x4,3x3)");
                 const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
@@ -702,6 +705,8 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         auto run = [&] {
             if (variant == 80) {
                 launch_wino_fused(p, dU, s);
+            } else if (variant >= 400 && variant <= 403) {  // 64-cout fused Winograd kernel: 400 production, 401 no weight traffic, 402 no patch traffic, 403 short U ring
+                launch_wino_fused64(p, dU, s, variant - 400);
             } else if (variant >= 83 && variant <= 82 + 255) {  // tuning aids: dflags = variant - 82 (1 no patch traffic, 2 no weight traffic, 4 / 8 producer / MFMA waves at s_setprio 2)
                 launch_wino_fused(p, dU, s, nullptr, variant - 82);
             } else if (variant == 81) {

@@ -102,7 +102,8 @@ struct Builder {
         p.silu = silu;
         if (res) { p.res = res->p; p.res_stride = res->C; }
         if (!naive) {  // prefer F(4x4,3x3), then F(2x2,3x3), then the direct implicit GEMM
-            if (w.wino_uf && push_wino_fused(p, w.wino_uf)) return out;
+            if (w.wino_uf64 && push_wino_fused(p, w.wino_uf64, true)) return out;
+            if (w.wino_uf && push_wino_fused(p, w.wino_uf, false)) return out;
             if (w.wino_u4 && wino_shape_ok(p, 4) && push_wino(p, w.wino_u4, 4)) return out;
             if (w.wino_u2 && wino_shape_ok(p, 2) && push_wino(p, w.wino_u2, 2)) return out;
         }
@@ -111,14 +112,15 @@ struct Builder {
     }
 
     // Winograd F(4x4,3x3) with both transforms inside the GEMM kernel (wino_fused.hip): the big feature maps
-    bool push_wino_fused(const ConvParams& d, const float* Uf) {
+    // (k64: the r03 kernel, 16 tiles x 64 couts per block; else 32 tiles x 32 couts)
+    bool push_wino_fused(const ConvParams& d, const float* Uf, bool k64) {
         ConvParams dd = d;
         dd.zeros = e->zeros;
-        if (!wino_fused_eligible(dd)) return false;
+        if (k64 ? !wino_fused64_eligible(dd) : !wino_fused_eligible(dd)) return false;
         const int Ctot = d.C0 + d.C1;
         const long long T = (long long)d.B * (d.Ho / 4) * (d.Wo / 4);
-        const long long blocks = (long long)d.B * ((d.Ho / 4 + 3) / 4) * ((d.Wo / 4 + 7) / 8) * (d.Cout / 32);
-        if (T < wino_fused_min_tiles() || blocks < 256) return false;
+        const long long blocks = k64 ? wino_fused64_num_blocks(dd) : (long long)d.B * ((d.Ho / 4 + 3) / 4) * ((d.Wo / 4 + 7) / 8) * (d.Cout / 32);
+        if (T < (k64 ? wino_fused64_min_tiles() : wino_fused_min_tiles()) || blocks < 256) return false;
         Op op;
         op.kind = OP_CONV;
         op.flops = conv_flops(d);
@@ -128,10 +130,13 @@ struct Builder {
         pl->conv_exec_flops += op.exec_flops;
         pl->conv_bytes += op.bytes;
         char buf[256];
-        snprintf(buf, sizeof buf, "conv(winograd F4 fused) T=%lld Cout=%d Cin=%d up=%d blocks=%lld flops=%.4g exec=%.4g", T, d.Cout, Ctot,
-                 d.in_shift, blocks, op.flops, op.exec_flops);
+        snprintf(buf, sizeof buf, "conv(winograd F4 fused) %s T=%lld Cout=%d Cin=%d up=%d blocks=%lld flops=%.4g exec=%.4g", k64 ? "16x64" : "32x32", T,
+                 d.Cout, Ctot, d.in_shift, blocks, op.flops, op.exec_flops);
         op.desc = buf;
-        op.fn = [dd, Uf](hipStream_t s) { launch_wino_fused(dd, Uf, s); };
+        if (k64)
+            op.fn = [dd, Uf](hipStream_t s) { launch_wino_fused64(dd, Uf, s); };
+        else
+            op.fn = [dd, Uf](hipStream_t s) { launch_wino_fused(dd, Uf, s); };
         pl->net_ops.push_back(std::move(op));
         return true;
     }

@@ -111,6 +111,12 @@ ConvW pack_conv(irsde_engine* e, const std::string& wname, const std::string& bn
                 wino_fused_pack_weights(U.data(), O, I, Uf.data());
                 c.wino_uf = e->upload(Uf);
             }
+            if (tile == 4 && !(e->cfg.flags & IRSDE_FLAG_NO_WINOGRAD_FUSED) && wino_fused64_enabled() && O % 64 == 0 && I % 64 == 0 &&
+                I <= wino_fused64_max_cin() && O <= wino_fused64_max_cout()) {
+                std::vector<float> Uf(U.size());
+                wino_fused64_pack_weights(U.data(), O, I, Uf.data());
+                c.wino_uf64 = e->upload(Uf);
+            }
         }
     }
     return c;

@@ -319,6 +319,257 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused_kernel(const ConvParams 
 
 #undef WF_STAMP
 
+// ================================================================================================================
+// r03: the 64-cout variant.  r02's kernel recomputes B^T d B of a patch once per 32-cout block and runs 4.5 vector
+// instructions per MFMA on SIMDs where f32 MFMAs and the other wave's vector instructions serialise
+// (tools/probe/mfma_valu_overlap.hip): 0.49 MFMA-busy.  Here a block owns 16 tiles (4 x 4 tiles = 16 x 16 output pixels)
+// x 64 output channels x all 36 components, K chunks of 32 input channels, on v_mfma_f32_16x16x4_f32 (same FLOP per cycle as
+// 32x32x2, same 144 accumulator registers per MFMA wave): per chunk the producers do the SAME number of loads, transform
+// operations and LDS writes as before while the MFMA waves have twice the work (288 MFMA-equivalents of 32 cycles... i.e.
+// 9216 matrix-pipe cycles per wave), so the vector work per MFMA halves; the patch is transformed Cout/64 instead of
+// Cout/32 times (once for the 64-channel level-0 layers).  Cost: the weight fragments (private to a wave) are 8 KB per
+// (component, chunk) instead of 4 KB per two blocks — the same bytes per FLOP from L2, twice the load instructions per MFMA.
+//   MFMA waves 0-3: wave zg owns components 9zg .. 9zg+8.  A operand = U (16 couts x 4 k), B operand = V (4 k x 16 tiles):
+//       D[cout][tile], lane (tile = l & 15, g = l >> 4) holds couts 4g .. 4g+3 of one 16-cout block -> one ds_write_b128
+//       per accumulator into the LDS staging of the output transform.  One ds_read_b128 of V per 16 MFMAs; U fragments
+//       come from L2 through a ring of W6_RING (component, 16-cout block) units refilled W6_RING - 1 units (x 128 cycles)
+//       ahead.
+//   producer waves 4-7: lane = (tile, channel pair of the 32-channel chunk): 16 lanes x 8 B = one full 128-byte line per
+//       patch pixel; same transform code as above.
+// V layout in LDS (floats): [component z][r = c >> 4][g = (c >> 2) & 3][tile ^ g][j = c & 3], r stride 272, z stride 544: the
+// MFMA waves' b128 reads are 1 KB contiguous per (z, r); the XOR spreads the producers' b64 writes of one tile over all banks.
+// ================================================================================================================
+constexpr int W6_KC = 32;
+constexpr int W6_RING = 18, W6_RING_ALT = 12;  // U units in flight per MFMA wave (x 4 registers); ALT: irsde_bench_conv variant 93
+constexpr int W6_RS = 272, W6_ZS = 544;      // floats between r halves / components (same footprint as the 32-cout kernel)
+constexpr int W6_VBUF = 36 * W6_ZS;
+constexpr int W6_MS = 68;                    // floats per (component, tile) row of the output staging: 64 couts + 4 pad
+constexpr int W6_LDS_BYTES = 2 * W6_VBUF * 4;  // 156 672 B = 36 * 16 * 68 * 4 (the staging aliases the V buffers)
+static_assert(36 * 16 * W6_MS * 4 <= W6_LDS_BYTES, "output staging must fit in the V buffers");
+
+__device__ __forceinline__ void wf64_epilogue(const ConvParams& p, const float* Ms, const int tid, const int b, const int gy,
+                                              const int gx, const int TH, const int TW, const int n0) {
+    // thread = (tile, 4 consecutive couts, row pair): 512 = 16 tiles x 16 quads x 2 row pairs
+    const int quad = tid & 15, half = (tid >> 4) & 1, t = tid >> 5;
+    const int tyy = gy * 4 + (t >> 2), txx = gx * 4 + (t & 3);
+    const int n = n0 + 4 * quad;
+    if (tyy >= TH || txx >= TW) return;
+    floatx4 bias = {0.f, 0.f, 0.f, 0.f}, fsc = {1.f, 1.f, 1.f, 1.f}, fsh = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias = *reinterpret_cast<const floatx4*>(p.bias + n);
+    if (p.film) {
+        const float* f = p.film + (size_t)b * p.film_bstride;
+        fsc = *reinterpret_cast<const floatx4*>(f + n) + 1.0f;
+        fsh = *reinterpret_cast<const floatx4*>(f + p.Cout + n);
+    }
+    const size_t pix0 = ((size_t)b * p.Ho + 4 * tyy + 2 * half) * p.Wo + 4 * txx;
+    floatx4 rv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (p.res) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[i][j] = *reinterpret_cast<const floatx4*>(p.res + (pix0 + (size_t)i * p.Wo + j) * p.res_stride + n);
+    }
+    const float c0 = half ? 0.f : 1.f, ka = half ? 4.f : 1.f, kb = half ? 8.f : 2.f, c5 = half ? 1.f : 0.f;
+    floatx4 u[2][6];
+    const float* mp = Ms + t * W6_MS + 4 * quad;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        floatx4 m[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m[r] = *reinterpret_cast<const floatx4*>(mp + (r * 6 + s) * (16 * W6_MS));
+        const floatx4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        u[0][s] = c0 * m[0] + s12 + ka * s34;
+        u[1][s] = d12 + kb * d34 + c5 * m[5];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const floatx4 s12 = u[i][1] + u[i][2], d12 = u[i][1] - u[i][2], s34 = u[i][3] + u[i][4], d34 = u[i][3] - u[i][4];
+        floatx4 y[4];
+        y[0] = u[i][0] + s12 + s34;
+        y[1] = d12 + 2.0f * d34;
+        y[2] = s12 + 4.0f * s34;
+        y[3] = d12 + 8.0f * d34 + u[i][5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            floatx4 v = (y[j] + bias) * fsc + fsh;
+            if (p.silu) {
+                v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w);
+            }
+            *reinterpret_cast<floatx4*>(p.out + (pix0 + (size_t)i * p.Wo + j) * p.out_stride + n) = v + rv[i][j];
+        }
+    }
+}
+
+// NOWT / NOPATCH: measurement twins (irsde_bench_conv variants 91 / 92: weight fragments resp. patch loads read zeros without
+// memory traffic) — template parameters, so the production instance <false, false> carries no run-time tuning branch.
+template <int RING, bool NOWT, bool NOPATCH>
+__global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX,
+                                                                  const int GY, const int NB, const unsigned in0_bytes,
+                                                                  const unsigned in1_bytes, const unsigned uf_bytes) {
+    static_assert(72 % RING == 0, "the ring must divide the 72 (component, r, cout block) units of a chunk");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wgid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int nblk = wgid % NB;
+    int g_ = wgid / NB;
+    const int gx = g_ % GX; g_ /= GX;
+    const int gy = g_ % GY;
+    const int b = g_ / GY;
+    const int TH = p.Ho >> 2, TW = p.Wo >> 2;
+    const int Ctot = p.C0 + p.C1;
+    const int nch = Ctot / W6_KC;
+    const int nsub = Ctot / 16;   // 16-channel k groups (one U unit row each)
+    float* Ms = smem;
+    const int n0 = nblk * 64;
+
+    if (wave < 4) {
+        // =============================== MFMA waves ===============================
+        const int zg = wave;
+        const int l15 = lane & 15, g = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Uf), 0, NOWT ? 0u : uf_bytes, 0x00020000);
+        floatx4 acc[9][4];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[i][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // unit u (global over the K loop) = ((s * 9) + zi) * 4 + cb with s = 2 chunk + r: fragment of (component zg*9+zi, 16-cout
+        // block cb, k group s) = 1 KB at Uf + ((((zg*9+zi) * NB + nblk) * nsub + s) * 4 + cb) * 1 KB; lane reads 16 B
+        const int uv_lane = lane * 16;
+        const int zstride = NB * nsub * 4096;                       // bytes between components
+        const int ubase = (zg * 9 * NB + nblk) * nsub * 4096;       // component zg*9, this cout block, s = 0
+        // unit K (counted from the start of chunk c; K may run past 71 into the following chunks): cout block K & 3, component
+        // (K >> 2) % 9 and k group 2c + (K >> 2) / 9 are compile-time functions of K except for c: a handful of scalar
+        // instructions per load.  Units past the end of the K loop re-read the last k group (never used).
+        auto unit_soff = [&](const int c, const int K) {
+            const int cb = K & 3, zi = (K >> 2) % 9;
+            int sidx = 2 * c + (K >> 2) / 9;
+            sidx = sidx < nsub ? sidx : nsub - 1;
+            return ubase + zi * zstride + sidx * 4096 + cb * 1024;
+        };
+        floatx4 ring[RING];
+#pragma unroll
+        for (int i = 0; i < RING; ++i)
+            ring[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uv_lane, unit_soff(0, i), 0));
+        const int v_lane = g * 64 + ((l15 ^ g) * 4);
+        __syncthreads();  // iteration 0: the producers fill V[0]
+        for (int c = 0; c < nch; ++c) {
+            const float* vb = smem + (c & 1) * W6_VBUF + zg * 9 * W6_ZS + v_lane;
+            floatx4 v_cur = *reinterpret_cast<const floatx4*>(vb);
+            // 18 groups (r major, component minor) of { V fragment of the next group, 4 units of { 4 MFMAs, refill of the unit's
+            // ring slot for RING units ahead } }.  The scheduling barriers pin that order (see the 32-cout kernel).
+#pragma unroll
+            for (int gi = 0; gi < 18; ++gi) {
+                const int r = gi / 9, zi = gi % 9;
+                floatx4 v_next = v_cur;
+                if (gi + 1 < 18) v_next = *reinterpret_cast<const floatx4*>(vb + ((gi + 1) % 9) * W6_ZS + ((gi + 1) / 9) * W6_RS);
+                // k step outer, cout block inner: consecutive MFMAs hit different accumulators (a dependent v_mfma_f32_16x16x4_f32
+                // issues after 40 cycles instead of 32, MI355X_MICROARCH.md)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[zi][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(gi * 4 + cb) % RING][j], v_cur[j], acc[zi][cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const int ul = gi * 4 + cb;            // unit index inside the chunk (72 % RING == 0: the slot is static)
+                    ring[ul % RING] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uv_lane, unit_soff(c, ul + RING), 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                (void)r;
+                v_cur = v_next;
+            }
+            __syncthreads();
+        }
+        // accumulators -> LDS: lane (tile = l15, g) holds couts 16 cb + 4 g .. + 3 of component zi: one 16-byte write each
+#pragma unroll
+        for (int zi = 0; zi < 9; ++zi)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                *reinterpret_cast<floatx4*>(Ms + ((zg * 9 + zi) * 16 + l15) * W6_MS + cb * 16 + 4 * g) = acc[zi][cb];
+        __syncthreads();
+        wf64_epilogue(p, Ms, tid, b, gy, gx, TH, TW, n0);
+    } else {
+        // =============================== producer waves ===============================
+        const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc1 =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1 ? p.in1 : p.in0), 0, p.in1 ? in1_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, 0u, 0x00020000);
+        const int cp = lane & 15;                          // channel pair of the chunk: channels 2cp, 2cp+1
+        const int tile = (wave - 4) * 4 + (lane >> 4);     // tile inside the 4 x 4 group
+        const int trow = tile >> 2, tcol = tile & 3;
+        const int kg = (cp >> 1) & 3;
+        // LDS float offset of (tile, channel pair): [r = cp >> 3][g = (cp >> 1) & 3][tile ^ g][j = 2 (cp & 1)]
+        const int vw_base = (cp >> 3) * W6_RS + kg * 64 + ((tile ^ kg) * 4) + 2 * (cp & 1);
+        const int tyy = gy * 4 + trow, txx = gx * 4 + tcol;
+        const bool tile_ok = tyy < TH && txx < TW && !NOPATCH;
+        const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
+        int rowpix[6], colpix[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int y = 4 * tyy - 1 + r, x = 4 * txx - 1 + r;
+            rowpix[r] = (tile_ok && (unsigned)y < (unsigned)Hv) ? (b * p.Hin + (y >> p.in_shift)) * p.Win : -1;
+            colpix[r] = (tile_ok && (unsigned)x < (unsigned)Wv) ? (x >> p.in_shift) : -1;
+        }
+        unsigned voff[36];
+        floatx2 rawA[36], rawB[36];
+#define W6_BUILD_VOFF(PIXF)                                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 6; ++r) _Pragma("unroll") for (int s = 0; s < 6; ++s) voff[r * 6 + s] =            \
+        (rowpix[r] >= 0 && colpix[s] >= 0) ? (unsigned)(rowpix[r] + colpix[s]) * (unsigned)((PIXF)*4) + (unsigned)(cp * 8) : WF_OOB;
+#define W6_LOAD_RAW(RAW, CI)                                                                                                 \
+    {                                                                                                                        \
+        const int cc_ = (CI)*W6_KC;                                                                                          \
+        const bool second_ = cc_ >= p.C0;                                                                                    \
+        const int soff_ = (second_ ? cc_ - p.C0 : cc_) * 4;                                                                  \
+        const __amdgpu_buffer_rsrc_t rs_ = (CI) >= nch ? rsrc_none : second_ ? rsrc1 : rsrc0;                                \
+        _Pragma("unroll") for (int e = 0; e < 36; ++e) RAW[e] =                                                              \
+            __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[e], soff_, 0));                 \
+    }
+#define W6_CHUNK(CUR, NXT, IT)                                                                                               \
+    {                                                                                                                        \
+        if (((IT) + 1) * W6_KC == p.C0) { W6_BUILD_VOFF(p.pix1) }                                                            \
+        W6_LOAD_RAW(NXT, (IT) + 1)                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        floatx2 w[6][6];                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 6; ++s) {                                                                      \
+            floatx2 col[6], tc[6];                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) col[r] = CUR[r * 6 + s];                                           \
+            bt6(col, tc);                                                                                                    \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) w[r][s] = tc[r];                                                   \
+        }                                                                                                                    \
+        float* vw = smem + ((IT)&1) * W6_VBUF + vw_base;                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                                      \
+            floatx2 o[6];                                                                                                    \
+            bt6(w[r], o);                                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < 6; ++s) *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * W6_ZS) = o[s];      \
+        }                                                                                                                    \
+        __syncthreads();                                                                                                     \
+    }
+        W6_BUILD_VOFF(p.pix0)
+        W6_LOAD_RAW(rawA, 0)
+        for (int it = 0; it < nch; it += 2) {   // Ctot is a multiple of 64: the chunk count is even
+            W6_CHUNK(rawA, rawB, it)
+            W6_CHUNK(rawB, rawA, it + 1)
+        }
+#undef W6_CHUNK
+#undef W6_BUILD_VOFF
+#undef W6_LOAD_RAW
+        __syncthreads();  // the MFMA waves' last chunk
+        __syncthreads();  // the accumulators are in LDS
+        wf64_epilogue(p, Ms, tid, b, gy, gx, TH, TW, n0);
+    }
+}
+
 }  // namespace
 
 // Blocks the launch of launch_wino_fused(p, ...) creates (the size of the variant-82 stamp buffer: 64 stamps per block)
@@ -331,6 +582,12 @@ void wino_fused_global_init() {
                                         160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         160 * 1024));
+#define W6_ATTR(...) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused64_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    W6_ATTR(W6_RING, false, false);
+    W6_ATTR(W6_RING, true, false);
+    W6_ATTR(W6_RING, false, true);
+    W6_ATTR(W6_RING_ALT, false, false);
+#undef W6_ATTR
 }
 
 // Geometry / feature check only (the plan decides where the fused kernel pays)
@@ -376,6 +633,50 @@ void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s, unsi
     else
         hipLaunchKernelGGL(wino4_fused_kernel<false>, dim3((unsigned)(p.B * GY * GX * NB)), dim3(WF_NT), WF_LDS_BYTES, s, p, Uf, GX, GY, NB,
                            in0_bytes, in1_bytes, uf_bytes, dbg, dflags);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+
+// ---- the 64-cout variant (r03) ----
+bool wino_fused64_eligible(const ConvParams& p) {
+    return wino_fused_eligible(p) && p.Cout % 64 == 0 && (p.C0 + p.C1) % 64 == 0;   // 32-channel chunks, processed in pairs
+}
+
+// U[z][n][c] -> Uf[z][n >> 6][c >> 4][(n >> 4) & 3][(c >> 2) & 3][n & 15][c & 3]: the fragment of one (component, 16-cout
+// block, 16-channel k group) is 1 KB contiguous, lane (cout = l & 15, g = l >> 4) reads the 16 bytes k = 4g .. 4g+3 of it.
+void wino_fused64_pack_weights(const float* U, int Cout, int Cin, float* Uf) {
+    const int NB = Cout / 64, nsub = Cin / 16;
+    for (int z = 0; z < 36; ++z)
+        for (int n = 0; n < Cout; ++n)
+            for (int c = 0; c < Cin; ++c) {
+                const size_t dst = ((((((size_t)(z * NB + (n >> 6)) * nsub + (c >> 4)) * 4 + ((n >> 4) & 3)) * 4 + ((c >> 2) & 3)) * 16 + (n & 15)) * 4) + (c & 3);
+                Uf[dst] = U[((size_t)z * Cout + n) * Cin + c];
+            }
+}
+
+int wino_fused64_num_blocks(const ConvParams& p) {
+    return p.B * ((p.Ho / 4 + 3) / 4) * ((p.Wo / 4 + 3) / 4) * (p.Cout / 64);
+}
+
+// variant: 0 production; 1 weight fragments read zeros (no L2 traffic); 2 patch loads read zeros; 3 the shorter U ring
+void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, int variant) {
+    if (!wino_fused64_eligible(p)) throw HipError("launch_wino_fused64: layer not eligible");
+    if (!Uf) throw HipError("launch_wino_fused64: fused weights missing");
+    const int TH = p.Ho / 4, TW = p.Wo / 4;
+    const int GX = (TW + 3) / 4, GY = (TH + 3) / 4, NB = p.Cout / 64;
+    const unsigned in0_bytes = (unsigned)((size_t)p.B * p.Hin * p.Win * p.pix0 * 4);
+    const unsigned in1_bytes = p.C1 ? (unsigned)((size_t)p.B * p.Hin * p.Win * p.pix1 * 4) : 0u;
+    const unsigned uf_bytes = (unsigned)((size_t)36 * p.Cout * (p.C0 + p.C1) * 4);
+    const dim3 grid((unsigned)(p.B * GY * GX * NB));
+#define W6_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64_kernel<__VA_ARGS__>), grid, dim3(WF_NT), W6_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes)
+    switch (variant) {
+        case 0: W6_LAUNCH(W6_RING, false, false); break;
+        case 1: W6_LAUNCH(W6_RING, true, false); break;
+        case 2: W6_LAUNCH(W6_RING, false, true); break;
+        case 3: W6_LAUNCH(W6_RING_ALT, false, false); break;
+        default: throw HipError("launch_wino_fused64: bad variant");
+    }
+#undef W6_LAUNCH
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

@@ -35,7 +35,8 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
  * variant: 0 production dispatch, 3 / 50 fp32 256x128 / 256x256 tiles, 5 one block per CU, 6 generic pointer staging instead of
  * buffer descriptors, 7 LDS-transposed instead of direct epilogue, 60 / 61 / 62 bf16 mode (256 tile / 128 tile / automatic
  * incl. the halo kernel), 63 = 62 with bf16 activation storage, 80 / 81 Winograd F(4x4,3x3) fused kernel / three-launch path (3x3 s1 only), 82 the fused kernel once with its
- * phase timeline printed to stdout; epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
+ * phase timeline printed to stdout, 400 the 64-cout fused Winograd kernel (r03; 401 / 402: its weight fragments / patch loads read zeros
+ * without memory traffic, 403: 12 instead of 18 weight units in flight); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out);
 

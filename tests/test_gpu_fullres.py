@@ -283,8 +283,9 @@ def test_ode_256_T100_vs_reference_golden(golden):
 
 # Stated tolerances for the reduced-precision T=100 trajectory (relative to max|x0| of the fp32 result).  The reverse
 # drift expands a per-evaluation perturbation ~200x over the high-theta steps t > 50, so these are ~200x the
-# 20-step figures r02 quoted (bf16 1.9e-5, fp16 2.4e-6): measured values are printed and recorded in DESIGN.md.
-_ODE_T100_TOL = {"bf16_act": 5e-2, "bf16": 5e-2, "fp16": 1e-2}
+# 20-step figures r02 quoted would suggest 4e-3 / 5e-4.  Measured on MI355X (profiles/r03_a_pytest_gpu.log, max|x0| = 28.8):
+# bf16_act 3.2e-4 (max-abs 9.2e-3), bf16 3.1e-4 (8.9e-3), fp16 3.8e-5 (1.1e-3); the fp32 engine itself 1.8e-6 (5e-5).
+_ODE_T100_TOL = {"bf16_act": 3e-3, "bf16": 3e-3, "fp16": 4e-4}
 
 
 @pytest.mark.parametrize("dtype", ["bf16_act", "bf16", "fp16"])

@@ -156,6 +156,9 @@ def test_conv_kernel(name):
         if C0 % 32 == 0 and C1 % 32 == 0 and Cout % 32 == 0:
             # the fused Winograd F(4x4,3x3) kernel (wino_fused.hip): transforms inside the GEMM kernel
             assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=33), ref) < 5e-5
+        if C0 % 32 == 0 and C1 % 32 == 0 and Cout % 64 == 0 and (C0 + C1) % 64 == 0:
+            # r03: the 64-cout fused Winograd kernel (16 tiles x 64 couts per block, v_mfma_f32_16x16x4_f32)
+            assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=34), ref) < 5e-5
 
 
 @pytest.mark.parametrize("shape", [(3, 32, 0, 36, 44, 96, 0), (2, 32, 64, 8, 12, 32, 1), (1, 64, 0, 64, 96, 64, 0), (5, 96, 32, 4, 4, 160, 0)])
@@ -177,6 +180,30 @@ def test_conv_wino_fused_edges(shape):
     # no epilogue at all
     ref = oracle_conv(x0, x1, w, None, 1, 1, up, None, 0, None)
     assert relerr(run_conv(x0, x1, w, None, 1, 1, up, None, 0, None, naive=33), ref) < 5e-5, shape
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 0, 36, 44, 64, 0), (2, 32, 32, 8, 12, 128, 1), (1, 128, 64, 20, 28, 128, 0), (5, 96, 32, 4, 4, 192, 0),
+                                   (1, 256, 0, 16, 16, 64, 1), (2, 64, 0, 64, 64, 64, 0)])
+def test_conv_wino_fused64_edges(shape):
+    """r03: the 64-cout fused Winograd kernel (wino4_fused64_kernel) on ragged 4 x 4 tile groups, concat sources whose boundary
+    falls on a 32-channel chunk, the fused upsample, per-sample FiLM rows, bias + SiLU + residual together, 2 .. 8 chunks."""
+    B, C0, C1, H, W, Cout, up = shape
+    rs = np.random.RandomState(B * 1000 + H + 7)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, 3, 3)) / np.sqrt((C0 + C1) * 9)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32)
+    film = (0.3 * rs.standard_normal((B, 2 * Cout))).astype(np.float32)
+    res = rs.standard_normal((B, Cout, H << up, W << up)).astype(np.float32)
+    ref = oracle_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, film_bstride=2 * Cout)
+    got = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=34, film_bstride=2 * Cout)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert relerr(got, ref) < 5e-5, shape
+    ref = oracle_conv(x0, x1, w, None, 1, 1, up, None, 0, None)
+    got = run_conv(x0, x1, w, None, 1, 1, up, None, 0, None, naive=34)
+    assert relerr(got, ref) < 5e-5, shape
+    # and bit-for-bit nothing but summation order away from the 32-cout kernel
+    assert relerr(got, run_conv(x0, x1, w, None, 1, 1, up, None, 0, None, naive=33)) < 2e-5, shape
 
 
 def test_conv_per_sample_film():

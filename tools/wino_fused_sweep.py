@@ -23,13 +23,17 @@ cases = [
     ("L2 256->256 film", 64, 64, 256, 256, 0, 1),
 ]
 cases = [c for c in cases if flt in c[0]]
-print("B=%d  %-20s %10s %10s %10s   %s" % (B, "layer", "fused ms", "3-launch", "direct", "fused: TF/s executed (of 157.3)"))
+cases += [("L2 512->256 film", 64, 64, 512, 256, 0, 1), ("L2 768->512 film", 64, 64, 768, 512, 0, 1), ("L2 512->512 res", 64, 64, 512, 512, 0, 2),
+          ("L3 512->512 res", 32, 32, 512, 512, 0, 2), ("L3 1024->1024", 32, 32, 1024, 1024, 0, 2)] if "deep" in sys.argv else []
+# 80: r02 fused kernel (32 tiles x 32 couts); 400: r03 (16 tiles x 64 couts); 401 / 402: 400 without weight / patch traffic; 403: short U ring
+print("B=%d  %-20s %9s %9s %9s %9s %9s %9s %9s   %s" % (B, "layer", "fused32", "fused64", "64 noW", "64 noPatch", "64 ring12", "3-launch", "direct",
+                                                         "TF/s executed (of 157.3): fused32 / fused64"))
 for name, H, W, Cin, Cout, up, epi in cases:
     Ho, Wo = H << up, W << up
     exec_flops = 36 * 2.0 * B * (Ho // 4) * (Wo // 4) * Cin * Cout
     res = []
-    for v in (80, 81, 0):
+    for v in (80, 400, 401, 402, 403, 81, 0):
         ms = ctypes.c_double()
         rc = L.irsde_bench_conv(v, B, H, W, Cin, Cout, 3, 1, up, epi, 10, ctypes.byref(ms))
         res.append(ms.value if rc == 0 else float("nan"))
-    print("      %-20s %10.4f %10.4f %10.4f   %.1f" % (name, res[0], res[1], res[2], exec_flops / res[0] / 1e9), flush=True)
+    print("      %-20s %9.4f %9.4f %9.4f %9.4f %9.4f %9.4f %9.4f   %.1f / %.1f" % ((name,) + tuple(res) + (exec_flops / res[0] / 1e9, exec_flops / res[1] / 1e9)), flush=True)
