@@ -98,6 +98,11 @@ struct WinoParams {
     int B = 0, TH = 0, TW = 0, T = 0;
     int tile = 2;               // output tile edge m of F(m x m, 3x3): 2 or 4; components = (m+2)^2
     float* V = nullptr;         // [(m+2)^2][T][C0+C1]
+    // split-operand mode (gemm_split.hip): V is written as `nplanes` bf16 planes instead, element (p, k, t, c) at
+    // Vs + p * v_plane + (k * T + t) * (C0 + C1) + c
+    unsigned short* Vs = nullptr;
+    int nplanes = 0;
+    long long v_plane = 0;
     const float* M = nullptr;   // [(m+2)^2][T][Cout]
     int Cout = 0;
     float* out = nullptr;
@@ -110,6 +115,22 @@ struct WinoParams {
     int res_stride = 0;
 };
 void launch_wino_input(const WinoParams& p, hipStream_t s);
+// fp32-equivalent GEMMs on the bf16 MFMA pipe (gemm_split.hip): C_z[m][n] = sum_k A_z[m][k] B_z[n][k] with both operands given
+// as 2 or 3 bf16 planes (hi / mid / lo pieces of the f32 value), f32 accumulate, z = 0 .. ncomp-1.
+struct SplitGemmArgs {
+    const unsigned short* a = nullptr;  // element (plane p, z, m, k) at a + p * plA + z * pA + m * lda + k
+    const unsigned short* b = nullptr;  // element (plane q, z, n, k) at b + q * plB + z * pB + n * K + k
+    float* out = nullptr;               // element (z, m, n) at out + z * pO + m * ldc + n
+    long long plA = 0, plB = 0, pA = 0, pB = 0, pO = 0;
+    int M = 0, N = 0, K = 0, lda = 0, ldc = 0;
+    int n_inner = 1;                    // components walked by one block (gemm_split_inner)
+    int nblk_n = 0;                     // set by the launcher
+};
+void gemm_split_global_init();
+int gemm_split_inner(int M, int N, int ncomp);
+void gemm_split_set_variant(int v);  // tuning: -1 automatic, 0 the 128 x 128 prototype kernel, 1 / 2 the 256 x 256 / 128 x 256 two-plane kernel
+void launch_gemm_split(const SplitGemmArgs& a, int nplanes, int ncomp, hipStream_t s);
+void launch_split_planes(const float* in, unsigned short* out, size_t n, size_t plane, int nplanes, hipStream_t s);  // f32 -> bf16 pieces
 void launch_wino_output(const WinoParams& p, hipStream_t s);
 void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U, int tile);  // host
 // Fused Winograd F(4x4,3x3) convolution (wino_fused.hip): transforms and the 36 component GEMMs in one kernel.  `p` is the

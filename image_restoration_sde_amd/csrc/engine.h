@@ -136,6 +136,28 @@ inline WinoPlan make_wino(const ConvParams& d, const float* U, float* V, float* 
     g.nz = ncomp; g.z_in = (long long)T * Ctot; g.z_w = (long long)d.Cout * Ctot; g.z_out = (long long)T * d.Cout;
     return w;
 }
+// Split-operand variant (gemm_split.hip): V as `nplanes` bf16 planes (Vs: nplanes * 36 * T * Ctot elements), Us the weights'
+// planes (nplanes * 36 * Cout * Ctot), the component GEMMs on the bf16 MFMA pipe, M and the output transform unchanged (f32)
+struct WinoSplitPlan {
+    WinoParams in, out;
+    SplitGemmArgs gemm;
+    int nplanes = 0;
+};
+inline WinoSplitPlan make_wino_split(const ConvParams& d, const unsigned short* Us, unsigned short* Vs, float* Mb, int nplanes) {
+    const WinoPlan w = make_wino(d, nullptr, nullptr, Mb, 4);
+    WinoSplitPlan sp;
+    sp.in = w.in; sp.out = w.out; sp.nplanes = nplanes;
+    const int Ctot = d.C0 + d.C1;
+    const long long T = w.in.T;
+    sp.in.Vs = Vs; sp.in.nplanes = nplanes; sp.in.v_plane = 36ll * T * Ctot;
+    SplitGemmArgs& g = sp.gemm;
+    g.a = Vs; g.b = Us; g.out = Mb;
+    g.plA = 36ll * T * Ctot; g.plB = 36ll * d.Cout * Ctot;
+    g.pA = T * Ctot; g.pB = (long long)d.Cout * Ctot; g.pO = T * d.Cout;
+    g.M = (int)T; g.N = d.Cout; g.K = Ctot; g.lda = Ctot; g.ldc = d.Cout;
+    g.n_inner = gemm_split_inner(g.M, g.N, 36);
+    return sp;
+}
 inline bool wino_shape_ok(const ConvParams& d, int tile) {
     return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.Ho % tile == 0 && d.Wo % tile == 0 &&
            (d.C0 + d.C1) % 32 == 0 && d.Cout % 4 == 0 && d.out_stride % 4 == 0 && (!d.res || d.res_stride % 4 == 0);

@@ -520,7 +520,27 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
             p.partial = dp;
         }
-        if (naive == 33 || naive == 34) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
+        if (naive == 42 || naive == 43) {  // three-launch Winograd F(4x4,3x3) with split-operand component GEMMs: 2 / 3 bf16 planes
+            const int npl = naive - 40;
+            if (!wino_shape_ok(p, 4)) throw HipError("debug_conv: shape not eligible for Winograd");
+            std::vector<float> U((size_t)36 * Cout * Cin);
+            wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
+            const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
+            float *dU = nullptr, *dM = nullptr;
+            unsigned short *dUs = nullptr, *dVs = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dU, U.size() * 4));
+            IRSDE_HIP_CHECK(hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+            IRSDE_HIP_CHECK(hipMalloc(&dUs, U.size() * 2 * npl));
+            IRSDE_HIP_CHECK(hipMalloc(&dVs, (size_t)36 * T * Cin * 2 * npl));
+            IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)36 * T * Cout * 4));
+            launch_split_planes(dU, dUs, U.size(), U.size(), npl, s);
+            const WinoSplitPlan sp = make_wino_split(p, dUs, dVs, dM, npl);
+            launch_wino_input(sp.in, s);
+            launch_gemm_split(sp.gemm, npl, 36, s);
+            launch_wino_output(sp.out, s);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(dU); (void)hipFree(dUs); (void)hipFree(dVs); (void)hipFree(dM);
+        } else if (naive == 33 || naive == 34) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
             if (naive == 33 ? !wino_fused_eligible(p) : !wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -603,6 +623,35 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
     });
 }
 
+int irsde_debug_split_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int ncomp, int nplanes, void* stream) {
+    return guard([&] {
+        // nplanes 2 / 3: automatic kernel choice; 12: the 128 x 128 prototype with 2 planes; 22 / 32: the 256 x 256 / 128 x 256 two-plane kernel
+        struct Restore { ~Restore() { gemm_split_set_variant(-1); } } restore;
+        if (nplanes > 3) {
+            gemm_split_set_variant(nplanes / 10 - 1);
+            nplanes = 2;
+        }
+        if (!A || !Bm || !C || M < 1 || N < 1 || K < 32 || ncomp < 1) throw HipError("debug_split_gemm: bad argument");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        conv_global_init();
+        const size_t na = (size_t)ncomp * M * K, nb = (size_t)ncomp * N * K;
+        unsigned short *da = nullptr, *db = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&da, na * 2 * nplanes));
+        IRSDE_HIP_CHECK(hipMalloc(&db, nb * 2 * nplanes));
+        launch_split_planes(A, da, na, na, nplanes, s);
+        launch_split_planes(Bm, db, nb, nb, nplanes, s);
+        SplitGemmArgs g;
+        g.a = da; g.b = db; g.out = C;
+        g.plA = (long long)na; g.plB = (long long)nb;
+        g.pA = (long long)M * K; g.pB = (long long)N * K; g.pO = (long long)M * N;
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
+        g.n_inner = gemm_split_inner(M, N, ncomp);
+        launch_gemm_split(g, nplanes, ncomp, s);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(da); (void)hipFree(db);
+    });
+}
+
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out) {
     return guard([&] {
@@ -651,18 +700,41 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         // 80: fused Winograd F(4x4,3x3) kernel; 81: the three-launch Winograd F(4x4,3x3) path (random U: timing only)
         float *dU = nullptr, *dV = nullptr, *dM = nullptr;
         WinoPlan wp{};
-        if (variant == 80 || variant == 81 || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 403)) {
+        struct RestoreSplit { ~RestoreSplit() { gemm_split_set_variant(-1); } } restore_split;
+        if (variant == 432 || variant == 442 || variant == 452 || (variant >= 461 && variant <= 464)) {
+            // the two-plane GEMMs alone on a forced kernel: 128 x 128 prototype / 256 x 256 / 128 x 256; 461 / 462 / 463: the 256 x 256 kernel
+            // without global loads / without LDS stores / without MFMAs (measurement twins)
+            gemm_split_set_variant(variant == 432 ? 0 : variant == 442 ? 1 : variant == 452 ? 2 : variant - 458);
+            variant = 422;
+        }
+        const bool split_v = variant == 412 || variant == 413 || variant == 422 || variant == 423;  // split-operand GEMMs: 41x whole three-launch layer, 42x the GEMM alone; x = planes
+        unsigned short *dUs = nullptr, *dVs = nullptr;
+        WinoSplitPlan sp{};
+        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 403)) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
-            if (variant != 81 && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
+            if (variant != 81 && variant != 421 && !split_v && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
             if (variant >= 400 && !wino_fused64_eligible(p)) throw HipError("bench_conv: shape not eligible for the 64-cout fused Winograd kernel");
-            if (variant == 81) {
+            if (variant == 81 || variant == 421) {
                 if (!wino_shape_ok(p, 4)) throw HipError("bench_conv: shape not eligible for Winograd F(4x4,3x3)");
                 const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
                 IRSDE_HIP_CHECK(hipMalloc(&dV, (size_t)36 * T * Cin * 4));
                 IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)36 * T * Cout * 4));
                 wp = make_wino(p, dU, dV, dM, 4);
+                if (variant == 421) launch_wino_input(wp.in, s);
+            }
+            if (split_v) {
+                if (!wino_shape_ok(p, 4)) throw HipError("bench_conv: shape not eligible for Winograd F(4x4,3x3)");
+                const int npl = variant % 10;
+                const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
+                const size_t nu = (size_t)36 * Cout * Cin;
+                IRSDE_HIP_CHECK(hipMalloc(&dUs, nu * 2 * npl));
+                IRSDE_HIP_CHECK(hipMalloc(&dVs, (size_t)36 * T * Cin * 2 * npl));
+                IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)36 * T * Cout * 4));
+                launch_split_planes(dU, dUs, nu, nu, npl, s);
+                sp = make_wino_split(p, dUs, dVs, dM, npl);
+                launch_wino_input(sp.in, s);
             }
         }
         if (variant == 82) {  // fused Winograd kernel once, with per-wave phase stamps: prints the averaged timeline
@@ -713,6 +785,14 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
                 launch_wino_input(wp.in, s);
                 launch_conv(wp.gemm, s);
                 launch_wino_output(wp.out, s);
+            } else if (variant == 421) {   // the f32 component GEMMs alone
+                launch_conv(wp.gemm, s);
+            } else if (variant == 412 || variant == 413) {
+                launch_wino_input(sp.in, s);
+                launch_gemm_split(sp.gemm, sp.nplanes, 36, s);
+                launch_wino_output(sp.out, s);
+            } else if (variant == 422 || variant == 423) {   // the split-operand component GEMMs alone
+                launch_gemm_split(sp.gemm, sp.nplanes, 36, s);
             } else {
                 launch_conv(p, s);
             }
@@ -735,6 +815,8 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         if (dabf) (void)hipFree(dabf);
         for (float* q : {dU, dV, dM})
             if (q) (void)hipFree(q);
+        if (dUs) (void)hipFree(dUs);
+        if (dVs) (void)hipFree(dVs);
         (void)hipStreamDestroy(s);
     });
 }

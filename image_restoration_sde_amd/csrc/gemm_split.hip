@@ -1,0 +1,451 @@
+// fp32-equivalent GEMM on the bf16 matrix pipe (r03 prototype; SURVEY.md 7 lists the route, VERDICT r02 #3 asks for it).
+//
+// gfx950 has no tf32 / xf32 MFMA: an exact-f32 product costs v_mfma_f32_32x32x2_f32 = 1/16 of the bf16 rate.  Split every
+// f32 operand into NPL bf16 pieces (round-to-nearest-even, the residual is exact in f32):
+//     a = a0 + a1 + a2 + e,   |a1| <= 2^-9 |a|,  |a2| <= 2^-18 |a|,  |e| <= 2^-27 |a|          (8 + 8 + 8 significand bits)
+// and a product of two pieces (8 x 8 bits) is exact in the MFMA's f32 accumulator, so
+//     NPL = 3:  a b ~= a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)      6 MFMAs, dropped terms <= 3 * 2^-27 |a b|
+//     NPL = 2:  a b ~= a0 b0 + (a0 b1 + a1 b0)                                3 MFMAs, dropped terms <= 3 * 2^-18 |a b|
+// i.e. NPL = 3 carries the operands' full 24 bits (the dropped part is below f32's own 2^-24 rounding of each
+// accumulation) at 6/16 of the f32-MFMA cycles; NPL = 2 is a 16-bit-significand mode at 3/16.  Accumulation is f32 in both.
+// This is NOT the bit-exact fmaf chain of the native kernels (different rounding points), so it is an opt-in engine mode
+// (IRSDE_FLAG_SPLIT_BF16 / IRSDE_FLAG_SPLIT_BF16X2) with its own measured error table (profiles/r03_split_gemm_*.txt).
+//
+// Where: the component GEMMs of the three-launch Winograd layers, M_z[t][n] = sum_c V_z[t][c] U_z[n][c] (reference call site:
+// Block.proj, module_util.py:108-122).  wino.hip writes V already split (NPL planes of bf16: 2 NPL bytes per element instead
+// of 4), U is split once at weight load, so the GEMM kernel below is a pure bf16 GEMM over NPL + NPL operand planes:
+//   block 128 x 128 outputs, 4 waves of 64 x 64 (2 x 2 tiles of v_mfma_f32_32x32x16_bf16), K-step 32;
+//   per K-step and plane one 128 x 32 bf16 slice of A and of B in LDS (80-byte rows: conflict-free ds_read_b128, the layout of
+//   the bf16 kernels in conv_igemm.hip), double-buffered, global -> register -> LDS staging one K-step ahead;
+//   per 16-k sub-step a wave reads NPL A + NPL B fragments per tile row / column and issues NPROD MFMAs per output tile:
+//   one LDS fragment read per MFMA (x3) instead of two for the plain bf16 kernel, which is LDS-read-bound.
+//   Like gemm_zloop_kernel a block walks n_inner components of its (row tile, column tile) as one pipelined K loop and
+//   writes finished accumulators straight from registers (buffer stores, rows past M dropped by the descriptor).
+#include "common.h"
+
+namespace irsde {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int SG_BK = 32;            // k per K-step and plane
+constexpr int SG_ROWB = 80;          // LDS bytes per row: 32 bf16 + 16 B pad
+constexpr int SG_PLANE = 128 * SG_ROWB;
+
+template <int NPL>
+__global__ __launch_bounds__(256, 1) void gemm_split_kernel(const SplitGemmArgs g) {
+    constexpr int NPROD = NPL == 3 ? 6 : 3;
+    // smallest terms first; consecutive MFMAs of one product hit the four different accumulators of the wave
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int P0 = 6 - NPROD;  // NPL = 2 uses the last three pairs: (0,1), (1,0), (0,0)
+    constexpr int A_BYTES = NPL * SG_PLANE;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* As = lds;
+    char* Bs = lds + 2 * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    int wgid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int mblk = wgid / g.nblk_n, nblk = wgid - mblk * g.nblk_n;
+    const int m0 = mblk * 128, n0 = nblk * 128;
+    const int plane0 = blockIdx.y * g.n_inner;  // first component of this block
+    const int nk = g.K / SG_BK;
+    const int steps = g.n_inner * nk;
+
+    const int piece = tid & 3, row0 = tid >> 2;  // 16-byte piece of a 64-byte row slice; rows row0 and row0 + 64
+    const char* arow[2];
+    const char* brow[2];
+    int st_i = 0;
+    auto set_tile_ptrs = [&]() {
+        const long long z = plane0 + st_i;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            int m = m0 + row0 + ps * 64;
+            m = m < g.M ? m : g.M - 1;   // clamped rows feed accumulator rows that are never stored
+            arow[ps] = reinterpret_cast<const char*>(g.a + z * g.pA + (long long)m * g.lda) + piece * 16;
+            int n = n0 + row0 + ps * 64;
+            n = n < g.N ? n : g.N - 1;
+            brow[ps] = reinterpret_cast<const char*>(g.b + z * g.pB + (long long)n * g.K) + piece * 16;
+        }
+    };
+    set_tile_ptrs();
+    uintx4 rs[4 * NPL];
+    int kk = 0;
+    const long long plA2 = g.plA * 2, plB2 = g.plB * 2;
+    auto load_all = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                rs[ps * NPL + p] = *reinterpret_cast<const uintx4*>(arow[ps] + p * plA2 + kk * 2);
+                rs[2 * NPL + ps * NPL + p] = *reinterpret_cast<const uintx4*>(brow[ps] + p * plB2 + kk * 2);
+            }
+    };
+    auto store_all = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                *reinterpret_cast<uintx4*>(As + buf * A_BYTES + p * SG_PLANE + (row0 + ps * 64) * SG_ROWB + piece * 16) = rs[ps * NPL + p];
+                *reinterpret_cast<uintx4*>(Bs + buf * A_BYTES + p * SG_PLANE + (row0 + ps * 64) * SG_ROWB + piece * 16) = rs[2 * NPL + ps * NPL + p];
+            }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_all();
+    store_all(0);
+    __syncthreads();
+
+    const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
+    unsigned o_voff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_voff[r] = (unsigned)(((r & 3) + 8 * (r >> 2) + 4 * h) * g.ldc + l31) * 4u;
+    auto flush = [&](int fi) {
+        const int rowb = m0 + wm_s * 64, colb = n0 + wn_s * 64;
+        float* ob = g.out + (long long)(plane0 + fi) * g.pO + (long long)rowb * g.ldc;
+        const int rows = g.M - rowb;
+        const unsigned nrec = rows <= 0 ? 0u : (unsigned)(rows < 64 ? rows : 64) * (unsigned)g.ldc * 4u;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, nrec, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int colu = colb + j * 32;
+                if (colu + l31 < g.N) {
+                    const int soff = (i * 32 * g.ldc + colu) * 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];  // (bit_cast straight on the vector element stored element 0 sixteen times: hipcc 7.2)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, (int)o_voff[r], soff, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+    };
+    int kdone = 0, cu_i = 0, fl_i = 0;
+    bool pending = false;
+    for (int st = 0; st < steps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < steps) {  // advance the staging position (the last step re-stages its own operands into the dead buffer)
+            kk += SG_BK;
+            if (kk == g.K) {
+                kk = 0;
+                ++st_i;
+                set_tile_ptrs();
+            }
+        }
+        if (pending) {
+            flush(fl_i);
+            pending = false;
+        }
+        load_all();
+        const char* a = As + buf * A_BYTES + (wm * 64 + l31) * SG_ROWB + h * 16;
+        const char* b = Bs + buf * A_BYTES + (wn * 64 + l31) * SG_ROWB + h * 16;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            bf16x8 fa[NPL][2], fb[NPL][2];
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[p][i] = *reinterpret_cast<const bf16x8*>(a + p * SG_PLANE + i * 32 * SG_ROWB + sb * 32);
+                    fb[p][i] = *reinterpret_cast<const bf16x8*>(b + p * SG_PLANE + i * 32 * SG_ROWB + sb * 32);
+                }
+#pragma unroll
+            for (int pr = P0; pr < 6; ++pr)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fb[PB[pr]][j], acc[i][j], 0, 0, 0);
+        }
+        store_all(buf ^ 1);
+        if (++kdone == nk) {
+            kdone = 0;
+            fl_i = cu_i++;
+            pending = true;
+        }
+        __syncthreads();
+    }
+    flush(fl_i);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2: the two-plane GEMM on big tiles.  The prototype above moves (128 + 128) x 64 B per plane and K-step for 128 x 128
+// outputs: at the bf16 MFMA rate that is > 30 B/clk/CU of L2 -> CU traffic in 64-byte row segments, and the kernel is bound
+// by the vector-memory path (measured: 3 planes 0.84 PFLOP/s = no faster than the native f32 GEMM, 2 planes 0.72 PFLOP/s).
+// Here: block tile (32 TM WM) x (32 TN WN) with 8 waves (WM x WN), 256 x 256 by default = half the bytes per FLOP; LDS rows
+// of 32 bf16 = 64 B WITHOUT padding (XOR swizzle of the four 16-byte pieces by (row >> 2) & 3: conflict-free ds_read_b128
+// lane groups and 8-lane-contiguous ds_write_b128), so two stages of two planes of 256 + 256 rows are 128 KB; buffer loads with
+// per-thread offsets formed once per tile and the K / plane position in scalar registers.
+// ---------------------------------------------------------------------------------------------------------------
+// ABL (measurement twins, irsde_bench_conv 46x): 1 = no global loads in the K loop, 2 = loads but no LDS stores, 3 = no MFMAs, 4 = no output stores
+template <int TM, int TN, int WM, int WN, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_split2_kernel(const SplitGemmArgs g, const unsigned a_bytes, const unsigned b_bytes) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;            // bytes per plane and stage
+    constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
+    constexpr int A_PASSES = BM * 4 / NT, B_PASSES = BN * 4 / NT;  // 16-byte pieces per thread, plane and stage
+    static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "tile rows must divide over the threads");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    int wgid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int mblk = wgid / g.nblk_n, nblk = wgid - mblk * g.nblk_n;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+    const int plane0 = blockIdx.y * g.n_inner;
+    const int nk = g.K / SG_BK;
+    const int steps = g.n_inner * nk;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.a), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.b), 0, b_bytes, 0x00020000);
+
+    // staging: thread = (row = tid / 4 + pass * NT / 4, 16-byte piece = tid % 4); rows past M / N are clamped
+    const int piece = tid & 3, srow = tid >> 2;
+    unsigned a_voff[A_PASSES], b_voff[B_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) {
+        int m = m0 + srow + ps * (NT / 4);
+        m = m < g.M ? m : g.M - 1;
+        a_voff[ps] = (unsigned)m * (unsigned)g.lda * 2u + piece * 16u;
+    }
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+        int n = n0 + srow + ps * (NT / 4);
+        n = n < g.N ? n : g.N - 1;
+        b_voff[ps] = (unsigned)n * (unsigned)g.K * 2u + piece * 16u;
+    }
+    const int st_lds = srow * 64 + ((piece ^ ((srow >> 2) & 3)) * 16);   // (NT / 4 is a multiple of 16: the swizzle term is pass-invariant)
+    const unsigned plA2 = (unsigned)(g.plA * 2), plB2 = (unsigned)(g.plB * 2);
+    uintx4 rs[2 * (A_PASSES + B_PASSES)];
+    int kk = 0, st_i = 0;
+    unsigned a_soff = (unsigned)((long long)plane0 * g.pA * 2), b_soff = (unsigned)((long long)plane0 * g.pB * 2);  // component base (bytes)
+    auto load_all = [&]() {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps)
+                rs[p * A_PASSES + ps] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)a_voff[ps], (int)(a_soff + p * plA2 + kk * 2), 0));
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps)
+                rs[2 * A_PASSES + p * B_PASSES + ps] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)b_voff[ps], (int)(b_soff + p * plB2 + kk * 2), 0));
+        }
+    };
+    auto store_all = [&](int buf) {
+        char* base = lds + buf * STAGE + st_lds;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) *reinterpret_cast<uintx4*>(base + p * A_PLANE + ps * (NT / 4) * 64) = rs[p * A_PASSES + ps];
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps)
+                *reinterpret_cast<uintx4*>(base + 2 * A_PLANE + p * B_PLANE + ps * (NT / 4) * 64) = rs[2 * A_PASSES + p * B_PASSES + ps];
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_all();
+    store_all(0);
+    __syncthreads();
+
+    const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
+    unsigned o_voff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_voff[r] = (unsigned)(((r & 3) + 8 * (r >> 2) + 4 * h) * g.ldc + l31) * 4u;
+    auto flush = [&](int fi) {
+        const int rowb = m0 + wm_s * TM * 32, colb = n0 + wn_s * TN * 32;
+        float* ob = g.out + (long long)(plane0 + fi) * g.pO + (long long)rowb * g.ldc;
+        const int rows = g.M - rowb;
+        const unsigned nrec = rows <= 0 ? 0u : (unsigned)(rows < TM * 32 ? rows : TM * 32) * (unsigned)g.ldc * 4u;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, nrec, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int colu = colb + j * 32;
+                if (colu + l31 < g.N && (ABL != 4 || acc[i][j][0] == 1.2345e30f)) {
+                    const int soff = (i * 32 * g.ldc + colu) * 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, (int)o_voff[r], soff, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+    };
+    // fragment offsets of this lane inside a plane: row (tile base + l31), piece 2 sb + h, swizzled by (l31 >> 2) & 3
+    const int swz = (l31 >> 2) & 3;
+    const int fr_off[2] = {l31 * 64 + ((h ^ swz) * 16), l31 * 64 + (((2 + h) ^ swz) * 16)};
+    int kdone = 0, cu_i = 0, fl_i = 0;
+    bool pending = false;
+    for (int st = 0; st < steps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < steps) {
+            kk += SG_BK;
+            if (kk == g.K) {
+                kk = 0;
+                ++st_i;
+                a_soff = (unsigned)((long long)(plane0 + st_i) * g.pA * 2);
+                b_soff = (unsigned)((long long)(plane0 + st_i) * g.pB * 2);
+            }
+        }
+        if (pending) {
+            flush(fl_i);
+            pending = false;
+        }
+        if (ABL != 1) load_all();
+        const char* a = lds + buf * STAGE + wm * TM * 32 * 64;
+        const char* b = lds + buf * STAGE + 2 * A_PLANE + wn * TN * 32 * 64;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(a + p * A_PLANE + i * 32 * 64 + fr_off[sb]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(b + p * B_PLANE + j * 32 * 64 + fr_off[sb]);
+            }
+            // (0,1), (1,0), (0,0): small terms first; consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (ABL != 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pr == 1 ? 1 : 0][i], fb[pr == 0 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                        else acc[i][j][0] += (float)fa[pr == 1 ? 1 : 0][i][0] * (float)fb[pr == 0 ? 1 : 0][j][0];   // keep the fragment reads alive
+        }
+        if (ABL != 2) store_all(buf ^ 1);
+        else if (rs[0].x == 0x12345678u) store_all(buf ^ 1);
+        if (++kdone == nk) {
+            kdone = 0;
+            fl_i = cu_i++;
+            pending = true;
+        }
+        __syncthreads();
+    }
+    flush(fl_i);
+}
+
+// f32 -> NPL bf16 planes (round to nearest even; every residual is exact in f32)
+template <int NPL>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, const size_t n,
+                                                           const size_t plane) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = in[i];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+        const __bf16 hb = (__bf16)r;
+        out[p * plane + i] = __builtin_bit_cast(unsigned short, hb);
+        r -= (float)hb;
+    }
+}
+
+}  // namespace
+
+void gemm_split_global_init() {
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<2, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+
+// components per block: the largest divisor of `ncomp` that still leaves >= 512 blocks (2 per CU)
+int gemm_split_inner(int M, int N, int ncomp) {
+    const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    for (int d = ncomp; d >= 1; --d)
+        if (ncomp % d == 0 && tiles * (ncomp / d) >= 512) return d;
+    return 1;
+}
+
+// big-tile two-plane kernel: variant 1 = 256 x 256, 2 = 128 x 256 tiles
+static void launch_gemm_split2(const SplitGemmArgs& a, int ncomp, int variant, hipStream_t s) {
+    const int BM = variant == 2 ? 128 : 256, BN = 256;   // variants 3 / 4 / 5: ablation twins of the 256 x 256 kernel
+    SplitGemmArgs g = a;
+    g.nblk_n = (a.N + BN - 1) / BN;
+    const long long tiles = (long long)((a.M + BM - 1) / BM) * g.nblk_n;
+    g.n_inner = 1;
+    for (int d = ncomp; d >= 1; --d)
+        if (ncomp % d == 0 && tiles * (ncomp / d) >= 512) { g.n_inner = d; break; }
+    const unsigned long long ab = (unsigned long long)(a.plA * 2) * 2ull, bb = (unsigned long long)(a.plB * 2) * 2ull;
+    if (ab >= 0xffffffffull || bb >= 0xffffffffull) throw HipError("gemm_split2: operand planes exceed the 32-bit buffer range");
+    const dim3 grid((unsigned)tiles, (unsigned)(ncomp / g.n_inner));
+    const size_t lds = (size_t)2 * 2 * (BM + BN) * 64;
+    if (variant == 3) hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4, 1>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
+    else if (variant == 4) hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4, 2>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
+    else if (variant == 5) hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4, 3>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
+    else if (variant == 6) hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4, 4>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
+    else if (variant == 2) hipLaunchKernelGGL((gemm_split2_kernel<2, 2, 2, 4>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
+    else hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+static int g_split2_variant = -1;   // -1: automatic; 0: the 128 x 128 prototype; 1 / 2: big-tile kernel (irsde_bench_conv tuning)
+void gemm_split_set_variant(int v) { g_split2_variant = v; }
+
+void launch_gemm_split(const SplitGemmArgs& a, int nplanes, int ncomp, hipStream_t s) {
+    if (nplanes != 2 && nplanes != 3) throw HipError("gemm_split: 2 or 3 planes");
+    if (nplanes == 2 && g_split2_variant != 0 && a.K % SG_BK == 0 && (unsigned long long)a.plA * 4ull < 0xffffffffull &&
+        (unsigned long long)a.plB * 4ull < 0xffffffffull && (size_t)a.M * a.ldc * 4 < 0xffffffffull) {
+        int v = g_split2_variant;
+        if (v < 0) v = (a.M >= 2048 && a.N % 256 == 0) ? 1 : 2;
+        launch_gemm_split2(a, ncomp, v, s);
+        return;
+    }
+    if (a.K % SG_BK || a.n_inner < 1 || ncomp % a.n_inner) throw HipError("gemm_split: K must be a multiple of 32, n_inner a divisor of the component count");
+    if ((size_t)a.M * a.ldc * 4 >= 0xffffffffull) throw HipError("gemm_split: output plane exceeds the 32-bit buffer range");
+    SplitGemmArgs g = a;
+    g.nblk_n = (a.N + 127) / 128;
+    const dim3 grid((unsigned)(((a.M + 127) / 128) * g.nblk_n), (unsigned)(ncomp / a.n_inner));
+    const size_t lds = (size_t)4 * nplanes * SG_PLANE;
+    if (nplanes == 3) hipLaunchKernelGGL(gemm_split_kernel<3>, grid, dim3(256), lds, s, g);
+    else hipLaunchKernelGGL(gemm_split_kernel<2>, grid, dim3(256), lds, s, g);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_split_planes(const float* in, unsigned short* out, size_t n, size_t plane, int nplanes, hipStream_t s) {
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (nplanes == 3) hipLaunchKernelGGL(split_planes_kernel<3>, grid, dim3(256), 0, s, in, out, n, plane);
+    else if (nplanes == 2) hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, s, in, out, n, plane);
+    else throw HipError("split_planes: 2 or 3 planes");
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace irsde

@@ -130,6 +130,85 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     }
 }
 
+// Split-operand mode (gemm_split.hip): the same F(4x4,3x3) input transform, 4 channels per thread, but every V element is
+// written as NPL bf16 pieces (round to nearest even, residual exact in f32) into NPL planes: 2 NPL bytes per element instead
+// of 4, and the component GEMMs become bf16 GEMMs with f32-equivalent (NPL = 3) or 16-bit (NPL = 2) operands.
+template <int NPL>
+__global__ __launch_bounds__(256) void wino_input_split_kernel(const WinoParams p) {
+    constexpr int A = 6;
+    const int C4 = (p.C0 + p.C1) / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)p.T * C4;
+    if (idx >= total) return;
+    const int cg = (int)(idx % C4);
+    const int t = (int)(idx / C4);
+    const int tx = t % p.TW;
+    const int t1 = t / p.TW;
+    const int ty = t1 % p.TH;
+    const int b = t1 / p.TH;
+    const int c = cg * 4;
+    const float* src;
+    int pix;
+    if (c < p.C0) {
+        src = p.in0 + c; pix = p.C0;
+    } else {
+        src = p.in1 + (c - p.C0); pix = p.C1;
+    }
+    const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
+    float4 w[A][A];
+    {
+        float4 d[A][A];
+#pragma unroll
+        for (int r = 0; r < A; ++r) {
+            const int iy = 4 * ty - 1 + r;
+#pragma unroll
+            for (int s = 0; s < A; ++s) {
+                const int ix = 4 * tx - 1 + s;
+                const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                const size_t pixel = (size_t)b * p.Hin * p.Win + (size_t)((ok ? iy : 0) >> p.in_shift) * p.Win +
+                                     ((ok ? ix : 0) >> p.in_shift);
+                const float4 v = *reinterpret_cast<const float4*>(src + pixel * pix);
+                d[r][s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < A; ++s) {
+            float4 col[A], tc[A];
+#pragma unroll
+            for (int r = 0; r < A; ++r) col[r] = d[r][s];
+            bt_apply<4, float4>(col, tc);
+#pragma unroll
+            for (int r = 0; r < A; ++r) w[r][s] = tc[r];
+        }
+    }
+    const size_t Ctot = (size_t)(p.C0 + p.C1);
+    unsigned short* vp = p.Vs + (size_t)t * Ctot + c;
+    const size_t kstride = (size_t)p.T * Ctot;
+#pragma unroll
+    for (int r = 0; r < A; ++r) {
+        float4 o[A];
+        bt_apply<4, float4>(w[r], o);
+#pragma unroll
+        for (int s = 0; s < A; ++s) {
+            float rem[4] = {o[s].x, o[s].y, o[s].z, o[s].w};
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                unsigned short q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const __bf16 hb = (__bf16)rem[e];
+                    q[e] = __builtin_bit_cast(unsigned short, hb);
+                    rem[e] -= (float)hb;
+                }
+                uint2 pk;
+                pk.x = (unsigned)q[0] | ((unsigned)q[1] << 16);
+                pk.y = (unsigned)q[2] | ((unsigned)q[3] << 16);
+                *reinterpret_cast<uint2*>(vp + (size_t)pl * p.v_plane + (size_t)(r * A + s) * kstride) = pk;
+            }
+        }
+    }
+}
+
 template <int TILE, typename V>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
     constexpr int A = TILE + 2;
@@ -197,6 +276,15 @@ static int wino_vec() {
 }
 
 void launch_wino_input(const WinoParams& p, hipStream_t s) {
+    if (p.Vs) {  // split-operand mode: bf16 planes
+        if (p.tile != 4 || (p.nplanes != 2 && p.nplanes != 3) || (p.C0 % 4) || (p.C1 % 4)) throw HipError("wino_input (split): F(4x4,3x3), 2 or 3 planes");
+        const long long tot = (long long)p.T * ((p.C0 + p.C1) / 4);
+        const dim3 gr((unsigned)((tot + 255) / 256));
+        if (p.nplanes == 3) hipLaunchKernelGGL(wino_input_split_kernel<3>, gr, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(wino_input_split_kernel<2>, gr, dim3(256), 0, s, p);
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
     const int vn = wino_vec() == 1 ? 1 : 4;
     const long long total = (long long)p.T * ((p.C0 + p.C1) / vn);
     const dim3 grid((unsigned)((total + 255) / 256));

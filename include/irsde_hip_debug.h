@@ -20,6 +20,8 @@ extern "C" {
  *   0 production dispatch      1 VALU cross-check kernel
  *   2 / 3 Winograd F(2x2,3x3) / F(4x4,3x3) (3x3 s1 p1 only); 12 / 13 and 22 / 23: the same with the component GEMMs forced
  *         onto the tile-loop kernel (all / 2 components per block)
+ *   42 / 43 three-launch Winograd F(4x4,3x3) with split-operand component GEMMs on the bf16 MFMA pipe (csrc/gemm_split.hip): 2 / 3 bf16 planes
+ *   34 the 64-cout fused Winograd kernel (r03: Cout and C0 + C1 multiples of 64)
  *   33 the fused Winograd F(4x4,3x3) kernel (csrc/wino_fused.hip; 3x3 s1 p1, H and W multiples of 4, C0, C1 and Cout multiples of 32)
  *   4 bf16-MFMA mode (halo kernel for eligible 3x3 layers); 160 / 161 its generic 256 / 128 tile
  *   5 fp16-MFMA mode (IRSDE_FLAG_FP16; halo kernel for eligible 3x3 layers); 165 its generic 128 tile
@@ -31,12 +33,18 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
                      const float* film, int film_bstride, int silu, const float* res, float* out, int naive,
                      int splits, void* stream);
 
+/* Kernel-level test hook of csrc/gemm_split.hip: C_z[M][N] = A_z[M][K] . B_z[N][K]^T for z < ncomp (device f32 tensors, z-major),
+ * operands split into `nplanes` (2 or 3) bf16 pieces on the device, products on v_mfma_f32_32x32x16_bf16, f32 accumulate.
+ * K a multiple of 32.  Synchronises `stream`. */
+int irsde_debug_split_gemm(const float* A, const float* B, float* C, int M, int N, int K, int ncomp, int nplanes, void* stream);
+
 /* Kernel tuning hook: average ms of one KxK convolution (pad K/2, or 4x4 s2 p1) on random NHWC data.
  * variant: 0 production dispatch, 3 / 50 fp32 256x128 / 256x256 tiles, 5 one block per CU, 6 generic pointer staging instead of
  * buffer descriptors, 7 LDS-transposed instead of direct epilogue, 60 / 61 / 62 bf16 mode (256 tile / 128 tile / automatic
  * incl. the halo kernel), 63 = 62 with bf16 activation storage, 80 / 81 Winograd F(4x4,3x3) fused kernel / three-launch path (3x3 s1 only), 82 the fused kernel once with its
  * phase timeline printed to stdout, 400 the 64-cout fused Winograd kernel (r03; 401 / 402: its weight fragments / patch loads read zeros
- * without memory traffic, 403: 12 instead of 18 weight units in flight); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
+ * without memory traffic, 403: 12 instead of 18 weight units in flight), 412 / 413 the three-launch Winograd layer with split-operand GEMMs (2 / 3
+ * bf16 planes), 421 / 422 / 423 the component GEMMs alone: native f32 / 2 planes / 3 planes; epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out);
 
