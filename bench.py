@@ -121,7 +121,7 @@ def cpu_baseline(size, T, budget_s=20.0):
 KERNEL_CLASSES = [
     ("conv(winograd F4 fused)", "wino4_fused_kernel (Winograd F(4x4,3x3): input transform + 36 component GEMMs + output transform + epilogue in one kernel)"),
     ("conv(winograd", "gemm_zloop_kernel (component GEMMs of the three-launch Winograd layers)"),
-    ("conv(split", "gemm_split_bf16_kernel (fp32 operands split into bf16 pieces, cross products on v_mfma_f32_32x32x16_bf16)"),
+    ("conv(split", "gemm_split2i_kernel (f32 operands as bf16 hi+lo pairs, 3 cross products on v_mfma_f32_32x32x16_bf16; FLOPs counted once per f32 product)"),
     ("conv M=", "conv_igemm_kernel / gemm_zloop_kernel (direct implicit-GEMM layers: 1x1, 4x4 s2, 7x7, narrow 3x3)"),
     ("conv", "conv kernels (other)"),
     ("wino_", "wino_input_kernel / wino_output_kernel (transforms of the three-launch Winograd layers)"),
@@ -197,7 +197,7 @@ def roofline_object(prof, op_text, w):
 DTYPE_LABEL = {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate+state",
                "bf16_act": "bf16 operands + bf16 activation storage / f32 accumulate+state",
                "fp16": "f16 operands / f32 accumulate+state",
-               "fp32_split": "f32 operands split into 3 bf16 pieces, 6 cross products on the bf16 MFMA, f32 accumulate (fp32-equivalent)"}
+               "fp32_split": "f32 storage / state / transforms; deep Winograd component GEMMs on bf16 hi+lo operand pairs (3 cross products on the bf16 MFMA, f32 accumulate)"}
 
 # the other BASELINE.json configs + the 512x512 batch north_star names: timed after the headline, reported under `secondary`
 SECONDARY = [
@@ -205,6 +205,8 @@ SECONDARY = [
     dict(tag="BASELINE configs[3]: Refusion NAFNet 8x512x512 T=200", model="nafnet", dtype="fp32", mode="sde", batch=8, size=512, T=200),
     dict(tag="BASELINE configs[4]: Latent-Refusion 64x64x4 latent, batch 64, fp16", model="latent", dtype="fp16", mode="sde", batch=64, size=256, T=100),
     dict(tag="north_star 512x512 batch: IR-SDE UNet 16x512x512", model="unet", dtype="fp32", mode="sde", batch=16, size=512, T=100),
+    dict(tag="BASELINE configs[1] workload in the opt-in fp32_split mode (IRSDE_FLAG_SPLIT_BF16X2; error table: profiles/r03_split_*)",
+         model="unet", dtype="fp32_split", mode="sde", batch=16, size=256, T=100),
 ]
 
 

@@ -103,6 +103,7 @@ struct WinoParams {
     unsigned short* Vs = nullptr;
     int nplanes = 0;
     long long v_plane = 0;
+    int v_pairs = 0;            // 1: two planes, pair-interleaved: element (k, t, c, p) at Vs + ((k * T + t) * (Ctot / 32) + c / 32) * 64 + p * 32 + c % 32
     const float* M = nullptr;   // [(m+2)^2][T][Cout]
     int Cout = 0;
     float* out = nullptr;
@@ -128,6 +129,10 @@ struct SplitGemmArgs {
 };
 void gemm_split_global_init();
 int gemm_split_inner(int M, int N, int ncomp);
+// two planes in the pair-interleaved layout [row][k / 32][plane][32 k] (v3 kernel: LDS-DMA, 256 x 256 tiles); pA / pB = elements
+// per component and plane (M * K resp. N * K), plA / plB unused
+void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, int abl = 0);
+void launch_split_pairs(const float* in, unsigned short* out, size_t rows, int K, hipStream_t s);  // f32 [rows][K] -> pair-interleaved hi / lo
 void gemm_split_set_variant(int v);  // tuning: -1 automatic, 0 the 128 x 128 prototype kernel, 1 / 2 the 256 x 256 / 128 x 256 two-plane kernel
 void launch_gemm_split(const SplitGemmArgs& a, int nplanes, int ncomp, hipStream_t s);
 void launch_split_planes(const float* in, unsigned short* out, size_t n, size_t plane, int nplanes, hipStream_t s);  // f32 -> bf16 pieces

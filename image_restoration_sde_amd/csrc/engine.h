@@ -72,6 +72,7 @@ struct ConvW {
     float* wino_u4 = nullptr;  // device [36][Cout][Cin]              F(4x4,3x3)  (3x3 layers with Cin,Cout >= 128)
     float* wino_uf = nullptr;  // the same F(4x4,3x3) weights in the fused kernel's fragment order (wino_fused.hip)
     float* wino_uf64 = nullptr;  // ... in the 64-cout fused kernel's fragment order (Cout, Cin multiples of 64)
+    unsigned short* wino_up = nullptr;  // IRSDE_FLAG_SPLIT_BF16X2: the F(4x4,3x3) weights as bf16 hi / lo pairs, [36][Cout][Cin / 32][2][32]
 };
 struct ResW {
     ConvW b1, b2, res;
@@ -158,6 +159,23 @@ inline WinoSplitPlan make_wino_split(const ConvParams& d, const unsigned short* 
     g.n_inner = gemm_split_inner(g.M, g.N, 36);
     return sp;
 }
+// IRSDE_FLAG_SPLIT_BF16X2: pair-interleaved operands for launch_gemm_split_pairs (Vs: 36 * T * Ctot * 2 elements)
+inline WinoSplitPlan make_wino_pairs(const ConvParams& d, const unsigned short* Up, unsigned short* Vs, float* Mb) {
+    const WinoPlan w = make_wino(d, nullptr, nullptr, Mb, 4);
+    WinoSplitPlan sp;
+    sp.in = w.in; sp.out = w.out; sp.nplanes = 2;
+    const int Ctot = d.C0 + d.C1;
+    const long long T = w.in.T;
+    sp.in.Vs = Vs; sp.in.nplanes = 2; sp.in.v_pairs = 1;
+    SplitGemmArgs& g = sp.gemm;
+    g.a = Vs; g.b = Up; g.out = Mb;
+    g.pA = T * Ctot; g.pB = (long long)d.Cout * Ctot; g.pO = T * d.Cout;
+    g.M = (int)T; g.N = d.Cout; g.K = Ctot; g.lda = Ctot; g.ldc = d.Cout;
+    return sp;
+}
+// split mode: three-launch Winograd layers with at least this many input channels run the pair GEMM (below it the fused
+// f32 kernel is faster: profiles/r03_split_gemm_bench.txt); IRSDE_SPLIT_MINC moves the crossover (tuning only)
+inline int split_min_cin() { return tuning_env_int("IRSDE_SPLIT_MINC", 256); }
 inline bool wino_shape_ok(const ConvParams& d, int tile) {
     return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.Ho % tile == 0 && d.Wo % tile == 0 &&
            (d.C0 + d.C1) % 32 == 0 && d.Cout % 4 == 0 && d.out_stride % 4 == 0 && (!d.res || d.res_stride % 4 == 0);

@@ -627,6 +627,23 @@ int irsde_debug_split_gemm(const float* A, const float* Bm, float* C, int M, int
     return guard([&] {
         // nplanes 2 / 3: automatic kernel choice; 12: the 128 x 128 prototype with 2 planes; 22 / 32: the 256 x 256 / 128 x 256 two-plane kernel
         struct Restore { ~Restore() { gemm_split_set_variant(-1); } } restore;
+        if (nplanes == 42) {   // the pair-interleaved two-plane kernel (v3: LDS-DMA, 256 x 256 tiles)
+            hipStream_t s2 = reinterpret_cast<hipStream_t>(stream);
+            conv_global_init();
+            unsigned short *pa = nullptr, *pb = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&pa, (size_t)ncomp * M * K * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&pb, (size_t)ncomp * N * K * 4));
+            launch_split_pairs(A, pa, (size_t)ncomp * M, K, s2);
+            launch_split_pairs(Bm, pb, (size_t)ncomp * N, K, s2);
+            SplitGemmArgs gp;
+            gp.a = pa; gp.b = pb; gp.out = C;
+            gp.pA = (long long)M * K; gp.pB = (long long)N * K; gp.pO = (long long)M * N;
+            gp.M = M; gp.N = N; gp.K = K; gp.lda = K; gp.ldc = N;
+            launch_gemm_split_pairs(gp, ncomp, s2);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s2));
+            (void)hipFree(pa); (void)hipFree(pb);
+            return;
+        }
         if (nplanes > 3) {
             gemm_split_set_variant(nplanes / 10 - 1);
             nplanes = 2;
@@ -706,6 +723,42 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
             // without global loads / without LDS stores / without MFMAs (measurement twins)
             gemm_split_set_variant(variant == 432 ? 0 : variant == 442 ? 1 : variant == 452 ? 2 : variant - 458);
             variant = 422;
+        }
+        if (variant >= 472 && variant <= 476) {   // the pair-interleaved two-plane component GEMMs alone (v3 kernel): 472 full, 473 no loads, 475 no MFMAs, 476 no output stores
+            if (K != 3 || stride != 1 || !wino_shape_ok(p, 4)) throw HipError("bench_conv: Winograd variants need an eligible 3x3 stride-1 layer");
+            const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
+            float *vf = nullptr, *uf = nullptr, *mo = nullptr;
+            unsigned short *vp = nullptr, *up = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&vf, (size_t)36 * T * Cin * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&uf, (size_t)36 * Cout * Cin * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&mo, (size_t)36 * T * Cout * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&vp, (size_t)36 * T * Cin * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&up, (size_t)36 * Cout * Cin * 4));
+            launch_fill_random(vf, (size_t)36 * T * Cin, 7, 1.0f, s);
+            launch_fill_random(uf, (size_t)36 * Cout * Cin, 8, 0.05f, s);
+            launch_split_pairs(vf, vp, (size_t)36 * T, Cin, s);
+            launch_split_pairs(uf, up, (size_t)36 * Cout, Cin, s);
+            SplitGemmArgs gp;
+            gp.a = vp; gp.b = up; gp.out = mo;
+            gp.pA = T * Cin; gp.pB = (long long)Cout * Cin; gp.pO = T * Cout;
+            gp.M = (int)T; gp.N = Cout; gp.K = Cin; gp.lda = Cin; gp.ldc = Cout;
+            const int abl = variant - 472;
+            hipEvent_t e0, e1;
+            IRSDE_HIP_CHECK(hipEventCreate(&e0));
+            IRSDE_HIP_CHECK(hipEventCreate(&e1));
+            for (int i = 0; i < 2; ++i) launch_gemm_split_pairs(gp, 36, s, abl);
+            IRSDE_HIP_CHECK(hipEventRecord(e0, s));
+            for (int i = 0; i < iters; ++i) launch_gemm_split_pairs(gp, 36, s, abl);
+            IRSDE_HIP_CHECK(hipEventRecord(e1, s));
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            float ms = 0;
+            IRSDE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            *ms_out = ms / iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            (void)hipFree(vf); (void)hipFree(uf); (void)hipFree(mo); (void)hipFree(vp); (void)hipFree(up);
+            (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
+            (void)hipStreamDestroy(s);
+            return;
         }
         const bool split_v = variant == 412 || variant == 413 || variant == 422 || variant == 423;  // split-operand GEMMs: 41x whole three-launch layer, 42x the GEMM alone; x = planes
         unsigned short *dUs = nullptr, *dVs = nullptr;

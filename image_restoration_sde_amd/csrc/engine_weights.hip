@@ -105,6 +105,14 @@ ConvW pack_conv(irsde_engine* e, const std::string& wname, const std::string& bn
             std::vector<float> U((size_t)(tile + 2) * (tile + 2) * O * I);
             wino_transform_weights(p.data(), O, I, U.data(), tile);
             (tile == 4 ? c.wino_u4 : c.wino_u2) = e->upload(U);
+            if (tile == 4 && (e->cfg.flags & IRSDE_FLAG_SPLIT_BF16X2) && I >= split_min_cin()) {
+                unsigned short* up = nullptr;   // bf16 hi / lo pairs of U, made on the device once
+                IRSDE_HIP_CHECK(hipMalloc(&up, U.size() * 4));
+                e->dev_allocs.push_back(reinterpret_cast<float*>(up));
+                launch_split_pairs(c.wino_u4, up, (size_t)36 * O, I, e->stream);
+                IRSDE_HIP_CHECK(hipStreamSynchronize(e->stream));
+                c.wino_up = up;
+            }
             if (tile == 4 && !(e->cfg.flags & IRSDE_FLAG_NO_WINOGRAD_FUSED) && O % 32 == 0 && I % 16 == 0 && I <= kWinoFusedMaxCin &&
                 O <= kWinoFusedMaxCout) {
                 std::vector<float> Uf(U.size());

@@ -22,6 +22,7 @@
 //   Like gemm_zloop_kernel a block walks n_inner components of its (row tile, column tile) as one pipelined K loop and
 //   writes finished accumulators straight from registers (buffer stores, rows past M dropped by the descriptor).
 #include "common.h"
+#include <algorithm>
 
 namespace irsde {
 
@@ -359,6 +360,173 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_split2_kernel(const Spli
     flush(fl_i);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v3: two planes, pair-interleaved operands, LDS-DMA.  What v2's ablation twins showed (profiles/r03_split_gemm_notes.md): without
+// its global loads the K loop takes 69 % of the time, without MFMAs 72 % — the 64 wave-loads of a K-step (1 KB each, but 16
+// separate 64-byte row segments) cost as much as the 96 MFMAs they feed, and the 64 ds_write_b128 (13 cycles each) and their
+// VGPR staging come on top.  Here:
+//   * operand layout [row][k / 32][plane][32 k]: the hi and lo pieces of a row's 32-k block are ONE 128-byte line, so a wave-load
+//     of 1 KB covers 8 rows x 128 B = 8 full lines instead of 16 half lines (wino_input / split_planes write this layout);
+//   * global_load_lds_dwordx4: global -> LDS without VGPRs or ds_write; the LDS image of a stage is lane-linear (1 KB per
+//     wave-load = 8 rows), the XOR swizzle of the 16-byte pieces (by (row >> 1) & 7: conflict-free ds_read_b128 lane groups on
+//     128-byte rows) is applied to the per-lane SOURCE address and to the fragment reads (cdna_hip_programming.md rule 21);
+//   * the loads of K-step t+1 are issued right after the barrier that ends step t-1 and have the whole MFMA phase of step t to
+//     land; __syncthreads() (vmcnt(0) + s_barrier) ends the step.
+// Block tile 256 x 256, 8 waves of 128 x 64, K-step 32, two LDS stages of 64 KB.
+// ---------------------------------------------------------------------------------------------------------------
+#define IRSDE_GLDS16(GPTR, LPTR) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR), (__attribute__((address_space(3))) void*)(LPTR), 16, 0, 0)
+
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_split2i_kernel(const SplitGemmArgs g) {
+    constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256;
+    constexpr int A_STAGE = BM * 128, STAGE = (BM + BN) * 128;   // bytes
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    // XCD-aware work assignment (workgroup id w runs on XCD w % 8): a unit = (component, row tile) with all its column tiles;
+    // XCD x owns the contiguous unit range [x U / 8, (x + 1) U / 8).  An A row tile is then read through ONE L2 (its column
+    // tiles run side by side on that XCD and walk K in step), a component's B through at most two; with the plain
+    // (tile, component) grid every A tile crossed two L2s and every B tile four, and the kernel sat on the HBM floor of
+    // that traffic (v3 without MFMAs = 0.19 of its 0.25 ms, profiles/r03_split_gemm_notes.md).
+    const int mtiles = (g.M + BM - 1) / BM;
+    const int units = mtiles * g.n_inner;          // (n_inner carries the component count here)
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int ulo = (int)((long long)xcd * units / 8), uhi = (int)((long long)(xcd + 1) * units / 8);
+    const int unit = ulo + jx / g.nblk_n;
+    if (unit >= uhi) return;
+    const int nblk = jx % g.nblk_n;
+    const int plane0 = unit / mtiles, mblk = unit - plane0 * mtiles;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+    const int nk = g.K / SG_BK;
+    const int steps = nk;
+    const unsigned rowb = (unsigned)nk * 128u;   // bytes per operand row: K / 32 blocks of (hi 64 B | lo 64 B)
+
+    // staging: wave-load (pass ps) = LDS chunk c = ps * 8 + wave = rows 8c .. 8c+7 of the A (B) tile; lane = (row 8c + lane / 8, slot lane % 8)
+    // fetches the row's piece slot ^ ((row >> 1) & 7)
+    unsigned a_voff[4], b_voff[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = (ps * 8 + wave) * 8 + (lane >> 3);
+        const unsigned pc = (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+        int m = m0 + row;
+        m = m < g.M ? m : g.M - 1;
+        a_voff[ps] = (unsigned)m * rowb + pc;
+        int n = n0 + row;
+        n = n < g.N ? n : g.N - 1;
+        b_voff[ps] = (unsigned)n * rowb + pc;
+    }
+    const char* abase = reinterpret_cast<const char*>(g.a);
+    const char* bbase = reinterpret_cast<const char*>(g.b);
+    const long long pA2 = g.pA * 4, pB2 = g.pB * 4;   // bytes between components: 2 planes x 2 bytes per element
+    int kb = 0;
+    const char* acomp = abase + (long long)plane0 * pA2;
+    const char* bcomp = bbase + (long long)plane0 * pB2;
+    auto issue_loads = [&](int buf) {
+        char* la = lds + buf * STAGE + wave * 1024;
+        const char* ga = acomp + kb * 128;
+        const char* gb = bcomp + kb * 128;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) IRSDE_GLDS16(ga + a_voff[ps], la + ps * 8192);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) IRSDE_GLDS16(gb + b_voff[ps], la + A_STAGE + ps * 8192);
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue_loads(0);
+    __syncthreads();
+
+    const int wm_s = wm, wn_s = wn;
+    unsigned o_voff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_voff[r] = (unsigned)(((r & 3) + 8 * (r >> 2) + 4 * h) * g.ldc + l31) * 4u;
+    auto flush = [&](int fi) {
+        const int rowb_ = m0 + wm_s * TM * 32, colb = n0 + wn_s * TN * 32;
+        float* ob = g.out + (long long)(plane0 + fi) * g.pO + (long long)rowb_ * g.ldc;
+        const int rows = g.M - rowb_;
+        const unsigned nrec = rows <= 0 ? 0u : (unsigned)(rows < TM * 32 ? rows : TM * 32) * (unsigned)g.ldc * 4u;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, nrec, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int colu = colb + j * 32;
+                if (colu + l31 < g.N && (ABL != 4 || acc[i][j][0] == 1.2345e30f)) {
+                    const int soff = (i * 32 * g.ldc + colu) * 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, (int)o_voff[r], soff, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+    };
+    // fragment offsets inside a 128-byte row: piece = plane * 4 + sb * 2 + h, swizzled by (l31 >> 1) & 7 (tile bases are multiples of 32 rows)
+    const int swz = (l31 >> 1) & 7;
+    int fr_off[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) fr_off[p][sb] = l31 * 128 + (((p * 4 + sb * 2 + h) ^ swz) * 16);
+    for (int st = 0; st < steps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < steps) {
+            ++kb;
+            if (ABL != 1) issue_loads(buf ^ 1);   // stage buf^1 was last read in step st-1: every wave is past that step's barrier
+        }
+        const char* a = lds + buf * STAGE + wm * TM * 32 * 128;
+        const char* b = lds + buf * STAGE + A_STAGE + wn * TN * 32 * 128;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * 128 + fr_off[p][sb]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * 128 + fr_off[p][sb]);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (ABL != 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pr == 1 ? 1 : 0][i], fb[pr == 0 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                        else acc[i][j][0] += (float)fa[pr == 1 ? 1 : 0][i][0] * (float)fb[pr == 0 ? 1 : 0][j][0];
+        }
+        __syncthreads();
+    }
+    flush(0);
+}
+#undef IRSDE_GLDS16
+
+// f32 -> pair-interleaved hi / lo bf16 pieces: element (row, k) of a [rows][K] matrix -> out[(row * K / 32 + k / 32) * 64 + plane * 32 + k % 32]
+__global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, const size_t n, const int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t row = i / K;
+    const int k = (int)(i - row * K);
+    float r = in[i];
+    const size_t base = (row * (size_t)(K / 32) + k / 32) * 64 + (k & 31);
+    const __bf16 hb = (__bf16)r;
+    out[base] = __builtin_bit_cast(unsigned short, hb);
+    r -= (float)hb;
+    const __bf16 lb = (__bf16)r;
+    out[base + 32] = __builtin_bit_cast(unsigned short, lb);
+}
+
 // f32 -> NPL bf16 planes (round to nearest even; every residual is exact in f32)
 template <int NPL>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, const size_t n,
@@ -379,6 +547,10 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 void gemm_split_global_init() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<2, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -414,6 +586,37 @@ static void launch_gemm_split2(const SplitGemmArgs& a, int ncomp, int variant, h
     else if (variant == 6) hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4, 4>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
     else if (variant == 2) hipLaunchKernelGGL((gemm_split2_kernel<2, 2, 2, 4>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
     else hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+// pair-interleaved operands (g.a / g.b in the [row][k/32][plane][32] layout, g.pA / g.pB = elements per component and plane)
+void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, int abl) {
+    if (a.K % SG_BK) throw HipError("gemm_split_pairs: K must be a multiple of 32");
+    if ((unsigned long long)a.M * a.K * 4ull >= 0xffffffffull || (unsigned long long)a.N * a.K * 4ull >= 0xffffffffull ||
+        (size_t)a.M * a.ldc * 4 >= 0xffffffffull)
+        throw HipError("gemm_split_pairs: a component exceeds the 32-bit offset range");
+    SplitGemmArgs g = a;
+    g.nblk_n = (a.N + 255) / 256;
+    g.n_inner = ncomp;   // this kernel: one (component, row tile, column tile) per block; n_inner carries the component count
+    const int units = ((a.M + 255) / 256) * ncomp;
+    int per_xcd = 0;
+    for (int x = 0; x < 8; ++x) per_xcd = std::max(per_xcd, (int)((long long)(x + 1) * units / 8) - (int)((long long)x * units / 8));
+    const dim3 grid((unsigned)(8 * per_xcd * g.nblk_n));
+    const size_t lds = (size_t)2 * 512 * 128;
+    switch (abl) {
+        case 0: hipLaunchKernelGGL(gemm_split2i_kernel<0>, grid, dim3(512), lds, s, g); break;
+        case 1: hipLaunchKernelGGL(gemm_split2i_kernel<1>, grid, dim3(512), lds, s, g); break;
+        case 3: hipLaunchKernelGGL(gemm_split2i_kernel<3>, grid, dim3(512), lds, s, g); break;
+        case 4: hipLaunchKernelGGL(gemm_split2i_kernel<4>, grid, dim3(512), lds, s, g); break;
+        default: throw HipError("gemm_split_pairs: bad ablation variant");
+    }
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_split_pairs(const float* in, unsigned short* out, size_t rows, int K, hipStream_t s) {
+    if (K % 32) throw HipError("split_pairs: K must be a multiple of 32");
+    const size_t n = rows * (size_t)K;
+    hipLaunchKernelGGL(split_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, K);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
 // Split-operand mode (gemm_split.hip): the same F(4x4,3x3) input transform, 4 channels per thread, but every V element is
 // written as NPL bf16 pieces (round to nearest even, residual exact in f32) into NPL planes: 2 NPL bytes per element instead
 // of 4, and the component GEMMs become bf16 GEMMs with f32-equivalent (NPL = 3) or 16-bit (NPL = 2) operands.
-template <int NPL>
+template <int NPL, bool PAIRS = false>
 __global__ __launch_bounds__(256) void wino_input_split_kernel(const WinoParams p) {
     constexpr int A = 6;
     const int C4 = (p.C0 + p.C1) / 4;
@@ -182,8 +182,10 @@ __global__ __launch_bounds__(256) void wino_input_split_kernel(const WinoParams 
         }
     }
     const size_t Ctot = (size_t)(p.C0 + p.C1);
-    unsigned short* vp = p.Vs + (size_t)t * Ctot + c;
-    const size_t kstride = (size_t)p.T * Ctot;
+    // PAIRS: [component][tile][c / 32][plane][c % 32] (both pieces of a 32-channel block in one 128-byte line)
+    unsigned short* vp = PAIRS ? p.Vs + ((size_t)t * (Ctot / 32) + c / 32) * 64 + (c & 31) : p.Vs + (size_t)t * Ctot + c;
+    const size_t kstride = PAIRS ? (size_t)p.T * Ctot * 2 : (size_t)p.T * Ctot;
+    const size_t plstride = PAIRS ? 32 : (size_t)p.v_plane;
 #pragma unroll
     for (int r = 0; r < A; ++r) {
         float4 o[A];
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void wino_input_split_kernel(const WinoParams 
                 uint2 pk;
                 pk.x = (unsigned)q[0] | ((unsigned)q[1] << 16);
                 pk.y = (unsigned)q[2] | ((unsigned)q[3] << 16);
-                *reinterpret_cast<uint2*>(vp + (size_t)pl * p.v_plane + (size_t)(r * A + s) * kstride) = pk;
+                *reinterpret_cast<uint2*>(vp + (size_t)pl * plstride + (size_t)(r * A + s) * kstride) = pk;
             }
         }
     }
@@ -280,8 +282,11 @@ void launch_wino_input(const WinoParams& p, hipStream_t s) {
         if (p.tile != 4 || (p.nplanes != 2 && p.nplanes != 3) || (p.C0 % 4) || (p.C1 % 4)) throw HipError("wino_input (split): F(4x4,3x3), 2 or 3 planes");
         const long long tot = (long long)p.T * ((p.C0 + p.C1) / 4);
         const dim3 gr((unsigned)((tot + 255) / 256));
-        if (p.nplanes == 3) hipLaunchKernelGGL(wino_input_split_kernel<3>, gr, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(wino_input_split_kernel<2>, gr, dim3(256), 0, s, p);
+        if (p.v_pairs) {
+            if (p.nplanes != 2 || (p.C0 + p.C1) % 32) throw HipError("wino_input (pairs): two planes, channels a multiple of 32");
+            hipLaunchKernelGGL((wino_input_split_kernel<2, true>), gr, dim3(256), 0, s, p);
+        } else if (p.nplanes == 3) hipLaunchKernelGGL((wino_input_split_kernel<3, false>), gr, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((wino_input_split_kernel<2, false>), gr, dim3(256), 0, s, p);
         IRSDE_HIP_CHECK(hipGetLastError());
         return;
     }

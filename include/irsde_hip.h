@@ -76,6 +76,12 @@ enum {
                                         fused kernel of csrc/wino_fused.hip, whose transformed tensors never reach HBM */
     IRSDE_FLAG_NO_FUSED_ATTN = 4096, /* LinearAttention with the whole to_qkv convolution and a q | k | v tensor in HBM (default for fp32, C <= 256:
                                         k / v projection + softmax over the pixels + context in one kernel, only q is a convolution) */
+    IRSDE_FLAG_SPLIT_BF16X2 = 16384, /* r03, opt-in, new behaviour (the reference is plain fp32): the component GEMMs of the three-launch Winograd
+                                        layers (Cin >= 256) run on the bf16 MFMA pipe with every f32 operand split into a bf16 pair hi + lo
+                                        (round to nearest even; the residual is exact) and the three cross products hi.hi + hi.lo + lo.hi accumulated
+                                        in f32 (csrc/gemm_split.hip): 16 significand bits per operand instead of 24 at 3/16 of the f32-MFMA cycles.
+                                        Everything else (transforms, other layers, epilogues, sampler state) stays native f32.  Measured error
+                                        and speed: profiles/r03_split_gemm_*.txt.  Not combinable with the 16-bit modes. */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };
