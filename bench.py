@@ -185,6 +185,9 @@ def roofline_object(prof, op_text, w):
                                 "executed_TFLOPs": v[1] / (v[0] * 1e-3) / 1e12, "frac": v[1] / (v[0] * 1e-3) / 1e12 / peak}
         r["per_kernel"] = [{"name": n, "time_share": v[0] / tot, "ms_per_evaluation": v[0], "executed_TFLOPs": v[1] / (v[0] * 1e-3) / 1e12,
                             "frac": v[1] / (v[0] * 1e-3) / 1e12 / peak} for n, v in mfma_classes]
+    if w["dtype"] == "fp32_split":
+        r["note"] = ("fp32_split: FLOPs are counted once per f32 product and compared with the f32 MFMA roof as a speed reference; the pair GEMMs "
+                     "themselves execute 3 bf16 MFMA products per f32 product on the bf16 pipe")
     if not fp32:
         # 16-bit operands: 16x the MFMA rate turns the convolutions L2/HBM-bound, so quote the HBM roof first
         gbps = prof["conv_bytes"] / (prof["conv_ms"] * 1e-3) / 1e9
