@@ -204,7 +204,7 @@ struct AttnWorkspace {
     float* ctx = nullptr;    // [B][4][32][32]
     int nch = 0;             // N-chunks per image
 };
-int attn_num_chunks(int N);
+int attn_num_chunks(int N, int B);
 // qkv: [B][N][384] (q | k | v, 4 heads x 32 each).  out: [B][N][128].
 void launch_linear_attention(const float* qkv, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s,
                              bool bf16 = false);

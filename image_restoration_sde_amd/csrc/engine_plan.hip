@@ -322,7 +322,7 @@ struct Builder {
             // whole Residual(PreNorm(LinearAttention)) block in two kernels + the context merge: PreNorm's LayerNorm runs on
             // the tiles both kernels stage, so no normalised copy of x, no q / k / v, no attention output reach HBM
             AttnWorkspace ws;
-            ws.nch = attn_num_chunks(N);
+            ws.nch = attn_num_chunks(N, x.B);
             ws.pmax = pl->alloc((size_t)x.B * ws.nch * 128, false);
             ws.pctx = pl->alloc((size_t)x.B * 4 * ws.nch * 1024, false);
             ws.psum = pl->alloc((size_t)x.B * 4 * ws.nch * 32, false);
@@ -351,7 +351,7 @@ struct Builder {
             // fp32 fused form: the k and v thirds of to_qkv never reach HBM — their projection, the softmax over the pixels and
             // the context run in one kernel on the LayerNorm output; only q (rows 0..127 of to_qkv.weight) is a convolution
             AttnWorkspace ws;
-            ws.nch = attn_num_chunks(N);
+            ws.nch = attn_num_chunks(N, x.B);
             ws.pmax = pl->alloc((size_t)x.B * ws.nch * 128, false);
             ws.pctx = pl->alloc((size_t)x.B * 4 * ws.nch * 1024, false);
             ws.psum = pl->alloc((size_t)x.B * 4 * ws.nch * 32, false);
@@ -391,7 +391,7 @@ struct Builder {
         }
         {
             AttnWorkspace ws;
-            ws.nch = attn_num_chunks(N);
+            ws.nch = attn_num_chunks(N, x.B);
             ws.pmax = pl->alloc((size_t)x.B * ws.nch * 128, false);
             ws.pctx = pl->alloc((size_t)x.B * 4 * ws.nch * 1024, false);
             ws.psum = pl->alloc((size_t)x.B * 4 * ws.nch * 32, false);

@@ -5,6 +5,7 @@
 //   time embedding / FiLM rows   module_util.py:29-41, DenoisingUNet_arch.py:42-47, module_util.py:127-141
 //   reverse-step update + RNG    sde_utils.py:44-48,175-223
 #include "common.h"
+#include <algorithm>
 
 namespace irsde {
 
@@ -1235,20 +1236,23 @@ void launch_row_gate(const float* in, float* out, int rows, int h, hipStream_t s
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-static int attn_chunk_len(int N) {
-    int len = (N + 31) / 32;
+// pixels per context chunk: 32 chunks per image, more for small batches so that the chunk grid (chunks x B blocks) still fills
+// the 256 CUs (r03: at B = 2 the 64-block k/v kernels ran 4-5x slower per image than at B = 16); never below one 128-pixel tile
+static int attn_chunk_len(int N, int B) {
+    const int want = std::max(32, (512 + B - 1) / std::max(B, 1));
+    int len = (N + want - 1) / want;
     if (len < 128) len = 128;
     return (len + 7) & ~7;
 }
-int attn_num_chunks(int N) {
-    const int len = attn_chunk_len(N);
+int attn_num_chunks(int N, int B) {
+    const int len = attn_chunk_len(N, B);
     return (N + len - 1) / len;
 }
 
 template <typename T>
 static void linear_attention_t(const T* qkv, T* out, int B, int N, const AttnWorkspace& ws, hipStream_t s) {
-    const int len = attn_chunk_len(N);
-    const int nch = attn_num_chunks(N);
+    const int len = attn_chunk_len(N, B);
+    const int nch = attn_num_chunks(N, B);
     if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
     hipLaunchKernelGGL(attn_ctx_partial_kernel<T>, dim3(nch, B * kHeads), dim3(256), 0, s, qkv, ws.pmax, ws.pctx, ws.psum,
                        N, len, nch);
@@ -1277,8 +1281,8 @@ void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N
                                  const float* ln_g, float ln_eps) {
     if (ln_g && (C & (C - 1))) throw HipError("attention_kv_context: the fused LayerNorm needs a power-of-two channel count");
     if (C % 32 || C > 256 || C < 32) throw HipError("attention_kv_context: C must be a multiple of 32, <= 256");
-    const int len = attn_chunk_len(N);
-    const int nch = attn_num_chunks(N);
+    const int len = attn_chunk_len(N, B);
+    const int nch = attn_num_chunks(N, B);
     if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
     const size_t lds = (size_t)kKvTile * (C + 4) * sizeof(float);
 #define IRSDE_KV_LAUNCH(CC) hipLaunchKernelGGL(attn_kv_ctx_kernel<CC>, dim3(nch, B), dim3(256), lds, s, xn, wkv, ws.pmax, ws.pctx, ws.psum, N, len, nch, ln_g, ln_eps)

@@ -554,6 +554,17 @@ def test_bench_self_launches_two_ranks():
     assert 0 < r["frac"] <= 1 and 0 < r["mfma_kernel_frac"] <= 1 and r["frac"] <= r["mfma_kernel_frac"] + 1e-9
 
 
+def test_bench_strong_scaling_ragged_two_ranks():
+    """`--scaling strong`: ONE global batch split over the ranks (north_star: "image batches shard across the 8 GPUs").  5 images
+    over 2 ranks = shards of 3 and 2 through `sample_shard` + the final gather; per-rank times are reported."""
+    two = torch.cuda.device_count() >= 2
+    res = _run_bench(["--gpus", "2", "--scaling", "strong", "--steps", "1", "--warmup", "1", "--batch", "5", "--size", "64", "--T", "6",
+                      "--no-cpu-baseline"], None if two else {"IRSDE_BENCH_OVERSUBSCRIBE": "1"})
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["global_batch"] == 5 and res["value"] > 0
+    assert 0 < res["rank_ms_per_step"]["min"] <= res["rank_ms_per_step"]["max"]
+    assert "secondary" not in res
+
+
 def test_bench_rejects_mismatched_world():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
