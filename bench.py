@@ -119,7 +119,7 @@ def cpu_baseline(size, T, budget_s=20.0):
 
 # kernel classes of the event pass: description prefix (engine_plan.hip `op.desc`) -> the HIP kernels behind it
 KERNEL_CLASSES = [
-    ("conv(winograd F4 fused)", "wino4_fused_kernel (Winograd F(4x4,3x3): input transform + 36 component GEMMs + output transform + epilogue in one kernel)"),
+    ("conv(winograd F4 fused)", "wino4_fused64_kernel / wino4_fused_kernel (Winograd F(4x4,3x3): input transform + 36 component GEMMs + output transform + epilogue in one kernel)"),
     ("conv(winograd", "gemm_zloop_kernel (component GEMMs of the three-launch Winograd layers)"),
     ("conv(split", "gemm_split2i_kernel (f32 operands as bf16 hi+lo pairs, 3 cross products on v_mfma_f32_32x32x16_bf16; FLOPs counted once per f32 product)"),
     ("conv M=", "conv_igemm_kernel / gemm_zloop_kernel (direct implicit-GEMM layers: 1x1, 4x4 s2, 7x7, narrow 3x3)"),
