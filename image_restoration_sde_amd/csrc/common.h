@@ -133,7 +133,6 @@ int gemm_split_inner(int M, int N, int ncomp);
 // per component and plane (M * K resp. N * K), plA / plB unused
 void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, int abl = 0);
 void launch_split_pairs(const float* in, unsigned short* out, size_t rows, int K, hipStream_t s);  // f32 [rows][K] -> pair-interleaved hi / lo
-void gemm_split_set_variant(int v);  // tuning: -1 automatic, 0 the 128 x 128 prototype kernel, 1 / 2 the 256 x 256 / 128 x 256 two-plane kernel
 void launch_gemm_split(const SplitGemmArgs& a, int nplanes, int ncomp, hipStream_t s);
 void launch_split_planes(const float* in, unsigned short* out, size_t n, size_t plane, int nplanes, hipStream_t s);  // f32 -> bf16 pieces
 void launch_wino_output(const WinoParams& p, hipStream_t s);

@@ -625,8 +625,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
 
 int irsde_debug_split_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int ncomp, int nplanes, void* stream) {
     return guard([&] {
-        // nplanes 2 / 3: automatic kernel choice; 12: the 128 x 128 prototype with 2 planes; 22 / 32: the 256 x 256 / 128 x 256 two-plane kernel
-        struct Restore { ~Restore() { gemm_split_set_variant(-1); } } restore;
+        // nplanes 2 / 3: the 128 x 128 plane-major prototype kernel; 42: the engine's pair-interleaved two-plane kernel
         if (nplanes == 42) {   // the pair-interleaved two-plane kernel (v3: LDS-DMA, 256 x 256 tiles)
             hipStream_t s2 = reinterpret_cast<hipStream_t>(stream);
             conv_global_init();
@@ -644,11 +643,7 @@ int irsde_debug_split_gemm(const float* A, const float* Bm, float* C, int M, int
             (void)hipFree(pa); (void)hipFree(pb);
             return;
         }
-        if (nplanes > 3) {
-            gemm_split_set_variant(nplanes / 10 - 1);
-            nplanes = 2;
-        }
-        if (!A || !Bm || !C || M < 1 || N < 1 || K < 32 || ncomp < 1) throw HipError("debug_split_gemm: bad argument");
+        if (nplanes != 2 && nplanes != 3) throw HipError("debug_split_gemm: nplanes must be 2, 3 or 42");
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         conv_global_init();
         const size_t na = (size_t)ncomp * M * K, nb = (size_t)ncomp * N * K;
@@ -717,13 +712,6 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         // 80: fused Winograd F(4x4,3x3) kernel; 81: the three-launch Winograd F(4x4,3x3) path (random U: timing only)
         float *dU = nullptr, *dV = nullptr, *dM = nullptr;
         WinoPlan wp{};
-        struct RestoreSplit { ~RestoreSplit() { gemm_split_set_variant(-1); } } restore_split;
-        if (variant == 432 || variant == 442 || variant == 452 || (variant >= 461 && variant <= 464)) {
-            // the two-plane GEMMs alone on a forced kernel: 128 x 128 prototype / 256 x 256 / 128 x 256; 461 / 462 / 463: the 256 x 256 kernel
-            // without global loads / without LDS stores / without MFMAs (measurement twins)
-            gemm_split_set_variant(variant == 432 ? 0 : variant == 442 ? 1 : variant == 452 ? 2 : variant - 458);
-            variant = 422;
-        }
         if (variant >= 472 && variant <= 476) {   // the pair-interleaved two-plane component GEMMs alone (v3 kernel): 472 full, 473 no loads, 475 no MFMAs, 476 no output stores
             if (K != 3 || stride != 1 || !wino_shape_ok(p, 4)) throw HipError("bench_conv: Winograd variants need an eligible 3x3 stride-1 layer");
             const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);

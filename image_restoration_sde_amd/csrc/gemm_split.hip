@@ -189,181 +189,10 @@ __global__ __launch_bounds__(256, 1) void gemm_split_kernel(const SplitGemmArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// v2: the two-plane GEMM on big tiles.  The prototype above moves (128 + 128) x 64 B per plane and K-step for 128 x 128
-// outputs: at the bf16 MFMA rate that is > 30 B/clk/CU of L2 -> CU traffic in 64-byte row segments, and the kernel is bound
-// by the vector-memory path (measured: 3 planes 0.84 PFLOP/s = no faster than the native f32 GEMM, 2 planes 0.72 PFLOP/s).
-// Here: block tile (32 TM WM) x (32 TN WN) with 8 waves (WM x WN), 256 x 256 by default = half the bytes per FLOP; LDS rows
-// of 32 bf16 = 64 B WITHOUT padding (XOR swizzle of the four 16-byte pieces by (row >> 2) & 3: conflict-free ds_read_b128
-// lane groups and 8-lane-contiguous ds_write_b128), so two stages of two planes of 256 + 256 rows are 128 KB; buffer loads with
-// per-thread offsets formed once per tile and the K / plane position in scalar registers.
-// ---------------------------------------------------------------------------------------------------------------
-// ABL (measurement twins, irsde_bench_conv 46x): 1 = no global loads in the K loop, 2 = loads but no LDS stores, 3 = no MFMAs, 4 = no output stores
-template <int TM, int TN, int WM, int WN, int ABL = 0>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_split2_kernel(const SplitGemmArgs g, const unsigned a_bytes, const unsigned b_bytes) {
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;            // bytes per plane and stage
-    constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
-    constexpr int A_PASSES = BM * 4 / NT, B_PASSES = BN * 4 / NT;  // 16-byte pieces per thread, plane and stage
-    static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "tile rows must divide over the threads");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, h = lane >> 5;
-    int wgid;
-    {
-        const int orig = blockIdx.x, nwg = gridDim.x;
-        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
-    const int mblk = wgid / g.nblk_n, nblk = wgid - mblk * g.nblk_n;
-    const int m0 = mblk * BM, n0 = nblk * BN;
-    const int plane0 = blockIdx.y * g.n_inner;
-    const int nk = g.K / SG_BK;
-    const int steps = g.n_inner * nk;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.a), 0, a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.b), 0, b_bytes, 0x00020000);
-
-    // staging: thread = (row = tid / 4 + pass * NT / 4, 16-byte piece = tid % 4); rows past M / N are clamped
-    const int piece = tid & 3, srow = tid >> 2;
-    unsigned a_voff[A_PASSES], b_voff[B_PASSES];
-#pragma unroll
-    for (int ps = 0; ps < A_PASSES; ++ps) {
-        int m = m0 + srow + ps * (NT / 4);
-        m = m < g.M ? m : g.M - 1;
-        a_voff[ps] = (unsigned)m * (unsigned)g.lda * 2u + piece * 16u;
-    }
-#pragma unroll
-    for (int ps = 0; ps < B_PASSES; ++ps) {
-        int n = n0 + srow + ps * (NT / 4);
-        n = n < g.N ? n : g.N - 1;
-        b_voff[ps] = (unsigned)n * (unsigned)g.K * 2u + piece * 16u;
-    }
-    const int st_lds = srow * 64 + ((piece ^ ((srow >> 2) & 3)) * 16);   // (NT / 4 is a multiple of 16: the swizzle term is pass-invariant)
-    const unsigned plA2 = (unsigned)(g.plA * 2), plB2 = (unsigned)(g.plB * 2);
-    uintx4 rs[2 * (A_PASSES + B_PASSES)];
-    int kk = 0, st_i = 0;
-    unsigned a_soff = (unsigned)((long long)plane0 * g.pA * 2), b_soff = (unsigned)((long long)plane0 * g.pB * 2);  // component base (bytes)
-    auto load_all = [&]() {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int ps = 0; ps < A_PASSES; ++ps)
-                rs[p * A_PASSES + ps] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)a_voff[ps], (int)(a_soff + p * plA2 + kk * 2), 0));
-#pragma unroll
-            for (int ps = 0; ps < B_PASSES; ++ps)
-                rs[2 * A_PASSES + p * B_PASSES + ps] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)b_voff[ps], (int)(b_soff + p * plB2 + kk * 2), 0));
-        }
-    };
-    auto store_all = [&](int buf) {
-        char* base = lds + buf * STAGE + st_lds;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int ps = 0; ps < A_PASSES; ++ps) *reinterpret_cast<uintx4*>(base + p * A_PLANE + ps * (NT / 4) * 64) = rs[p * A_PASSES + ps];
-#pragma unroll
-            for (int ps = 0; ps < B_PASSES; ++ps)
-                *reinterpret_cast<uintx4*>(base + 2 * A_PLANE + p * B_PLANE + ps * (NT / 4) * 64) = rs[2 * A_PASSES + p * B_PASSES + ps];
-        }
-    };
-
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    load_all();
-    store_all(0);
-    __syncthreads();
-
-    const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
-    unsigned o_voff[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_voff[r] = (unsigned)(((r & 3) + 8 * (r >> 2) + 4 * h) * g.ldc + l31) * 4u;
-    auto flush = [&](int fi) {
-        const int rowb = m0 + wm_s * TM * 32, colb = n0 + wn_s * TN * 32;
-        float* ob = g.out + (long long)(plane0 + fi) * g.pO + (long long)rowb * g.ldc;
-        const int rows = g.M - rowb;
-        const unsigned nrec = rows <= 0 ? 0u : (unsigned)(rows < TM * 32 ? rows : TM * 32) * (unsigned)g.ldc * 4u;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, nrec, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int colu = colb + j * 32;
-                if (colu + l31 < g.N && (ABL != 4 || acc[i][j][0] == 1.2345e30f)) {
-                    const int soff = (i * 32 * g.ldc + colu) * 4;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[i][j][r];
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, (int)o_voff[r], soff, 0);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            }
-    };
-    // fragment offsets of this lane inside a plane: row (tile base + l31), piece 2 sb + h, swizzled by (l31 >> 2) & 3
-    const int swz = (l31 >> 2) & 3;
-    const int fr_off[2] = {l31 * 64 + ((h ^ swz) * 16), l31 * 64 + (((2 + h) ^ swz) * 16)};
-    int kdone = 0, cu_i = 0, fl_i = 0;
-    bool pending = false;
-    for (int st = 0; st < steps; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < steps) {
-            kk += SG_BK;
-            if (kk == g.K) {
-                kk = 0;
-                ++st_i;
-                a_soff = (unsigned)((long long)(plane0 + st_i) * g.pA * 2);
-                b_soff = (unsigned)((long long)(plane0 + st_i) * g.pB * 2);
-            }
-        }
-        if (pending) {
-            flush(fl_i);
-            pending = false;
-        }
-        if (ABL != 1) load_all();
-        const char* a = lds + buf * STAGE + wm * TM * 32 * 64;
-        const char* b = lds + buf * STAGE + 2 * A_PLANE + wn * TN * 32 * 64;
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            bf16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(a + p * A_PLANE + i * 32 * 64 + fr_off[sb]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(b + p * B_PLANE + j * 32 * 64 + fr_off[sb]);
-            }
-            // (0,1), (1,0), (0,0): small terms first; consecutive MFMAs hit different accumulators
-#pragma unroll
-            for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (ABL != 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pr == 1 ? 1 : 0][i], fb[pr == 0 ? 1 : 0][j], acc[i][j], 0, 0, 0);
-                        else acc[i][j][0] += (float)fa[pr == 1 ? 1 : 0][i][0] * (float)fb[pr == 0 ? 1 : 0][j][0];   // keep the fragment reads alive
-        }
-        if (ABL != 2) store_all(buf ^ 1);
-        else if (rs[0].x == 0x12345678u) store_all(buf ^ 1);
-        if (++kdone == nk) {
-            kdone = 0;
-            fl_i = cu_i++;
-            pending = true;
-        }
-        __syncthreads();
-    }
-    flush(fl_i);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// v3: two planes, pair-interleaved operands, LDS-DMA.  What v2's ablation twins showed (profiles/r03_split_gemm_notes.md): without
-// its global loads the K loop takes 69 % of the time, without MFMAs 72 % — the 64 wave-loads of a K-step (1 KB each, but 16
-// separate 64-byte row segments) cost as much as the 96 MFMAs they feed, and the 64 ds_write_b128 (13 cycles each) and their
+// The engine's kernel: two planes, pair-interleaved operands, LDS-DMA, 256 x 256 tiles.  Its predecessor (v2, removed: plane-major
+// operands, register-staged ds_write_b128, same tiles; numbers in profiles/r03_split_gemm_notes.md) showed with ablation twins that
+// without its global loads the K loop takes 69 % of the time and without MFMAs 72 %: the 64 wave-loads of a K-step (1 KB each, but
+// 16 separate 64-byte row segments) cost as much as the 96 MFMAs they feed, and the 64 ds_write_b128 (13 cycles each) and their
 // VGPR staging come on top.  Here:
 //   * operand layout [row][k / 32][plane][32 k]: the hi and lo pieces of a row's 32-k block are ONE 128-byte line, so a wave-load
 //     of 1 KB covers 8 rows x 128 B = 8 full lines instead of 16 half lines (wino_input / split_planes write this layout);
@@ -377,6 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_split2_kernel(const Spli
 #define IRSDE_GLDS16(GPTR, LPTR) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR), (__attribute__((address_space(3))) void*)(LPTR), 16, 0, 0)
 
+// ABL: measurement twins (irsde_bench_conv 473 / 475 / 476): 1 = no global loads in the K loop, 3 = no MFMAs, 4 = no output stores
 template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_split2i_kernel(const SplitGemmArgs g) {
     constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256;
@@ -545,16 +375,10 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 }  // namespace
 
 void gemm_split_global_init() {
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<2, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2_kernel<4, 2, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
@@ -565,28 +389,6 @@ int gemm_split_inner(int M, int N, int ncomp) {
     for (int d = ncomp; d >= 1; --d)
         if (ncomp % d == 0 && tiles * (ncomp / d) >= 512) return d;
     return 1;
-}
-
-// big-tile two-plane kernel: variant 1 = 256 x 256, 2 = 128 x 256 tiles
-static void launch_gemm_split2(const SplitGemmArgs& a, int ncomp, int variant, hipStream_t s) {
-    const int BM = variant == 2 ? 128 : 256, BN = 256;   // variants 3 / 4 / 5: ablation twins of the 256 x 256 kernel
-    SplitGemmArgs g = a;
-    g.nblk_n = (a.N + BN - 1) / BN;
-    const long long tiles = (long long)((a.M + BM - 1) / BM) * g.nblk_n;
-    g.n_inner = 1;
-    for (int d = ncomp; d >= 1; --d)
-        if (ncomp % d == 0 && tiles * (ncomp / d) >= 512) { g.n_inner = d; break; }
-    const unsigned long long ab = (unsigned long long)(a.plA * 2) * 2ull, bb = (unsigned long long)(a.plB * 2) * 2ull;
-    if (ab >= 0xffffffffull || bb >= 0xffffffffull) throw HipError("gemm_split2: operand planes exceed the 32-bit buffer range");
-    const dim3 grid((unsigned)tiles, (unsigned)(ncomp / g.n_inner));
-    const size_t lds = (size_t)2 * 2 * (BM + BN) * 64;
-    if (variant == 3) hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4, 1>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
-    else if (variant == 4) hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4, 2>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
-    else if (variant == 5) hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4, 3>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
-    else if (variant == 6) hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4, 4>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
-    else if (variant == 2) hipLaunchKernelGGL((gemm_split2_kernel<2, 2, 2, 4>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
-    else hipLaunchKernelGGL((gemm_split2_kernel<4, 2, 2, 4>), grid, dim3(512), lds, s, g, (unsigned)ab, (unsigned)bb);
-    IRSDE_HIP_CHECK(hipGetLastError());
 }
 
 // pair-interleaved operands (g.a / g.b in the [row][k/32][plane][32] layout, g.pA / g.pB = elements per component and plane)
@@ -620,18 +422,8 @@ void launch_split_pairs(const float* in, unsigned short* out, size_t rows, int K
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-static int g_split2_variant = -1;   // -1: automatic; 0: the 128 x 128 prototype; 1 / 2: big-tile kernel (irsde_bench_conv tuning)
-void gemm_split_set_variant(int v) { g_split2_variant = v; }
-
 void launch_gemm_split(const SplitGemmArgs& a, int nplanes, int ncomp, hipStream_t s) {
     if (nplanes != 2 && nplanes != 3) throw HipError("gemm_split: 2 or 3 planes");
-    if (nplanes == 2 && g_split2_variant != 0 && a.K % SG_BK == 0 && (unsigned long long)a.plA * 4ull < 0xffffffffull &&
-        (unsigned long long)a.plB * 4ull < 0xffffffffull && (size_t)a.M * a.ldc * 4 < 0xffffffffull) {
-        int v = g_split2_variant;
-        if (v < 0) v = (a.M >= 2048 && a.N % 256 == 0) ? 1 : 2;
-        launch_gemm_split2(a, ncomp, v, s);
-        return;
-    }
     if (a.K % SG_BK || a.n_inner < 1 || ncomp % a.n_inner) throw HipError("gemm_split: K must be a multiple of 32, n_inner a divisor of the component count");
     if ((size_t)a.M * a.ldc * 4 >= 0xffffffffull) throw HipError("gemm_split: output plane exceeds the 32-bit buffer range");
     SplitGemmArgs g = a;

@@ -34,8 +34,8 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
                      int splits, void* stream);
 
 /* Kernel-level test hook of csrc/gemm_split.hip: C_z[M][N] = A_z[M][K] . B_z[N][K]^T for z < ncomp (device f32 tensors, z-major),
- * operands split into `nplanes` (2 or 3) bf16 pieces on the device, products on v_mfma_f32_32x32x16_bf16, f32 accumulate.
- * K a multiple of 32.  Synchronises `stream`. */
+ * operands split into `nplanes` (2 or 3) bf16 pieces on the device (plane-major prototype kernel; nplanes = 42: the engine's
+ * pair-interleaved two-piece kernel), products on v_mfma_f32_32x32x16_bf16, f32 accumulate.  K a multiple of 32.  Synchronises `stream`. */
 int irsde_debug_split_gemm(const float* A, const float* B, float* C, int M, int N, int K, int ncomp, int nplanes, void* stream);
 
 /* Kernel tuning hook: average ms of one KxK convolution (pad K/2, or 4x4 s2 p1) on random NHWC data.
@@ -44,7 +44,8 @@ int irsde_debug_split_gemm(const float* A, const float* B, float* C, int M, int 
  * incl. the halo kernel), 63 = 62 with bf16 activation storage, 80 / 81 Winograd F(4x4,3x3) fused kernel / three-launch path (3x3 s1 only), 82 the fused kernel once with its
  * phase timeline printed to stdout, 400 the 64-cout fused Winograd kernel (r03; 401 / 402: its weight fragments / patch loads read zeros
  * without memory traffic, 403: 12 instead of 18 weight units in flight), 412 / 413 the three-launch Winograd layer with split-operand GEMMs (2 / 3
- * bf16 planes), 421 / 422 / 423 the component GEMMs alone: native f32 / 2 planes / 3 planes; epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
+ * bf16 planes on the 128 x 128 plane-major prototype kernel), 421 / 422 / 423 the component GEMMs alone: native f32 / 2 planes / 3 planes, 472 the
+ * engine's pair-interleaved two-plane GEMM alone (473 / 475 / 476: without its global loads / MFMAs / output stores); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out);
 

@@ -76,12 +76,12 @@ def test_split_gemm_error_table_written():
 # ---------------------------------------------------------------------------------------------
 # kernel level: the three GEMM kernels against float64
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant,tol", [(3, 2e-6), (12, 2e-5), (22, 2e-5), (32, 2e-5), (42, 2e-5)])
+@pytest.mark.parametrize("variant,tol", [(3, 2e-6), (2, 2e-5), (42, 2e-5)])
 @pytest.mark.parametrize("shape", [(256, 256, 32, 1), (100, 96, 64, 3), (1000, 520, 96, 4), (777, 256, 512, 5)])
 def test_split_gemm_kernels_vs_float64(variant, tol, shape):
-    """C_z = A_z . B_z^T with f32 operands split on the device: 3 = three bf16 pieces (128 x 128 prototype kernel), 12 / 22 / 32 =
-    two pieces on the prototype / 256 x 256 / 128 x 256 kernel, 42 = two pieces pair-interleaved on the LDS-DMA kernel the engine
-    uses.  Ragged M / N, several components.  Tolerances relative to max|C|: 24-bit operands 2e-6, 16-bit operands 2e-5."""
+    """C_z = A_z . B_z^T with f32 operands split on the device: 3 / 2 = three / two bf16 pieces on the 128 x 128 plane-major
+    prototype kernel, 42 = two pieces pair-interleaved on the LDS-DMA kernel the engine uses.  Ragged M / N, several components.
+    Tolerances relative to max|C|: 24-bit operands 2e-6, 16-bit operands 2e-5."""
     M, N, K, ncomp = shape
     rs = np.random.RandomState(M + K)
     A = rs.standard_normal((ncomp, M, K)).astype(np.float32)

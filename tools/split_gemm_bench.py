@@ -18,14 +18,15 @@ def run(v, H, W, Cin, Cout):
     ms = ctypes.c_double()
     rc = L.irsde_bench_conv(v, B, H, W, Cin, Cout, 3, 1, 0, 2, 10, ctypes.byref(ms))
     return ms.value if rc == 0 else float("nan")
-# GEMM variants: 421 native f32 (gemm_zloop), 423 three planes (128 x 128 prototype), 432 / 442 / 452 two planes on the 128 x 128 prototype /
-# 256 x 256 / 128 x 256 kernel, 422 two planes automatic
-print("B=%d %-16s | GEMMs alone (ms): %7s %7s %7s %7s %7s | TF/s-equiv: %6s %6s %6s %6s %6s | whole layer (ms): %7s %7s %7s %7s" % (
-    B, "layer", "f32", "x3", "x2 128", "x2 256", "x2 128x256", "f32", "x3", "x2 128", "x2 256", "128x256", "f32 3-l", "split3", "split2", "fused64"))
+# GEMM variants: 421 native f32 (gemm_zloop), 423 / 422 three / two planes on the 128 x 128 plane-major prototype, 472 the engine's
+# pair-interleaved LDS-DMA kernel (473 / 475 / 476: without global loads / MFMAs / output stores)
+print("B=%d %-16s | GEMMs alone (ms): %7s %7s %7s %7s | TF/s-equiv: %6s %6s %6s %6s | pairs kernel without: %7s %7s %7s | whole layer (ms): %7s %7s" % (
+    B, "layer", "f32", "x3 128", "x2 128", "x2 pairs", "f32", "x3", "x2 128", "pairs", "loads", "MFMAs", "stores", "f32 3-l", "fused64"))
 for name, H, W, Cin, Cout in cases:
     fl = 36 * 2.0 * B * (H // 4) * (W // 4) * Cin * Cout
-    g = [run(v, H, W, Cin, Cout) for v in (421, 423, 432, 442, 452)]
-    w = [run(v, H, W, Cin, Cout) for v in (81, 413, 412)]
+    g = [run(v, H, W, Cin, Cout) for v in (421, 423, 422, 472)]
+    ab = [run(v, H, W, Cin, Cout) for v in (473, 475, 476)]
+    w = run(81, H, W, Cin, Cout)
     f64 = run(400, H, W, Cin, Cout) if Cin <= 1024 else float("nan")
-    print("     %-16s |                   %7.4f %7.4f %7.4f %7.4f %7.4f |             %6.1f %6.1f %6.1f %6.1f %6.1f |                   %7.4f %7.4f %7.4f %7.4f" % (
-        (name,) + tuple(g) + tuple(fl / x / 1e9 for x in g) + (w[0], w[1], w[2], f64)), flush=True)
+    print("     %-16s |                   %7.4f %7.4f %7.4f %7.4f |             %6.1f %6.1f %6.1f %6.1f |                        %7.4f %7.4f %7.4f |                   %7.4f %7.4f" % (
+        (name,) + tuple(g) + tuple(fl / x / 1e9 for x in g) + tuple(ab) + (w, f64)), flush=True)
