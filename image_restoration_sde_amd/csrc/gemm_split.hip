@@ -264,6 +264,24 @@ __global__ __launch_bounds__(512, 2) void gemm_split2i_kernel(const SplitGemmArg
         for (int ps = 0; ps < 4; ++ps) IRSDE_GLDS16(gb + b_voff[ps], la + A_STAGE + ps * 8192);
     };
 
+    auto issue_loads_part = [&](int buf, int part) {   // the 8 loads of a stage in three groups: A 0-2 | A 3, B 0-1 | B 2-3
+        char* la = lds + buf * STAGE + wave * 1024;
+        const char* ga = acomp + kb * 128;
+        const char* gb = bcomp + kb * 128;
+        if (part == 0) {
+            IRSDE_GLDS16(ga + a_voff[0], la);
+            IRSDE_GLDS16(ga + a_voff[1], la + 8192);
+            IRSDE_GLDS16(ga + a_voff[2], la + 2 * 8192);
+        } else if (part == 1) {
+            IRSDE_GLDS16(ga + a_voff[3], la + 3 * 8192);
+            IRSDE_GLDS16(gb + b_voff[0], la + A_STAGE);
+            IRSDE_GLDS16(gb + b_voff[1], la + A_STAGE + 8192);
+        } else {
+            IRSDE_GLDS16(gb + b_voff[2], la + A_STAGE + 2 * 8192);
+            IRSDE_GLDS16(gb + b_voff[3], la + A_STAGE + 3 * 8192);
+        }
+    };
+
     floatx16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -311,31 +329,36 @@ __global__ __launch_bounds__(512, 2) void gemm_split2i_kernel(const SplitGemmArg
         for (int sb = 0; sb < 2; ++sb) fr_off[p][sb] = l31 * 128 + (((p * 4 + sb * 2 + h) ^ swz) * 16);
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
-        if (st + 1 < steps) {
-            ++kb;
-            if (ABL != 1) issue_loads(buf ^ 1);   // stage buf^1 was last read in step st-1: every wave is past that step's barrier
-        }
+        const bool more = st + 1 < steps;
+        if (more) ++kb;   // (stage buf^1 was last read in step st-1: every wave is past that step's barrier when the loads below are issued)
         const char* a = lds + buf * STAGE + wm * TM * 32 * 128;
         const char* b = lds + buf * STAGE + A_STAGE + wn * TN * 32 * 128;
+        // Pinned order (r03, A/B in profiles/r03_split_gemm_notes.md): fragments of both 16-k sub-steps up front (the second set lands
+        // while the first multiplies), the next stage's LDS-DMA loads spread behind the first MFMA groups instead of one burst
+        bf16x8 fa[2][2][TM], fb[2][2][TN];
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            bf16x8 fa[2][TM], fb[2][TN];
+        for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * 128 + fr_off[p][sb]);
+                for (int i = 0; i < TM; ++i) fa[sb][p][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * 128 + fr_off[p][sb]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * 128 + fr_off[p][sb]);
+                for (int j = 0; j < TN; ++j) fb[sb][p][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * 128 + fr_off[p][sb]);
             }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr)
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        if (ABL != 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pr == 1 ? 1 : 0][i], fb[pr == 0 ? 1 : 0][j], acc[i][j], 0, 0, 0);
-                        else acc[i][j][0] += (float)fa[pr == 1 ? 1 : 0][i][0] * (float)fb[pr == 0 ? 1 : 0][j][0];
-        }
+                        if (ABL != 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sb][pr == 1 ? 1 : 0][i], fb[sb][pr == 0 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                        else acc[i][j][0] += (float)fa[sb][pr == 1 ? 1 : 0][i][0] * (float)fb[sb][pr == 0 ? 1 : 0][j][0];
+                if (sb == 0 && ABL != 1 && more) issue_loads_part(buf ^ 1, pr);   // 3 + 3 + 2 loads behind the first three MFMA groups
+                __builtin_amdgcn_sched_barrier(0);
+            }
         __syncthreads();
     }
     flush(0);
