@@ -9,8 +9,8 @@ from collections import OrderedDict
 
 
 def group(name):
-    if "conv_igemm" in name or "gemm_zloop" in name or "conv3x3_halo" in name or "wino4_fused" in name or "conv3x3_narrow" in name:
-        return "conv (conv_igemm / gemm_zloop / wino4_fused / conv3x3_halo)"
+    if "conv_igemm" in name or "gemm_zloop" in name or "conv3x3_halo" in name or "wino4_fused" in name or "conv3x3_narrow" in name or "gemm_split" in name:
+        return "conv (conv_igemm / gemm_zloop / wino4_fused[64] / gemm_split / conv3x3_halo)"
     if "wino_" in name:
         return "wino_transform"
     if "attn_" in name:
@@ -45,7 +45,7 @@ for title, agg in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
     for g, (n, kib) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lines.append("%-48s %10d %16.3f %18.2f" % (g, n, kib * 1024 / 1e9, kib * 1024 / 1e6 / n))
     lines.append("")
-ck, wk = "conv (conv_igemm / gemm_zloop / wino4_fused / conv3x3_halo)", "wino_transform"
+ck, wk = "conv (conv_igemm / gemm_zloop / wino4_fused[64] / gemm_split / conv3x3_halo)", "wino_transform"
 conv_launches = fetch[ck][0]
 conv_bytes = (2 * fetch[ck][1] + write[ck][1]) * 1024
 wino_bytes = (2 * fetch.get(wk, [0, 0.0])[1] + write.get(wk, [0, 0.0])[1]) * 1024

@@ -8,7 +8,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-secondary $*"
 # 1. per-kernel durations (the same command bench.py times: 1 warm-up + 1 timed sampler call + the untimed profiled pass)
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- $BENCH --steps 1 --warmup 1 > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
 DB=$(find "$OUT/kt" -name "*.db" | head -1)
