@@ -184,6 +184,10 @@ def test_compute_dtype_flags_and_metrics_fail_loudly_on_cpu():
     assert m.engine_flags == _lib.FLAG_BF16
     m.set_compute_dtype("bf16_act")
     assert m.engine_flags == _lib.FLAG_BF16 | _lib.FLAG_BF16_ACT
+    m.set_compute_dtype("fp32_split")   # r03: f32 everywhere, deep Winograd GEMMs on bf16 hi + lo pairs
+    assert m.engine_flags == _lib.FLAG_SPLIT_BF16X2 == 16384
+    m.set_compute_dtype("fp16")
+    assert m.engine_flags == _lib.FLAG_FP16
     m.set_compute_dtype("fp32")
     assert m.engine_flags == 0
     with pytest.raises(P.IrsdeError):
@@ -251,3 +255,54 @@ def test_tuning_env_knobs_are_inert_without_IRSDE_TUNING():
             src = open(os.path.join(root, f)).read()
             for m in re.finditer(r"getenv\(\"(\w+)\"\)", src):
                 assert f == "common.h" and m.group(1) == "IRSDE_TUNING", (f, m.group(0))
+
+
+def test_bench_roofline_object_from_an_op_profile():
+    """bench.py's host logic (no GPU): the per-class parse of irsde_op_profile's text and the roofline object built from it —
+    fractions are true fractions of the roof, the dominant class is the one with the largest time share, the split mode is
+    labelled, the 16-bit modes quote the HBM roof first."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    text = ("   0.0284 ms  other\n"
+            "   1.0000 ms  conv(winograd F4 fused) 16x64 T=65536 Cout=128 Cin=128 up=0 blocks=8192 flops=3.2e+11 exec=8.0e+10\n"
+            "   0.5000 ms  conv(winograd F4 gemm x36) T=1024 Cout=1024 Cin=1024 flops=3.2e+11 exec=7.0e+10\n"
+            "   0.2500 ms  conv(split bf16x2 winograd F4 gemm x36) T=1024 Cout=1024 Cin=1024 flops=3.2e+11 exec=7.0e+10\n"
+            "   0.4000 ms  conv M=16384 Cout=1024 Cin=1536 k=1x1 s=1 up=0 splits=1 blocks=1024 flops=5.0e+10\n"
+            "   0.0500 ms  wino_input T=1024 C=1024\n"
+            "   0.3000 ms  linear_attention LayerNorm + k,v projection + context (fused) C=128\n"
+            "   0.0200 ms  layernorm\n")
+    cls = bench.op_classes(text)
+    assert len(cls) == 8 and abs(sum(v[0] for v in cls.values()) - 2.5484) < 1e-9
+    fused = [k for k in cls if k.startswith("wino4_fused64_kernel")][0]
+    assert cls[fused] == [1.0, 8.0e10]
+    assert any(k.startswith("gemm_split2i_kernel") for k in cls)
+    prof = {"conv_ms": 2.15, "wino_ms": 0.05, "conv_exec_flops": 2.7e11, "conv_flops": 1.01e12, "conv_launches": 4.0, "net_evals": 1.0,
+            "conv_bytes": 1.0e9, "wall_ms": 2.55, "ln_ms": 0.02, "attn_ms": 0.3, "other_ms": 0.03}
+    r = bench.roofline_object(prof, text, {"dtype": "fp32"})
+    assert r["bound"] == "mfma" and r["peak"] == bench.PEAK_FP32_TFLOPS and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0 < r["frac"] <= r["mfma_kernel_frac"] <= 1
+    assert r["dominant_kernel"]["name"] == fused and abs(r["dominant_kernel"]["executed_TFLOPs"] - 80.0) < 1e-9
+    assert abs(sum(k["time_share"] for k in r["per_kernel"]) - (2.15 / 2.5484)) < 1e-3
+    assert "note" in bench.roofline_object(prof, text, {"dtype": "fp32_split"})
+    rb = bench.roofline_object(prof, text, {"dtype": "bf16_act"})
+    assert rb["bound"] == "hbm" and rb["unit"] == "GB/s" and rb["peak"] == bench.PEAK_HBM_GBPS
+    # every secondary workload names a model / dtype the Workload class knows, and the headline stays out of the list
+    for w in bench.SECONDARY:
+        assert w["model"] in ("unet", "nafnet", "latent", "dsde") and w["dtype"] in bench.DTYPE_LABEL and w["mode"] in ("sde", "ode", "posterior")
+    assert not any((w["model"], w["dtype"], w["batch"], w["size"], w["T"], w["mode"]) == ("unet", "fp32", 16, 256, 100, "sde") for w in bench.SECONDARY)
+
+
+def test_strong_scaling_shards_cover_the_global_batch():
+    """`bench.py --scaling strong` / `sample_shard`: the shards of ONE global batch over 1 .. 8 ranks are contiguous, disjoint, cover
+    the batch, differ by at most one image, and ranks beyond the batch get an empty shard (16 images over 8 GPUs = 2 each)."""
+    for n in (1, 5, 16):
+        for w in (1, 2, 3, 8):
+            b = [P.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n
+    assert [P.shard_bounds(16, 8, r) for r in range(8)] == [(2 * r, 2 * r + 2) for r in range(8)]
