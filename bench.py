@@ -121,7 +121,7 @@ def cpu_baseline(size, T, budget_s=20.0):
 KERNEL_CLASSES = [
     ("conv(winograd F4 fused)", "wino4_fused64_kernel / wino4_fused_kernel (Winograd F(4x4,3x3): input transform + 36 component GEMMs + output transform + epilogue in one kernel)"),
     ("conv(winograd", "gemm_zloop_kernel (component GEMMs of the three-launch Winograd layers)"),
-    ("conv(split", "gemm_split2i_kernel (f32 operands as bf16 hi+lo pairs, 3 cross products on v_mfma_f32_32x32x16_bf16; FLOPs counted once per f32 product)"),
+    ("conv(split", "gemm_split2i_kernel (f32 operands as 16-bit hi+lo pairs, 3 cross products on v_mfma_f32_32x32x16_bf16 / _f16; FLOPs counted once per f32 product)"),
     ("conv M=", "conv_igemm_kernel / gemm_zloop_kernel (direct implicit-GEMM layers: 1x1, 4x4 s2, 7x7, narrow 3x3)"),
     ("conv", "conv kernels (other)"),
     ("wino_", "wino_input_kernel / wino_output_kernel (transforms of the three-launch Winograd layers)"),
@@ -155,7 +155,7 @@ def roofline_object(prof, op_text, w):
     ach = prof["conv_exec_flops"] / conv_t / 1e12
     exe = prof["conv_exec_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
     alg = prof["conv_flops"] / conv_t / 1e12
-    fp32 = w["dtype"] in ("fp32", "fp32_split")
+    fp32 = w["dtype"] in ("fp32", "fp32_split", "fp32_split_f16")
     peak = PEAK_FP32_TFLOPS if fp32 else PEAK_BF16_TFLOPS
     classes = op_classes(op_text)
     tot = sum(v[0] for v in classes.values()) or 1.0
@@ -185,9 +185,9 @@ def roofline_object(prof, op_text, w):
                                 "executed_TFLOPs": v[1] / (v[0] * 1e-3) / 1e12, "frac": v[1] / (v[0] * 1e-3) / 1e12 / peak}
         r["per_kernel"] = [{"name": n, "time_share": v[0] / tot, "ms_per_evaluation": v[0], "executed_TFLOPs": v[1] / (v[0] * 1e-3) / 1e12,
                             "frac": v[1] / (v[0] * 1e-3) / 1e12 / peak} for n, v in mfma_classes]
-    if w["dtype"] == "fp32_split":
-        r["note"] = ("fp32_split: FLOPs are counted once per f32 product and compared with the f32 MFMA roof as a speed reference; the pair GEMMs "
-                     "themselves execute 3 bf16 MFMA products per f32 product on the bf16 pipe")
+    if w["dtype"] in ("fp32_split", "fp32_split_f16"):
+        r["note"] = ("split modes: FLOPs are counted once per f32 product and compared with the f32 MFMA roof as a speed reference; the pair GEMMs "
+                     "themselves execute 3 16-bit MFMA products per f32 product on the bf16 / f16 pipe")
     if not fp32:
         # 16-bit operands: 16x the MFMA rate turns the convolutions L2/HBM-bound, so quote the HBM roof first
         gbps = prof["conv_bytes"] / (prof["conv_ms"] * 1e-3) / 1e9
@@ -200,7 +200,8 @@ def roofline_object(prof, op_text, w):
 DTYPE_LABEL = {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate+state",
                "bf16_act": "bf16 operands + bf16 activation storage / f32 accumulate+state",
                "fp16": "f16 operands / f32 accumulate+state",
-               "fp32_split": "f32 storage / state / transforms; deep Winograd component GEMMs on bf16 hi+lo operand pairs (3 cross products on the bf16 MFMA, f32 accumulate)"}
+               "fp32_split": "f32 storage / state / transforms; deep Winograd component GEMMs on bf16 hi+lo operand pairs (3 cross products on the bf16 MFMA, f32 accumulate)",
+               "fp32_split_f16": "f32 storage / state / transforms; deep Winograd component GEMMs on fp16 hi+lo operand pairs (22+ significand bits: fp32-equivalent per layer; 3 cross products on the f16 MFMA, f32 accumulate)"}
 
 # the other BASELINE.json configs + the 512x512 batch north_star names: timed after the headline, reported under `secondary`
 SECONDARY = [
@@ -208,7 +209,9 @@ SECONDARY = [
     dict(tag="BASELINE configs[3]: Refusion NAFNet 8x512x512 T=200", model="nafnet", dtype="fp32", mode="sde", batch=8, size=512, T=200),
     dict(tag="BASELINE configs[4]: Latent-Refusion 64x64x4 latent, batch 64, fp16", model="latent", dtype="fp16", mode="sde", batch=64, size=256, T=100),
     dict(tag="north_star 512x512 batch: IR-SDE UNet 16x512x512", model="unet", dtype="fp32", mode="sde", batch=16, size=512, T=100),
-    dict(tag="BASELINE configs[1] workload in the opt-in fp32_split mode (IRSDE_FLAG_SPLIT_BF16X2; error table: profiles/r03_split_*)",
+    dict(tag="BASELINE configs[1] workload in the opt-in fp32_split_f16 mode (IRSDE_FLAG_SPLIT_F16X2: fp32-equivalent per layer; error table: profiles/r03_split_error_table.txt)",
+         model="unet", dtype="fp32_split_f16", mode="sde", batch=16, size=256, T=100),
+    dict(tag="BASELINE configs[1] workload in the opt-in fp32_split mode (IRSDE_FLAG_SPLIT_BF16X2: 16-bit operand pairs, f32 exponent range)",
          model="unet", dtype="fp32_split", mode="sde", batch=16, size=256, T=100),
 ]
 

@@ -103,6 +103,8 @@ struct WinoParams {
     unsigned short* Vs = nullptr;
     int nplanes = 0;
     long long v_plane = 0;
+    int v_f16 = 0;              // pairs only: 1 = IEEE fp16 pieces of V * v_scale (v_scale a power of two), 0 = bf16 pieces of V
+    float v_scale = 1.f;
     int v_pairs = 0;            // 1: two planes, pair-interleaved: element (k, t, c, p) at Vs + ((k * T + t) * (Ctot / 32) + c / 32) * 64 + p * 32 + c % 32
     const float* M = nullptr;   // [(m+2)^2][T][Cout]
     int Cout = 0;
@@ -124,6 +126,7 @@ struct SplitGemmArgs {
     float* out = nullptr;               // element (z, m, n) at out + z * pO + m * ldc + n
     long long plA = 0, plB = 0, pA = 0, pB = 0, pO = 0;
     int M = 0, N = 0, K = 0, lda = 0, ldc = 0;
+    float out_scale = 1.f;              // fp16 pairs: the power of two that undoes the operand scales (applied to the accumulators)
     int n_inner = 1;                    // components walked by one block (gemm_split_inner)
     int nblk_n = 0;                     // set by the launcher
 };
@@ -131,8 +134,11 @@ void gemm_split_global_init();
 int gemm_split_inner(int M, int N, int ncomp);
 // two planes in the pair-interleaved layout [row][k / 32][plane][32 k] (v3 kernel: LDS-DMA, 256 x 256 tiles); pA / pB = elements
 // per component and plane (M * K resp. N * K), plA / plB unused
-void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, int abl = 0);
-void launch_split_pairs(const float* in, unsigned short* out, size_t rows, int K, hipStream_t s);  // f32 [rows][K] -> pair-interleaved hi / lo
+// f16: IEEE binary16 pieces (hi + lo = 22+ significand bits: fp32-equivalent products) instead of bf16 (16 bits); a.out_scale undoes
+// the power-of-two scales the operand writers applied to stay inside fp16's range
+void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, int abl = 0, bool f16 = false);
+void launch_split_pairs(const float* in, unsigned short* out, size_t rows, int K, hipStream_t s, bool f16 = false,
+                        float scale = 1.0f);  // f32 [rows][K] -> pair-interleaved hi / lo (f16: of in * scale)
 void launch_gemm_split(const SplitGemmArgs& a, int nplanes, int ncomp, hipStream_t s);
 void launch_split_planes(const float* in, unsigned short* out, size_t n, size_t plane, int nplanes, hipStream_t s);  // f32 -> bf16 pieces
 void launch_wino_output(const WinoParams& p, hipStream_t s);

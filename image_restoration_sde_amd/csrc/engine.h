@@ -72,7 +72,8 @@ struct ConvW {
     float* wino_u4 = nullptr;  // device [36][Cout][Cin]              F(4x4,3x3)  (3x3 layers with Cin,Cout >= 128)
     float* wino_uf = nullptr;  // the same F(4x4,3x3) weights in the fused kernel's fragment order (wino_fused.hip)
     float* wino_uf64 = nullptr;  // ... in the 64-cout fused kernel's fragment order (Cout, Cin multiples of 64)
-    unsigned short* wino_up = nullptr;  // IRSDE_FLAG_SPLIT_BF16X2: the F(4x4,3x3) weights as bf16 hi / lo pairs, [36][Cout][Cin / 32][2][32]
+    unsigned short* wino_up = nullptr;  // IRSDE_FLAG_SPLIT_BF16X2 / _F16X2: the F(4x4,3x3) weights as hi / lo pairs, [36][Cout][Cin / 32][2][32]
+    float wino_up_scale = 1.f;          // fp16 pairs: the power of two U was multiplied by (max |U| * scale <= 512)
 };
 struct ResW {
     ConvW b1, b2, res;
@@ -143,6 +144,7 @@ struct WinoSplitPlan {
     WinoParams in, out;
     SplitGemmArgs gemm;
     int nplanes = 0;
+    bool f16 = false;
 };
 inline WinoSplitPlan make_wino_split(const ConvParams& d, const unsigned short* Us, unsigned short* Vs, float* Mb, int nplanes) {
     const WinoPlan w = make_wino(d, nullptr, nullptr, Mb, 4);
@@ -160,14 +162,19 @@ inline WinoSplitPlan make_wino_split(const ConvParams& d, const unsigned short* 
     return sp;
 }
 // IRSDE_FLAG_SPLIT_BF16X2: pair-interleaved operands for launch_gemm_split_pairs (Vs: 36 * T * Ctot * 2 elements)
-inline WinoSplitPlan make_wino_pairs(const ConvParams& d, const unsigned short* Up, unsigned short* Vs, float* Mb) {
+constexpr float kSplitF16VScale = 1.0f / 16.0f;   // fp16 pairs: V is written as V / 16 (finite up to |V| = 1e6)
+inline WinoSplitPlan make_wino_pairs(const ConvParams& d, const unsigned short* Up, unsigned short* Vs, float* Mb, bool f16 = false,
+                                     float u_scale = 1.f) {
     const WinoPlan w = make_wino(d, nullptr, nullptr, Mb, 4);
     WinoSplitPlan sp;
     sp.in = w.in; sp.out = w.out; sp.nplanes = 2;
     const int Ctot = d.C0 + d.C1;
     const long long T = w.in.T;
     sp.in.Vs = Vs; sp.in.nplanes = 2; sp.in.v_pairs = 1;
+    sp.in.v_f16 = f16 ? 1 : 0; sp.in.v_scale = f16 ? kSplitF16VScale : 1.f;
     SplitGemmArgs& g = sp.gemm;
+    g.out_scale = f16 ? 1.0f / (kSplitF16VScale * u_scale) : 1.f;
+    sp.f16 = f16;
     g.a = Vs; g.b = Up; g.out = Mb;
     g.pA = T * Ctot; g.pB = (long long)d.Cout * Ctot; g.pO = T * d.Cout;
     g.M = (int)T; g.N = d.Cout; g.K = Ctot; g.lda = Ctot; g.ldc = d.Cout;

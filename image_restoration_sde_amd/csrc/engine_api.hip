@@ -8,6 +8,7 @@
 //               eager or as one captured hipGraph replayed T times; the step index lives in device
 //               memory (StepState) so the graph is t-invariant.
 #include "engine.h"
+#include <cmath>
 #include "../../include/irsde_hip_debug.h"
 
 using namespace irsde;
@@ -520,7 +521,30 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dp, (size_t)splits * B * p.Ho * p.Wo * Cout * 4));
             p.partial = dp;
         }
-        if (naive == 42 || naive == 43) {  // three-launch Winograd F(4x4,3x3) with split-operand component GEMMs: 2 / 3 bf16 planes
+        if (naive == 44 || naive == 45) {  // three-launch Winograd F(4x4,3x3) with the engine's pair GEMM: 44 fp16 pairs, 45 bf16 pairs
+            const bool f16 = naive == 44;
+            if (!wino_shape_ok(p, 4) || Cin % 32) throw HipError("debug_conv: shape not eligible for the pair GEMM");
+            std::vector<float> U((size_t)36 * Cout * Cin);
+            wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
+            float mx = 0.f;
+            for (float v : U) mx = std::max(mx, std::fabs(v));
+            const float us = f16 && mx > 0.f ? std::exp2(std::floor(std::log2(512.0f / mx))) : 1.f;
+            const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
+            float *dU = nullptr, *dM = nullptr;
+            unsigned short *dUp = nullptr, *dVp = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dU, U.size() * 4));
+            IRSDE_HIP_CHECK(hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+            IRSDE_HIP_CHECK(hipMalloc(&dUp, U.size() * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&dVp, (size_t)36 * T * Cin * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&dM, (size_t)36 * T * Cout * 4));
+            launch_split_pairs(dU, dUp, (size_t)36 * Cout, Cin, s, f16, us);
+            const WinoSplitPlan sp = make_wino_pairs(p, dUp, dVp, dM, f16, us);
+            launch_wino_input(sp.in, s);
+            launch_gemm_split_pairs(sp.gemm, 36, s, 0, f16);
+            launch_wino_output(sp.out, s);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(dU); (void)hipFree(dUp); (void)hipFree(dVp); (void)hipFree(dM);
+        } else if (naive == 42 || naive == 43) {  // three-launch Winograd F(4x4,3x3) with split-operand component GEMMs: 2 / 3 bf16 planes
             const int npl = naive - 40;
             if (!wino_shape_ok(p, 4)) throw HipError("debug_conv: shape not eligible for Winograd");
             std::vector<float> U((size_t)36 * Cout * Cin);
@@ -626,24 +650,27 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
 int irsde_debug_split_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int ncomp, int nplanes, void* stream) {
     return guard([&] {
         // nplanes 2 / 3: the 128 x 128 plane-major prototype kernel; 42: the engine's pair-interleaved two-plane kernel
-        if (nplanes == 42) {   // the pair-interleaved two-plane kernel (v3: LDS-DMA, 256 x 256 tiles)
+        if (nplanes == 42 || nplanes == 44) {   // the pair-interleaved two-plane kernel (LDS-DMA, 256 x 256 tiles): 42 bf16 pieces, 44 fp16 pieces
+            const bool f16 = nplanes == 44;
+            const float sa = f16 ? 1.0f / 16.0f : 1.f, sb = f16 ? 64.0f : 1.f;   // (any powers of two: the hook exercises the scaling)
             hipStream_t s2 = reinterpret_cast<hipStream_t>(stream);
             conv_global_init();
             unsigned short *pa = nullptr, *pb = nullptr;
             IRSDE_HIP_CHECK(hipMalloc(&pa, (size_t)ncomp * M * K * 4));
             IRSDE_HIP_CHECK(hipMalloc(&pb, (size_t)ncomp * N * K * 4));
-            launch_split_pairs(A, pa, (size_t)ncomp * M, K, s2);
-            launch_split_pairs(Bm, pb, (size_t)ncomp * N, K, s2);
+            launch_split_pairs(A, pa, (size_t)ncomp * M, K, s2, f16, sa);
+            launch_split_pairs(Bm, pb, (size_t)ncomp * N, K, s2, f16, sb);
             SplitGemmArgs gp;
             gp.a = pa; gp.b = pb; gp.out = C;
             gp.pA = (long long)M * K; gp.pB = (long long)N * K; gp.pO = (long long)M * N;
             gp.M = M; gp.N = N; gp.K = K; gp.lda = K; gp.ldc = N;
-            launch_gemm_split_pairs(gp, ncomp, s2);
+            gp.out_scale = 1.0f / (sa * sb);
+            launch_gemm_split_pairs(gp, ncomp, s2, 0, f16);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s2));
             (void)hipFree(pa); (void)hipFree(pb);
             return;
         }
-        if (nplanes != 2 && nplanes != 3) throw HipError("debug_split_gemm: nplanes must be 2, 3 or 42");
+        if (nplanes != 2 && nplanes != 3) throw HipError("debug_split_gemm: nplanes must be 2, 3, 42 or 44");
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         conv_global_init();
         const size_t na = (size_t)ncomp * M * K, nb = (size_t)ncomp * N * K;

@@ -102,7 +102,7 @@ struct Builder {
         p.silu = silu;
         if (res) { p.res = res->p; p.res_stride = res->C; }
         if (!naive) {  // prefer F(4x4,3x3), then F(2x2,3x3), then the direct implicit GEMM
-            if (w.wino_up && wino_shape_ok(p, 4) && push_wino(p, w.wino_u4, 4, w.wino_up)) return out;
+            if (w.wino_up && wino_shape_ok(p, 4) && push_wino(p, w.wino_u4, 4, w.wino_up, w.wino_up_scale)) return out;
             if (w.wino_uf64 && push_wino_fused(p, w.wino_uf64, true)) return out;
             if (w.wino_uf && push_wino_fused(p, w.wino_uf, false)) return out;
             if (w.wino_u4 && wino_shape_ok(p, 4) && push_wino(p, w.wino_u4, 4)) return out;
@@ -144,7 +144,7 @@ struct Builder {
 
     // Winograd F(2x2,3x3): input transform -> 16 batched GEMMs on the MFMA kernel -> output transform + epilogue
     // (Up: IRSDE_FLAG_SPLIT_BF16X2 — the component GEMMs on bf16 hi / lo pairs, gemm_split.hip)
-    bool push_wino(const ConvParams& d, const float* U, int tile, const unsigned short* Up = nullptr) {
+    bool push_wino(const ConvParams& d, const float* U, int tile, const unsigned short* Up = nullptr, float up_scale = 1.f) {
         const int Ctot = d.C0 + d.C1;
         const int ncomp = (tile + 2) * (tile + 2);
         const long long T = (long long)d.B * (d.Ho / tile) * (d.Wo / tile);
@@ -158,7 +158,7 @@ struct Builder {
         WinoPlan wp = make_wino(dd, U, V, Mb, tile);
         WinoSplitPlan sp;
         if (Up) {
-            sp = make_wino_pairs(dd, Up, reinterpret_cast<unsigned short*>(V), Mb);
+            sp = make_wino_pairs(dd, Up, reinterpret_cast<unsigned short*>(V), Mb, (e->cfg.flags & IRSDE_FLAG_SPLIT_F16X2) != 0, up_scale);
             wp.in = sp.in;
         }
         const double direct = conv_flops(d);
@@ -181,12 +181,13 @@ struct Builder {
             pl->conv_exec_flops += op.exec_flops;
             pl->conv_bytes += op.bytes;
             char buf[256];
-            snprintf(buf, sizeof buf, "conv(%s F%d gemm x%d) T=%lld Cout=%d Cin=%d flops=%.4g exec=%.4g", Up ? "split bf16x2 winograd" : "winograd", tile, ncomp, T,
+            snprintf(buf, sizeof buf, "conv(%s F%d gemm x%d) T=%lld Cout=%d Cin=%d flops=%.4g exec=%.4g", Up ? (sp.f16 ? "split f16x2 winograd" : "split bf16x2 winograd") : "winograd", tile, ncomp, T,
                      d.Cout, Ctot, op.flops, op.exec_flops);
             op.desc = buf;
             if (Up) {
                 const SplitGemmArgs sg = sp.gemm;
-                op.fn = [sg](hipStream_t s) { launch_gemm_split_pairs(sg, 36, s); };
+                const bool f16 = sp.f16;
+                op.fn = [sg, f16](hipStream_t s) { launch_gemm_split_pairs(sg, 36, s, 0, f16); };
             } else {
                 const ConvParams g = wp.gemm;
                 op.fn = [g](hipStream_t s) { launch_conv(g, s); };

@@ -1,6 +1,7 @@
 // Weight side of the engine: inventory under the reference's state_dict names, repacking into the kernel layouts
 // ([Cout][KH][KW][Cin], Winograd U = G g G^T, interleaved SimpleGate rows, ...), FiLM / time-embedding rows.
 #include "engine.h"
+#include <cmath>
 
 using namespace irsde;
 
@@ -105,11 +106,17 @@ ConvW pack_conv(irsde_engine* e, const std::string& wname, const std::string& bn
             std::vector<float> U((size_t)(tile + 2) * (tile + 2) * O * I);
             wino_transform_weights(p.data(), O, I, U.data(), tile);
             (tile == 4 ? c.wino_u4 : c.wino_u2) = e->upload(U);
-            if (tile == 4 && (e->cfg.flags & IRSDE_FLAG_SPLIT_BF16X2) && I >= split_min_cin()) {
-                unsigned short* up = nullptr;   // bf16 hi / lo pairs of U, made on the device once
+            if (tile == 4 && (e->cfg.flags & (IRSDE_FLAG_SPLIT_BF16X2 | IRSDE_FLAG_SPLIT_F16X2)) && I >= split_min_cin()) {
+                unsigned short* up = nullptr;   // hi / lo pairs of U, made on the device once
                 IRSDE_HIP_CHECK(hipMalloc(&up, U.size() * 4));
                 e->dev_allocs.push_back(reinterpret_cast<float*>(up));
-                launch_split_pairs(c.wino_u4, up, (size_t)36 * O, I, e->stream);
+                const bool f16 = (e->cfg.flags & IRSDE_FLAG_SPLIT_F16X2) != 0;
+                if (f16) {   // power-of-two scale that brings max |U| to (256, 512]: exact, undone by the GEMM
+                    float mx = 0.f;
+                    for (float v : U) mx = std::max(mx, std::fabs(v));
+                    c.wino_up_scale = mx > 0.f ? std::exp2(std::floor(std::log2(512.0f / mx))) : 1.f;
+                }
+                launch_split_pairs(c.wino_u4, up, (size_t)36 * O, I, e->stream, f16, c.wino_up_scale);
                 IRSDE_HIP_CHECK(hipStreamSynchronize(e->stream));
                 c.wino_up = up;
             }

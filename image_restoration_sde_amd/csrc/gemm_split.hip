@@ -23,11 +23,13 @@
 //   writes finished accumulators straight from registers (buffer stores, rows past M dropped by the descriptor).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace irsde {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -207,8 +209,12 @@ __global__ __launch_bounds__(256, 1) void gemm_split_kernel(const SplitGemmArgs 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR), (__attribute__((address_space(3))) void*)(LPTR), 16, 0, 0)
 
 // ABL: measurement twins (irsde_bench_conv 473 / 475 / 476): 1 = no global loads in the K loop, 3 = no MFMAs, 4 = no output stores
-template <int ABL = 0>
+// F16: the two pieces are IEEE binary16 (11 significand bits each: hi + lo carry 22+ of f32's 24 bits, products exact in f32) on
+// v_mfma_f32_32x32x16_f16 — fp32-equivalent per product at the same three MFMAs; the writers scale the operands by powers of two
+// into fp16's range and g.out_scale undoes it here.
+template <int ABL = 0, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_split2i_kernel(const SplitGemmArgs g) {
+    using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
     constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256;
     constexpr int A_STAGE = BM * 128, STAGE = (BM + BN) * 128;   // bytes
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split2i_kernel(const SplitGemmArg
                     const int soff = (i * 32 * g.ldc + colu) * 4;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = acc[i][j][r];
+                        const float v = F16 ? acc[i][j][r] * g.out_scale : acc[i][j][r];   // (exact: a power of two)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, (int)o_voff[r], soff, 0);
                     }
                 }
@@ -335,15 +341,15 @@ __global__ __launch_bounds__(512, 2) void gemm_split2i_kernel(const SplitGemmArg
         const char* b = lds + buf * STAGE + A_STAGE + wn * TN * 32 * 128;
         // Pinned order (r03, A/B in profiles/r03_split_gemm_notes.md): fragments of both 16-k sub-steps up front (the second set lands
         // while the first multiplies), the next stage's LDS-DMA loads spread behind the first MFMA groups instead of one burst
-        bf16x8 fa[2][2][TM], fb[2][2][TN];
+        frag_t fa[2][2][TM], fb[2][2][TN];
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[sb][p][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * 128 + fr_off[p][sb]);
+                for (int i = 0; i < TM; ++i) fa[sb][p][i] = *reinterpret_cast<const frag_t*>(a + i * 32 * 128 + fr_off[p][sb]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[sb][p][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * 128 + fr_off[p][sb]);
+                for (int j = 0; j < TN; ++j) fb[sb][p][j] = *reinterpret_cast<const frag_t*>(b + j * 32 * 128 + fr_off[p][sb]);
             }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -354,7 +360,10 @@ __global__ __launch_bounds__(512, 2) void gemm_split2i_kernel(const SplitGemmArg
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        if (ABL != 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sb][pr == 1 ? 1 : 0][i], fb[sb][pr == 0 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                        if (ABL != 3) {
+                            if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sb][pr == 1 ? 1 : 0][i], fb[sb][pr == 0 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sb][pr == 1 ? 1 : 0][i], fb[sb][pr == 0 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                        }
                         else acc[i][j][0] += (float)fa[sb][pr == 1 ? 1 : 0][i][0] * (float)fb[sb][pr == 0 ? 1 : 0][j][0];
                 if (sb == 0 && ABL != 1 && more) issue_loads_part(buf ^ 1, pr);   // 3 + 3 + 2 loads behind the first three MFMA groups
                 __builtin_amdgcn_sched_barrier(0);
@@ -365,19 +374,31 @@ __global__ __launch_bounds__(512, 2) void gemm_split2i_kernel(const SplitGemmArg
 }
 #undef IRSDE_GLDS16
 
-// f32 -> pair-interleaved hi / lo bf16 pieces: element (row, k) of a [rows][K] matrix -> out[(row * K / 32 + k / 32) * 64 + plane * 32 + k % 32]
-__global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, const size_t n, const int K) {
+// f32 -> pair-interleaved hi / lo pieces: element (row, k) of a [rows][K] matrix -> out[(row * K / 32 + k / 32) * 64 + plane * 32 + k % 32].
+// F16: the pieces are IEEE binary16 of in * scale (scale = a power of two that brings the tensor into fp16's range).
+template <bool F16>
+__global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, const size_t n, const int K,
+                                                          const float scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t row = i / K;
     const int k = (int)(i - row * K);
     float r = in[i];
     const size_t base = (row * (size_t)(K / 32) + k / 32) * 64 + (k & 31);
-    const __bf16 hb = (__bf16)r;
-    out[base] = __builtin_bit_cast(unsigned short, hb);
-    r -= (float)hb;
-    const __bf16 lb = (__bf16)r;
-    out[base + 32] = __builtin_bit_cast(unsigned short, lb);
+    if constexpr (F16) {
+        r *= scale;
+        const _Float16 hb = (_Float16)r;
+        out[base] = __builtin_bit_cast(unsigned short, hb);
+        r -= (float)hb;
+        const _Float16 lb = (_Float16)r;
+        out[base + 32] = __builtin_bit_cast(unsigned short, lb);
+    } else {
+        const __bf16 hb = (__bf16)r;
+        out[base] = __builtin_bit_cast(unsigned short, hb);
+        r -= (float)hb;
+        const __bf16 lb = (__bf16)r;
+        out[base + 32] = __builtin_bit_cast(unsigned short, lb);
+    }
 }
 
 // f32 -> NPL bf16 planes (round to nearest even; every residual is exact in f32)
@@ -399,6 +420,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 void gemm_split_global_init() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split2i_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -415,7 +437,7 @@ int gemm_split_inner(int M, int N, int ncomp) {
 }
 
 // pair-interleaved operands (g.a / g.b in the [row][k/32][plane][32] layout, g.pA / g.pB = elements per component and plane)
-void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, int abl) {
+void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, int abl, bool f16) {
     if (a.K % SG_BK) throw HipError("gemm_split_pairs: K must be a multiple of 32");
     if ((unsigned long long)a.M * a.K * 4ull >= 0xffffffffull || (unsigned long long)a.N * a.K * 4ull >= 0xffffffffull ||
         (size_t)a.M * a.ldc * 4 >= 0xffffffffull)
@@ -428,6 +450,12 @@ void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, i
     for (int x = 0; x < 8; ++x) per_xcd = std::max(per_xcd, (int)((long long)(x + 1) * units / 8) - (int)((long long)x * units / 8));
     const dim3 grid((unsigned)(8 * per_xcd * g.nblk_n));
     const size_t lds = (size_t)2 * 512 * 128;
+    if (f16) {
+        if (abl != 0) throw HipError("gemm_split_pairs: the ablation twins exist for the bf16 kernel only");
+        hipLaunchKernelGGL((gemm_split2i_kernel<0, true>), grid, dim3(512), lds, s, g);
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
     switch (abl) {
         case 0: hipLaunchKernelGGL(gemm_split2i_kernel<0>, grid, dim3(512), lds, s, g); break;
         case 1: hipLaunchKernelGGL(gemm_split2i_kernel<1>, grid, dim3(512), lds, s, g); break;
@@ -438,10 +466,11 @@ void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, i
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-void launch_split_pairs(const float* in, unsigned short* out, size_t rows, int K, hipStream_t s) {
+void launch_split_pairs(const float* in, unsigned short* out, size_t rows, int K, hipStream_t s, bool f16, float scale) {
     if (K % 32) throw HipError("split_pairs: K must be a multiple of 32");
     const size_t n = rows * (size_t)K;
-    hipLaunchKernelGGL(split_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, K);
+    if (f16) hipLaunchKernelGGL(split_pairs_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, K, scale);
+    else hipLaunchKernelGGL(split_pairs_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, K, 1.0f);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

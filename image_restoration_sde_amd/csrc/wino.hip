@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
 // Split-operand mode (gemm_split.hip): the same F(4x4,3x3) input transform, 4 channels per thread, but every V element is
 // written as NPL bf16 pieces (round to nearest even, residual exact in f32) into NPL planes: 2 NPL bytes per element instead
 // of 4, and the component GEMMs become bf16 GEMMs with f32-equivalent (NPL = 3) or 16-bit (NPL = 2) operands.
-template <int NPL, bool PAIRS = false>
+template <int NPL, bool PAIRS = false, bool F16 = false>
 __global__ __launch_bounds__(256) void wino_input_split_kernel(const WinoParams p) {
     constexpr int A = 6;
     const int C4 = (p.C0 + p.C1) / 4;
@@ -193,14 +193,24 @@ __global__ __launch_bounds__(256) void wino_input_split_kernel(const WinoParams 
 #pragma unroll
         for (int s = 0; s < A; ++s) {
             float rem[4] = {o[s].x, o[s].y, o[s].z, o[s].w};
+            if constexpr (F16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rem[e] *= p.v_scale;
+            }
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
                 unsigned short q[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const __bf16 hb = (__bf16)rem[e];
-                    q[e] = __builtin_bit_cast(unsigned short, hb);
-                    rem[e] -= (float)hb;
+                    if constexpr (F16) {
+                        const _Float16 hb = (_Float16)rem[e];
+                        q[e] = __builtin_bit_cast(unsigned short, hb);
+                        rem[e] -= (float)hb;
+                    } else {
+                        const __bf16 hb = (__bf16)rem[e];
+                        q[e] = __builtin_bit_cast(unsigned short, hb);
+                        rem[e] -= (float)hb;
+                    }
                 }
                 uint2 pk;
                 pk.x = (unsigned)q[0] | ((unsigned)q[1] << 16);
@@ -284,7 +294,8 @@ void launch_wino_input(const WinoParams& p, hipStream_t s) {
         const dim3 gr((unsigned)((tot + 255) / 256));
         if (p.v_pairs) {
             if (p.nplanes != 2 || (p.C0 + p.C1) % 32) throw HipError("wino_input (pairs): two planes, channels a multiple of 32");
-            hipLaunchKernelGGL((wino_input_split_kernel<2, true>), gr, dim3(256), 0, s, p);
+            if (p.v_f16) hipLaunchKernelGGL((wino_input_split_kernel<2, true, true>), gr, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((wino_input_split_kernel<2, true, false>), gr, dim3(256), 0, s, p);
         } else if (p.nplanes == 3) hipLaunchKernelGGL((wino_input_split_kernel<3, false>), gr, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((wino_input_split_kernel<2, false>), gr, dim3(256), 0, s, p);
         IRSDE_HIP_CHECK(hipGetLastError());

@@ -149,13 +149,15 @@ class ConditionalUNet(nn.Module):
         """'fp32' (default: exact-fp32 MFMA + Winograd), 'bf16' (BASELINE configs[2]: conv operands rounded to bf16,
         fp32 accumulation, everything else fp32), 'bf16_act' (+ bf16 activation storage) or 'fp16' (BASELINE configs[4]:
         the 'bf16' mode with IEEE fp16 operands), or 'fp32_split' (r03: fp32 everywhere, but the deep Winograd component GEMMs
-        multiply bf16 hi + lo pairs of their fp32 operands on the bf16 MFMA pipe, IRSDE_FLAG_SPLIT_BF16X2).  New behaviour — the
+        multiply bf16 hi + lo pairs of their fp32 operands on the bf16 MFMA pipe, IRSDE_FLAG_SPLIT_BF16X2; 'fp32_split_f16': fp16 pairs).  New behaviour — the
         reference is fp32 only."""
-        self.engine_flags &= ~(_lib.FLAG_BF16 | _lib.FLAG_BF16_ACT | _lib.FLAG_FP16 | _lib.FLAG_SPLIT_BF16X2)
+        self.engine_flags &= ~(_lib.FLAG_BF16 | _lib.FLAG_BF16_ACT | _lib.FLAG_FP16 | _lib.FLAG_SPLIT_BF16X2 | _lib.FLAG_SPLIT_F16X2)
         if dtype in ("fp32", "f32", torch.float32):
             pass
         elif dtype == "fp32_split":
             self.engine_flags |= _lib.FLAG_SPLIT_BF16X2
+        elif dtype == "fp32_split_f16":   # the same path with fp16 hi + lo pieces: fp32-equivalent per layer, range-limited (|activation| < ~1e4)
+            self.engine_flags |= _lib.FLAG_SPLIT_F16X2
         elif dtype in ("bf16", torch.bfloat16):
             self.engine_flags |= _lib.FLAG_BF16
         elif dtype == "bf16_act":  # + bf16 storage of the activation tensors (conditional UNet only)
@@ -163,7 +165,7 @@ class ConditionalUNet(nn.Module):
         elif dtype in ("fp16", "f16", torch.float16):
             self.engine_flags |= _lib.FLAG_FP16
         else:
-            raise _lib.IrsdeError("compute dtype must be 'fp32', 'fp32_split', 'bf16', 'bf16_act' or 'fp16'")
+            raise _lib.IrsdeError("compute dtype must be 'fp32', 'fp32_split', 'fp32_split_f16', 'bf16', 'bf16_act' or 'fp16'")
         return self
 
     # ---- reference interface -----------------------------------------------------------------

@@ -18,7 +18,7 @@
  *   100  round 1.
  *   101  irsde_sample: T == 0 runs NO step and copies xT to out (the reference's `range(1, T + 1)` is empty); only T < 0
  *        selects the full schedule.  (Version 100 treated T <= 0 as "full schedule".)
- *   102  IRSDE_FLAG_SPLIT_BF16 / IRSDE_FLAG_SPLIT_BF16X2 (fp32-equivalent split-operand GEMMs on the bf16 MFMA pipe).
+ *   102  IRSDE_FLAG_SPLIT_BF16X2 / IRSDE_FLAG_SPLIT_F16X2 (split-operand GEMMs on the 16-bit MFMA pipe for the deep Winograd layers).
  */
 #ifndef IRSDE_HIP_H
 #define IRSDE_HIP_H
@@ -82,6 +82,11 @@ enum {
                                         in f32 (csrc/gemm_split.hip): 16 significand bits per operand instead of 24 at 3/16 of the f32-MFMA cycles.
                                         Everything else (transforms, other layers, epilogues, sampler state) stays native f32.  Measured error
                                         and speed: profiles/r03_split_gemm_*.txt.  Not combinable with the 16-bit modes. */
+    IRSDE_FLAG_SPLIT_F16X2 = 32768,  /* r03, opt-in: IRSDE_FLAG_SPLIT_BF16X2's path with IEEE fp16 pieces instead of bf16 ones (hi + lo = 22+ of f32's 24
+                                        significand bits: fp32-equivalent per product and per layer, same three MFMAs).  fp16's exponent range is
+                                        handled by exact power-of-two scales: V is written as V / 16 (|V| <= 1e6, i.e. activations up to ~1e4,
+                                        stay finite; larger values overflow to inf), U is scaled per layer to max |U| <= 512, the GEMM undoes
+                                        both.  Wins over IRSDE_FLAG_SPLIT_BF16X2 when both are set. */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };

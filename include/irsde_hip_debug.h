@@ -20,6 +20,7 @@ extern "C" {
  *   0 production dispatch      1 VALU cross-check kernel
  *   2 / 3 Winograd F(2x2,3x3) / F(4x4,3x3) (3x3 s1 p1 only); 12 / 13 and 22 / 23: the same with the component GEMMs forced
  *         onto the tile-loop kernel (all / 2 components per block)
+ *   44 / 45 three-launch Winograd F(4x4,3x3) with the engine's pair GEMM (pair-interleaved operands, LDS-DMA): fp16 / bf16 hi + lo pieces
  *   42 / 43 three-launch Winograd F(4x4,3x3) with split-operand component GEMMs on the bf16 MFMA pipe (csrc/gemm_split.hip): 2 / 3 bf16 planes
  *   34 the 64-cout fused Winograd kernel (r03: Cout and C0 + C1 multiples of 64)
  *   33 the fused Winograd F(4x4,3x3) kernel (csrc/wino_fused.hip; 3x3 s1 p1, H and W multiples of 4, C0, C1 and Cout multiples of 32)
@@ -34,8 +35,8 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
                      int splits, void* stream);
 
 /* Kernel-level test hook of csrc/gemm_split.hip: C_z[M][N] = A_z[M][K] . B_z[N][K]^T for z < ncomp (device f32 tensors, z-major),
- * operands split into `nplanes` (2 or 3) bf16 pieces on the device (plane-major prototype kernel; nplanes = 42: the engine's
- * pair-interleaved two-piece kernel), products on v_mfma_f32_32x32x16_bf16, f32 accumulate.  K a multiple of 32.  Synchronises `stream`. */
+ * operands split into `nplanes` (2 or 3) bf16 pieces on the device (plane-major prototype kernel; nplanes = 42 / 44: the engine's
+ * pair-interleaved two-piece kernel with bf16 / fp16 pieces), products on v_mfma_f32_32x32x16_bf16, f32 accumulate.  K a multiple of 32.  Synchronises `stream`. */
 int irsde_debug_split_gemm(const float* A, const float* B, float* C, int M, int N, int K, int ncomp, int nplanes, void* stream);
 
 /* Kernel tuning hook: average ms of one KxK convolution (pad K/2, or 4x4 s2 p1) on random NHWC data.

@@ -49,14 +49,17 @@ def test_split_gemm_error_vs_float64(shape):
     res = rs.standard_normal((B, Cout, H, W)).astype(np.float32)
     ref = oracle_conv(x0, x1, w, bias, 1, 1, 0, None, 1, res)
     e = {}
-    for name, naive in (("direct f32", 0), ("winograd f32", 3), ("winograd split x3", 43), ("winograd split x2", 42)):
+    for name, naive in (("direct f32", 0), ("winograd f32", 3), ("winograd split x3", 43), ("winograd split x2", 42), ("winograd pairs bf16", 45),
+                        ("winograd pairs f16", 44)):
         got = run_conv(x0, x1, w, bias, 1, 1, 0, None, 1, res, naive=naive)
         assert np.isfinite(got).all(), name
         e[name] = relerr(got, ref)
     _ROWS.append((shape, e))
     print("split table %s: %s" % (shape, "  ".join("%s %.3g" % kv for kv in e.items())))
     assert e["winograd split x3"] <= 2.0 * e["winograd f32"] + 1e-7, e
-    assert e["winograd split x2"] <= 2e-4, e
+    assert e["winograd split x2"] <= 2e-4 and e["winograd pairs bf16"] <= 2e-4, e
+    # the engine's two modes: bf16 pairs = the 2-plane prototype's arithmetic; fp16 pairs = fp32-equivalent per layer
+    assert e["winograd pairs f16"] <= 2.0 * e["winograd f32"] + 1e-7, e
 
 
 def test_split_gemm_error_table_written():
@@ -64,9 +67,11 @@ def test_split_gemm_error_table_written():
     if not _ROWS:
         pytest.skip("the parametrised error tests did not run")
     lines = ["# per-layer max-abs error / max|ref| vs the float64 oracle convolution (tests/test_gpu_split.py)",
-             "%-28s %12s %12s %12s %12s" % ("layer (B,C0,C1,H,W,Cout)", "direct f32", "wino f32", "wino split x3", "wino split x2")]
+             "%-28s %12s %12s %14s %14s %16s %16s" % ("layer (B,C0,C1,H,W,Cout)", "direct f32", "wino f32", "wino 3 x bf16", "wino 2 x bf16",
+                                                     "pairs bf16 (eng)", "pairs f16 (eng)")]
     for shape, e in _ROWS:
-        lines.append("%-28s %12.3g %12.3g %12.3g %12.3g" % (str(shape), e["direct f32"], e["winograd f32"], e["winograd split x3"], e["winograd split x2"]))
+        lines.append("%-28s %12.3g %12.3g %14.3g %14.3g %16.3g %16.3g" % (str(shape), e["direct f32"], e["winograd f32"], e["winograd split x3"],
+                                                                    e["winograd split x2"], e["winograd pairs bf16"], e["winograd pairs f16"]))
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         open(os.path.join(out, "split_error_table.txt"), "w").write("\n".join(lines) + "\n")
@@ -76,12 +81,13 @@ def test_split_gemm_error_table_written():
 # ---------------------------------------------------------------------------------------------
 # kernel level: the three GEMM kernels against float64
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant,tol", [(3, 2e-6), (2, 2e-5), (42, 2e-5)])
+@pytest.mark.parametrize("variant,tol", [(3, 2e-6), (2, 2e-5), (42, 2e-5), (44, 1e-6)])
 @pytest.mark.parametrize("shape", [(256, 256, 32, 1), (100, 96, 64, 3), (1000, 520, 96, 4), (777, 256, 512, 5)])
 def test_split_gemm_kernels_vs_float64(variant, tol, shape):
     """C_z = A_z . B_z^T with f32 operands split on the device: 3 / 2 = three / two bf16 pieces on the 128 x 128 plane-major
-    prototype kernel, 42 = two pieces pair-interleaved on the LDS-DMA kernel the engine uses.  Ragged M / N, several components.
-    Tolerances relative to max|C|: 24-bit operands 2e-6, 16-bit operands 2e-5."""
+    prototype kernel, 42 / 44 = two bf16 / fp16 pieces pair-interleaved on the LDS-DMA kernel the engine uses (44 with operand scales
+    2^-4 and 2^6 undone in the kernel).  Ragged M / N, several components.  Tolerances relative to max|C|: 24-bit operands 2e-6,
+    16-bit operands 2e-5, fp16 pairs (22+ bits) 1e-6."""
     M, N, K, ncomp = shape
     rs = np.random.RandomState(M + K)
     A = rs.standard_normal((ncomp, M, K)).astype(np.float32)
@@ -109,13 +115,17 @@ def _unet(dtype):
     return m
 
 
-def test_split_mode_plan_and_forward_vs_reference_golden(golden):
-    """The fp32_split plan at 2 x 256 x 256 really runs the pair GEMM on the deep layers, and one network evaluation stays
+_MODE_TAG = {"fp32_split": b"split bf16x2 winograd", "fp32_split_f16": b"split f16x2 winograd"}
+
+
+@pytest.mark.parametrize("mode", ["fp32_split", "fp32_split_f16"])
+def test_split_mode_plan_and_forward_vs_reference_golden(golden, mode):
+    """The split plans at 2 x 256 x 256 really run the pair GEMM on the deep layers, and one network evaluation stays
     within 2e-4 of the REAL reference's fp32 output (native plan: 1.5e-6)."""
-    m = _unet("fp32_split")
+    m = _unet(mode)
     buf = ctypes.create_string_buffer(1 << 16)
     _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 2, 256, 256, buf, len(buf)))
-    assert buf.value.count(b"split bf16x2 winograd") >= 10, buf.value.decode()
+    assert buf.value.count(_MODE_TAG[mode]) >= 10, buf.value.decode()
     lq, xT = O.synth_inputs(1234, 1, 256, 256)
     x, c = torch.from_numpy(xT).cuda(), torch.from_numpy(lq).cuda()
     xx, cc = torch.cat([x, x.flip(-1)]), torch.cat([c, c.flip(-1)])
@@ -123,20 +133,21 @@ def test_split_mode_plan_and_forward_vs_reference_golden(golden):
         y = m(xx, cc, t).cpu().numpy()[:1]
         ref = golden.fullres["unet_1x256x256/t%d" % t]
         e = relerr(y if t == 50 else y[..., 1::3, 2::3], ref)
-        print("fp32_split forward 256x256 t=%d vs reference: %.3g" % (t, e))
+        print("%s forward 256x256 t=%d vs reference: %.3g" % (mode, t, e))
         assert e < 2e-4, t
 
 
-def test_split_mode_samplers_T100_vs_reference_golden(golden):
-    """Full T=100 reverse_ode and reverse_sde at 256 x 256 in the fp32_split mode vs the REAL reference (fp32), through a
+@pytest.mark.parametrize("mode", ["fp32_split", "fp32_split_f16"])
+def test_split_mode_samplers_T100_vs_reference_golden(golden, mode):
+    """Full T=100 reverse_ode and reverse_sde at 256 x 256 in the split modes vs the REAL reference (fp32), through a
     batch of 4 (so that every deep layer, also the 32 x 32 level with 4 x 64 = 256 Winograd tiles, runs the pair GEMM as in the
     16-image plan); image 2 of the batch is the golden's input.  north_star tolerance: 1e-3 max-abs; published: the measured values."""
-    m = _unet("fp32_split")
+    m = _unet(mode)
     buf = ctypes.create_string_buffer(1 << 16)
     _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 4, 256, 256, buf, len(buf)))
-    nsplit = buf.value.count(b"split bf16x2 winograd")
+    nsplit = buf.value.count(_MODE_TAG[mode])
     _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 16, 256, 256, buf, len(buf)))
-    assert nsplit == buf.value.count(b"split bf16x2 winograd") and nsplit >= 20, nsplit
+    assert nsplit == buf.value.count(_MODE_TAG[mode]) and nsplit >= 20, nsplit
     lq1, xT1 = O.synth_inputs(1234, 1, 256, 256)
     lq, xT = O.synth_inputs(99, 4, 256, 256)
     lq[2], xT[2] = lq1[0], xT1[0]
@@ -146,7 +157,7 @@ def test_split_mode_samplers_T100_vs_reference_golden(golden):
     sde.set_mu(c)
     y = sde.reverse_ode(x).cpu().numpy()[2:3]
     ref = golden.fullres2["unet_1x256x256/sampler_ode"]
-    print("fp32_split reverse_ode T=100 vs reference: rel %.3g, max-abs %.3g (max|x0| %.3g)" % (relerr(y, ref), np.abs(y - ref).max(), np.abs(ref).max()))
+    print(mode + " reverse_ode T=100 vs reference: rel %.3g, max-abs %.3g (max|x0| %.3g)" % (relerr(y, ref), np.abs(y - ref).max(), np.abs(ref).max()))
     assert relerr(y, ref) < 2e-4 and np.abs(y - ref).max() < 1e-3
     z = O.synth_noise(7, 100, (1, 3, 256, 256))
     zz = np.random.RandomState(5).standard_normal((z.shape[0], 4, 3, 256, 256)).astype(np.float32)
@@ -154,5 +165,18 @@ def test_split_mode_samplers_T100_vs_reference_golden(golden):
     sde.injected_noise = torch.from_numpy(zz).cuda()
     y = sde.reverse_sde(x).cpu().numpy()[2:3]
     ref = golden.fullres["unet_1x256x256/sampler_sde"]
-    print("fp32_split reverse_sde T=100 vs reference: rel %.3g, max-abs %.3g (max|x0| %.3g)" % (relerr(y, ref), np.abs(y - ref).max(), np.abs(ref).max()))
+    print(mode + " reverse_sde T=100 vs reference: rel %.3g, max-abs %.3g (max|x0| %.3g)" % (relerr(y, ref), np.abs(y - ref).max(), np.abs(ref).max()))
     assert relerr(y, ref) < 2e-4 and np.abs(y - ref).max() < 1e-3
+
+
+def test_split_f16_large_activations_stay_finite():
+    """fp16 pairs: V is written as V / 16, so activations of several thousand (V = B^T d B up to ~100 x) stay finite and accurate;
+    the bf16 pairs have f32's exponent range by construction."""
+    rs = np.random.RandomState(3)
+    x0 = (rs.standard_normal((1, 256, 16, 16)) * 2000.0).astype(np.float32)
+    w = (rs.standard_normal((256, 256, 3, 3)) / np.sqrt(256 * 9)).astype(np.float32)
+    ref = oracle_conv(x0, None, w, None, 1, 1, 0, None, 0, None)
+    for naive in (44, 45):
+        got = run_conv(x0, None, w, None, 1, 1, 0, None, 0, None, naive=naive)
+        assert np.isfinite(got).all()
+        assert relerr(got, ref) < (3e-5 if naive == 44 else 2e-4), naive

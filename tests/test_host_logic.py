@@ -186,6 +186,8 @@ def test_compute_dtype_flags_and_metrics_fail_loudly_on_cpu():
     assert m.engine_flags == _lib.FLAG_BF16 | _lib.FLAG_BF16_ACT
     m.set_compute_dtype("fp32_split")   # r03: f32 everywhere, deep Winograd GEMMs on bf16 hi + lo pairs
     assert m.engine_flags == _lib.FLAG_SPLIT_BF16X2 == 16384
+    m.set_compute_dtype("fp32_split_f16")   # the same path with fp16 pieces: fp32-equivalent per layer
+    assert m.engine_flags == _lib.FLAG_SPLIT_F16X2 == 32768
     m.set_compute_dtype("fp16")
     assert m.engine_flags == _lib.FLAG_FP16
     m.set_compute_dtype("fp32")
@@ -287,7 +289,7 @@ def test_bench_roofline_object_from_an_op_profile():
     assert 0 < r["frac"] <= r["mfma_kernel_frac"] <= 1
     assert r["dominant_kernel"]["name"] == fused and abs(r["dominant_kernel"]["executed_TFLOPs"] - 80.0) < 1e-9
     assert abs(sum(k["time_share"] for k in r["per_kernel"]) - (2.15 / 2.5484)) < 1e-3
-    assert "note" in bench.roofline_object(prof, text, {"dtype": "fp32_split"})
+    assert "note" in bench.roofline_object(prof, text, {"dtype": "fp32_split"}) and "note" in bench.roofline_object(prof, text, {"dtype": "fp32_split_f16"})
     rb = bench.roofline_object(prof, text, {"dtype": "bf16_act"})
     assert rb["bound"] == "hbm" and rb["unit"] == "GB/s" and rb["peak"] == bench.PEAK_HBM_GBPS
     # every secondary workload names a model / dtype the Workload class knows, and the headline stays out of the list
