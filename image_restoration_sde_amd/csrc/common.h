@@ -50,7 +50,12 @@ struct ConvParams {
     int in_shift = 0;            // 1: fused nearest x2 upsample
     const float* w = nullptr;    // [Cout][KH*KW][C0+C1]
     const unsigned short* w_bf = nullptr;  // same layout rounded to bf16: selects the bf16-MFMA kernel (fp32 accumulate)
-    int f16 = 0;                 // 1: w_bf holds IEEE fp16 (IRSDE_FLAG_FP16): operands rounded to fp16, v_mfma_f32_32x32x16_f16
+    int f16 = 0;                 // 1: w_bf / w_pair hold IEEE fp16 (IRSDE_FLAG_FP16 / _SPLIT_F16X2): v_mfma_f32_32x32x16_f16
+    // split-operand arithmetic on fp32 storage (IRSDE_FLAG_SPLIT_BF16X2 / _F16X2; conv_igemm.hip PAIR kernels): the weights as two
+    // 16-bit planes hi / lo ([2][Cout][KH*KW][C0+C1], w_pair_plane elements apart); fp16: pieces of w * 2^k, pair_scale = 2^-k
+    const unsigned short* w_pair = nullptr;
+    long long w_pair_plane = 0;
+    float pair_scale = 1.f;
     int Cout = 0;
     int KH = 1, KW = 1, stride = 1, pad_y = 0, pad_x = 0;
     int B = 0, Ho = 0, Wo = 0;
@@ -140,7 +145,8 @@ void launch_gemm_split_pairs(const SplitGemmArgs& a, int ncomp, hipStream_t s, i
 void launch_split_pairs(const float* in, unsigned short* out, size_t rows, int K, hipStream_t s, bool f16 = false,
                         float scale = 1.0f);  // f32 [rows][K] -> pair-interleaved hi / lo (f16: of in * scale)
 void launch_gemm_split(const SplitGemmArgs& a, int nplanes, int ncomp, hipStream_t s);
-void launch_split_planes(const float* in, unsigned short* out, size_t n, size_t plane, int nplanes, hipStream_t s);  // f32 -> bf16 pieces
+void launch_split_planes(const float* in, unsigned short* out, size_t n, size_t plane, int nplanes, hipStream_t s, bool f16 = false,
+                         float scale = 1.0f);  // f32 -> bf16 pieces (f16: two IEEE fp16 pieces of in * scale), plane-major
 void launch_wino_output(const WinoParams& p, hipStream_t s);
 void wino_transform_weights(const float* w_packed, int Cout, int Cin, float* U, int tile);  // host
 // Fused Winograd F(4x4,3x3) convolution (wino_fused.hip): transforms and the 36 component GEMMs in one kernel.  `p` is the

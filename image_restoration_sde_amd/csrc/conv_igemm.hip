@@ -58,7 +58,7 @@ struct Op16<true> {
 
 constexpr int BK = 32;  // k per K-step (channels of one tap)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF16, bool ABF = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF16, bool ABF = false, int PL = 1>
 struct Cfg {
     static constexpr int NT = 64 * WAVES_M * WAVES_N;
     static constexpr int ROW_BYTES = BK * (BF16 ? 2 : 4) + 16;  // LDS tile row: 32 k + 16-B pad
@@ -73,7 +73,7 @@ struct Cfg {
     static constexpr int B_ROWS = NT / B_CHUNKS;
     static constexpr int B_PASSES = (BN + B_ROWS - 1) / B_ROWS;
     static constexpr int LDS_C = BN + 4;  // epilogue tile row stride (floats): 16-B aligned, odd number of slots
-    static constexpr int MAIN_BYTES = 2 * (BM + BN) * ROW_BYTES;
+    static constexpr int MAIN_BYTES = 2 * PL * (BM + BN) * ROW_BYTES;   // PL = 2: hi and lo operand planes (PAIR kernels)
     // the epilogue transposes EPI_ROWS tile rows per pass (bf16: smaller passes keep 3+ blocks per CU resident)
     static constexpr int EPI_ROWS = BF16 ? BM / WAVES_M : (BM > 128 ? 128 : BM);
     static constexpr int EPI_BYTES = EPI_ROWS * LDS_C * 4;
@@ -104,12 +104,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 // no vector instruction.  On gfx950 the f32 MFMA shares the SIMD's vector ALU: vector instructions between MFMAs are paid
 // in full (4+ cycles each) plus ~16 cycles per MFMA they follow (tools/probe/mfma_valu_samewave.hip), and the pointer
 // arithmetic of the generic path was ~100 of them per K-step.  Needs every operand tensor < 2 GiB (launch_cfg checks).
+// PAIR (r03, IRSDE_FLAG_SPLIT_BF16X2 / _F16X2): fp32 activations and fp32-derived weights, but every operand is split into a 16-bit
+// hi + lo pair (hi = round(x), lo = round(x - hi): exact residual) and the three cross products hi.hi + hi.lo + lo.hi run on the
+// 16-bit MFMA — the arithmetic of gemm_split.hip for the direct (implicit-GEMM) layers.  Activations are split while they are
+// staged (two LDS planes per operand), the weights come pre-split (p.w_pair: two planes); fp16 pieces carry 22+ significand
+// bits (fp32-equivalent), their weight plane is scaled by a power of two that p.pair_scale undoes on the accumulators.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MIN_WAVES_PER_SIMD, bool BF16, bool INSCALE, bool ABF = false, bool F16 = false,
-          bool BUFA = false>
+          bool BUFA = false, bool PAIR = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void conv_igemm_kernel(
     const ConvParams pin, const int nblk_n, const int M, const int nk_total) {
-    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16, ABF>;
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16, ABF, PAIR ? 2 : 1>;
     using H16 = Op16<F16>;
+    static_assert(!PAIR || (BF16 && !ABF && !BUFA), "PAIR: 16-bit MFMA on fp32 activation storage, generic staging");
+    constexpr int PL = PAIR ? 2 : 1;
     static_assert(!ABF || (BF16 && !INSCALE), "bf16 activation storage belongs to the bf16-MFMA mode");
     static_assert(!F16 || (BF16 && !ABF), "fp16 operands: the 16-bit MFMA mode with fp32 activation storage");
     ConvParams p = pin;  // batched launch: component blockIdx.z works on its own slice of in0 / w / out
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);
-    char* Bs = As + 2 * BM * C::ROW_BYTES;
+    char* Bs = As + 2 * PL * BM * C::ROW_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     // zeroed: they only feed output columns n >= Cout, which the epilogue never stores.
     const char* wrow[C::B_PASSES];
     constexpr int WESZ = BF16 ? 2 : 4;
-    const char* wbase = BF16 ? reinterpret_cast<const char*>(p.w_bf) : reinterpret_cast<const char*>(p.w);
+    const char* wbase = PAIR ? reinterpret_cast<const char*>(p.w_pair) : BF16 ? reinterpret_cast<const char*>(p.w_bf) : reinterpret_cast<const char*>(p.w);
     if (BF16 && pin.nz > 1) wbase += (long long)blockIdx.z * pin.z_w * WESZ;
 #pragma unroll
     for (int ps = 0; ps < C::B_PASSES; ++ps) {
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     };
 
     // ---- staging pieces: A rows (A_PASSES) then B rows (B_PASSES), one 16-byte load each ----
-    constexpr int NP = C::A_PASSES + C::B_PASSES;
+    constexpr int NP = C::A_PASSES + PL * C::B_PASSES;   // PAIR: the hi and the lo weight plane of every staged B row
     floatx4 rs[NP];  // (ext_vector: HIP's float4 struct copies become memcpys that can pin the array to scratch)
     floatx4 rscale[INSCALE ? C::A_PASSES : 1];  // NAFNet SCA: the per-(image, channel) scales of the A pieces in flight
     constexpr int AESZ = ABF ? 2 : 4;        // bytes per activation element in HBM
@@ -283,11 +290,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
             rs[q] = *reinterpret_cast<const floatx4*>(g);
             if constexpr (INSCALE)  // single source (C1 == 0); multiplied when the piece is written to LDS (store_piece)
                 rscale[q < C::A_PASSES ? q : 0] = *reinterpret_cast<const floatx4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + chunk * 4);
+        } else if constexpr (PAIR) {
+            const int qb = q - C::A_PASSES;
+            rs[q] = *reinterpret_cast<const floatx4*>(wrow[qb % C::B_PASSES] + (size_t)(qb / C::B_PASSES) * (size_t)p.w_pair_plane * 2 + cur_wk);
         } else {
             rs[q] = *reinterpret_cast<const floatx4*>(wrow[q - C::A_PASSES] + cur_wk);
         }
     };
     auto store_piece = [&](int q, int buf) {
+        if constexpr (PAIR) {
+            if (q < C::A_PASSES) {
+                floatx4 v = rs[q];
+                if constexpr (INSCALE) v *= rscale[q < C::A_PASSES ? q : 0];
+                const typename H16::x4 hi = __builtin_convertvector(v, typename H16::x4);          // RNE
+                const floatx4 r = v - __builtin_convertvector(hi, floatx4);                        // exact in f32
+                const typename H16::x4 lo = __builtin_convertvector(r, typename H16::x4);
+                char* dst = As + ((buf * 2) * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES + chunk * 8;
+                *reinterpret_cast<typename H16::x4*>(dst) = hi;
+                *reinterpret_cast<typename H16::x4*>(dst + BM * C::ROW_BYTES) = lo;
+            } else {
+                const int qb = q - C::A_PASSES, ps = qb % C::B_PASSES, pln = qb / C::B_PASSES;
+                if (C::B_PASSES * C::B_ROWS == BN || brow0 + ps * C::B_ROWS < BN)
+                    *reinterpret_cast<floatx4*>(Bs + ((buf * 2 + pln) * BN + brow0 + ps * C::B_ROWS) * C::ROW_BYTES + bchunk * 16) = rs[q];
+            }
+            return;
+        }
         if (q < C::A_PASSES) {
             char* dst = As + (buf * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES;
             if (ABF) {
@@ -335,9 +362,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
             advance();
             stage_setup();
         }
-        const char* a = As + (buf * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
-        const char* b = Bs + (buf * BN + wn * C::TN * 32 + l31) * C::ROW_BYTES + h * 16;
-        if constexpr (BF16) {
+        const char* a = As + (buf * PL * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
+        const char* b = Bs + (buf * PL * BN + wn * C::TN * 32 + l31) * C::ROW_BYTES + h * 16;
+        if constexpr (PAIR) {
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) load_piece(q);
+            }
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                typename H16::x8 fa[2][C::TM], fb[2][C::TN];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+                        fa[pl][i] = *reinterpret_cast<const typename H16::x8*>(a + (pl * BM + i * 32) * C::ROW_BYTES + sb * 32);
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j)
+                        fb[pl][j] = *reinterpret_cast<const typename H16::x8*>(b + (pl * BN + j * 32) * C::ROW_BYTES + sb * 32);
+                }
+                // hi.lo, lo.hi, hi.hi: small terms first; consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j)
+                            acc[i][j] = H16::mfma(fa[pr == 1 ? 1 : 0][i], fb[pr == 0 ? 1 : 0][j], acc[i][j]);
+            }
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) store_piece(q, buf ^ 1);
+            }
+        } else if constexpr (BF16) {
             if (more) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) load_piece(q);
@@ -415,6 +472,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         k_step((kt - kt_begin) & 1, kt + 1 < kt_end);
         __syncthreads();
+    }
+    if constexpr (PAIR && F16) {   // undo the power-of-two scale of the fp16 weight planes (exact)
+        const float ps = p.pair_scale;
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= ps;
     }
 
     // ---- direct epilogue (BUFA kernels, plain output layouts): straight from the accumulator registers through buffer
@@ -1003,6 +1069,31 @@ __global__ void conv_naive_kernel(const ConvParams p, const int M) {
 
 int g_variant = 0;  // tuning experiments only (irsde_bench_conv); 6 = generic pointer staging instead of buffer descriptors
 
+// PAIR kernels (split-operand arithmetic on fp32 storage): bf16 or fp16 pieces by p.f16
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool INSCALE>
+void launch_cfg_pair(const ConvParams& p, int M, int nk_total, hipStream_t s) {
+    using C = Cfg<BM, BN, WAVES_M, WAVES_N, true, false, 2>;
+    const int nblk_m = (M + BM - 1) / BM;
+    const int nblk_n = (p.Cout + BN - 1) / BN;
+    dim3 grid(nblk_m * nblk_n, p.splits, 1);
+    if (p.f16)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, true, INSCALE, false, true, false, true>), grid, dim3(C::NT),
+                           C::LDS_BYTES, s, p, nblk_n, M, nk_total);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, true, INSCALE, false, false, false, true>), grid, dim3(C::NT),
+                           C::LDS_BYTES, s, p, nblk_n, M, nk_total);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool INSCALE>
+void init_cfg_pair() {
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, true, INSCALE, false, true, false, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MINW, true, INSCALE, false, false, false, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool BF16, bool INSCALE = false, bool ABF = false, bool F16 = false>
 void launch_cfg(const ConvParams& p, int M, int nk_total, hipStream_t s, int lds_override = 0) {
     using C = Cfg<BM, BN, WAVES_M, WAVES_N, BF16, ABF>;
@@ -1109,6 +1200,12 @@ void conv_global_init() {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<64, 128, 1, 4, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    init_cfg_pair<256, 256, 2, 4, 2, false>();
+    init_cfg_pair<256, 256, 2, 4, 2, true>();
+    init_cfg_pair<256, 128, 4, 2, 2, false>();
+    init_cfg_pair<256, 128, 4, 2, 2, true>();
+    init_cfg_pair<128, 64, 2, 2, 2, false>();
+    init_cfg_pair<128, 64, 2, 2, 2, true>();
     init_cfg<128, 128, 2, 2, 2, false>();
     init_cfg<128, 64, 2, 2, 2, false>();
     init_cfg<128, 32, 4, 1, 2, false>();
@@ -1152,6 +1249,29 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.ln_g && (p.splits != 1 || (p.Cout != 64 && p.Cout != 128) || p.nz != 1 || (p.out_stride & 3) || (p.res && (p.res_stride & 3))))
         throw HipError("launch_conv: fused LayerNorm needs Cout == 64 or 128 in one tile, no split-K");
     if (!p.zeros) throw HipError("launch_conv: ConvParams::zeros (zero page for out-of-image taps) is not set");
+    if (p.w_pair) {   // split-operand arithmetic (IRSDE_FLAG_SPLIT_BF16X2 / _F16X2): the PAIR kernels on fp32 storage
+        if (p.w_bf || p.in_bf16 || p.out_bf16 || p.nz != 1) throw HipError("launch_conv: split-operand pairs go with fp32 storage, one component");
+        if (p.in_scale && p.C1) throw HipError("launch_conv: in_scale needs a single source");
+        const int nk = p.KH * p.KW * (Ctot / 32);
+        static const int t256 = tuning_env_int("IRSDE_PAIR_TILE256", 1);
+        // 256 x 256: half the staging work per MFMA (160 KB of LDS: one block per CU) — where it still fills the 256 CUs
+        if (t256 && p.Cout % 256 == 0 && (long long)((M + 255) / 256) * (p.Cout / 256) * p.splits >= 256 && g_variant != 61) {
+            if (p.in_scale) launch_cfg_pair<256, 256, 2, 4, 2, true>(p, M, nk, s);
+            else launch_cfg_pair<256, 256, 2, 4, 2, false>(p, M, nk, s);
+        } else if (p.Cout >= 128 && M >= 256) {
+            if (p.in_scale) launch_cfg_pair<256, 128, 4, 2, 2, true>(p, M, nk, s);
+            else launch_cfg_pair<256, 128, 4, 2, 2, false>(p, M, nk, s);
+        } else {
+            if (p.in_scale) launch_cfg_pair<128, 64, 2, 2, 2, true>(p, M, nk, s);
+            else launch_cfg_pair<128, 64, 2, 2, 2, false>(p, M, nk, s);
+        }
+        if (p.splits > 1) {
+            const size_t total = (size_t)M * p.Cout;
+            hipLaunchKernelGGL(conv_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, M);
+            IRSDE_HIP_CHECK(hipGetLastError());
+        }
+        return;
+    }
     if (!p.w_bf && g_variant == 0 && p.Cout <= 3 && p.C0 == 64 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 &&
         !p.in_shift && !p.C1 && !p.film && !p.silu && !p.res && p.splits == 1 && p.nz == 1 && !p.gate && !p.shuffle &&
         !p.ch_scale && !p.in_scale && !p.ln_g && M >= 65536) {  // final_conv: vector-pipe kernel (big feature maps only)

@@ -183,6 +183,9 @@ inline WinoSplitPlan make_wino_pairs(const ConvParams& d, const unsigned short* 
 // split mode: three-launch Winograd layers with at least this many input channels run the pair GEMM (below it the fused
 // f32 kernel is faster: profiles/r03_split_gemm_bench.txt); IRSDE_SPLIT_MINC moves the crossover (tuning only)
 inline int split_min_cin() { return tuning_env_int("IRSDE_SPLIT_MINC", 256); }
+// split mode: direct (implicit-GEMM) layers with K = KH * KW * Cin of at least this and >= 64 output channels run the PAIR kernel
+// (conv_igemm.hip); below it the layer is HBM-bound and the native f32 kernel is as fast.  IRSDE_SPLIT_DIRECT_MINK (tuning only)
+inline int split_direct_min_k() { return tuning_env_int("IRSDE_SPLIT_DIRECT_MINK", 128); }   // measured crossover: profiles/r03_pair_conv_sweep.txt
 inline bool wino_shape_ok(const ConvParams& d, int tile) {
     return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.Ho % tile == 0 && d.Wo % tile == 0 &&
            (d.C0 + d.C1) % 32 == 0 && d.Cout % 4 == 0 && d.out_stride % 4 == 0 && (!d.res || d.res_stride % 4 == 0);
@@ -348,6 +351,32 @@ struct irsde_engine {
         IRSDE_HIP_CHECK(hipStreamSynchronize(stream));
         bf16_copies[w] = d;
         return d;
+    }
+    // hi / lo operand planes of a packed fp32 weight tensor for the PAIR convolution kernels (IRSDE_FLAG_SPLIT_BF16X2 / _F16X2), made
+    // once per tensor.  fp16 pieces: the tensor is scaled by the power of two that brings max |w| into (256, 512]; `scale` returns
+    // its inverse (what the kernel multiplies the accumulators by).
+    struct PairCopy { unsigned short* p; float inv_scale; };
+    std::map<const float*, PairCopy> pair_copies;
+    PairCopy pair_copy(const float* w, size_t n) {
+        auto it = pair_copies.find(w);
+        if (it != pair_copies.end()) return it->second;
+        const bool f16 = (cfg.flags & IRSDE_FLAG_SPLIT_F16X2) != 0;
+        float sc = 1.f;
+        if (f16) {
+            std::vector<float> h(n);
+            IRSDE_HIP_CHECK(hipMemcpy(h.data(), w, n * sizeof(float), hipMemcpyDeviceToHost));
+            float mx = 0.f;
+            for (float v : h) mx = std::max(mx, std::fabs(v));
+            if (mx > 0.f) sc = std::exp2(std::floor(std::log2(512.0f / mx)));
+        }
+        unsigned short* d = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&d, 2 * n * sizeof(unsigned short)));
+        dev_allocs.push_back(reinterpret_cast<float*>(d));
+        launch_split_planes(w, d, n, n, 2, stream, f16, sc);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(stream));
+        const PairCopy pc{d, 1.0f / sc};
+        pair_copies[w] = pc;
+        return pc;
     }
     float* upload(const std::vector<float>& v) {
         float* p = dmalloc(v.size());

@@ -597,6 +597,18 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             launch_wino_output(wp.out, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dU); (void)hipFree(dV); (void)hipFree(dM);
+        } else if (naive == 46 || naive == 47) {   // direct implicit GEMM on the PAIR kernels: 46 fp16 hi + lo pieces, 47 bf16
+            const bool f16 = naive == 46;
+            float mx = 0.f;
+            for (float v : pk) mx = std::max(mx, std::fabs(v));
+            const float sc = f16 && mx > 0.f ? std::exp2(std::floor(std::log2(512.0f / mx))) : 1.f;
+            unsigned short* dwp = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dwp, pk.size() * 4));
+            launch_split_planes(dw, dwp, pk.size(), pk.size(), 2, s, f16, sc);
+            p.w_pair = dwp; p.w_pair_plane = (long long)pk.size(); p.pair_scale = 1.0f / sc; p.f16 = f16 ? 1 : 0;
+            launch_conv(p, s);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(dwp);
         } else if (naive == 1) {
             launch_conv_naive(p, s);
         } else {
@@ -739,6 +751,13 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         // 80: fused Winograd F(4x4,3x3) kernel; 81: the three-launch Winograd F(4x4,3x3) path (random U: timing only)
         float *dU = nullptr, *dV = nullptr, *dM = nullptr;
         WinoPlan wp{};
+        unsigned short* dwp = nullptr;
+        if (variant == 480 || variant == 481 || variant == 482) {   // direct convolution on the PAIR kernels: 480 fp16 pieces, 481 bf16 pieces, 482 = 480 without the 256 x 256 tile
+            IRSDE_HIP_CHECK(hipMalloc(&dwp, nw * 4));
+            launch_split_planes(dw, dwp, nw, nw, 2, s, variant != 481, 64.0f);
+            p.w_pair = dwp; p.w_pair_plane = (long long)nw; p.pair_scale = 1.0f / 64.0f; p.f16 = variant != 481 ? 1 : 0;
+            variant = variant == 482 ? 61 : 0;
+        }
         if (variant >= 472 && variant <= 476) {   // the pair-interleaved two-plane component GEMMs alone (v3 kernel): 472 full, 473 no loads, 475 no MFMAs, 476 no output stores
             if (K != 3 || stride != 1 || !wino_shape_ok(p, 4)) throw HipError("bench_conv: Winograd variants need an eligible 3x3 stride-1 layer");
             const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
@@ -881,6 +900,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
         if (dbf) (void)hipFree(dbf);
         if (dabf) (void)hipFree(dabf);
+        if (dwp) (void)hipFree(dwp);
         for (float* q : {dU, dV, dM})
             if (q) (void)hipFree(q);
         if (dUs) (void)hipFree(dUs);

@@ -49,6 +49,13 @@ struct Builder {
         if (!naive && (e->cfg.flags & IRSDE_FLAG_BF16)) {
             p.w_bf = e->bf16_copy(p.w, (size_t)p.Cout * p.KH * p.KW * (p.C0 + p.C1));
             p.f16 = (e->cfg.flags & IRSDE_FLAG_FP16) ? 1 : 0;
+        } else if (!naive && (e->cfg.flags & (IRSDE_FLAG_SPLIT_BF16X2 | IRSDE_FLAG_SPLIT_F16X2)) && p.Cout >= 64 && p.nz == 1 &&
+                   p.KH * p.KW * (p.C0 + p.C1) >= split_direct_min_k()) {
+            // split-operand arithmetic for the direct layers too (PAIR kernels): fp32 storage, 16-bit hi + lo operand pairs
+            const size_t nw = (size_t)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
+            const auto pc = e->pair_copy(p.w, nw);
+            p.w_pair = pc.p; p.w_pair_plane = (long long)nw; p.pair_scale = pc.inv_scale;
+            p.f16 = (e->cfg.flags & IRSDE_FLAG_SPLIT_F16X2) ? 1 : 0;
         }
         Op op;
         op.kind = OP_CONV;
@@ -63,7 +70,7 @@ struct Builder {
         {
             char buf[256];
             snprintf(buf, sizeof buf, "conv%s M=%d Cout=%d Cin=%d k=%dx%d s=%d up=%d splits=%d blocks=%d flops=%.4g",
-                     p.w_bf ? (p.f16 ? "(fp16)" : "(bf16)") : "", M, p.Cout, p.C0 + p.C1, p.KH, p.KW, p.stride, p.in_shift, splits, blocks, op.flops);
+                     p.w_pair ? (p.f16 ? "(split f16x2)" : "(split bf16x2)") : p.w_bf ? (p.f16 ? "(fp16)" : "(bf16)") : "", M, p.Cout, p.C0 + p.C1, p.KH, p.KW, p.stride, p.in_shift, splits, blocks, op.flops);
             op.desc = buf;
         }
         const bool nv = naive;

@@ -401,18 +401,24 @@ __global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restric
     }
 }
 
-// f32 -> NPL bf16 planes (round to nearest even; every residual is exact in f32)
-template <int NPL>
+// f32 -> NPL bf16 planes (round to nearest even; every residual is exact in f32); F16: IEEE fp16 pieces of in * scale
+template <int NPL, bool F16 = false>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, const size_t n,
-                                                           const size_t plane) {
+                                                           const size_t plane, const float scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float r = in[i];
+    float r = F16 ? in[i] * scale : in[i];
 #pragma unroll
     for (int p = 0; p < NPL; ++p) {
-        const __bf16 hb = (__bf16)r;
-        out[p * plane + i] = __builtin_bit_cast(unsigned short, hb);
-        r -= (float)hb;
+        if constexpr (F16) {
+            const _Float16 hb = (_Float16)r;
+            out[p * plane + i] = __builtin_bit_cast(unsigned short, hb);
+            r -= (float)hb;
+        } else {
+            const __bf16 hb = (__bf16)r;
+            out[p * plane + i] = __builtin_bit_cast(unsigned short, hb);
+            r -= (float)hb;
+        }
     }
 }
 
@@ -487,10 +493,12 @@ void launch_gemm_split(const SplitGemmArgs& a, int nplanes, int ncomp, hipStream
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-void launch_split_planes(const float* in, unsigned short* out, size_t n, size_t plane, int nplanes, hipStream_t s) {
+void launch_split_planes(const float* in, unsigned short* out, size_t n, size_t plane, int nplanes, hipStream_t s, bool f16, float scale) {
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (nplanes == 3) hipLaunchKernelGGL(split_planes_kernel<3>, grid, dim3(256), 0, s, in, out, n, plane);
-    else if (nplanes == 2) hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, s, in, out, n, plane);
+    if (f16 && nplanes != 2) throw HipError("split_planes: fp16 pieces come in pairs");
+    if (f16) hipLaunchKernelGGL((split_planes_kernel<2, true>), grid, dim3(256), 0, s, in, out, n, plane, scale);
+    else if (nplanes == 3) hipLaunchKernelGGL((split_planes_kernel<3, false>), grid, dim3(256), 0, s, in, out, n, plane, 1.0f);
+    else if (nplanes == 2) hipLaunchKernelGGL((split_planes_kernel<2, false>), grid, dim3(256), 0, s, in, out, n, plane, 1.0f);
     else throw HipError("split_planes: 2 or 3 planes");
     IRSDE_HIP_CHECK(hipGetLastError());
 }

@@ -20,6 +20,8 @@ extern "C" {
  *   0 production dispatch      1 VALU cross-check kernel
  *   2 / 3 Winograd F(2x2,3x3) / F(4x4,3x3) (3x3 s1 p1 only); 12 / 13 and 22 / 23: the same with the component GEMMs forced
  *         onto the tile-loop kernel (all / 2 components per block)
+ *   46 / 47 the direct implicit GEMM on the PAIR kernels (conv_igemm.hip: fp32 storage, activations split into 16-bit hi + lo pieces while
+ *           staged, three cross products on the 16-bit MFMA): fp16 / bf16 pieces
  *   44 / 45 three-launch Winograd F(4x4,3x3) with the engine's pair GEMM (pair-interleaved operands, LDS-DMA): fp16 / bf16 hi + lo pieces
  *   42 / 43 three-launch Winograd F(4x4,3x3) with split-operand component GEMMs on the bf16 MFMA pipe (csrc/gemm_split.hip): 2 / 3 bf16 planes
  *   34 the 64-cout fused Winograd kernel (r03: Cout and C0 + C1 multiples of 64)

@@ -16,7 +16,7 @@ import torch
 import image_restoration_sde_amd as P
 from image_restoration_sde_amd import _lib
 from oracle import irsde_oracle as O
-from test_gpu_parity import oracle_conv, relerr, run_conv
+from test_gpu_parity import CONV_CASES, naf_model, oracle_conv, relerr, run_conv
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -180,3 +180,50 @@ def test_split_f16_large_activations_stay_finite():
         got = run_conv(x0, None, w, None, 1, 1, 0, None, 0, None, naive=naive)
         assert np.isfinite(got).all()
         assert relerr(got, ref) < (3e-5 if naive == 44 else 2e-4), naive
+
+
+# ---------------------------------------------------------------------------------------------
+# the PAIR kernels of conv_igemm.hip: split-operand arithmetic for the direct (implicit-GEMM) layers
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [n for n, c in CONV_CASES.items() if c[5] >= 64])
+def test_conv_pair_kernels_vs_oracle(name):
+    """Every conv class with >= 64 output channels (1x1, 3x3, 4x4 s2, concat sources, fused upsample, bias / FiLM / SiLU / residual,
+    ragged M) on the PAIR kernels: fp16 pieces (46) at the native kernel's tolerance, bf16 pieces (47) at the 16-bit one; and the
+    forced split-K path."""
+    B, C0, C1, H, W, Cout, K, stride, pad, in_shift, has_bias, has_film, silu, has_res = CONV_CASES[name]
+    rs = np.random.RandomState(hash(name) % 2 ** 31)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, K, K)) / np.sqrt((C0 + C1) * K * K)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32) if has_bias else None
+    film = (0.3 * rs.standard_normal((1, 2 * Cout))).astype(np.float32) if has_film else None
+    Ho = ((H << in_shift) + 2 * pad - K) // stride + 1
+    Wo = ((W << in_shift) + 2 * pad - K) // stride + 1
+    res = rs.standard_normal((B, Cout, Ho, Wo)).astype(np.float32) if has_res else None
+    ref = oracle_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res)
+    e16 = relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=46), ref)
+    eb = relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=47), ref)
+    e32 = relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res), ref)
+    print("pair conv %s: native %.3g  f16 pairs %.3g  bf16 pairs %.3g" % (name, e32, e16, eb))
+    assert e16 < 2e-5 and eb < 2e-4, name
+    assert relerr(run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=46, splits=3), ref) < 2e-5
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32_split_f16", 1e-4), ("fp32_split", 1e-3)])
+def test_nafnet_split_modes_vs_reference_golden(golden, mode, tol):
+    """Refusion ConditionalNAFNet (all 1x1 GEMMs with SimpleGate / PixelShuffle / SCA-scale / beta-gamma residual epilogues on the PAIR
+    kernels) vs the REAL reference: fp16 pairs at the native tolerance, bf16 pairs at 1e-3."""
+    g = golden.nafnet
+    flags = _lib.FLAG_SPLIT_F16X2 if mode == "fp32_split_f16" else _lib.FLAG_SPLIT_BF16X2
+    m, _ = naf_model("refusion", flags=flags)
+    buf = ctypes.create_string_buffer(1 << 18)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 2, 40, 56, buf, len(buf)))
+    assert buf.value.count(b"conv(split") >= 50, buf.value.decode()[:2000]
+    for tag in ("refusion_1x64x64", "refusion_2x40x56"):
+        B, H, W = (int(v) for v in g[tag + "/shape"])
+        lq, xT = O.synth_inputs(1234, B, H, W, max_sigma=50)
+        x, c = torch.from_numpy(xT).cuda(), torch.from_numpy(lq).cuda()
+        for t in g[tag + "/ts"]:
+            e = relerr(m(x, c, int(t)).cpu().numpy(), g[tag + "/t%d" % t])
+            print("nafnet %s %s t=%d: %.3g" % (mode, tag, int(t), e))
+            assert e < tol, (tag, int(t))
