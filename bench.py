@@ -213,6 +213,8 @@ SECONDARY = [
          model="unet", dtype="fp32_split_f16", mode="sde", batch=16, size=256, T=100),
     dict(tag="BASELINE configs[1] workload in the opt-in fp32_split mode (IRSDE_FLAG_SPLIT_BF16X2: 16-bit operand pairs, f32 exponent range)",
          model="unet", dtype="fp32_split", mode="sde", batch=16, size=256, T=100),
+    dict(tag="BASELINE configs[3] workload (Refusion NAFNet 8x512x512 T=200) in the opt-in fp32_split_f16 mode",
+         model="nafnet", dtype="fp32_split_f16", mode="sde", batch=8, size=512, T=200),
 ]
 
 

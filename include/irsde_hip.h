@@ -76,17 +76,22 @@ enum {
                                         fused kernel of csrc/wino_fused.hip, whose transformed tensors never reach HBM */
     IRSDE_FLAG_NO_FUSED_ATTN = 4096, /* LinearAttention with the whole to_qkv convolution and a q | k | v tensor in HBM (default for fp32, C <= 256:
                                         k / v projection + softmax over the pixels + context in one kernel, only q is a convolution) */
-    IRSDE_FLAG_SPLIT_BF16X2 = 16384, /* r03, opt-in, new behaviour (the reference is plain fp32): the component GEMMs of the three-launch Winograd
-                                        layers (Cin >= 256) run on the bf16 MFMA pipe with every f32 operand split into a bf16 pair hi + lo
-                                        (round to nearest even; the residual is exact) and the three cross products hi.hi + hi.lo + lo.hi accumulated
-                                        in f32 (csrc/gemm_split.hip): 16 significand bits per operand instead of 24 at 3/16 of the f32-MFMA cycles.
-                                        Everything else (transforms, other layers, epilogues, sampler state) stays native f32.  Measured error
-                                        and speed: profiles/r03_split_gemm_*.txt.  Not combinable with the 16-bit modes. */
-    IRSDE_FLAG_SPLIT_F16X2 = 32768,  /* r03, opt-in: IRSDE_FLAG_SPLIT_BF16X2's path with IEEE fp16 pieces instead of bf16 ones (hi + lo = 22+ of f32's 24
-                                        significand bits: fp32-equivalent per product and per layer, same three MFMAs).  fp16's exponent range is
-                                        handled by exact power-of-two scales: V is written as V / 16 (|V| <= 1e6, i.e. activations up to ~1e4,
-                                        stay finite; larger values overflow to inf), U is scaled per layer to max |U| <= 512, the GEMM undoes
-                                        both.  Wins over IRSDE_FLAG_SPLIT_BF16X2 when both are set. */
+    IRSDE_FLAG_SPLIT_BF16X2 = 16384, /* r03, opt-in, new behaviour (the reference is plain fp32): split-operand arithmetic on the 16-bit MFMA pipe with
+                                        fp32 storage everywhere.  Every f32 GEMM operand is split into a 16-bit pair hi + lo (hi = round(x), lo =
+                                        round(x - hi): the residual is exact) and the three cross products hi.hi + hi.lo + lo.hi are accumulated in
+                                        f32, at 3/16 of the f32-MFMA cycles.  Covered: the component GEMMs of the three-launch Winograd layers with
+                                        >= 256 input channels (csrc/gemm_split.hip: V written as pairs, U split at weight load) and the direct
+                                        implicit-GEMM layers with K = KH KW Cin >= 128 and >= 64 output channels (csrc/conv_igemm.hip PAIR kernels:
+                                        activations split while staged) incl. every NAFNet 1x1 GEMM and its epilogues.  Transforms, the fused
+                                        Winograd kernel, attention, LayerNorm, epilogues and the sampler state stay native f32.  With bf16 pieces
+                                        (this flag) an operand carries 16 significand bits and f32's exponent range.  Error / speed tables:
+                                        profiles/r03_split_*.txt, r03_pair_conv_sweep.txt.  Not combinable with the 16-bit modes. */
+    IRSDE_FLAG_SPLIT_F16X2 = 32768,  /* r03, opt-in: the same paths with IEEE fp16 pieces (hi + lo = 22+ of f32's 24 significand bits: fp32-equivalent
+                                        per product and per layer — measured 0.5 .. 1.0 x the native kernels' error against float64).  fp16's
+                                        exponent range is handled by exact power-of-two scales: Winograd V is written as V / 16 (|V| <= 1e6 stays
+                                        finite), weights are scaled per tensor to max |w| in (256, 512], the kernels undo both on the accumulators;
+                                        activations of the direct layers are used unscaled (|x| < 65504; larger values become inf).  Wins over
+                                        IRSDE_FLAG_SPLIT_BF16X2 when both are set. */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };
