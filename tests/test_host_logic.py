@@ -289,7 +289,10 @@ def test_bench_roofline_object_from_an_op_profile():
     assert 0 < r["frac"] <= r["mfma_kernel_frac"] <= 1
     assert r["dominant_kernel"]["name"] == fused and abs(r["dominant_kernel"]["executed_TFLOPs"] - 80.0) < 1e-9
     assert abs(sum(k["time_share"] for k in r["per_kernel"]) - (2.15 / 2.5484)) < 1e-3
-    assert "note" in bench.roofline_object(prof, text, {"dtype": "fp32_split"}) and "note" in bench.roofline_object(prof, text, {"dtype": "fp32_split_f16"})
+    for dt in ("fp32_split", "fp32_split_f16"):   # two pipes: the fraction is taken against each kernel's own roof and stays <= 1
+        rs_ = bench.roofline_object(prof, text, {"dtype": dt})
+        assert "note" in rs_ and rs_["peak"] is None and 0 < rs_["frac"] <= rs_["mfma_kernel_frac"] <= 1
+        assert rs_["frac"] < r["frac"]   # the pair class is priced at the 16-bit roof, not at the f32 one
     rb = bench.roofline_object(prof, text, {"dtype": "bf16_act"})
     assert rb["bound"] == "hbm" and rb["unit"] == "GB/s" and rb["peak"] == bench.PEAK_HBM_GBPS
     # every secondary workload names a model / dtype the Workload class knows, and the headline stays out of the list
