@@ -228,6 +228,8 @@ SECONDARY = [
          model="unet", dtype="fp32_split", mode="sde", batch=16, size=256, T=100),
     dict(tag="BASELINE configs[3] workload (Refusion NAFNet 8x512x512 T=200) in the opt-in fp32_split_f16 mode",
          model="nafnet", dtype="fp32_split_f16", mode="sde", batch=8, size=512, T=200),
+    dict(tag="north_star 512x512 batch (IR-SDE UNet 16x512x512) in the opt-in fp32_split_f16 mode",
+         model="unet", dtype="fp32_split_f16", mode="sde", batch=16, size=512, T=100),
 ]
 
 
