@@ -223,15 +223,19 @@ void launch_linear_attention(const float* qkv, float* out, int B, int N, const A
 // fp32 fused form of the same block: k, v and their softmax / context from the LayerNorm output and the k | v rows of
 // to_qkv.weight ([256][C]) without a k / v tensor in HBM; q is a separate [B][N][128] tensor (its own 1x1 convolution).
 // ln_g != nullptr: `xn` is the un-normalised block input and PreNorm's LayerNorm (* ln_g, eps) runs inside the kernel.
+// wkv_pair != nullptr (IRSDE_FLAG_SPLIT_F16X2; C = 64 / 128 / 256): the projection on fp16 hi + lo operand pairs — wkv_pair = the two
+// planes [2][256][C] of wkv * 2^k, w_inv_scale = 2^-k
 void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s,
-                                 const float* ln_g = nullptr, float ln_eps = 1e-5f);
+                                 const float* ln_g = nullptr, float ln_eps = 1e-5f, const unsigned short* wkv_pair = nullptr,
+                                 float w_inv_scale = 1.f);
 void launch_attention_q_out(const float* q, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s);
 // C = 64 / 128 / 256: q projection, softmax over d, context product, to_out (+ bias), LayerNorm (* g2) and the residual in one
 // kernel: y = LayerNorm(Wout . (ctx^T softmax(Wq . xn)) + bias) * g2 + x.  wq = rows 0..127 of to_qkv.weight ([128][C]),
 // wout = to_out.0.weight ([C][128]); needs ws.ctx from launch_attention_kv_context.
 void launch_attention_q_out_fused(const float* xn, const float* x, const float* wq, const float* wout, const float* bias,
                                   const float* g2, float* y, int B, int N, int C, float eps, const AttnWorkspace& ws, hipStream_t s,
-                                  const float* ln_g = nullptr);
+                                  const float* ln_g = nullptr, const unsigned short* wq_pair = nullptr, const unsigned short* wout_pair = nullptr,
+                                  float wq_inv = 1.f, float wout_inv = 1.f);   // *_pair: fp16 hi / lo planes (IRSDE_FLAG_SPLIT_F16X2), see kernels_misc.hip
 
 // Full softmax attention over N tokens (denoising-sde bottleneck): qkv [B][N][384] -> out [B][N][128].
 void launch_full_attention(const float* qkv, float* out, int B, int N, hipStream_t s);

@@ -342,10 +342,25 @@ struct Builder {
             float* yp = y.p;
             const int B = x.B, C = x.C;
             if (!bo) throw HipError("attention: to_out.0.bias missing");
-            push_other(OP_ATTN, [=](hipStream_t s) { launch_attention_kv_context(xp, wkv, B, N, C, ws, s, g1, 1e-5f); });
-            pl->net_ops.back().desc = "linear_attention LayerNorm + k,v projection + context (fused) C=" + std::to_string(C);
-            push_other(OP_ATTN, [=](hipStream_t s) { launch_attention_q_out_fused(xp, xp, wq, wo, bo, g2, yp, B, N, C, 1e-5f, ws, s, g1); });
-            pl->net_ops.back().desc = "linear_attention LayerNorm + q projection + softmax + context + to_out + LayerNorm + residual (fused) C=" + std::to_string(C);
+            const unsigned short* wkv_pair = nullptr;
+            float kv_inv = 1.f;
+            if (e->cfg.flags & IRSDE_FLAG_SPLIT_F16X2) {   // the k / v projection on fp16 hi + lo operand pairs
+                const auto pc = e->pair_copy(wkv, (size_t)256 * C);
+                wkv_pair = pc.p; kv_inv = pc.inv_scale;
+            }
+            push_other(OP_ATTN, [=](hipStream_t s) { launch_attention_kv_context(xp, wkv, B, N, C, ws, s, g1, 1e-5f, wkv_pair, kv_inv); });
+            pl->net_ops.back().desc = std::string("linear_attention LayerNorm + k,v projection") + (wkv_pair ? " (split f16x2)" : "") + " + context (fused) C=" + std::to_string(C);
+            const unsigned short *wq_pair = nullptr, *wo_pair = nullptr;
+            float wq_inv = 1.f, wo_inv = 1.f;
+            if (e->cfg.flags & IRSDE_FLAG_SPLIT_F16X2) {   // the q and to_out projections on fp16 hi + lo operand pairs
+                const auto pq = e->pair_copy(wq, (size_t)128 * C), po = e->pair_copy(wo, (size_t)C * 128);
+                wq_pair = pq.p; wq_inv = pq.inv_scale; wo_pair = po.p; wo_inv = po.inv_scale;
+            }
+            push_other(OP_ATTN, [=](hipStream_t s) {
+                launch_attention_q_out_fused(xp, xp, wq, wo, bo, g2, yp, B, N, C, 1e-5f, ws, s, g1, wq_pair, wo_pair, wq_inv, wo_inv);
+            });
+            pl->net_ops.back().desc = std::string("linear_attention LayerNorm + q projection") + (wq_pair ? " (split f16x2)" : "") +
+                                      " + softmax + context + to_out + LayerNorm + residual (fused) C=" + std::to_string(C);
             return y;
         }
         Tensor xn = talloc(x.B, x.H, x.W, x.C);

@@ -13,6 +13,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -279,12 +281,18 @@ __device__ __forceinline__ floatx4 ln_piece(floatx4 v, const floatx4 g, const fl
 // straight from L2 (a wave's 64 weight rows x 8 k = two 16-byte loads per lane, one K step ahead).
 // Output = the (max, sum, context) partials of attn_ctx_partial_kernel, merged by attn_ctx_finalize_kernel.
 constexpr int kKvTile = 128;
-template <int C>
+// PAIR (r03, IRSDE_FLAG_SPLIT_F16X2): the k / v projection on v_mfma_f32_32x32x16_f16 with every operand as an fp16 hi + lo pair (three
+// cross products per f32 product: fp32-equivalent, 3/16 of the f32-MFMA cycles): the staged tile is split while it is written to LDS
+// (two planes of [128][C] fp16, rows of 2 C + 16 bytes), the weights come as two pre-split planes (wkv_pair: [2][256][C], scaled by
+// the power of two that w_inv_scale undoes on the accumulators).  Everything after the projection (softmax, context) is unchanged f32.
+template <int C, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __restrict__ xn, const float* __restrict__ wkv,
                                                              float* __restrict__ pmax, float* __restrict__ pctx,
                                                              float* __restrict__ psum, const int N, const int chunk_len,
-                                                             const int nch, const float* __restrict__ ln_g, const float ln_eps) {
+                                                             const int nch, const float* __restrict__ ln_g, const float ln_eps,
+                                                             const unsigned short* __restrict__ wkv_pair = nullptr, const float w_inv_scale = 1.f) {
     extern __shared__ __attribute__((aligned(16))) float kv_smem[];
+    constexpr int RB = 2 * C + 16;   // PAIR: bytes per fp16 LDS row (an odd number of 16-byte slots)
     const int ch = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -319,7 +327,15 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
                     // on the staged pieces (power-of-two C only: a row = C/4 consecutive lanes)
                     if constexpr ((c4n & (c4n - 1)) == 0)
                         if (ln_g) st[j] = ln_piece<c4n>(st[j], *reinterpret_cast<const floatx4*>(ln_g + 4 * c4), ln_eps);
-                    *reinterpret_cast<floatx4*>(kv_smem + row * LDA + 4 * c4) = st[j];
+                    if constexpr (PAIR) {
+                        const f16x4 hi = __builtin_convertvector(st[j], f16x4);
+                        const f16x4 lo = __builtin_convertvector(st[j] - __builtin_convertvector(hi, floatx4), f16x4);
+                        char* dst = reinterpret_cast<char*>(kv_smem) + row * RB + 8 * c4;
+                        *reinterpret_cast<f16x4*>(dst) = hi;
+                        *reinterpret_cast<f16x4*>(dst + kKvTile * RB) = lo;
+                    } else {
+                        *reinterpret_cast<floatx4*>(kv_smem + row * LDA + 4 * c4) = st[j];
+                    }
                 }
             }
         }
@@ -329,38 +345,76 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { ak[rt][r] = 0.f; av[rt][r] = 0.f; }
-        const float* arow = kv_smem + l31 * LDA + 4 * h;
-        // weight fragments (from L2) one K step = 32 MFMAs (2048 cycles) ahead of their use: two register slots, K loop
-        // unrolled by two only (a full unroll of up to 32 steps x 32 MFMAs spills)
-        constexpr int NK = C / 8;
-        static_assert(NK % 2 == 0, "C must be a multiple of 16");
-        floatx4 wkr[2], wvr[2];
-        wkr[0] = *reinterpret_cast<const floatx4*>(wk);
-        wvr[0] = *reinterpret_cast<const floatx4*>(wv);
-#pragma unroll 1
-        for (int ks0 = 0; ks0 < NK; ks0 += 2)
+        if constexpr (PAIR) {
+            // K steps of 16: lane (row l31, half h) holds k = 16 ks + 8 h .. + 7 of the A rows (pixels) and of its weight row
+            const char* arow = reinterpret_cast<const char*>(kv_smem) + l31 * RB + 16 * h;
+            const char* wkp = reinterpret_cast<const char*>(wkv_pair) + ((size_t)(head * kDh + l31) * C + 8 * h) * 2;
+            const char* wvp = reinterpret_cast<const char*>(wkv_pair) + ((size_t)(kHid + head * kDh + l31) * C + 8 * h) * 2;
+            constexpr size_t WPL = (size_t)2 * kHid * C * 2;   // bytes between the hi and the lo weight plane
+            constexpr int NK16 = C / 16;
+            f16x8 wk2[2][2], wv2[2][2];   // [slot][plane], one K step ahead
+            wk2[0][0] = *reinterpret_cast<const f16x8*>(wkp);
+            wk2[0][1] = *reinterpret_cast<const f16x8*>(wkp + WPL);
+            wv2[0][0] = *reinterpret_cast<const f16x8*>(wvp);
+            wv2[0][1] = *reinterpret_cast<const f16x8*>(wvp + WPL);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int ks = ks0 + u;
-            const int k8 = 8 * ks;
-            {
-                const int kp = ks + 1 < NK ? k8 + 8 : k8;  // past the end: a harmless reload
-                wkr[u ^ 1] = *reinterpret_cast<const floatx4*>(wk + kp);
-                wvr[u ^ 1] = *reinterpret_cast<const floatx4*>(wv + kp);
+            for (int ks = 0; ks < NK16; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                const int kp = (ks + 1 < NK16 ? ks + 1 : ks) * 32;
+                wk2[nxt][0] = *reinterpret_cast<const f16x8*>(wkp + kp);
+                wk2[nxt][1] = *reinterpret_cast<const f16x8*>(wkp + WPL + kp);
+                wv2[nxt][0] = *reinterpret_cast<const f16x8*>(wvp + kp);
+                wv2[nxt][1] = *reinterpret_cast<const f16x8*>(wvp + WPL + kp);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + rt * 32 * RB + 32 * ks);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(arow + kKvTile * RB + rt * 32 * RB + 32 * ks);
+                    ak[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wk2[cur][1], ak[rt], 0, 0, 0);
+                    av[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wv2[cur][1], av[rt], 0, 0, 0);
+                    ak[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wk2[cur][0], ak[rt], 0, 0, 0);
+                    av[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wv2[cur][0], av[rt], 0, 0, 0);
+                    ak[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wk2[cur][0], ak[rt], 0, 0, 0);
+                    av[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wv2[cur][0], av[rt], 0, 0, 0);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of this step's MFMAs
-            const floatx4 bk = wkr[u], bv = wvr[u];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                const floatx4 a = *reinterpret_cast<const floatx4*>(arow + rt * 32 * LDA + k8);
-                ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bk.x, ak[rt], 0, 0, 0);
-                av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, av[rt], 0, 0, 0);
-                ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bk.y, ak[rt], 0, 0, 0);
-                av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, av[rt], 0, 0, 0);
-                ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bk.z, ak[rt], 0, 0, 0);
-                av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, av[rt], 0, 0, 0);
-                ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bk.w, ak[rt], 0, 0, 0);
-                av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, av[rt], 0, 0, 0);
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ak[rt][r] *= w_inv_scale; av[rt][r] *= w_inv_scale; }
+        } else {
+            const float* arow = kv_smem + l31 * LDA + 4 * h;
+            // weight fragments (from L2) one K step = 32 MFMAs (2048 cycles) ahead of their use: two register slots, K loop
+            // unrolled by two only (a full unroll of up to 32 steps x 32 MFMAs spills)
+            constexpr int NK = C / 8;
+            static_assert(NK % 2 == 0, "C must be a multiple of 16");
+            floatx4 wkr[2], wvr[2];
+            wkr[0] = *reinterpret_cast<const floatx4*>(wk);
+            wvr[0] = *reinterpret_cast<const floatx4*>(wv);
+#pragma unroll 1
+            for (int ks0 = 0; ks0 < NK; ks0 += 2)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ks = ks0 + u;
+                const int k8 = 8 * ks;
+                {
+                    const int kp = ks + 1 < NK ? k8 + 8 : k8;  // past the end: a harmless reload
+                    wkr[u ^ 1] = *reinterpret_cast<const floatx4*>(wk + kp);
+                    wvr[u ^ 1] = *reinterpret_cast<const floatx4*>(wv + kp);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of this step's MFMAs
+                const floatx4 bk = wkr[u], bv = wvr[u];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const floatx4 a = *reinterpret_cast<const floatx4*>(arow + rt * 32 * LDA + k8);
+                    ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bk.x, ak[rt], 0, 0, 0);
+                    av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, av[rt], 0, 0, 0);
+                    ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bk.y, ak[rt], 0, 0, 0);
+                    av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, av[rt], 0, 0, 0);
+                    ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bk.z, ak[rt], 0, 0, 0);
+                    av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, av[rt], 0, 0, 0);
+                    ak[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bk.w, ak[rt], 0, 0, 0);
+                    av[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, av[rt], 0, 0, 0);
+                }
             }
         }
         // accumulator register r of row tile rt: pixel t0 + 32 rt + (r&3) + 8 (r>>2) + 4h, column d (k) / e (v) = l31
@@ -509,13 +563,21 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const T* __restrict__ qkv
 //   F  wave = 32-pixel tile: y^T[c][px] = Wout . out^T  (A = to_out rows from L2, B = Os rows), + bias
 //   G  LayerNorm over c in registers (C/32 x 16 values + the other lane half), * g, -> LDS (the wave's own rows), then
 //      coalesced 16-byte passes: + x (residual), store y.
-template <int C>
+// PAIR (r03, IRSDE_FLAG_SPLIT_F16X2): the two projections (B: q, F: to_out) on v_mfma_f32_32x32x16_f16 with fp16 hi + lo operand
+// pairs (three cross products per f32 product): the xn tile and the attention-output tile are written to LDS as two fp16 planes
+// (rows of 2 C + 16 resp. 272 bytes), the weights come as pre-split planes (wq_pair [2][128][C], wout_pair [2][C][128], scaled by powers
+// of two that wq_inv / wout_inv undo on the accumulators).  Softmax, the context product, LayerNorm and the residual stay f32.
+template <int C, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* __restrict__ xn, const float* __restrict__ xres,
                                                                const float* __restrict__ wq, const float* __restrict__ ctx,
                                                                const float* __restrict__ wout, const float* __restrict__ bias,
                                                                const float* __restrict__ g2, float* __restrict__ y, const int N,
-                                                               const float eps, const float* __restrict__ ln_g) {
+                                                               const float eps, const float* __restrict__ ln_g,
+                                                               const unsigned short* __restrict__ wq_pair = nullptr,
+                                                               const unsigned short* __restrict__ wout_pair = nullptr, const float wq_inv = 1.f,
+                                                               const float wout_inv = 1.f) {
     constexpr int TP = 128, LDA = C + 4, LDO = kHid + 4, RT = C / 32;
+    constexpr int RBX = 2 * C + 16, RBO = 2 * kHid + 16;   // PAIR: bytes per fp16 row of the xn / attention-output planes
     constexpr int LDY = C > kHid ? C + 4 : LDO;  // row stride of the normalised rows (phase G): they must not overlap the next wave's rows
     extern __shared__ __attribute__((aligned(16))) float qo_smem[];
     // one LDS region (67.6 KB -> two blocks per CU, whose phases overlap): the xn tile (phases A, B), then — behind a barrier —
@@ -545,7 +607,15 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
                 const int i = tid + 256 * (j0 + j), row = i / C4, c4 = i - row * C4;
                 // ln_g != nullptr: xn == the block's x and PreNorm's LayerNorm runs here on the staged pieces
                 if (ln_g) st[j] = ln_piece<C4>(st[j], *reinterpret_cast<const floatx4*>(ln_g + 4 * c4), eps);
-                *reinterpret_cast<floatx4*>(Xs + row * LDA + 4 * c4) = st[j];
+                if constexpr (PAIR) {
+                    const f16x4 hi = __builtin_convertvector(st[j], f16x4);
+                    const f16x4 lo = __builtin_convertvector(st[j] - __builtin_convertvector(hi, floatx4), f16x4);
+                    char* dst = reinterpret_cast<char*>(qo_smem) + row * RBX + 8 * c4;
+                    *reinterpret_cast<f16x4*>(dst) = hi;
+                    *reinterpret_cast<f16x4*>(dst + TP * RBX) = lo;
+                } else {
+                    *reinterpret_cast<floatx4*>(Xs + row * LDA + 4 * c4) = st[j];
+                }
             }
         }
     }
@@ -564,6 +634,34 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) q[ct][r] = 0.f;
+    if constexpr (PAIR) {
+        const char* wrow = reinterpret_cast<const char*>(wq_pair) + ((size_t)(wave * kDh + l31) * C + 8 * h) * 2;
+        constexpr size_t WPL = (size_t)kHid * C * 2;   // bytes between the hi and the lo plane of Wq
+        const char* brow = reinterpret_cast<const char*>(qo_smem) + l31 * RBX + 16 * h;
+        constexpr int NK16 = C / 16;
+        f16x8 wa2[2][2];
+        wa2[0][0] = *reinterpret_cast<const f16x8*>(wrow);
+        wa2[0][1] = *reinterpret_cast<const f16x8*>(wrow + WPL);
+#pragma unroll
+        for (int ks = 0; ks < NK16; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            const int kp = (ks + 1 < NK16 ? ks + 1 : ks) * 32;
+            wa2[nxt][0] = *reinterpret_cast<const f16x8*>(wrow + kp);
+            wa2[nxt][1] = *reinterpret_cast<const f16x8*>(wrow + WPL + kp);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(brow + ct * 32 * RBX + 32 * ks);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(brow + TP * RBX + ct * 32 * RBX + 32 * ks);
+                q[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][0], bl, q[ct], 0, 0, 0);
+                q[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][1], bh, q[ct], 0, 0, 0);
+                q[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][0], bh, q[ct], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[ct][r] *= wq_inv;
+    } else
     {
         const float* wrow = wq + (size_t)(wave * kDh + l31) * C + 4 * h;
         const float* brow = Xs + l31 * LDA + 4 * h;
@@ -610,10 +708,22 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) o = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[s2], q[ct][s2] * iz, o, 0, 0, 0);
         // o[r] = out[pixel 32 ct + l31][e = (r&3) + 8(r>>2) + 4h]: four 16-byte groups per lane
-        float* orow = Os + (ct * 32 + l31) * LDO + wave * kDh + 4 * h;
+        if constexpr (PAIR) {
+            char* orow = reinterpret_cast<char*>(qo_smem) + (ct * 32 + l31) * RBO + (wave * kDh + 4 * h) * 2;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-            *reinterpret_cast<floatx4*>(orow + 8 * gq) = floatx4{o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]};
+            for (int gq = 0; gq < 4; ++gq) {
+                const floatx4 v = floatx4{o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]};
+                const f16x4 hi = __builtin_convertvector(v, f16x4);
+                const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), f16x4);
+                *reinterpret_cast<f16x4*>(orow + 16 * gq) = hi;
+                *reinterpret_cast<f16x4*>(orow + TP * RBO + 16 * gq) = lo;
+            }
+        } else {
+            float* orow = Os + (ct * 32 + l31) * LDO + wave * kDh + 4 * h;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<floatx4*>(orow + 8 * gq) = floatx4{o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]};
+        }
     }
     __syncthreads();  // Os complete
 
@@ -623,6 +733,40 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) yv[rt][r] = 0.f;
+    if constexpr (PAIR) {
+        const char* wrow = reinterpret_cast<const char*>(wout_pair) + ((size_t)l31 * kHid + 8 * h) * 2;
+        constexpr size_t WPL = (size_t)C * kHid * 2;   // bytes between the hi and the lo plane of Wout
+        const char* brow = reinterpret_cast<const char*>(qo_smem) + (wave * 32 + l31) * RBO + 16 * h;
+        constexpr int NK16 = kHid / 16;
+        f16x8 wa2[2][2][RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            wa2[0][0][rt] = *reinterpret_cast<const f16x8*>(wrow + (size_t)rt * 32 * kHid * 2);
+            wa2[0][1][rt] = *reinterpret_cast<const f16x8*>(wrow + WPL + (size_t)rt * 32 * kHid * 2);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK16; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            const int kp = (ks + 1 < NK16 ? ks + 1 : ks) * 32;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                wa2[nxt][0][rt] = *reinterpret_cast<const f16x8*>(wrow + (size_t)rt * 32 * kHid * 2 + kp);
+                wa2[nxt][1][rt] = *reinterpret_cast<const f16x8*>(wrow + WPL + (size_t)rt * 32 * kHid * 2 + kp);
+            }
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(brow + 32 * ks);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(brow + TP * RBO + 32 * ks);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) yv[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][0][rt], bl, yv[rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) yv[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][1][rt], bh, yv[rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) yv[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][0][rt], bh, yv[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yv[rt][r] *= wout_inv;
+    } else
     {
         const float* wrow = wout + (size_t)l31 * kHid + 4 * h;
         const float* brow = Os + (wave * 32 + l31) * LDO + 4 * h;
@@ -677,7 +821,8 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
     const float rstd = 1.0f / sqrtf(sq * (1.0f / (float)C) + eps);
     // Ys = this wave's own 32 rows of the region.  C <= 128: row stride LDO, exactly the Os rows only this wave read in phase F.
     // C = 256: the rows are wider than an Os row, so they overlap other waves' Os rows -> wait until every wave has left phase F.
-    if constexpr (C > kHid) __syncthreads();
+    // PAIR: the fp16 planes put other waves' Os rows inside this wave's Ys rows for every C -> always wait.
+    if constexpr (C > kHid || PAIR) __syncthreads();
     float* yrow = Os + (wave * 32 + l31) * LDY + 4 * h;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -1269,6 +1414,12 @@ void attention_global_init() {
 #define IRSDE_KV_ATTR(CC) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     IRSDE_KV_ATTR(32); IRSDE_KV_ATTR(64); IRSDE_KV_ATTR(96); IRSDE_KV_ATTR(128); IRSDE_KV_ATTR(160); IRSDE_KV_ATTR(192); IRSDE_KV_ATTR(224); IRSDE_KV_ATTR(256);
 #undef IRSDE_KV_ATTR
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<64>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<128>),
@@ -1278,12 +1429,27 @@ void attention_global_init() {
 }
 // fp32 fused form: context from xn and the k / v weight rows (attn_kv_ctx_kernel), then q (its own [B][N][128] tensor) -> out
 void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s,
-                                 const float* ln_g, float ln_eps) {
+                                 const float* ln_g, float ln_eps, const unsigned short* wkv_pair, float w_inv_scale) {
     if (ln_g && (C & (C - 1))) throw HipError("attention_kv_context: the fused LayerNorm needs a power-of-two channel count");
     if (C % 32 || C > 256 || C < 32) throw HipError("attention_kv_context: C must be a multiple of 32, <= 256");
     const int len = attn_chunk_len(N, B);
     const int nch = attn_num_chunks(N, B);
     if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
+    if (wkv_pair) {   // fp16-pair projection (IRSDE_FLAG_SPLIT_F16X2): C = 64 / 128 / 256
+        const size_t ldsp = (size_t)2 * kKvTile * (2 * C + 16);
+#define IRSDE_KVP_LAUNCH(CC) hipLaunchKernelGGL((attn_kv_ctx_kernel<CC, true>), dim3(nch, B), dim3(256), ldsp, s, xn, wkv, ws.pmax, ws.pctx, ws.psum, N, len, nch, ln_g, ln_eps, wkv_pair, w_inv_scale)
+        switch (C) {
+            case 64: IRSDE_KVP_LAUNCH(64); break;
+            case 128: IRSDE_KVP_LAUNCH(128); break;
+            case 256: IRSDE_KVP_LAUNCH(256); break;
+            default: throw HipError("attention_kv_context: the fp16-pair projection exists for C = 64, 128, 256");
+        }
+#undef IRSDE_KVP_LAUNCH
+        hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
+                           1.0f / (float)N, 1.0f / sqrtf((float)kDh));
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
     const size_t lds = (size_t)kKvTile * (C + 4) * sizeof(float);
 #define IRSDE_KV_LAUNCH(CC) hipLaunchKernelGGL(attn_kv_ctx_kernel<CC>, dim3(nch, B), dim3(256), lds, s, xn, wkv, ws.pmax, ws.pctx, ws.psum, N, len, nch, ln_g, ln_eps)
     switch (C) {
@@ -1312,8 +1478,26 @@ void launch_attention_q_out(const float* q, float* out, int B, int N, const Attn
 // y = LayerNorm(to_out(softmax(q) . ctx)) * g + x with q = Wq . xn computed in the kernel (C = 64, 128 or 256)
 void launch_attention_q_out_fused(const float* xn, const float* x, const float* wq, const float* wout, const float* bias,
                                   const float* g2, float* y, int B, int N, int C, float eps, const AttnWorkspace& ws, hipStream_t s,
-                                  const float* ln_g) {
+                                  const float* ln_g, const unsigned short* wq_pair, const unsigned short* wout_pair, float wq_inv,
+                                  float wout_inv) {
     if (C != 64 && C != 128 && C != 256) throw HipError("attention_q_out_fused: C must be 64, 128 or 256");
+    if (wq_pair && wout_pair) {   // fp16-pair projections (IRSDE_FLAG_SPLIT_F16X2)
+        const size_t planes_x = (size_t)2 * 128 * (2 * C + 16), planes_o = (size_t)2 * 128 * (2 * kHid + 16);
+        const size_t ys = (size_t)128 * ((C > kHid ? C : kHid) + 4) * sizeof(float);
+        const size_t ldsp = std::max(std::max(planes_x, planes_o), ys);
+        const dim3 gridp((N + 127) / 128, B);
+        if (C == 64)
+            hipLaunchKernelGGL((attn_q_out_fused_kernel<64, true>), gridp, dim3(256), ldsp, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g,
+                               wq_pair, wout_pair, wq_inv, wout_inv);
+        else if (C == 128)
+            hipLaunchKernelGGL((attn_q_out_fused_kernel<128, true>), gridp, dim3(256), ldsp, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g,
+                               wq_pair, wout_pair, wq_inv, wout_inv);
+        else
+            hipLaunchKernelGGL((attn_q_out_fused_kernel<256, true>), gridp, dim3(256), ldsp, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g,
+                               wq_pair, wout_pair, wq_inv, wout_inv);
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
     const size_t lds = (size_t)128 * ((C > kHid ? C : kHid) + 4) * sizeof(float);  // one region: max(xn tile, out tile)
     const dim3 grid((N + 127) / 128, B);
     if (C == 64)
