@@ -90,7 +90,8 @@ enum {
                                         per product and per layer — measured 0.5 .. 1.0 x the native kernels' error against float64).  fp16's
                                         exponent range is handled by exact power-of-two scales: Winograd V is written as V / 16 (|V| <= 1e6 stays
                                         finite), weights are scaled per tensor to max |w| in (256, 512], the kernels undo both on the accumulators;
-                                        activations of the direct layers are used unscaled (|x| < 65504; larger values become inf).  Wins over
+                                        activations of the direct layers are used unscaled (|x| < 65504; larger values become inf).  This flag
+                                        also moves the k / v, q and to_out projections of the fused LinearAttention kernels onto fp16 pairs.  Wins over
                                         IRSDE_FLAG_SPLIT_BF16X2 when both are set. */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
