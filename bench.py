@@ -213,8 +213,8 @@ def roofline_object(prof, op_text, w):
 DTYPE_LABEL = {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate+state",
                "bf16_act": "bf16 operands + bf16 activation storage / f32 accumulate+state",
                "fp16": "f16 operands / f32 accumulate+state",
-               "fp32_split": "f32 storage / state / transforms; deep Winograd component GEMMs on bf16 hi+lo operand pairs (3 cross products on the bf16 MFMA, f32 accumulate)",
-               "fp32_split_f16": "f32 storage / state / transforms; deep Winograd component GEMMs on fp16 hi+lo operand pairs (22+ significand bits: fp32-equivalent per layer; 3 cross products on the f16 MFMA, f32 accumulate)"}
+               "fp32_split": "f32 storage / state / transforms; deep Winograd component GEMMs and direct layers on bf16 hi+lo operand pairs (3 cross products on the bf16 MFMA, f32 accumulate)",
+               "fp32_split_f16": "f32 storage / state / transforms; deep Winograd component GEMMs, direct layers and attention projections on fp16 hi+lo operand pairs (22+ significand bits: fp32-equivalent per layer; 3 cross products on the f16 MFMA, f32 accumulate)"}
 
 # the other BASELINE.json configs + the 512x512 batch north_star names: timed after the headline, reported under `secondary`
 SECONDARY = [
