@@ -121,6 +121,7 @@ def cpu_baseline(size, T, budget_s=20.0):
 KERNEL_CLASSES = [
     ("conv(winograd F4 fused)", "wino4_fused64_kernel / wino4_fused_kernel (Winograd F(4x4,3x3): input transform + 36 component GEMMs + output transform + epilogue in one kernel)"),
     ("conv(winograd", "gemm_zloop_kernel (component GEMMs of the three-launch Winograd layers)"),
+    ("conv(split f16x2 winograd F4 fused)", "wino4_fused64_kernel<PAIR> (the fused Winograd kernel with f32 operands as fp16 hi+lo pairs: 4 cross products on v_mfma_f32_16x16x32_f16; FLOPs counted once per f32 product)"),
     ("conv(split", "gemm_split2i_kernel (f32 operands as 16-bit hi+lo pairs, 3 cross products on v_mfma_f32_32x32x16_bf16 / _f16; FLOPs counted once per f32 product)"),
     ("conv M=", "conv_igemm_kernel / gemm_zloop_kernel (direct implicit-GEMM layers: 1x1, 4x4 s2, 7x7, narrow 3x3)"),
     ("conv", "conv kernels (other)"),
@@ -188,19 +189,18 @@ def roofline_object(prof, op_text, w):
     if w["dtype"] in ("fp32_split", "fp32_split_f16"):
         # two pipes in one evaluation: a pair kernel issues 3 16-bit MFMA products per f32 product.  `frac` = the pipe time the executed
         # work needs at each kernel's own roof / the measured MFMA-kernel time: a true fraction (<= 1); `achieved` stays f32-equivalent
-        need = sum(v[1] * (3.0 / (PEAK_BF16_TFLOPS * 1e12) if n.startswith("gemm_split2i_kernel") else 1.0 / (PEAK_FP32_TFLOPS * 1e12))
-                   for n, v in classes.items())
+        def products(n):   # 16-bit MFMA products per f32 product (0: an f32-MFMA kernel)
+            return 3.0 if n.startswith("gemm_split2i_kernel") else 4.0 if n.startswith("wino4_fused64_kernel<PAIR>") else 0.0
+        need = sum(v[1] * (products(n) / (PEAK_BF16_TFLOPS * 1e12) if products(n) else 1.0 / (PEAK_FP32_TFLOPS * 1e12)) for n, v in classes.items())
         r["frac"] = need / conv_t
         r["mfma_kernel_frac"] = need / (prof["conv_ms"] * 1e-3)
         r["peak"] = None
         r["achieved_vs_f32_roof"] = ach / PEAK_FP32_TFLOPS
-        for k in r.get("per_kernel", []):
-            if k["name"].startswith("gemm_split2i_kernel"):
-                k["frac"] = 3.0 * k["executed_TFLOPs"] / PEAK_BF16_TFLOPS
-        if r.get("dominant_kernel", {}).get("name", "").startswith("gemm_split2i_kernel"):
-            r["dominant_kernel"]["frac"] = 3.0 * r["dominant_kernel"]["executed_TFLOPs"] / PEAK_BF16_TFLOPS
+        for k in r.get("per_kernel", []) + ([r["dominant_kernel"]] if "dominant_kernel" in r else []):
+            if products(k["name"]):
+                k["frac"] = products(k["name"]) * k["executed_TFLOPs"] / PEAK_BF16_TFLOPS
         r["note"] = ("split modes: FLOPs are counted once per f32 product and compared with the f32 MFMA roof as a speed reference; the pair GEMMs "
-                     "themselves execute 3 16-bit MFMA products per f32 product on the bf16 / f16 pipe; frac = pipe time needed at each kernel's own roof / measured time")
+                     "themselves execute 3 (the fused Winograd twin: 4) 16-bit MFMA products per f32 product on the bf16 / f16 pipe; frac = pipe time needed at each kernel's own roof / measured time")
     if not fp32:
         # 16-bit operands: 16x the MFMA rate turns the convolutions L2/HBM-bound, so quote the HBM roof first
         gbps = prof["conv_bytes"] / (prof["conv_ms"] * 1e-3) / 1e9

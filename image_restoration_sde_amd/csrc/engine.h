@@ -34,6 +34,7 @@ inline long long wino_fused_min_tiles() { return tuning_env_int("IRSDE_WINO_FUSE
 // r03: the 64-cout fused kernel (16 tiles x 64 couts per block) takes the layers whose channel counts are multiples of 64;
 // IRSDE_WINO_FUSED64=0 keeps them on the 32-cout kernel, IRSDE_WINO_FUSED64_MAXCIN / _MAXCOUT move its crossover (tuning only)
 inline bool wino_fused64_enabled() { return tuning_env_int("IRSDE_WINO_FUSED64", 1) != 0; }
+inline bool wino_fused64_pair_enabled() { return tuning_env_int("IRSDE_WINO_FUSED64_PAIR", 1) != 0; }   // fp32_split_f16: the kernel's fp16-pair twin
 inline int wino_fused64_max_cin() { return tuning_env_int("IRSDE_WINO_FUSED64_MAXCIN", 512); }
 inline int wino_fused64_max_cout() { return tuning_env_int("IRSDE_WINO_FUSED64_MAXCOUT", 512); }
 inline long long wino_fused64_min_tiles() { return tuning_env_int("IRSDE_WINO_FUSED64_MINT", 1024); }
@@ -72,6 +73,8 @@ struct ConvW {
     float* wino_u4 = nullptr;  // device [36][Cout][Cin]              F(4x4,3x3)  (3x3 layers with Cin,Cout >= 128)
     float* wino_uf = nullptr;  // the same F(4x4,3x3) weights in the fused kernel's fragment order (wino_fused.hip)
     float* wino_uf64 = nullptr;  // ... in the 64-cout fused kernel's fragment order (Cout, Cin multiples of 64)
+    unsigned short* wino_uf64p = nullptr;   // IRSDE_FLAG_SPLIT_F16X2: wino_uf64 as fp16 hi / lo halves (wf64_split_weights_kernel), scaled by wino_uf64p_scale
+    float wino_uf64p_scale = 1.f;
     unsigned short* wino_up = nullptr;  // IRSDE_FLAG_SPLIT_BF16X2 / _F16X2: the F(4x4,3x3) weights as hi / lo pairs, [36][Cout][Cin / 32][2][32]
     float wino_up_scale = 1.f;          // fp16 pairs: the power of two U was multiplied by (max |U| * scale <= 512)
 };

@@ -564,6 +564,24 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             launch_wino_output(sp.out, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dU); (void)hipFree(dUs); (void)hipFree(dVs); (void)hipFree(dM);
+        } else if (naive == 35) {  // the 64-cout fused Winograd kernel on fp16 hi + lo operand pairs (IRSDE_FLAG_SPLIT_F16X2's big-feature-map path)
+            if (!wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
+            std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
+            wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
+            wino_fused64_pack_weights(U.data(), Cout, Cin, Uf.data());
+            float mx = 0.f;
+            for (float v : U) mx = std::max(mx, std::fabs(v));
+            const float usc = mx > 0.f ? std::exp2(std::floor(std::log2(512.0f / mx))) : 1.f;
+            float* dUf = nullptr;
+            unsigned short* dUp = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dUf, Uf.size() * 4));
+            IRSDE_HIP_CHECK(hipMalloc(&dUp, Uf.size() * 4));
+            IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
+            launch_wino_fused64_split_weights(dUf, dUp, Uf.size(), usc, s);
+            p.pair_scale = 1.0f / (kWinoFused64PairVScale * usc);
+            launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, 4);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(dUf); (void)hipFree(dUp);
         } else if (naive == 33 || naive == 34) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
             if (naive == 33 ? !wino_fused_eligible(p) : !wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
@@ -797,12 +815,21 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         const bool split_v = variant == 412 || variant == 413 || variant == 422 || variant == 423;  // split-operand GEMMs: 41x whole three-launch layer, 42x the GEMM alone; x = planes
         unsigned short *dUs = nullptr, *dVs = nullptr;
         WinoSplitPlan sp{};
-        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 403)) {
+        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 405)) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
             if (variant != 81 && variant != 421 && !split_v && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
             if (variant >= 400 && !wino_fused64_eligible(p)) throw HipError("bench_conv: shape not eligible for the 64-cout fused Winograd kernel");
+            if (variant == 404 || variant == 405) {  // the fp16-pair twin: the random weights as hi / lo halves
+                float* dUp = nullptr;
+                IRSDE_HIP_CHECK(hipMalloc(&dUp, (size_t)36 * nw / 9 * 4));
+                launch_wino_fused64_split_weights(dU, reinterpret_cast<unsigned short*>(dUp), (size_t)36 * nw / 9, 256.0f, s);
+                IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+                (void)hipFree(dU);
+                dU = dUp;
+                p.pair_scale = 1.0f / (kWinoFused64PairVScale * 256.0f);
+            }
             if (variant == 81 || variant == 421) {
                 if (!wino_shape_ok(p, 4)) throw HipError("bench_conv: shape not eligible for Winograd F(4x4,3x3)");
                 const long long T = (long long)B * (p.Ho / 4) * (p.Wo / 4);
@@ -864,7 +891,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         auto run = [&] {
             if (variant == 80) {
                 launch_wino_fused(p, dU, s);
-            } else if (variant >= 400 && variant <= 403) {  // 64-cout fused Winograd kernel: 400 production, 401 no weight traffic, 402 no patch traffic, 403 short U ring
+            } else if (variant >= 400 && variant <= 405) {  // 64-cout fused Winograd kernel: 400 production, 401 no weight traffic, 402 no patch traffic, 403 short U ring, 404 / 405 fp16 pairs (ring 12 / 18)
                 launch_wino_fused64(p, dU, s, variant - 400);
             } else if (variant >= 83 && variant <= 82 + 255) {  // tuning aids: dflags = variant - 82 (1 no patch traffic, 2 no weight traffic, 4 / 8 producer / MFMA waves at s_setprio 2)
                 launch_wino_fused(p, dU, s, nullptr, variant - 82);

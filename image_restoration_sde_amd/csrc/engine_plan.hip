@@ -110,6 +110,7 @@ struct Builder {
         if (res) { p.res = res->p; p.res_stride = res->C; }
         if (!naive) {  // prefer F(4x4,3x3), then F(2x2,3x3), then the direct implicit GEMM
             if (w.wino_up && wino_shape_ok(p, 4) && push_wino(p, w.wino_u4, 4, w.wino_up, w.wino_up_scale)) return out;
+            if (w.wino_uf64p && push_wino_fused(p, reinterpret_cast<const float*>(w.wino_uf64p), true, w.wino_uf64p_scale)) return out;
             if (w.wino_uf64 && push_wino_fused(p, w.wino_uf64, true)) return out;
             if (w.wino_uf && push_wino_fused(p, w.wino_uf, false)) return out;
             if (w.wino_u4 && wino_shape_ok(p, 4) && push_wino(p, w.wino_u4, 4)) return out;
@@ -121,9 +122,11 @@ struct Builder {
 
     // Winograd F(4x4,3x3) with both transforms inside the GEMM kernel (wino_fused.hip): the big feature maps
     // (k64: the r03 kernel, 16 tiles x 64 couts per block; else 32 tiles x 32 couts)
-    bool push_wino_fused(const ConvParams& d, const float* Uf, bool k64) {
+    // pair_uscale != 0: Uf holds fp16 hi / lo halves of pair_uscale * U (the PAIR instance of the 64-cout kernel)
+    bool push_wino_fused(const ConvParams& d, const float* Uf, bool k64, float pair_uscale = 0.f) {
         ConvParams dd = d;
         dd.zeros = e->zeros;
+        if (pair_uscale != 0.f) dd.pair_scale = 1.0f / (kWinoFused64PairVScale * pair_uscale);
         if (k64 ? !wino_fused64_eligible(dd) : !wino_fused_eligible(dd)) return false;
         const int Ctot = d.C0 + d.C1;
         const long long T = (long long)d.B * (d.Ho / 4) * (d.Wo / 4);
@@ -138,11 +141,12 @@ struct Builder {
         pl->conv_exec_flops += op.exec_flops;
         pl->conv_bytes += op.bytes;
         char buf[256];
-        snprintf(buf, sizeof buf, "conv(winograd F4 fused) %s T=%lld Cout=%d Cin=%d up=%d blocks=%lld flops=%.4g exec=%.4g", k64 ? "16x64" : "32x32", T,
-                 d.Cout, Ctot, d.in_shift, blocks, op.flops, op.exec_flops);
+        const bool pair = pair_uscale != 0.f;
+        snprintf(buf, sizeof buf, "conv(%swinograd F4 fused) %s T=%lld Cout=%d Cin=%d up=%d blocks=%lld flops=%.4g exec=%.4g", pair ? "split f16x2 " : "",
+                 k64 ? "16x64" : "32x32", T, d.Cout, Ctot, d.in_shift, blocks, op.flops, op.exec_flops);
         op.desc = buf;
         if (k64)
-            op.fn = [dd, Uf](hipStream_t s) { launch_wino_fused64(dd, Uf, s); };
+            op.fn = [dd, Uf, pair](hipStream_t s) { launch_wino_fused64(dd, Uf, s, pair ? 4 : 0); };
         else
             op.fn = [dd, Uf](hipStream_t s) { launch_wino_fused(dd, Uf, s); };
         pl->net_ops.push_back(std::move(op));

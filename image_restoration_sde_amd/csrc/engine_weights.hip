@@ -131,6 +131,17 @@ ConvW pack_conv(irsde_engine* e, const std::string& wname, const std::string& bn
                 std::vector<float> Uf(U.size());
                 wino_fused64_pack_weights(U.data(), O, I, Uf.data());
                 c.wino_uf64 = e->upload(Uf);
+                if ((e->cfg.flags & IRSDE_FLAG_SPLIT_F16X2) && wino_fused64_pair_enabled()) {   // the fp16-pair twin of the kernel: same fragment order
+                    float mx = 0.f;
+                    for (float v : U) mx = std::max(mx, std::fabs(v));
+                    c.wino_uf64p_scale = mx > 0.f ? std::exp2(std::floor(std::log2(512.0f / mx))) : 1.f;
+                    unsigned short* up = nullptr;
+                    IRSDE_HIP_CHECK(hipMalloc(&up, Uf.size() * 4));
+                    e->dev_allocs.push_back(reinterpret_cast<float*>(up));
+                    launch_wino_fused64_split_weights(c.wino_uf64, up, Uf.size(), c.wino_uf64p_scale, e->stream);
+                    IRSDE_HIP_CHECK(hipStreamSynchronize(e->stream));
+                    c.wino_uf64p = up;
+                }
             }
         }
     }

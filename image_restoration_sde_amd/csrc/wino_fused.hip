@@ -347,6 +347,45 @@ constexpr int W6_MS = 68;                    // floats per (component, tile) row
 constexpr int W6_LDS_BYTES = 2 * W6_VBUF * 4;  // 156 672 B = 36 * 16 * 68 * 4 (the staging aliases the V buffers)
 static_assert(36 * 16 * W6_MS * 4 <= W6_LDS_BYTES, "output staging must fit in the V buffers");
 
+typedef _Float16 wf_f16x8 __attribute__((ext_vector_type(8)));
+
+// (x0, x1) -> the 8 bytes [hi x0, hi x1, lo x0, lo x1] of fp16 pieces of x / 16 (round to nearest even; the residual x - hi is exact in f32)
+__device__ __forceinline__ floatx2 wf_split_pair(const floatx2 v) {
+    const float a0 = v.x * kWinoFused64PairVScale, a1 = v.y * kWinoFused64PairVScale;
+    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+    const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+    const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    floatx2 o;
+    o.x = __builtin_bit_cast(float, hi);
+    o.y = __builtin_bit_cast(float, lo);
+    return o;
+}
+
+// Uf (wino_fused64_pack_weights order, f32) -> the PAIR kernel's weights: every group of 4 consecutive floats (one lane's 4
+// channels of a fragment) becomes the 8 halves [hi c0, hi c1, lo c0, lo c1, hi c2, hi c3, lo c2, lo c3] of scale * U
+__global__ __launch_bounds__(256) void wf64_split_weights_kernel(const float* __restrict__ Uf, uint4* __restrict__ out, const size_t nquads,
+                                                                 const float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nquads) return;
+    const float4 u = reinterpret_cast<const float4*>(Uf)[i];
+    const float a[4] = {u.x * scale, u.y * scale, u.z * scale, u.w * scale};
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 hb = (_Float16)a[e];
+        const _Float16 lb = (_Float16)(a[e] - (float)hb);
+        h[e] = __builtin_bit_cast(unsigned short, hb);
+        l[e] = __builtin_bit_cast(unsigned short, lb);
+    }
+    uint4 o;
+    o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+    o.y = (unsigned)l[0] | ((unsigned)l[1] << 16);
+    o.z = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    o.w = (unsigned)l[2] | ((unsigned)l[3] << 16);
+    out[i] = o;
+}
+
 __device__ __forceinline__ void wf64_epilogue(const ConvParams& p, const float* Ms, const int tid, const int b, const int gy,
                                               const int gx, const int TH, const int TW, const int n0) {
     // thread = (tile, 4 consecutive couts, row pair): 512 = 16 tiles x 16 quads x 2 row pairs
@@ -406,7 +445,15 @@ __device__ __forceinline__ void wf64_epilogue(const ConvParams& p, const float* 
 
 // NOWT / NOPATCH: measurement twins (irsde_bench_conv variants 91 / 92: weight fragments resp. patch loads read zeros without
 // memory traffic) — template parameters, so the production instance <false, false> carries no run-time tuning branch.
-template <int RING, bool NOWT, bool NOPATCH>
+//
+// PAIR (IRSDE_FLAG_SPLIT_F16X2): the same kernel with the component GEMMs on v_mfma_f32_16x16x32_f16.  Every f32 operand value x
+// is the exact sum of two fp16 pieces hi = RNE(x), lo = RNE(x - hi) (V scaled by 1/16, U by a per-layer power of two: exact,
+// undone on the accumulators).  The 16 bytes a lane holds of a (16 rows x 16 channels) fragment — 4 floats in the f32 kernel —
+// are the 8 halves [hi c0, hi c1, lo c0, lo c1, hi c2, hi c3, lo c2, lo c3] of its 4 channels: same LDS layout, same weight
+// fragment order, same producer write (8 bytes per channel pair).  With B1 = the V fragment as stored and B2 = the same
+// registers with the (hi, lo) dwords swapped,  A.B1 = sum hi.hi + lo.lo  and  A.B2 = sum hi.lo + lo.hi : two MFMAs of
+// ~17 cycles per unit give all FOUR cross products of 16 channels where the f32 kernel issues four MFMAs of 32 cycles.
+template <int RING, bool NOWT, bool NOPATCH, bool PAIR = false>
 __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX,
                                                                   const int GY, const int NB, const unsigned in0_bytes,
                                                                   const unsigned in1_bytes, const unsigned uf_bytes) {
@@ -475,11 +522,22 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParam
                 if (gi + 1 < 18) v_next = *reinterpret_cast<const floatx4*>(vb + ((gi + 1) % 9) * W6_ZS + ((gi + 1) / 9) * W6_RS);
                 // k step outer, cout block inner: consecutive MFMAs hit different accumulators (a dependent v_mfma_f32_16x16x4_f32
                 // issues after 40 cycles instead of 32, MI355X_MICROARCH.md)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                if constexpr (PAIR) {
+                    const floatx4 v_sw = {v_cur[1], v_cur[0], v_cur[3], v_cur[2]};
+                    const wf_f16x8 b1 = __builtin_bit_cast(wf_f16x8, v_cur), b2 = __builtin_bit_cast(wf_f16x8, v_sw);
 #pragma unroll
                     for (int cb = 0; cb < 4; ++cb)
-                        acc[zi][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(gi * 4 + cb) % RING][j], v_cur[j], acc[zi][cb], 0, 0, 0);
+                        acc[zi][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wf_f16x8, ring[(gi * 4 + cb) % RING]), b1, acc[zi][cb], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[zi][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wf_f16x8, ring[(gi * 4 + cb) % RING]), b2, acc[zi][cb], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+                            acc[zi][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(gi * 4 + cb) % RING][j], v_cur[j], acc[zi][cb], 0, 0, 0);
+                }
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     const int ul = gi * 4 + cb;            // unit index inside the chunk (72 % RING == 0: the slot is static)
@@ -496,7 +554,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParam
         for (int zi = 0; zi < 9; ++zi)
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
-                *reinterpret_cast<floatx4*>(Ms + ((zg * 9 + zi) * 16 + l15) * W6_MS + cb * 16 + 4 * g) = acc[zi][cb];
+                *reinterpret_cast<floatx4*>(Ms + ((zg * 9 + zi) * 16 + l15) * W6_MS + cb * 16 + 4 * g) = PAIR ? acc[zi][cb] * p.pair_scale : acc[zi][cb];
         __syncthreads();
         wf64_epilogue(p, Ms, tid, b, gy, gx, TH, TW, n0);
     } else {
@@ -551,7 +609,8 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParam
         _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                                      \
             floatx2 o[6];                                                                                                    \
             bt6(w[r], o);                                                                                                    \
-            _Pragma("unroll") for (int s = 0; s < 6; ++s) *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * W6_ZS) = o[s];      \
+            _Pragma("unroll") for (int s = 0; s < 6; ++s)                                                                    \
+                *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * W6_ZS) = PAIR ? wf_split_pair(o[s]) : o[s];                  \
         }                                                                                                                    \
         __syncthreads();                                                                                                     \
     }
@@ -587,6 +646,8 @@ void wino_fused_global_init() {
     W6_ATTR(W6_RING, true, false);
     W6_ATTR(W6_RING, false, true);
     W6_ATTR(W6_RING_ALT, false, false);
+    W6_ATTR(W6_RING, false, false, true);
+    W6_ATTR(W6_RING_ALT, false, false, true);
 #undef W6_ATTR
 }
 
@@ -658,7 +719,16 @@ int wino_fused64_num_blocks(const ConvParams& p) {
     return p.B * ((p.Ho / 4 + 3) / 4) * ((p.Wo / 4 + 3) / 4) * (p.Cout / 64);
 }
 
-// variant: 0 production; 1 weight fragments read zeros (no L2 traffic); 2 patch loads read zeros; 3 the shorter U ring
+void launch_wino_fused64_split_weights(const float* Uf, unsigned short* out, size_t nfloats, float scale, hipStream_t s) {
+    const size_t nq = nfloats / 4;
+    hipLaunchKernelGGL(wf64_split_weights_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, Uf, reinterpret_cast<uint4*>(out), nq, scale);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+// variant: 0 production; 1 weight fragments read zeros (no L2 traffic); 2 patch loads read zeros; 3 the shorter U ring;
+// 4 / 5: the fp16-pair kernel (Uf = the wf64_split_weights_kernel output, p.pair_scale = 1 / (kWinoFused64PairVScale * weight scale)), ring 12 (production:
+// 3 - 6 % faster than 18 on every layer class, profiles/r03_wino_fused64_pair_sweep.txt — the MFMAs of a unit take 34 instead of 128 cycles, the
+// deeper ring only costs registers) / 18
 void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, int variant) {
     if (!wino_fused64_eligible(p)) throw HipError("launch_wino_fused64: layer not eligible");
     if (!Uf) throw HipError("launch_wino_fused64: fused weights missing");
@@ -674,6 +744,8 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
         case 1: W6_LAUNCH(W6_RING, true, false); break;
         case 2: W6_LAUNCH(W6_RING, false, true); break;
         case 3: W6_LAUNCH(W6_RING_ALT, false, false); break;
+        case 4: W6_LAUNCH(W6_RING_ALT, false, false, true); break;
+        case 5: W6_LAUNCH(W6_RING, false, false, true); break;
         default: throw HipError("launch_wino_fused64: bad variant");
     }
 #undef W6_LAUNCH

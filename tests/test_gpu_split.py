@@ -183,6 +183,50 @@ def test_split_f16_large_activations_stay_finite():
 
 
 # ---------------------------------------------------------------------------------------------
+# the PAIR instance of the fused Winograd kernel (wino4_fused64_kernel<.., PAIR = true>): the big-feature-map layers of fp32_split_f16
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 64, 0, 36, 44, 64, 0), (2, 32, 32, 8, 12, 128, 1), (1, 128, 64, 20, 28, 128, 0), (5, 96, 32, 4, 4, 192, 0),
+                                   (1, 256, 0, 16, 16, 64, 1), (2, 64, 0, 64, 64, 64, 0), (1, 512, 0, 16, 16, 512, 0)])
+def test_wino_fused64_pair_vs_float64(shape):
+    """debug_conv code 35: ragged 4 x 4 tile groups, concat sources, the fused upsample, per-sample FiLM rows, bias + SiLU +
+    residual, 2 .. 16 chunks.  Gate as for the pair GEMMs: error against the float64 oracle <= 2 x the f32 kernel's (34) —
+    fp32-equivalent; the kernel computes all four hi / lo cross products."""
+    B, C0, C1, H, W, Cout, up = shape
+    rs = np.random.RandomState(B * 1000 + H + 11)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, 3, 3)) / np.sqrt((C0 + C1) * 9)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32)
+    film = (0.3 * rs.standard_normal((B, 2 * Cout))).astype(np.float32)
+    res = rs.standard_normal((B, Cout, H << up, W << up)).astype(np.float32)
+    ref = oracle_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, film_bstride=2 * Cout)
+    got = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=35, film_bstride=2 * Cout)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    e35 = relerr(got, ref)
+    e34 = relerr(run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=34, film_bstride=2 * Cout), ref)
+    print("fused64 pair %s: f32 kernel %.3g  fp16-pair kernel %.3g" % (shape, e34, e35))
+    assert e35 < 5e-5 and e35 <= 2.0 * e34 + 1e-7, shape
+    ref = oracle_conv(x0, x1, w, None, 1, 1, up, None, 0, None)
+    assert relerr(run_conv(x0, x1, w, None, 1, 1, up, None, 0, None, naive=35), ref) < 5e-5, shape
+
+
+def test_wino_fused64_pair_large_activations():
+    """V is split as V / 16: activations of a few thousand stay finite and accurate.  The small end: an fp16 pair has an ABSOLUTE
+    granularity of 2^-25 (half an fp16 subnormal step), so operands far below the network's O(1) activations lose relative
+    accuracy — |x| ~ 0.02: 3e-5 (6 x the f32 kernel's), |x| ~ 1e-3: ~1e-4 or worse (documented in irsde_hip.h; the bf16 pairs
+    have f32's exponent range)."""
+    rs = np.random.RandomState(5)
+    w = (rs.standard_normal((64, 128, 3, 3)) / np.sqrt(128 * 9)).astype(np.float32)
+    for scale, tol in ((2000.0, 3e-5), (0.02, 6e-5), (1e-3, 1e-3)):   # measured 5.2e-6 / 3.0e-5 / (see the printed line)
+        x0 = (rs.standard_normal((1, 128, 16, 16)) * scale).astype(np.float32)
+        ref = oracle_conv(x0, None, w, None, 1, 1, 0, None, 0, None)
+        got = run_conv(x0, None, w, None, 1, 1, 0, None, 0, None, naive=35)
+        assert np.isfinite(got).all()
+        print("fused64 pair |x| ~ %g: %.3g" % (scale, relerr(got, ref)))
+        assert relerr(got, ref) < tol, scale
+
+
+# ---------------------------------------------------------------------------------------------
 # the PAIR kernels of conv_igemm.hip: split-operand arithmetic for the direct (implicit-GEMM) layers
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", [n for n, c in CONV_CASES.items() if c[5] >= 64])
