@@ -119,9 +119,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     constexpr int PL = PAIR ? 2 : 1;
     static_assert(!ABF || (BF16 && !INSCALE), "bf16 activation storage belongs to the bf16-MFMA mode");
     static_assert(!F16 || (BF16 && !ABF), "fp16 operands: the 16-bit MFMA mode with fp32 activation storage");
-    ConvParams p = pin;  // batched launch: component blockIdx.z works on its own slice of in0 / w / out
+    // XCD-aware block remap (bijective): each XCD (linear block id % 8) walks a contiguous range of tiles so
+    // that neighbouring tiles (same activation rows, other Cout slices / halo rows) share one L2.  Batched launches (Winograd
+    // components, blockIdx.z) fold the component into the walk: an XCD then owns WHOLE components (A and B of a component are
+    // fetched by one L2 instead of eight: 1.37 -> 0.35 GB of fabric reads for a 1024 x 1024 x 1024 x 36 layer, r03 PMC).
+    int wgid, zc = 0;
+    {
+        const int tiles = gridDim.x;
+        const bool fold = pin.nz > 1 && gridDim.y == 1;
+        const int nwg = fold ? tiles * (int)gridDim.z : tiles;
+        const int orig = fold ? (int)(blockIdx.x + tiles * blockIdx.z) : (int)blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int c = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        zc = fold ? c / tiles : (int)blockIdx.z;
+        wgid = fold ? c - zc * tiles : c;
+    }
+    ConvParams p = pin;  // batched launch: component zc works on its own slice of in0 / w / out
     if (pin.nz > 1) {
-        const long long z = blockIdx.z;
+        const long long z = zc;
         p.in0 = pin.in0 + z * pin.z_in;
         p.w = pin.w + z * pin.z_w;
         p.out = pin.out + z * pin.z_out;
@@ -138,14 +153,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    // XCD-aware block remap (bijective): each XCD (block id % 8) walks a contiguous range of tiles so
-    // that neighbouring tiles (same activation rows, other Cout slices / halo rows) share one L2.
-    int wgid;
-    {
-        const int orig = blockIdx.x, nwg = gridDim.x;
-        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
     const int mblk = wgid / nblk_n;
     const int nblk = wgid - mblk * nblk_n;
     const int m0 = mblk * BM;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     const char* wrow[C::B_PASSES];
     constexpr int WESZ = BF16 ? 2 : 4;
     const char* wbase = PAIR ? reinterpret_cast<const char*>(p.w_pair) : BF16 ? reinterpret_cast<const char*>(p.w_bf) : reinterpret_cast<const char*>(p.w);
-    if (BF16 && pin.nz > 1) wbase += (long long)blockIdx.z * pin.z_w * WESZ;
+    if (BF16 && pin.nz > 1) wbase += (long long)zc * pin.z_w * WESZ;
 #pragma unroll
     for (int ps = 0; ps < C::B_PASSES; ++ps) {
         const int n = n0 + brow0 + ps * C::B_ROWS;
@@ -776,15 +783,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, h = lane >> 5;
-    int wgid;
+    int wgid, zg;   // XCD-aware walk over (component group, tile): an XCD owns whole component groups (see conv_igemm_kernel)
     {
-        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int tiles = gridDim.x, nwg = tiles * (int)gridDim.y;
+        const int orig = (int)(blockIdx.x + tiles * blockIdx.y);
         const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const int c = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        zg = c / tiles;
+        wgid = c - zg * tiles;
     }
     const int mblk = wgid / g.nblk_n, nblk = wgid - mblk * g.nblk_n;
     const int m0 = mblk * BM * (g.row_step ? g.n_outer : 1), n0 = nblk * BN;
-    const int plane0 = blockIdx.y * g.n_inner;  // Winograd: first component of this block
+    const int plane0 = zg * g.n_inner;  // Winograd: first component of this block
     const int nk = g.K / BK;
     const int steps = g.n_inner * g.n_outer * nk;
 

@@ -386,6 +386,8 @@ __global__ __launch_bounds__(256) void wf64_split_weights_kernel(const float* __
     out[i] = o;
 }
 
+// NT: residual loads and output stores carry the non-temporal hint (streamed once: they should not evict the weight fragments from L2)
+template <bool NT>
 __device__ __forceinline__ void wf64_epilogue(const ConvParams& p, const float* Ms, const int tid, const int b, const int gy,
                                               const int gx, const int TH, const int TW, const int n0) {
     // thread = (tile, 4 consecutive couts, row pair): 512 = 16 tiles x 16 quads x 2 row pairs
@@ -410,7 +412,10 @@ __device__ __forceinline__ void wf64_epilogue(const ConvParams& p, const float* 
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rv[i][j] = *reinterpret_cast<const floatx4*>(p.res + (pix0 + (size_t)i * p.Wo + j) * p.res_stride + n);
+            for (int j = 0; j < 4; ++j) {
+                const floatx4* rp = reinterpret_cast<const floatx4*>(p.res + (pix0 + (size_t)i * p.Wo + j) * p.res_stride + n);
+                rv[i][j] = NT ? __builtin_nontemporal_load(rp) : *rp;
+            }
     }
     const float c0 = half ? 0.f : 1.f, ka = half ? 4.f : 1.f, kb = half ? 8.f : 2.f, c5 = half ? 1.f : 0.f;
     floatx4 u[2][6];
@@ -438,7 +443,9 @@ __device__ __forceinline__ void wf64_epilogue(const ConvParams& p, const float* 
             if (p.silu) {
                 v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w);
             }
-            *reinterpret_cast<floatx4*>(p.out + (pix0 + (size_t)i * p.Wo + j) * p.out_stride + n) = v + rv[i][j];
+            floatx4* op = reinterpret_cast<floatx4*>(p.out + (pix0 + (size_t)i * p.Wo + j) * p.out_stride + n);
+            if (NT) __builtin_nontemporal_store(v + rv[i][j], op);
+            else *op = v + rv[i][j];
         }
     }
 }
@@ -453,7 +460,8 @@ __device__ __forceinline__ void wf64_epilogue(const ConvParams& p, const float* 
 // fragment order, same producer write (8 bytes per channel pair).  With B1 = the V fragment as stored and B2 = the same
 // registers with the (hi, lo) dwords swapped,  A.B1 = sum hi.hi + lo.lo  and  A.B2 = sum hi.lo + lo.hi : two MFMAs of
 // ~17 cycles per unit give all FOUR cross products of 16 channels where the f32 kernel issues four MFMAs of 32 cycles.
-template <int RING, bool NOWT, bool NOPATCH, bool PAIR = false>
+// NTMODE (irsde_bench_conv 406 / 407): 1 = non-temporal residual loads / output stores, 2 = also the patch loads
+template <int RING, bool NOWT, bool NOPATCH, bool PAIR = false, int NTMODE = 0>
 __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX,
                                                                   const int GY, const int NB, const unsigned in0_bytes,
                                                                   const unsigned in1_bytes, const unsigned uf_bytes) {
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParam
             for (int cb = 0; cb < 4; ++cb)
                 *reinterpret_cast<floatx4*>(Ms + ((zg * 9 + zi) * 16 + l15) * W6_MS + cb * 16 + 4 * g) = PAIR ? acc[zi][cb] * p.pair_scale : acc[zi][cb];
         __syncthreads();
-        wf64_epilogue(p, Ms, tid, b, gy, gx, TH, TW, n0);
+        wf64_epilogue<(NTMODE >= 1)>(p, Ms, tid, b, gy, gx, TH, TW, n0);
     } else {
         // =============================== producer waves ===============================
         const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParam
         const int soff_ = (second_ ? cc_ - p.C0 : cc_) * 4;                                                                  \
         const __amdgpu_buffer_rsrc_t rs_ = (CI) >= nch ? rsrc_none : second_ ? rsrc1 : rsrc0;                                \
         _Pragma("unroll") for (int e = 0; e < 36; ++e) RAW[e] =                                                              \
-            __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[e], soff_, 0));                 \
+            __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[e], soff_, NTMODE >= 2 ? 2 : 0)); \
     }
 #define W6_CHUNK(CUR, NXT, IT)                                                                                               \
     {                                                                                                                        \
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParam
 #undef W6_LOAD_RAW
         __syncthreads();  // the MFMA waves' last chunk
         __syncthreads();  // the accumulators are in LDS
-        wf64_epilogue(p, Ms, tid, b, gy, gx, TH, TW, n0);
+        wf64_epilogue<(NTMODE >= 1)>(p, Ms, tid, b, gy, gx, TH, TW, n0);
     }
 }
 
@@ -648,6 +656,8 @@ void wino_fused_global_init() {
     W6_ATTR(W6_RING_ALT, false, false);
     W6_ATTR(W6_RING, false, false, true);
     W6_ATTR(W6_RING_ALT, false, false, true);
+    W6_ATTR(W6_RING, false, false, false, 1);
+    W6_ATTR(W6_RING, false, false, false, 2);
 #undef W6_ATTR
 }
 
@@ -746,6 +756,8 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
         case 3: W6_LAUNCH(W6_RING_ALT, false, false); break;
         case 4: W6_LAUNCH(W6_RING_ALT, false, false, true); break;
         case 5: W6_LAUNCH(W6_RING, false, false, true); break;
+        case 6: W6_LAUNCH(W6_RING, false, false, false, 1); break;
+        case 7: W6_LAUNCH(W6_RING, false, false, false, 2); break;
         default: throw HipError("launch_wino_fused64: bad variant");
     }
 #undef W6_LAUNCH

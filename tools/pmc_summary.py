@@ -22,17 +22,32 @@ def group(name):
     return "torch / runtime (bench harness)"
 
 
+FAMILIES = ("wino4_fused64", "wino4_fused", "gemm_zloop", "gemm_split2i", "gemm_split", "conv_igemm", "conv3x3_halo", "conv3x3_narrow", "wino_input",
+            "wino_output", "attn_kv_ctx", "attn_q_out_fused", "attn_", "layernorm")
+
+
+def family(name):
+    return next((f for f in FAMILIES if f in name), None)
+
+
 def load(path):
-    agg = OrderedDict()
-    for r in csv.DictReader(open(path)):
+    """-> ({group: [launches, KiB]}, [(family, grid size, KiB) of every irsde kernel launch, in dispatch order])"""
+    agg, seq = OrderedDict(), []
+    rows = list(csv.DictReader(open(path)))
+    if rows and "Dispatch_Id" in rows[0]:
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
         g = group(r["Kernel_Name"])
         a = agg.setdefault(g, [0, 0.0])
         a[0] += 1
         a[1] += float(r["Counter_Value"])
-    return agg
+        f = family(r["Kernel_Name"])
+        if f:
+            seq.append((f, r.get("Grid_Size", "?"), float(r["Counter_Value"])))
+    return agg, seq
 
 
-fetch, write = load(sys.argv[1]), load(sys.argv[2])
+(fetch, fseq), (write, wseq) = load(sys.argv[1]), load(sys.argv[2])
 evals = int(sys.argv[3])
 out = sys.argv[4]
 lines = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv), production plan:",
@@ -55,6 +70,23 @@ lines += ["corrected HBM bytes (2 x FETCH + WRITE):",
           (conv_bytes / evals / 1e9, conv_bytes / conv_launches / 1e6, conv_launches // evals),
           "  + Winograd transform kernels %.2f GB per evaluation" % (wino_bytes / evals / 1e9),
           "  whole network evaluation     %.2f GB" % (total / evals / 1e9)]
+# per kernel family, and the launches of the LAST evaluation one by one (dispatch order = plan order: compare with irsde_op_profile's lines)
+if len(fseq) == len(wseq) and all(a[0] == b[0] for a, b in zip(fseq, wseq)):
+    fam = OrderedDict()
+    for (f, _, fk), (_, _, wk_) in zip(fseq, wseq):
+        a = fam.setdefault(f, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += 2 * fk * 1024
+        a[2] += wk_ * 1024
+    lines += ["", "per kernel family (corrected bytes per evaluation):", "%-22s %9s %12s %12s" % ("family", "launches", "read GB", "write GB")]
+    for f, (n, rb, wb) in sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+        lines.append("%-22s %9d %12.3f %12.3f" % (f, n // evals, rb / evals / 1e9, wb / evals / 1e9))
+    per = len(fseq) // evals
+    lines += ["", "launches of the last evaluation (dispatch order):", "%4s %-22s %12s %12s %12s" % ("#", "family", "grid", "read MB", "write MB")]
+    for i, ((f, grid, fk), (_, _, wk_)) in enumerate(zip(fseq[-per:], wseq[-per:])):
+        lines.append("%4d %-22s %12s %12.1f %12.1f" % (i, f, grid, 2 * fk * 1024 / 1e6, wk_ * 1024 / 1e6))
+else:
+    lines += ["", "(per-launch table skipped: the two passes did not record the same launch sequence)"]
 open(out + ".txt", "w").write("\n".join(lines) + "\n")
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_summary.py, see %s.txt" % out.split("/")[-1],
            "kernel": "convolution kernels (conv_igemm + gemm_zloop + wino4_fused) + wino transforms",
@@ -62,4 +94,4 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 
            "traffic_bytes_per_launch": (conv_bytes + wino_bytes) / conv_launches,
            "conv_traffic_bytes_per_launch": conv_bytes / conv_launches,
            "bytes_per_evaluation": total / evals}, open(out + ".json", "w"), indent=1)
-print("\n".join(lines))
+print("\n".join(lines[:40]))
