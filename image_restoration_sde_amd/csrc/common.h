@@ -163,6 +163,7 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
 constexpr float kWinoFused64PairVScale = 0.0625f;
 void launch_wino_fused64_split_weights(const float* Uf, unsigned short* out, size_t nfloats, float scale, hipStream_t s);
 int wino_fused64_num_blocks(const ConvParams& p);
+bool wino_fused64_xcd_nb(const ConvParams& p);   // the launch maps cout blocks to XCDs (layers whose input is small next to U x rounds)
 void wino_fused_global_init();
 void attention_global_init();
 

@@ -464,20 +464,30 @@ __device__ __forceinline__ void wf64_epilogue(const ConvParams& p, const float* 
 template <int RING, bool NOWT, bool NOPATCH, bool PAIR = false, int NTMODE = 0>
 __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX,
                                                                   const int GY, const int NB, const unsigned in0_bytes,
-                                                                  const unsigned in1_bytes, const unsigned uf_bytes) {
+                                                                  const unsigned in1_bytes, const unsigned uf_bytes, const int xcd_nb) {
     static_assert(72 % RING == 0, "the ring must divide the 72 (component, r, cout block) units of a chunk");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int wgid;
-    {
+    // Block -> (cout block, tile group).  Default: each XCD (block id % 8) walks a contiguous range of (tile group, cout block) with the
+    // cout block fastest: the NB blocks of a tile group share its patches in one L2, but every round of 32 blocks touches ALL of U, and
+    // U (36 Cout Cin floats: 2.4 .. 38 MB) does not survive in a 4 MB L2 next to the streamed patches — it is re-fetched every round
+    // (r03 PMC: 22 of the kernel's 35 GB of fabric reads per evaluation).  xcd_nb (the launcher's choice, layers whose input is small next
+    // to U x rounds): the cout block is a function of the XCD (NB in {1, 2, 4, 8}: cout block = xcd % NB, 8 / NB XCDs share the tile
+    // groups of one cout block): an XCD then reads one U slice only, the patches are fetched by NB XCDs instead of one.
+    int nblk, g_;
+    if (xcd_nb) {
+        const int orig = blockIdx.x, xcd = orig & 7;
+        nblk = xcd % NB;
+        g_ = (xcd / NB) * (int)(gridDim.x / 8) + (orig >> 3);   // gridDim.x = G NB, G % (8 / NB) == 0: each XCD owns G NB / 8 tile groups
+    } else {
         const int orig = blockIdx.x, nwg = gridDim.x;
         const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        nblk = wgid % NB;
+        g_ = wgid / NB;
     }
-    const int nblk = wgid % NB;
-    int g_ = wgid / NB;
     const int gx = g_ % GX; g_ /= GX;
     const int gy = g_ % GY;
     const int b = g_ / GY;
@@ -726,6 +736,26 @@ void wino_fused64_pack_weights(const float* U, int Cout, int Cin, float* Uf) {
             }
 }
 
+// Block mapping of the 64-cout kernel (see the kernel): true = cout block by XCD.  Modelled fabric reads per launch:
+//   default  : patches x 1.27 (halo) + U x (blocks / 32)            (every round of 32 blocks on an XCD streams all of U)
+//   xcd_nb   : patches x 1.27 x NB   + U slice per XCD, once if it fits L2 (<= 3 MB) else once per round
+// (IRSDE_TUNING=1: IRSDE_WINO_FUSED64_XNB = 0 never / 1 whenever legal / -1 the model)
+bool wino_fused64_xcd_nb(const ConvParams& p) {
+    static const int mode = tuning_env_int("IRSDE_WINO_FUSED64_XNB", -1);
+    if (mode == 0) return false;
+    const int NB = p.Cout / 64;
+    const long long G = (long long)p.B * ((p.Ho / 4 + 3) / 4) * ((p.Wo / 4 + 3) / 4);
+    if (NB < 2 || 8 % NB || G % (8 / NB)) return false;
+    if (mode == 1) return true;
+    const double Ctot = p.C0 + p.C1;
+    const double in_b = 4.0 * p.B * p.Hin * p.Win * Ctot * 1.27, u_b = 36.0 * 4.0 * p.Cout * Ctot;
+    const double blocks = (double)G * NB;
+    const double a = in_b + u_b * blocks / 32.0;
+    const double slice = u_b / NB, rounds = blocks / 256.0;
+    const double b = in_b * NB + (slice <= 3.0e6 ? u_b * (8.0 / NB) : 8.0 * slice * rounds);
+    return b < 0.75 * a;
+}
+
 int wino_fused64_num_blocks(const ConvParams& p) {
     return p.B * ((p.Ho / 4 + 3) / 4) * ((p.Wo / 4 + 3) / 4) * (p.Cout / 64);
 }
@@ -751,7 +781,8 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
     const unsigned in1_bytes = p.C1 ? (unsigned)((size_t)p.B * p.Hin * p.Win * p.pix1 * 4) : 0u;
     const unsigned uf_bytes = (unsigned)((size_t)36 * p.Cout * (p.C0 + p.C1) * 4);
     const dim3 grid((unsigned)(p.B * GY * GX * NB));
-#define W6_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64_kernel<__VA_ARGS__>), grid, dim3(WF_NT), W6_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes)
+    const int xcd_nb = wino_fused64_xcd_nb(p) ? 1 : 0;
+#define W6_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64_kernel<__VA_ARGS__>), grid, dim3(WF_NT), W6_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, xcd_nb)
     static const bool nt = tuning_env_int("IRSDE_WINO_FUSED64_NT", 1) != 0;
     if (variant == 0 && nt) variant = 6;
     if (variant == 4 && nt) variant = 9;
