@@ -979,7 +979,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
 constexpr int kNarrowPPG = 8;  // pixels per 16-lane group
 __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const ConvParams p, const int M) {
     const int l = threadIdx.x & 15;
-    const int group = blockIdx.x * 16 + (threadIdx.x >> 4);
+    // XCD-aware walk: consecutive blocks (= neighbouring half rows) stay on one XCD, so the rows above / below a block's pixels come
+    // out of the same L2 (round-robin placement had every input row fetched by ~4 XCDs: 1.05 GB of fabric reads for a 268 MB input)
+    int wgid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int group = wgid * 16 + (threadIdx.x >> 4);
     const int C = p.C0;  // == 64
     float4 w[3][9];
 #pragma unroll

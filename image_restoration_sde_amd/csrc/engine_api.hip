@@ -564,7 +564,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             launch_wino_output(sp.out, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dU); (void)hipFree(dUs); (void)hipFree(dVs); (void)hipFree(dM);
-        } else if (naive == 35) {  // the 64-cout fused Winograd kernel on fp16 hi + lo operand pairs (IRSDE_FLAG_SPLIT_F16X2's big-feature-map path)
+        } else if (naive == 35 || naive == 37) {  // the 64-cout fused Winograd kernel on fp16 hi + lo operand pairs (IRSDE_FLAG_SPLIT_F16X2's big-feature-map path)
             if (!wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -579,10 +579,10 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             launch_wino_fused64_split_weights(dUf, dUp, Uf.size(), usc, s);
             p.pair_scale = 1.0f / (kWinoFused64PairVScale * usc);
-            launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, 4);
+            launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, naive == 37 ? 4 + 16 : 4);   // 37: + cout block by XCD where legal
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf); (void)hipFree(dUp);
-        } else if (naive == 33 || naive == 34) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
+        } else if (naive == 33 || naive == 34 || naive == 36) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
             if (naive == 33 ? !wino_fused_eligible(p) : !wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -592,7 +592,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dUf, Uf.size() * 4));
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             if (naive == 33) launch_wino_fused(p, dUf, s);
-            else launch_wino_fused64(p, dUf, s);
+            else launch_wino_fused64(p, dUf, s, naive == 36 ? 16 : 0);   // 36: + cout block by XCD where legal
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf);
         } else if (wino_tile) {  // naive / 10: 0 = production dispatch, 1 / 2 = force the batch-loop GEMM kernel (all / 2 components per block)

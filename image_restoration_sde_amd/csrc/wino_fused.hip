@@ -781,7 +781,11 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
     const unsigned in1_bytes = p.C1 ? (unsigned)((size_t)p.B * p.Hin * p.Win * p.pix1 * 4) : 0u;
     const unsigned uf_bytes = (unsigned)((size_t)36 * p.Cout * (p.C0 + p.C1) * 4);
     const dim3 grid((unsigned)(p.B * GY * GX * NB));
-    const int xcd_nb = wino_fused64_xcd_nb(p) ? 1 : 0;
+    // variant + 16: the cout-block-by-XCD mapping wherever it is legal (test hook: the production choice follows the traffic model)
+    const bool force_xnb = (variant & 16) != 0;
+    variant &= 15;
+    const long long G_ = (long long)p.B * GY * GX;
+    const int xcd_nb = (force_xnb ? (NB >= 2 && 8 % NB == 0 && G_ % (8 / NB) == 0) : wino_fused64_xcd_nb(p)) ? 1 : 0;
 #define W6_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64_kernel<__VA_ARGS__>), grid, dim3(WF_NT), W6_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, xcd_nb)
     static const bool nt = tuning_env_int("IRSDE_WINO_FUSED64_NT", 1) != 0;
     if (variant == 0 && nt) variant = 6;

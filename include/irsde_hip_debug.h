@@ -24,7 +24,8 @@ extern "C" {
  *           staged, three cross products on the 16-bit MFMA): fp16 / bf16 pieces
  *   44 / 45 three-launch Winograd F(4x4,3x3) with the engine's pair GEMM (pair-interleaved operands, LDS-DMA): fp16 / bf16 hi + lo pieces
  *   42 / 43 three-launch Winograd F(4x4,3x3) with split-operand component GEMMs on the bf16 MFMA pipe (csrc/gemm_split.hip): 2 / 3 bf16 planes
- *   34 the 64-cout fused Winograd kernel (r03: Cout and C0 + C1 multiples of 64)
+ *   34 the 64-cout fused Winograd kernel (r03: Cout and C0 + C1 multiples of 64); 36: with its cout-block-by-XCD block mapping forced wherever legal
+ *   35 / 37 the same kernel's fp16-pair twin (IRSDE_FLAG_SPLIT_F16X2; all four hi / lo cross products on v_mfma_f32_16x16x32_f16) / with the mapping forced
  *   33 the fused Winograd F(4x4,3x3) kernel (csrc/wino_fused.hip; 3x3 s1 p1, H and W multiples of 4, C0, C1 and Cout multiples of 32)
  *   4 bf16-MFMA mode (halo kernel for eligible 3x3 layers); 160 / 161 its generic 256 / 128 tile
  *   5 fp16-MFMA mode (IRSDE_FLAG_FP16; halo kernel for eligible 3x3 layers); 165 its generic 128 tile

@@ -204,6 +204,28 @@ def test_conv_wino_fused64_edges(shape):
     assert relerr(got, ref) < 5e-5, shape
     # and bit-for-bit nothing but summation order away from the 32-cout kernel
     assert relerr(got, run_conv(x0, x1, w, None, 1, 1, up, None, 0, None, naive=33)) < 2e-5, shape
+    # the cout-block-by-XCD block mapping (forced where legal: NB in {2, 4, 8}, tile groups divisible) is the same arithmetic per block: bit-exact
+    assert np.array_equal(got, run_conv(x0, x1, w, None, 1, 1, up, None, 0, None, naive=36)), shape
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 0, 32, 32, 128, 0), (1, 64, 64, 16, 16, 256, 1), (4, 64, 0, 16, 32, 512, 0), (3, 64, 0, 16, 16, 128, 0)])
+def test_conv_wino_fused64_xcd_mapping(shape):
+    """wino4_fused64_kernel with cout block = XCD % NB (NB = 2 / 4 / 8; the last shape has 3 x 16 tile groups... an odd count the mapping
+    must refuse for NB = 2 -> falls back): f32 (36) and fp16-pair (37) instances against the oracle and bit-exact against the default mapping."""
+    B, C0, C1, H, W, Cout, up = shape
+    rs = np.random.RandomState(B * 77 + Cout)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, 3, 3)) / np.sqrt((C0 + C1) * 9)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32)
+    res = rs.standard_normal((B, Cout, H << up, W << up)).astype(np.float32)
+    ref = oracle_conv(x0, x1, w, bias, 1, 1, up, None, 1, res)
+    a = run_conv(x0, x1, w, bias, 1, 1, up, None, 1, res, naive=34)
+    b = run_conv(x0, x1, w, bias, 1, 1, up, None, 1, res, naive=36)
+    assert relerr(b, ref) < 5e-5 and np.array_equal(a, b), shape
+    c = run_conv(x0, x1, w, bias, 1, 1, up, None, 1, res, naive=35)
+    d = run_conv(x0, x1, w, bias, 1, 1, up, None, 1, res, naive=37)
+    assert relerr(d, ref) < 5e-5 and np.array_equal(c, d), shape
 
 
 def test_conv_per_sample_film():
