@@ -191,7 +191,9 @@ def roofline_object(prof, op_text, w):
         # work needs at each kernel's own roof / the measured MFMA-kernel time: a true fraction (<= 1); `achieved` stays f32-equivalent
         def products(n):   # 16-bit MFMA products per f32 product (0: an f32-MFMA kernel)
             return 3.0 if n.startswith("gemm_split2i_kernel") else 4.0 if n.startswith("wino4_fused64_kernel<PAIR>") else 0.0
-        need = sum(v[1] * (products(n) / (PEAK_BF16_TFLOPS * 1e12) if products(n) else 1.0 / (PEAK_FP32_TFLOPS * 1e12)) for n, v in classes.items())
+        # (`classes` is ONE evaluation of the plan, the profile's times cover net_evals of them)
+        need = max(prof["net_evals"], 1) * sum(v[1] * (products(n) / (PEAK_BF16_TFLOPS * 1e12) if products(n) else 1.0 / (PEAK_FP32_TFLOPS * 1e12))
+                                               for n, v in classes.items())
         r["frac"] = need / conv_t
         r["mfma_kernel_frac"] = need / (prof["conv_ms"] * 1e-3)
         r["peak"] = None

@@ -293,6 +293,10 @@ def test_bench_roofline_object_from_an_op_profile():
         rs_ = bench.roofline_object(prof, text, {"dtype": dt})
         assert "note" in rs_ and rs_["peak"] is None and 0 < rs_["frac"] <= rs_["mfma_kernel_frac"] <= 1
         assert rs_["frac"] < r["frac"]   # the pair class is priced at the 16-bit roof, not at the f32 one
+        # the op text describes ONE evaluation, the profile covers net_evals of them: the fraction does not depend on how many were timed
+        prof3 = dict(prof, net_evals=3.0, **{k: 3 * prof[k] for k in ("conv_ms", "wino_ms", "conv_exec_flops", "conv_flops", "conv_launches", "conv_bytes",
+                                                                      "wall_ms", "ln_ms", "attn_ms", "other_ms")})
+        assert abs(bench.roofline_object(prof3, text, {"dtype": dt})["frac"] - rs_["frac"]) < 1e-12
     rb = bench.roofline_object(prof, text, {"dtype": "bf16_act"})
     assert rb["bound"] == "hbm" and rb["unit"] == "GB/s" and rb["peak"] == bench.PEAK_HBM_GBPS
     # every secondary workload names a model / dtype the Workload class knows, and the headline stays out of the list
