@@ -95,7 +95,7 @@ enum {
                                         fused Winograd kernel of the big feature maps onto its fp16-pair twin (all four hi / lo cross products).
                                         Small end: an fp16 pair resolves 2^-25 ABSOLUTE (after the scale), so the 22+ bits hold for operands of
                                         magnitude >~ 0.1 — the network's O(1) activations; a layer fed |x| ~ 0.02 is at 3e-5 instead of 5e-6
-                                        (tests/test_gpu_split.py), |x| ~ 1e-3 at ~1e-4: use IRSDE_FLAG_SPLIT_BF16X2 (f32 exponent range) or the
+                                        (tests/test_gpu_split.py), |x| ~ 1e-3 at 4e-4: use IRSDE_FLAG_SPLIT_BF16X2 (f32 exponent range) or the
                                         native mode for data scaled that far from unit range.  Wins over IRSDE_FLAG_SPLIT_BF16X2 when both are set. */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
