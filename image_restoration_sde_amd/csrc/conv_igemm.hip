@@ -351,15 +351,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt_begin < kt_end) {
-        set_tap();
-        stage_setup(true);  // (a split-K range may start in the middle of a tap)
+    if constexpr (!PAIR) {
+        if (kt_begin < kt_end) {
+            set_tap();
+            stage_setup(true);  // (a split-K range may start in the middle of a tap)
 #pragma unroll
-        for (int q = 0; q < NP; ++q) load_piece(q);
+            for (int q = 0; q < NP; ++q) load_piece(q);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) store_piece(q, 0);
+            for (int q = 0; q < NP; ++q) store_piece(q, 0);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // One K-step: next-tile loads issued first, then the MFMAs (the compiler streams the fragment reads
     // between them), then the LDS writes.  The other block on the CU covers the gaps.
@@ -476,9 +478,132 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         }
     };
 
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        k_step((kt - kt_begin) & 1, kt + 1 < kt_end);
-        __syncthreads();
+    if constexpr (PAIR) {
+        // r03 (late): deeper staging for the direct PAIR layers.  The first PAIR loop staged A and B through registers ONE K step ahead
+        // behind __syncthreads(), which on gfx9 drains vmcnt: a step cost the load latency (7.4k cycles at 3k of MFMAs, f16 pipe 0.27
+        // busy on the NAFNet 1x1 layers).  Now A (activations: HBM / Infinity Cache latency) is loaded TWO steps ahead into a register
+        // ping-pong, B (weights, pre-interleaved [Cout][K / 32][hi 32 | lo 32]: one 128-byte line per row and K step, L2-hot) one step
+        // ahead; both are split / written to LDS one step ahead, and the step ends with s_waitcnt lgkmcnt(0) + s_barrier only — the
+        // loads of the following steps stay in flight across the barrier (the compiler counts vmcnt per register).  Staging is
+        // unconditional: the last steps re-stage into dead buffers (reads stay inside the tensors).
+        constexpr int NA = C::A_PASSES, BP = BN * 8 / C::NT;   // 16-byte pieces per thread and step: A rows / B row pieces
+        static_assert(BN * 8 % C::NT == 0 && C::NT % 8 == 0, "B tile pieces per pass");
+        const int nkb = taps * steps_per_tap;     // 128-byte blocks per weight row
+        const int bpiece = tid & 7, brow = tid >> 3;   // piece p of a row's line: plane p >> 2, k = 8 (p & 3) .. + 7
+        const char* bsrc[BP];
+#pragma unroll
+        for (int ps = 0; ps < BP; ++ps) {
+            const int n = n0 + brow + ps * (C::NT / 8);
+            bsrc[ps] = reinterpret_cast<const char*>(p.w_pair) + (size_t)(n < p.Cout ? n : p.Cout - 1) * nkb * 128 + bpiece * 16;
+        }
+        floatx4 ra[2][NA], rb[BP];
+        floatx4 rsc[INSCALE ? NA : 1];
+        auto load_b = [&](const int kb) {
+#pragma unroll
+            for (int ps = 0; ps < BP; ++ps) rb[ps] = *reinterpret_cast<const floatx4*>(bsrc[ps] + (size_t)kb * 128);
+        };
+        auto store_b = [&](const int buf) {
+#pragma unroll
+            for (int ps = 0; ps < BP; ++ps)
+                *reinterpret_cast<floatx4*>(Bs + ((buf * 2 + (bpiece >> 2)) * BN + brow + ps * (C::NT / 8)) * C::ROW_BYTES + (bpiece & 3) * 16) = rb[ps];
+        };
+        auto load_a = [&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const char* g = a_poff[q] >= 0 ? cur_src + (size_t)a_poff[q] * cur_pix : reinterpret_cast<const char*>(p.zeros);
+                ra[ph][q] = *reinterpret_cast<const floatx4*>(g);
+            }
+        };
+        auto load_scale = [&]() {   // (state = the step whose A pieces are written next)
+            if constexpr (INSCALE) {
+#pragma unroll
+                for (int q = 0; q < NA; ++q) rsc[q] = *reinterpret_cast<const floatx4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + chunk * 4);
+            }
+        };
+        auto store_a = [&](auto phc, const int buf) {
+            constexpr int ph = decltype(phc)::value;
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                floatx4 v = ra[ph][q];
+                if constexpr (INSCALE) v *= rsc[q];
+                const typename H16::x4 hi = __builtin_convertvector(v, typename H16::x4);          // RNE
+                const floatx4 r = v - __builtin_convertvector(hi, floatx4);                        // exact in f32
+                const typename H16::x4 lo = __builtin_convertvector(r, typename H16::x4);
+                char* dst = As + ((buf * 2) * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES + chunk * 8;
+                *reinterpret_cast<typename H16::x4*>(dst) = hi;
+                *reinterpret_cast<typename H16::x4*>(dst + BM * C::ROW_BYTES) = lo;
+            }
+        };
+        auto mfma_step = [&](const int buf) {
+            const char* a = As + (buf * 2 * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
+            const char* b = Bs + (buf * 2 * BN + wn * C::TN * 32 + l31) * C::ROW_BYTES + h * 16;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                typename H16::x8 fa[2][C::TM], fb[2][C::TN];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+                        fa[pl][i] = *reinterpret_cast<const typename H16::x8*>(a + (pl * BM + i * 32) * C::ROW_BYTES + sb * 32);
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j)
+                        fb[pl][j] = *reinterpret_cast<const typename H16::x8*>(b + (pl * BN + j * 32) * C::ROW_BYTES + sb * 32);
+                }
+                // hi.lo, lo.hi, hi.hi: small terms first; consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j)
+                            acc[i][j] = H16::mfma(fa[pr == 1 ? 1 : 0][i], fb[pr == 0 ? 1 : 0][j], acc[i][j]);
+            }
+        };
+        if (kt_begin < kt_end) {
+            // prologue: A(k0) -> ra[0], scales(k0), B(k0), A(k0 + 1) -> ra[1]; then A(k0), B(k0) -> buffer 0
+            set_tap();
+            stage_setup(true);
+            load_a(std::integral_constant<int, 0>{});
+            load_scale();
+            load_b(kt_begin);
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+            stage_setup();
+            load_a(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            store_a(std::integral_constant<int, 0>{}, 0);
+            store_b(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // step k (ph = parity): ra[ph] held A(k) (already in LDS) and is refilled with A(k + 2); ra[ph ^ 1] holds A(k + 1)
+        auto pstep = [&](auto phc, const int kt) {
+            constexpr int ph = decltype(phc)::value;
+            const int buf = ph;
+            load_b(kt + 1 < nk_total ? kt + 1 : nk_total - 1);
+            load_scale();          // the state machine stands at step k + 1 here
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+            stage_setup();
+            load_a(phc);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(buf);
+            store_a(std::integral_constant<int, ph ^ 1>{}, buf ^ 1);
+            store_b(buf ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        int kt = kt_begin;
+        for (; kt + 1 < kt_end; kt += 2) {
+            pstep(std::integral_constant<int, 0>{}, kt);
+            pstep(std::integral_constant<int, 1>{}, kt + 1);
+        }
+        if (kt < kt_end) pstep(std::integral_constant<int, 0>{}, kt);
+        __syncthreads();   // (drains the stray loads of the last steps; the epilogue re-uses the LDS)
+    } else {
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            k_step((kt - kt_begin) & 1, kt + 1 < kt_end);
+            __syncthreads();
+        }
     }
     if constexpr (PAIR && F16) {   // undo the power-of-two scale of the fp16 weight planes (exact)
         const float ps = p.pair_scale;
@@ -1273,7 +1398,11 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
         const int nk = p.KH * p.KW * (Ctot / 32);
         static const int t256 = tuning_env_int("IRSDE_PAIR_TILE256", 1);
         // 256 x 256: half the staging work per MFMA (160 KB of LDS: one block per CU) — where it still fills the 256 CUs
-        if (t256 && p.Cout % 256 == 0 && (long long)((M + 255) / 256) * (p.Cout / 256) * p.splits >= 256 && g_variant != 61) {
+        // (the INSCALE instance of that tile spills since the two-step A staging: SCA-scaled layers take 256 x 128 unless IRSDE_PAIR_INSCALE256=1)
+        static const int inscale256 = tuning_env_int("IRSDE_PAIR_INSCALE256", 0);
+        // (measured and dropped: a 128 x 128 tile at two blocks per CU, so that one block's write-back overlaps the other's K loop — 10-20 %
+        //  SLOWER on every layer class, profiles/r03_pair_conv_sweep.txt: the doubled L2 -> CU operand traffic costs more than the overlap buys)
+        if (t256 && (!p.in_scale || inscale256) && p.Cout % 256 == 0 && (long long)((M + 255) / 256) * (p.Cout / 256) * p.splits >= 256 && g_variant != 61) {
             if (p.in_scale) launch_cfg_pair<256, 256, 2, 4, 2, true>(p, M, nk, s);
             else launch_cfg_pair<256, 256, 2, 4, 2, false>(p, M, nk, s);
         } else if (p.Cout >= 128 && M >= 256) {

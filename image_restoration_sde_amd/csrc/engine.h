@@ -381,6 +381,31 @@ struct irsde_engine {
         pair_copies[w] = pc;
         return pc;
     }
+    // The PAIR kernels of conv_igemm.hip read their weights pair-interleaved: [rows][K / 32][hi 32 | lo 32] (split_pairs_kernel), one
+    // 128-byte line per 32-k block, fetched global -> LDS by global_load_lds.  K must be a multiple of 32.
+    std::map<const float*, PairCopy> pair_copies_il;
+    PairCopy pair_copy_il(const float* w, size_t rows, int K) {
+        auto it = pair_copies_il.find(w);
+        if (it != pair_copies_il.end()) return it->second;
+        const bool f16 = (cfg.flags & IRSDE_FLAG_SPLIT_F16X2) != 0;
+        const size_t n = rows * (size_t)K;
+        float sc = 1.f;
+        if (f16) {
+            std::vector<float> h(n);
+            IRSDE_HIP_CHECK(hipMemcpy(h.data(), w, n * sizeof(float), hipMemcpyDeviceToHost));
+            float mx = 0.f;
+            for (float v : h) mx = std::max(mx, std::fabs(v));
+            if (mx > 0.f) sc = std::exp2(std::floor(std::log2(512.0f / mx)));
+        }
+        unsigned short* d = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&d, 2 * n * sizeof(unsigned short)));
+        dev_allocs.push_back(reinterpret_cast<float*>(d));
+        launch_split_pairs(w, d, rows, K, stream, f16, sc);
+        IRSDE_HIP_CHECK(hipStreamSynchronize(stream));
+        const PairCopy pc{d, 1.0f / sc};
+        pair_copies_il[w] = pc;
+        return pc;
+    }
     float* upload(const std::vector<float>& v) {
         float* p = dmalloc(v.size());
         IRSDE_HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));

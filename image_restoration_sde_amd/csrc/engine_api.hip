@@ -622,8 +622,8 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             const float sc = f16 && mx > 0.f ? std::exp2(std::floor(std::log2(512.0f / mx))) : 1.f;
             unsigned short* dwp = nullptr;
             IRSDE_HIP_CHECK(hipMalloc(&dwp, pk.size() * 4));
-            launch_split_planes(dw, dwp, pk.size(), pk.size(), 2, s, f16, sc);
-            p.w_pair = dwp; p.w_pair_plane = (long long)pk.size(); p.pair_scale = 1.0f / sc; p.f16 = f16 ? 1 : 0;
+            launch_split_pairs(dw, dwp, (size_t)Cout, KH * KW * (C0 + C1), s, f16, sc);
+            p.w_pair = dwp; p.pair_scale = 1.0f / sc; p.f16 = f16 ? 1 : 0;
             launch_conv(p, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dwp);
@@ -772,8 +772,8 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         unsigned short* dwp = nullptr;
         if (variant == 480 || variant == 481 || variant == 482) {   // direct convolution on the PAIR kernels: 480 fp16 pieces, 481 bf16 pieces, 482 = 480 without the 256 x 256 tile
             IRSDE_HIP_CHECK(hipMalloc(&dwp, nw * 4));
-            launch_split_planes(dw, dwp, nw, nw, 2, s, variant != 481, 64.0f);
-            p.w_pair = dwp; p.w_pair_plane = (long long)nw; p.pair_scale = 1.0f / 64.0f; p.f16 = variant != 481 ? 1 : 0;
+            launch_split_pairs(dw, dwp, (size_t)Cout, K * K * Cin, s, variant != 481, 64.0f);
+            p.w_pair = dwp; p.pair_scale = 1.0f / 64.0f; p.f16 = variant != 481 ? 1 : 0;
             variant = variant == 482 ? 61 : 0;
         }
         if (variant >= 472 && variant <= 476) {   // the pair-interleaved two-plane component GEMMs alone (v3 kernel): 472 full, 473 no loads, 475 no MFMAs, 476 no output stores

@@ -53,8 +53,9 @@ struct Builder {
                    p.KH * p.KW * (p.C0 + p.C1) >= split_direct_min_k()) {
             // split-operand arithmetic for the direct layers too (PAIR kernels): fp32 storage, 16-bit hi + lo operand pairs
             const size_t nw = (size_t)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
-            const auto pc = e->pair_copy(p.w, nw);
-            p.w_pair = pc.p; p.w_pair_plane = (long long)nw; p.pair_scale = pc.inv_scale;
+            const auto pc = e->pair_copy_il(p.w, (size_t)p.Cout, p.KH * p.KW * (p.C0 + p.C1));
+            (void)nw;
+            p.w_pair = pc.p; p.pair_scale = pc.inv_scale;
             p.f16 = (e->cfg.flags & IRSDE_FLAG_SPLIT_F16X2) ? 1 : 0;
         }
         Op op;
