@@ -577,6 +577,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         // step k (ph = parity): ra[ph] held A(k) (already in LDS) and is refilled with A(k + 2); ra[ph ^ 1] holds A(k + 1)
+        // (What a step is made of, measured with run-time switches that have since been removed — they cost the production instance 10 %:
+        //  NAFNet 512 -> 1024 @ 64^2: without the K loop's global loads -13 %, without MFMAs -40 %, without the LDS stores -11 %, without the
+        //  epilogue -26 %: the parts add up, nothing overlaps; profiles/r03_pair_conv_sweep.txt.)
         auto pstep = [&](auto phc, const int kt) {
             constexpr int ph = decltype(phc)::value;
             const int buf = ph;
