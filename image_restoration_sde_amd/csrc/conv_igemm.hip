@@ -624,7 +624,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     // goes in an SGPR, rows past M fall outside the descriptor.  bias -> FiLM (one row for the batch) -> SiLU -> channel
     // scale -> + residual, per column = per lane.  No LDS round trip, no per-row index arithmetic: ~4 vector instructions
     // per output instead of ~10 (vector instructions are paid in f32-MFMA time on gfx950).
-    if constexpr (BUFA) {
+    // (PAIR kernels too, late r03: their LDS-transposed epilogue was 26 % of a 512 -> 1024 NAFNet layer; the descriptors here only concern out / res)
+    if constexpr (BUFA || PAIR) {
         if (p.splits == 1 && !p.ln_g && !p.gate && !p.shuffle && !(p.film && p.film_bstride != 0) && !p.out_bf16 && !p.no_direct_epi) {
             const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
             const int rowb = m0 + wm_s * C::TM * 32, colb = n0 + wn_s * C::TN * 32;
