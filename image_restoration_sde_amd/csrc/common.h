@@ -53,9 +53,7 @@ struct ConvParams {
     int f16 = 0;                 // 1: w_bf / w_pair hold IEEE fp16 (IRSDE_FLAG_FP16 / _SPLIT_F16X2): v_mfma_f32_32x32x16_f16
     // split-operand arithmetic on fp32 storage (IRSDE_FLAG_SPLIT_BF16X2 / _F16X2; conv_igemm.hip PAIR kernels): the weights as two
     // pair-interleaved 16-bit pieces [Cout][KH*KW*(C0+C1) / 32][hi 32 | lo 32] (split_pairs_kernel); fp16: pieces of w * 2^k, pair_scale = 2^-k
-    // (w_pair_plane: unused since the PAIR kernels fetch the weights by global_load_lds)
     const unsigned short* w_pair = nullptr;
-    long long w_pair_plane = 0;
     float pair_scale = 1.f;
     int Cout = 0;
     int KH = 1, KW = 1, stride = 1, pad_y = 0, pad_x = 0;

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
     };
 
     // ---- staging pieces: A rows (A_PASSES) then B rows (B_PASSES), one 16-byte load each ----
-    constexpr int NP = C::A_PASSES + PL * C::B_PASSES;   // PAIR: the hi and the lo weight plane of every staged B row
+    constexpr int NP = C::A_PASSES + C::B_PASSES;   // (the PAIR kernels stage through their own lambdas further down)
     floatx4 rs[NP];  // (ext_vector: HIP's float4 struct copies become memcpys that can pin the array to scratch)
     floatx4 rscale[INSCALE ? C::A_PASSES : 1];  // NAFNet SCA: the per-(image, channel) scales of the A pieces in flight
     constexpr int AESZ = ABF ? 2 : 4;        // bytes per activation element in HBM
@@ -297,31 +297,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
             rs[q] = *reinterpret_cast<const floatx4*>(g);
             if constexpr (INSCALE)  // single source (C1 == 0); multiplied when the piece is written to LDS (store_piece)
                 rscale[q < C::A_PASSES ? q : 0] = *reinterpret_cast<const floatx4*>(p.in_scale + (size_t)a_b[q] * p.C0 + cc + chunk * 4);
-        } else if constexpr (PAIR) {
-            const int qb = q - C::A_PASSES;
-            rs[q] = *reinterpret_cast<const floatx4*>(wrow[qb % C::B_PASSES] + (size_t)(qb / C::B_PASSES) * (size_t)p.w_pair_plane * 2 + cur_wk);
         } else {
             rs[q] = *reinterpret_cast<const floatx4*>(wrow[q - C::A_PASSES] + cur_wk);
         }
     };
     auto store_piece = [&](int q, int buf) {
-        if constexpr (PAIR) {
-            if (q < C::A_PASSES) {
-                floatx4 v = rs[q];
-                if constexpr (INSCALE) v *= rscale[q < C::A_PASSES ? q : 0];
-                const typename H16::x4 hi = __builtin_convertvector(v, typename H16::x4);          // RNE
-                const floatx4 r = v - __builtin_convertvector(hi, floatx4);                        // exact in f32
-                const typename H16::x4 lo = __builtin_convertvector(r, typename H16::x4);
-                char* dst = As + ((buf * 2) * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES + chunk * 8;
-                *reinterpret_cast<typename H16::x4*>(dst) = hi;
-                *reinterpret_cast<typename H16::x4*>(dst + BM * C::ROW_BYTES) = lo;
-            } else {
-                const int qb = q - C::A_PASSES, ps = qb % C::B_PASSES, pln = qb / C::B_PASSES;
-                if (C::B_PASSES * C::B_ROWS == BN || brow0 + ps * C::B_ROWS < BN)
-                    *reinterpret_cast<floatx4*>(Bs + ((buf * 2 + pln) * BN + brow0 + ps * C::B_ROWS) * C::ROW_BYTES + bchunk * 16) = rs[q];
-            }
-            return;
-        }
         if (q < C::A_PASSES) {
             char* dst = As + (buf * BM + row0 + q * C::A_ROWS) * C::ROW_BYTES;
             if (ABF) {
@@ -373,37 +353,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void co
         }
         const char* a = As + (buf * PL * BM + wm * C::TM * 32 + l31) * C::ROW_BYTES + h * 16;
         const char* b = Bs + (buf * PL * BN + wn * C::TN * 32 + l31) * C::ROW_BYTES + h * 16;
-        if constexpr (PAIR) {
-            if (more) {
-#pragma unroll
-                for (int q = 0; q < NP; ++q) load_piece(q);
-            }
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                typename H16::x8 fa[2][C::TM], fb[2][C::TN];
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-                    for (int i = 0; i < C::TM; ++i)
-                        fa[pl][i] = *reinterpret_cast<const typename H16::x8*>(a + (pl * BM + i * 32) * C::ROW_BYTES + sb * 32);
-#pragma unroll
-                    for (int j = 0; j < C::TN; ++j)
-                        fb[pl][j] = *reinterpret_cast<const typename H16::x8*>(b + (pl * BN + j * 32) * C::ROW_BYTES + sb * 32);
-                }
-                // hi.lo, lo.hi, hi.hi: small terms first; consecutive MFMAs hit different accumulators
-#pragma unroll
-                for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-                    for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < C::TN; ++j)
-                            acc[i][j] = H16::mfma(fa[pr == 1 ? 1 : 0][i], fb[pr == 0 ? 1 : 0][j], acc[i][j]);
-            }
-            if (more) {
-#pragma unroll
-                for (int q = 0; q < NP; ++q) store_piece(q, buf ^ 1);
-            }
-        } else if constexpr (BF16) {
+        if constexpr (BF16) {
             if (more) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) load_piece(q);
