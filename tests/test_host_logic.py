@@ -259,6 +259,29 @@ def test_tuning_env_knobs_are_inert_without_IRSDE_TUNING():
                 assert f == "common.h" and m.group(1) == "IRSDE_TUNING", (f, m.group(0))
 
 
+def test_every_tuning_knob_is_documented():
+    """DESIGN.md's "Tuning knobs" section lists exactly the knobs the code reads (tuning_env_int("IRSDE_...", default))."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(P.__file__), "csrc")
+    knobs = set()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(root, f)).read()
+            knobs |= set(re.findall(r"tuning_env_int\(\"(IRSDE_\w+)\"", src))
+            for m in re.finditer(r"tuning_env_int\(([^;]*?\?[^;]*?),", src):   # a name chosen by a conditional expression
+                knobs |= set(re.findall(r"\"(IRSDE_\w+)\"", m.group(1)))
+    design = open(os.path.join(os.path.dirname(os.path.dirname(P.__file__)), "DESIGN.md")).read()
+    sec = design[design.index("### Tuning knobs"):design.index("### Sampler loop")]
+    # the section abbreviates families: `IRSDE_X_MAXCIN` / `_MAXCOUT` — expand "/ `_SUFFIX`" against the preceding full name
+    named = set(re.findall(r"`(IRSDE_\w+)`", sec))
+    for full, rest in re.findall(r"`(IRSDE_\w+)`((?:\s*(?:\([^)]*\))?\s*/\s*`_\w+`)+)", sec):
+        for suf in re.findall(r"`(_\w+)`", rest):
+            named.add(full[:full.rindex("_")] + suf)
+    assert knobs <= named, sorted(knobs - named)
+    assert named - knobs <= {"IRSDE_TUNING"}, sorted(named - knobs)
+
+
 def test_bench_roofline_object_from_an_op_profile():
     """bench.py's host logic (no GPU): the per-class parse of irsde_op_profile's text and the roofline object built from it —
     fractions are true fractions of the roof, the dominant class is the one with the largest time share, the split mode is
