@@ -815,7 +815,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         const bool split_v = variant == 412 || variant == 413 || variant == 422 || variant == 423;  // split-operand GEMMs: 41x whole three-launch layer, 42x the GEMM alone; x = planes
         unsigned short *dUs = nullptr, *dVs = nullptr;
         WinoSplitPlan sp{};
-        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 408)) {
+        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410)) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
@@ -891,7 +891,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         auto run = [&] {
             if (variant == 80) {
                 launch_wino_fused(p, dU, s);
-            } else if (variant >= 400 && variant <= 408) {  // 406 / 407 / 408: non-temporal epilogue traffic / + patch loads / no hint at all
+            } else if (variant >= 400 && variant <= 410) {  // 406 / 407 / 408: non-temporal epilogue traffic / + patch loads / no hint at all
                  // 64-cout fused Winograd kernel: 400 production, 401 no weight traffic, 402 no patch traffic, 403 short U ring, 404 / 405 fp16 pairs (ring 12 / 18)
                 launch_wino_fused64(p, dU, s, variant - 400);
             } else if (variant >= 83 && variant <= 82 + 255) {  // tuning aids: dflags = variant - 82 (1 no patch traffic, 2 no weight traffic, 4 / 8 producer / MFMA waves at s_setprio 2)

@@ -669,6 +669,7 @@ void wino_fused_global_init() {
     W6_ATTR(W6_RING, false, false, false, 1);
     W6_ATTR(W6_RING, false, false, false, 2);
     W6_ATTR(W6_RING_ALT, false, false, true, 1);
+    W6_ATTR(W6_RING_ALT, false, false, false, 1);
 #undef W6_ATTR
 }
 
@@ -766,11 +767,12 @@ void launch_wino_fused64_split_weights(const float* Uf, unsigned short* out, siz
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
-// variant: 0 production; 1 weight fragments read zeros (no L2 traffic); 2 patch loads read zeros; 3 the shorter U ring;
+// variant: 0 production (= 10 unless IRSDE_WINO_FUSED64_NT=0); 1 weight fragments read zeros (no L2 traffic); 2 patch loads read zeros; 3 the shorter U ring;
 // 4 / 5: the fp16-pair kernel (Uf = the wf64_split_weights_kernel output, p.pair_scale = 1 / (kWinoFused64PairVScale * weight scale)), ring 12 (production:
 // 3 - 6 % faster than 18 on every layer class, profiles/r03_wino_fused64_pair_sweep.txt — the MFMAs of a unit take 34 instead of 128 cycles, the
 // deeper ring only costs registers) / 18; 6 / 7 / 8: the f32 kernel with non-temporal residual loads + output stores / + patch loads / without
-// any hint.  Production (0, 4) carries the epilogue hint (IRSDE_WINO_FUSED64_NT=0 under IRSDE_TUNING=1 switches it off): the streamed
+// any hint; 10: 12 units in flight + the epilogue hint = production since late r03 (0 .. -4 % against 6 on every layer class,
+// profiles/r03_wino_fused64_nt.txt).  Production (0, 4) carries the epilogue hint (IRSDE_WINO_FUSED64_NT=0 under IRSDE_TUNING=1 switches it off): the streamed
 // epilogue traffic no longer evicts the weight fragments from the XCD's 4 MB L2 - 128 -> 128 @ 256^2 1.14 -> 1.01 ms, profiles/r03_wino_fused64_nt.txt
 void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, int variant) {
     if (!wino_fused64_eligible(p)) throw HipError("launch_wino_fused64: layer not eligible");
@@ -788,11 +790,12 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
     const int xcd_nb = (force_xnb ? (NB >= 2 && 8 % NB == 0 && G_ % (8 / NB) == 0) : wino_fused64_xcd_nb(p)) ? 1 : 0;
 #define W6_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64_kernel<__VA_ARGS__>), grid, dim3(WF_NT), W6_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, xcd_nb)
     static const bool nt = tuning_env_int("IRSDE_WINO_FUSED64_NT", 1) != 0;
-    if (variant == 0 && nt) variant = 6;
+    if (variant == 0 && nt) variant = 10;   // 12 units in flight: with the epilogue hint the weights hit L2 more often, and the shorter ring has no spills (237 VGPRs)
     if (variant == 4 && nt) variant = 9;
     switch (variant) {
         case 0: case 8: W6_LAUNCH(W6_RING, false, false); break;
         case 9: W6_LAUNCH(W6_RING_ALT, false, false, true, 1); break;
+        case 10: W6_LAUNCH(W6_RING_ALT, false, false, false, 1); break;   // f32, 12 units in flight, non-temporal epilogue (irsde_bench_conv 410)
         case 1: W6_LAUNCH(W6_RING, true, false); break;
         case 2: W6_LAUNCH(W6_RING, false, true); break;
         case 3: W6_LAUNCH(W6_RING_ALT, false, false); break;

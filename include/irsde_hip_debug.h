@@ -47,7 +47,7 @@ int irsde_debug_split_gemm(const float* A, const float* B, float* C, int M, int 
  * buffer descriptors, 7 LDS-transposed instead of direct epilogue, 60 / 61 / 62 bf16 mode (256 tile / 128 tile / automatic
  * incl. the halo kernel), 63 = 62 with bf16 activation storage, 80 / 81 Winograd F(4x4,3x3) fused kernel / three-launch path (3x3 s1 only), 82 the fused kernel once with its
  * phase timeline printed to stdout, 400 the 64-cout fused Winograd kernel (r03; 401 / 402: its weight fragments / patch loads read zeros
- * without memory traffic, 403: 12 instead of 18 weight units in flight, 404 / 405: its fp16-pair twin with 12 / 18 units in flight, 406 / 407 / 408: non-temporal hint on the epilogue traffic (= 400) / also on the patch loads / nowhere), 412 / 413 the three-launch Winograd layer with split-operand GEMMs (2 / 3
+ * without memory traffic, 403: 12 instead of 18 weight units in flight, 404 / 405: its fp16-pair twin with 12 / 18 units in flight, 406 / 407 / 408: 18 weight units in flight with the non-temporal hint on the epilogue traffic / also on the patch loads / nowhere, 410: 12 units + the epilogue hint (= 400, production)), 412 / 413 the three-launch Winograd layer with split-operand GEMMs (2 / 3
  * bf16 planes on the 128 x 128 plane-major prototype kernel), 421 / 422 / 423 the component GEMMs alone: native f32 / 2 planes / 3 planes, 480 / 481 / 482 a direct layer on the PAIR kernels (fp16 / bf16 pieces / without the 256 x 256 tile), 472 the
  * engine's pair-interleaved two-plane GEMM alone (473 / 475 / 476: without its global loads / MFMAs / output stores); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
