@@ -109,45 +109,62 @@ def cpu_baseline(size, T, budget_s=20.0):
         n += 1
     per_step = (time.time() - t0) / n
     return {"value": 1.0 / (per_step * T), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "B=1 %dx%d, %d of T=%d reverse_sde steps timed (%.2f s/step), extrapolated x%d; torch %s CPU, "
-                      "%d threads (affinity/cgroup quota; host has %d logical CPUs). kind=port: oracle/torch_cpu_port.py, the "
-                      "reference's algorithm restated in torch-CPU functional ops and golden-checked against the reference "
-                      "(tests/test_oracle_golden.py) - /root/reference itself does not exist on the GPU box.  The unmodified "
-                      "reference classes measured in the build container (SURVEY.md 8d): 0.034 images/s at 1x128x128, T=100, 8 vCPU"
-                      % (size, size, n, T, per_step, T, torch.__version__, cores, os.cpu_count() or 0)}
+            "sample": "B=1 %dx%d, %d of T=%d reverse_sde steps timed (%.2f s/step), extrapolated; torch %s CPU, %d threads of %d logical CPUs; "
+                      "kind=port: oracle/torch_cpu_port.py (golden-checked against the reference, which does not exist on the GPU box; the "
+                      "reference itself in the build container: 0.034 images/s at 1x128x128 T=100, 8 vCPU)"
+                      % (size, size, n, T, per_step, torch.__version__, cores, os.cpu_count() or 0)}
 
 
-# kernel classes of the event pass: description prefix (engine_plan.hip `op.desc`) -> the HIP kernels behind it
+# kernel classes of the event pass: description prefix (engine_plan.hip `op.desc`) -> the HIP kernel behind it (short names: the
+# whole JSON line has to fit the driver's 8 KB record; what each kernel does is in DESIGN.md section 3)
 KERNEL_CLASSES = [
-    ("conv(winograd F4 fused)", "wino4_fused64_kernel / wino4_fused_kernel (Winograd F(4x4,3x3): input transform + 36 component GEMMs + output transform + epilogue in one kernel)"),
-    ("conv(winograd", "gemm_zloop_kernel (component GEMMs of the three-launch Winograd layers)"),
-    ("conv(split f16x2 winograd F4 fused)", "wino4_fused64_kernel<PAIR> (the fused Winograd kernel with f32 operands as fp16 hi+lo pairs: 4 cross products on v_mfma_f32_16x16x32_f16; FLOPs counted once per f32 product)"),
-    ("conv(split", "gemm_split2i_kernel (f32 operands as 16-bit hi+lo pairs, 3 cross products on v_mfma_f32_32x32x16_bf16 / _f16; FLOPs counted once per f32 product)"),
-    ("conv M=", "conv_igemm_kernel / gemm_zloop_kernel (direct implicit-GEMM layers: 1x1, 4x4 s2, 7x7, narrow 3x3)"),
+    ("conv(winograd F4 fused)", "wino4_fused64_kernel"),
+    ("conv(winograd", "gemm_zloop_kernel (Winograd component GEMMs)"),
+    ("conv(split f16x2 winograd F4 fused)", "wino4_fused64_kernel<PAIR>"),
+    ("conv(split f16x2) M=", "conv_igemm_kernel<PAIR>"),
+    ("conv(split bf16x2) M=", "conv_igemm_kernel<PAIR>"),
+    ("conv(split", "gemm_split2i_kernel"),
+    ("conv(bf16) M=", "conv_igemm_kernel<bf16>"),
+    ("conv(fp16) M=", "conv_igemm_kernel<f16>"),
+    ("conv M=", "conv_igemm_kernel / gemm_zloop_kernel (direct layers)"),
     ("conv", "conv kernels (other)"),
-    ("wino_", "wino_input_kernel / wino_output_kernel (transforms of the three-launch Winograd layers)"),
-    ("linear_attention", "attn_kv_ctx_kernel / attn_q_out_fused_kernel / attn_ctx_* (LinearAttention)"),
+    ("naf_chain", "naf_chain_kernel"),
+    ("wino_", "wino_input_kernel / wino_output_kernel"),
+    ("linear_attention", "attn_kv_ctx_kernel / attn_q_out_fused_kernel"),
     ("full_attention", "full_attn_kernel"),
     ("layernorm", "layernorm_kernel"),
 ]
+OTHER_CLASS = "other (prep / FiLM row / update / pointwise)"
+
+
+def op_class(desc):
+    name = next((n for pre, n in KERNEL_CLASSES if desc.startswith(pre)), OTHER_CLASS)
+    if name in ("conv_igemm_kernel<bf16>", "conv_igemm_kernel<f16>") and " k=3x3 s=1 " in desc:
+        return "conv3x3_halo_bf16_kernel" + ("<f16>" if "f16" in name else "")   # LDS-resident halo tile (conv_halo.hip)
+    return name
 
 
 def op_classes(op_text):
     """Parse irsde_op_profile's text (one line per launch group of ONE network evaluation: `ms  description`) into
-    {class name: [ms, executed flops]}."""
+    {class name: [ms, executed flops, launches]}."""
     out = {}
     for line in op_text.splitlines():
         parts = line.split(None, 2)
         if len(parts) < 3 or parts[1] != "ms":
             continue
         ms, desc = float(parts[0]), parts[2]
-        name = next((n for pre, n in KERNEL_CLASSES if desc.startswith(pre)), "other (prep / FiLM row / state update / NAFNet pointwise)")
         fl = float(desc.split("flops=")[1].split()[0]) if "flops=" in desc else 0.0
         ex = float(desc.split("exec=")[1].split()[0]) if "exec=" in desc else fl
-        acc = out.setdefault(name, [0.0, 0.0])
+        acc = out.setdefault(op_class(desc), [0.0, 0.0, 0])
         acc[0] += ms
         acc[1] += ex
+        acc[2] += 1
     return out
+
+
+def _r(x, nd=4):
+    """Round to nd significant digits (keeps the JSON line short)."""
+    return float("%.*g" % (nd, x)) if isinstance(x, float) else x
 
 
 def roofline_object(prof, op_text, w):
@@ -160,78 +177,73 @@ def roofline_object(prof, op_text, w):
     peak = PEAK_FP32_TFLOPS if fp32 else PEAK_BF16_TFLOPS
     classes = op_classes(op_text)
     tot = sum(v[0] for v in classes.values()) or 1.0
-    mfma_classes = sorted(((n, v) for n, v in classes.items() if v[1] > 0), key=lambda kv: -kv[1][0])
+    nev = max(prof["net_evals"], 1)
     r = {
         "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "mfma_kernel_frac": exe / peak,
         "algorithmic_equiv_TFLOPs": alg,
-        "timing": "separate untimed pass after the timed region: eager launches, hipEvent pair around every kernel on the engine stream, %d network evaluations" % int(prof["net_evals"]),
-        "kernel": "; ".join("%s: %.1f%% of the evaluation" % (n, 100.0 * v[0] / tot) for n, v in sorted(classes.items(), key=lambda kv: -kv[1][0])),
-        "launches_per_evaluation": int(round(prof["conv_launches"] / max(prof["net_evals"], 1))),
+        "timing": "untimed pass after the timed region: hipEvent pair around every kernel on the engine stream, %d evaluations" % int(nev),
+        "launches_per_evaluation": sum(v[2] for v in classes.values()),
+        "conv_launches_per_evaluation": int(round(prof["conv_launches"] / nev)),
         "avg_launch_ms": (prof["conv_ms"] + prof["wino_ms"]) / max(prof["conv_launches"], 1),
-        "flops_per_launch": prof["conv_flops"] / max(prof["conv_launches"], 1),
         "executed_flops_per_launch": prof["conv_exec_flops"] / max(prof["conv_launches"], 1),
         "algorithmic_bytes_per_launch": prof["conv_bytes"] / max(prof["conv_launches"], 1),
-        "executed_TFLOPs_mfma_kernels_only": exe,
-        "kernel_time_share": {"conv": prof["conv_ms"] / prof["wall_ms"], "layernorm": prof["ln_ms"] / prof["wall_ms"],
-                              "attention": prof["attn_ms"] / prof["wall_ms"], "winograd_transforms": prof["wino_ms"] / prof["wall_ms"],
-                              "other": prof["other_ms"] / prof["wall_ms"]},
         # north_star also asks for the HBM-roofline fraction: ideal-fusion conv bytes / wall / 8 TB/s
         "hbm_algorithmic_GBps": prof["conv_bytes"] / (prof["wall_ms"] * 1e-3) / 1e9,
         "hbm_frac": prof["conv_bytes"] / (prof["wall_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
         "whole_path_TFLOPs": prof["conv_flops"] / (prof["wall_ms"] * 1e-3) / 1e12,
     }
-    if mfma_classes:
-        n, v = mfma_classes[0]
-        r["dominant_kernel"] = {"name": n, "time_share": v[0] / tot, "ms_per_evaluation": v[0],
-                                "executed_TFLOPs": v[1] / (v[0] * 1e-3) / 1e12, "frac": v[1] / (v[0] * 1e-3) / 1e12 / peak}
-        r["per_kernel"] = [{"name": n, "time_share": v[0] / tot, "ms_per_evaluation": v[0], "executed_TFLOPs": v[1] / (v[0] * 1e-3) / 1e12,
-                            "frac": v[1] / (v[0] * 1e-3) / 1e12 / peak} for n, v in mfma_classes]
+
+    def products(n):   # 16-bit MFMA products a split-mode kernel issues per f32 product (0: the kernel runs at `peak`)
+        if w["dtype"] not in ("fp32_split", "fp32_split_f16"):
+            return 0.0
+        return 4.0 if n.startswith("wino4_fused64_kernel<PAIR>") else 3.0 if (n.startswith("gemm_split2i") or "<PAIR>" in n) else 0.0
+
+    def kfrac(n, v):
+        tf = v[1] / (v[0] * 1e-3) / 1e12
+        return products(n) * tf / PEAK_BF16_TFLOPS if products(n) else tf / peak
+
+    # per kernel class of ONE evaluation, by time: share of the evaluation, ms, launches, executed TFLOP/s and fraction of its roof
+    per = [{"name": n, "share": _r(v[0] / tot, 3), "ms": _r(v[0], 4), "n": v[2],
+            **({"TFLOPs": _r(v[1] / (v[0] * 1e-3) / 1e12, 4), "frac": _r(kfrac(n, v), 3)} if v[1] > 0 and v[0] > 0 else {})}
+           for n, v in sorted(classes.items(), key=lambda kv: -kv[1][0])]
+    r["per_kernel"] = per
+    dom = next((k for k in per if "frac" in k), None)
+    if dom:
+        r["dominant_kernel"] = {"name": dom["name"], "time_share": dom["share"], "ms_per_evaluation": dom["ms"],
+                                "executed_TFLOPs": dom["TFLOPs"], "frac": dom["frac"]}
     if w["dtype"] in ("fp32_split", "fp32_split_f16"):
-        # two pipes in one evaluation: a pair kernel issues 3 16-bit MFMA products per f32 product.  `frac` = the pipe time the executed
-        # work needs at each kernel's own roof / the measured MFMA-kernel time: a true fraction (<= 1); `achieved` stays f32-equivalent
-        def products(n):   # 16-bit MFMA products per f32 product (0: an f32-MFMA kernel)
-            return 3.0 if n.startswith("gemm_split2i_kernel") else 4.0 if n.startswith("wino4_fused64_kernel<PAIR>") else 0.0
-        # (`classes` is ONE evaluation of the plan, the profile's times cover net_evals of them)
-        need = max(prof["net_evals"], 1) * sum(v[1] * (products(n) / (PEAK_BF16_TFLOPS * 1e12) if products(n) else 1.0 / (PEAK_FP32_TFLOPS * 1e12))
-                                               for n, v in classes.items())
+        # two pipes in one evaluation: `frac` = the pipe time the executed work needs at each kernel's own roof / the measured
+        # MFMA-kernel time (a true fraction); `achieved` stays f32-equivalent (FLOPs counted once per f32 product)
+        need = nev * sum(v[1] * (products(n) / (PEAK_BF16_TFLOPS * 1e12) if products(n) else 1.0 / (PEAK_FP32_TFLOPS * 1e12))
+                         for n, v in classes.items())
         r["frac"] = need / conv_t
         r["mfma_kernel_frac"] = need / (prof["conv_ms"] * 1e-3)
         r["peak"] = None
         r["achieved_vs_f32_roof"] = ach / PEAK_FP32_TFLOPS
-        for k in r.get("per_kernel", []) + ([r["dominant_kernel"]] if "dominant_kernel" in r else []):
-            if products(k["name"]):
-                k["frac"] = products(k["name"]) * k["executed_TFLOPs"] / PEAK_BF16_TFLOPS
-        r["note"] = ("split modes: FLOPs are counted once per f32 product and compared with the f32 MFMA roof as a speed reference; the pair GEMMs "
-                     "themselves execute 3 (the fused Winograd twin: 4) 16-bit MFMA products per f32 product on the bf16 / f16 pipe; frac = pipe time needed at each kernel's own roof / measured time")
     if not fp32:
         # 16-bit operands: 16x the MFMA rate turns the convolutions L2/HBM-bound, so quote the HBM roof first
         gbps = prof["conv_bytes"] / (prof["conv_ms"] * 1e-3) / 1e9
         r.update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                  "mfma_TFLOPs": alg, "mfma_frac": alg / PEAK_BF16_TFLOPS,
-                  "achieved_note": "ideal-fusion conv bytes / conv kernel time (v_mfma_f32_32x32x16_bf16|f16 kernels)"})
-    return r
+                  "mfma_TFLOPs": alg, "mfma_frac": alg / PEAK_BF16_TFLOPS})
+    return {k: _r(v) for k, v in r.items()}
 
 
 DTYPE_LABEL = {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate+state",
                "bf16_act": "bf16 operands + bf16 activation storage / f32 accumulate+state",
                "fp16": "f16 operands / f32 accumulate+state",
-               "fp32_split": "f32 storage / state / transforms; deep Winograd component GEMMs and direct layers on bf16 hi+lo operand pairs (3 cross products on the bf16 MFMA, f32 accumulate)",
-               "fp32_split_f16": "f32 storage / state / transforms; deep Winograd component GEMMs, direct layers and attention projections on fp16 hi+lo operand pairs (22+ significand bits: fp32-equivalent per layer; 3 cross products on the f16 MFMA, f32 accumulate)"}
+               "fp32_split": "f32 storage+state; GEMM operands as bf16 hi+lo pairs (3 products on the bf16 MFMA)",
+               "fp32_split_f16": "f32 storage+state; GEMM operands as fp16 hi+lo pairs (22+ significand bits, 3 products on the f16 MFMA)"}
 
 # the other BASELINE.json configs + the 512x512 batch north_star names: timed after the headline, reported under `secondary`
+# (tags are short on purpose: every entry has to survive in the driver's 8 KB record; DESIGN.md section 5 spells them out)
 SECONDARY = [
-    dict(tag="BASELINE configs[2]: reverse_ode, bf16", model="unet", dtype="bf16_act", mode="ode", batch=16, size=256, T=100),
-    dict(tag="BASELINE configs[3]: Refusion NAFNet 8x512x512 T=200", model="nafnet", dtype="fp32", mode="sde", batch=8, size=512, T=200),
-    dict(tag="BASELINE configs[4]: Latent-Refusion 64x64x4 latent, batch 64, fp16", model="latent", dtype="fp16", mode="sde", batch=64, size=256, T=100),
-    dict(tag="north_star 512x512 batch: IR-SDE UNet 16x512x512", model="unet", dtype="fp32", mode="sde", batch=16, size=512, T=100),
-    dict(tag="BASELINE configs[1] workload in the opt-in fp32_split_f16 mode (IRSDE_FLAG_SPLIT_F16X2: fp32-equivalent per layer; error table: profiles/r03_split_error_table.txt)",
-         model="unet", dtype="fp32_split_f16", mode="sde", batch=16, size=256, T=100),
-    dict(tag="BASELINE configs[1] workload in the opt-in fp32_split mode (IRSDE_FLAG_SPLIT_BF16X2: 16-bit operand pairs, f32 exponent range)",
-         model="unet", dtype="fp32_split", mode="sde", batch=16, size=256, T=100),
-    dict(tag="BASELINE configs[3] workload (Refusion NAFNet 8x512x512 T=200) in the opt-in fp32_split_f16 mode",
-         model="nafnet", dtype="fp32_split_f16", mode="sde", batch=8, size=512, T=200),
-    dict(tag="north_star 512x512 batch (IR-SDE UNet 16x512x512) in the opt-in fp32_split_f16 mode",
-         model="unet", dtype="fp32_split_f16", mode="sde", batch=16, size=512, T=100),
+    dict(tag="configs[2] unet 16x256 ode bf16_act", model="unet", dtype="bf16_act", mode="ode", batch=16, size=256, T=100),
+    dict(tag="configs[3] nafnet 8x512 T=200 f32", model="nafnet", dtype="fp32", mode="sde", batch=8, size=512, T=200),
+    dict(tag="configs[4] latent 64x(64x64x4) fp16", model="latent", dtype="fp16", mode="sde", batch=64, size=256, T=100),
+    dict(tag="unet 16x512 f32", model="unet", dtype="fp32", mode="sde", batch=16, size=512, T=100),
+    dict(tag="configs[1] in fp32_split_f16", model="unet", dtype="fp32_split_f16", mode="sde", batch=16, size=256, T=100),
+    dict(tag="configs[3] in fp32_split_f16", model="nafnet", dtype="fp32_split_f16", mode="sde", batch=8, size=512, T=200),
+    dict(tag="strong-scaling shard: unet 2x256 f32", model="unet", dtype="fp32", mode="sde", batch=2, size=256, T=100),
 ]
 
 
@@ -449,9 +461,30 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    if a.scaling == "strong" and a.batch < world:
+        sys.exit("bench.py: --scaling strong needs --batch >= --gpus (%d images over %d ranks leaves empty shards)" % (a.batch, world))
+
+    def all_ok(ok):
+        """True only if EVERY rank says ok (so a failure on one rank makes all ranks skip the phase together instead of leaving the
+        others blocked in the next collective)."""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
     head = dict(model=a.model, dtype=a.dtype, mode=a.mode, batch=a.batch, size=a.size, T=a.T, max_sigma=a.max_sigma)
     is_default = (a.model, a.dtype, a.mode, a.batch, a.size, a.T, a.max_sigma, a.scaling) == ("unet", "fp32", "sde", 16, 256, 100, None, "weak")
+    t_setup = time.perf_counter()
     wl = Workload(P, head, dev, rank, world, a.scaling)
+    wl.short_call(2)          # untimed: weight upload + repack, plan build, graph capture (what 8 simultaneous ranks would contend on)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    setup_s = [t_setup]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, t_setup)
+        setup_s = [float(x) for x in parts]
     dt, per_rank, out = timed(wl, a.steps, a.warmup, world, dev)
     assert out.shape[0] == wl.nglobal and bool(torch.isfinite(out).all())
 
@@ -471,8 +504,9 @@ def main():
             "vs_baseline": None, "dtype": DTYPE_LABEL[a.dtype], "data": "synthetic",
             "config": {"workload": workload_text(head, wl.n_evals), "compute_dtype": a.dtype, "global_batch": wl.nglobal,
                        "parallelism": "batch-shard x%d (%s scaling; no collective in the T loop; final all_gather over %s)" % (world, a.scaling, gather_txt)},
-            "rank_ms_per_step": {"min": 1000.0 * min(per_rank) / a.steps, "max": 1000.0 * max(per_rank) / a.steps,
-                                 "note": "each rank's own sampler time (before the closing barrier)"},
+            "rank_ms_per_step": {"min": _r(1000.0 * min(per_rank) / a.steps), "max": _r(1000.0 * max(per_rank) / a.steps)},
+            # per rank: model build + weight upload / repack + plan + graph capture + a 2-step sampler call, before the timed region
+            "rank_setup_s": {"min": _r(min(setup_s), 3), "max": _r(max(setup_s), 3)},
         }
         if prof is not None and prof["conv_ms"] > 0:
             r = roofline_object(prof, op_text, head)
@@ -483,39 +517,49 @@ def main():
                 if is_default:
                     pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc_hbm.json"))
                     traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"]
-                    traffic_src = "profiles/%s (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)" % pm[-1]
+                    traffic_src = "profiles/%s (builder's rocprofv3 PMC passes of this command; not measured in this run)" % pm[-1]
             except (OSError, IndexError, KeyError, ValueError):
                 traffic, traffic_src = None, None
             r.update({"traffic": traffic, "traffic_source": traffic_src,
-                      "traffic_unit": "bytes per conv launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes, profiles/*_bench_pmc_hbm.txt)"})
+                      "traffic_unit": "bytes per conv launch (2 x FETCH_SIZE + WRITE_SIZE)"})
             res["roofline"] = r
 
-    # ---- secondary workloads: the other BASELINE configs, after the headline has been timed; failures never lose the headline
+    # ---- secondary workloads: the other BASELINE configs, after the headline has been timed.  Every phase that ends in a collective
+    # is entered only if ALL ranks got there (all_ok), so one rank's failure (OOM, plan error) cannot strand the others and lose the headline
     if is_default and not a.no_secondary and not oversub:
         del wl, out
         torch.cuda.empty_cache()
         sec = []
         for w in SECONDARY:
-            entry = {"workload": None, "tag": w["tag"]}
+            entry = {"tag": w["tag"]}
+            swl, ok = None, True
             try:
                 swl = Workload(P, w, dev, rank, world, "weak")
-                entry["workload"] = workload_text(w, swl.n_evals)
                 swl.short_call(3)                                   # untimed: plan, graph capture, clocks
-                sdt, sranks, sout = timed(swl, 1, 0, world, dev)
-                assert sout.shape[0] == swl.nglobal and bool(torch.isfinite(sout).all())
-                entry.update({"value": swl.nglobal / sdt, "unit": "images/s", "ms_per_step": 1000.0 * sdt, "steps": 1,
-                              "warmup": "one 3-step sampler call (plan + graph capture)", "n_gpus": world, "global_batch": swl.nglobal,
-                              "dtype": DTYPE_LABEL[w["dtype"]], "mode": "reverse_" + w["mode"], "T": w["T"]})
-                if rank == 0:
-                    sp, sop = swl.profile_pass(3)
-                    if sp["conv_ms"] > 0:
-                        rr = roofline_object(sp, sop, w)
-                        entry["roofline"] = {k: rr[k] for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_kernel_frac", "hbm_frac",
-                                                                "whole_path_TFLOPs", "algorithmic_equiv_TFLOPs", "dominant_kernel",
-                                                                "achieved_vs_f32_roof", "note") if k in rr}
-                del swl, sout
             except Exception as ex:  # noqa: BLE001
-                entry["error"] = repr(ex)
+                entry["error"], ok = repr(ex)[:200], False
+            if all_ok(ok):
+                try:
+                    sdt, sranks, sout = timed(swl, 1, 0, world, dev)
+                    assert sout.shape[0] == swl.nglobal and bool(torch.isfinite(sout).all())
+                    entry.update({"value": _r(swl.nglobal / sdt), "unit": "images/s", "ms_per_step": _r(1000.0 * sdt), "steps": 1,
+                                  "ms_per_evaluation": _r(1000.0 * sdt / swl.n_evals), "n_gpus": world, "global_batch": swl.nglobal,
+                                  "mode": "reverse_" + w["mode"], "T": w["T"], "dtype": w["dtype"]})
+                    if rank == 0:
+                        sp, sop = swl.profile_pass(3)
+                        if sp["conv_ms"] > 0:
+                            rr = roofline_object(sp, sop, w)
+                            keep = {k: rr[k] for k in ("bound", "achieved", "unit", "frac", "mfma_kernel_frac", "hbm_frac", "whole_path_TFLOPs",
+                                                       "launches_per_evaluation", "achieved_vs_f32_roof") if k in rr}
+                            if "dominant_kernel" in rr:
+                                keep["dominant_kernel"] = {k: rr["dominant_kernel"][k] for k in ("name", "time_share", "frac")}
+                            entry["roofline"] = keep
+                    del sout
+                except Exception as ex:  # noqa: BLE001
+                    entry["error"] = repr(ex)[:200]
+            elif "error" not in entry:
+                entry["error"] = "skipped: another rank failed to set this workload up"
+            del swl
             torch.cuda.empty_cache()
             sec.append(entry)
         if rank == 0:
@@ -527,7 +571,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(a.size, a.T)
             except Exception as ex:  # the GPU number must not be lost to a host-side problem
                 res["cpu_baseline"] = {"value": None, "error": repr(ex)}
-        print(json.dumps(res))
+        print(json.dumps(res, separators=(",", ":")))
     if world > 1:
         dist.destroy_process_group()
 

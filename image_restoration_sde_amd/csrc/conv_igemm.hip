@@ -1349,6 +1349,7 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.w_pair) {   // split-operand arithmetic (IRSDE_FLAG_SPLIT_BF16X2 / _F16X2): the PAIR kernels on fp32 storage
         if (p.w_bf || p.in_bf16 || p.out_bf16 || p.nz != 1) throw HipError("launch_conv: split-operand pairs go with fp32 storage, one component");
         if (p.in_scale && p.C1) throw HipError("launch_conv: in_scale needs a single source");
+        if (p.ln_g) throw HipError("launch_conv: the fused LayerNorm epilogue (BN == Cout) is not available on the PAIR tiles");
         const int nk = p.KH * p.KW * (Ctot / 32);
         static const int t256 = tuning_env_int("IRSDE_PAIR_TILE256", 1);
         // 256 x 256: half the staging work per MFMA (160 KB of LDS: one block per CU) — where it still fills the 256 CUs

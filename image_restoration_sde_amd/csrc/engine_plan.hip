@@ -49,8 +49,10 @@ struct Builder {
         if (!naive && (e->cfg.flags & IRSDE_FLAG_BF16)) {
             p.w_bf = e->bf16_copy(p.w, (size_t)p.Cout * p.KH * p.KW * (p.C0 + p.C1));
             p.f16 = (e->cfg.flags & IRSDE_FLAG_FP16) ? 1 : 0;
-        } else if (!naive && (e->cfg.flags & (IRSDE_FLAG_SPLIT_BF16X2 | IRSDE_FLAG_SPLIT_F16X2)) && p.Cout >= 64 && p.nz == 1 &&
+        } else if (!naive && (e->cfg.flags & (IRSDE_FLAG_SPLIT_BF16X2 | IRSDE_FLAG_SPLIT_F16X2)) && p.Cout >= 64 && p.nz == 1 && !p.ln_g &&
                    p.KH * p.KW * (p.C0 + p.C1) >= split_direct_min_k()) {
+            // (!ln_g: the fused LayerNorm epilogue normalises over the tile's BN columns and needs BN == Cout, which the PAIR tile
+            //  choice does not guarantee — to_out layers of the IRSDE_FLAG_NO_FUSED_ATTN plan stay on the f32 kernel)
             // split-operand arithmetic for the direct layers too (PAIR kernels): fp32 storage, 16-bit hi + lo operand pairs
             const size_t nw = (size_t)p.Cout * p.KH * p.KW * (p.C0 + p.C1);
             const auto pc = e->pair_copy_il(p.w, (size_t)p.Cout, p.KH * p.KW * (p.C0 + p.C1));

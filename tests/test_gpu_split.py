@@ -128,6 +128,31 @@ def test_split_mode_plan_and_forward_vs_reference_golden(golden, mode):
 
 
 @pytest.mark.parametrize("mode", ["fp32_split", "fp32_split_f16"])
+def test_split_mode_with_qkv_tensor_attention_small_maps(mode):
+    """SPLIT | NO_FUSED_ATTN on small feature maps.  attn_tail fuses LayerNorm g2 into the to_out 1x1 conv (K = 128,
+    Cout = 128: pair-eligible); that epilogue normalises over the tile's BN columns, so the layer must stay on a BN == Cout tile
+    (the f32 kernel) instead of the PAIR <128, 64> tile that M < 256 would select.  nf=32 depth=3: C = 128 at 8 x 8 (M = 128)."""
+    nf, depth = 32, 3
+    params = O.synth_params(seed=3, nf=nf, depth=depth)
+    outs = []
+    for flags in (_lib.FLAG_NO_FUSED_ATTN, _lib.FLAG_NO_FUSED_ATTN | {"fp32_split": _lib.FLAG_SPLIT_BF16X2, "fp32_split_f16": _lib.FLAG_SPLIT_F16X2}[mode]):
+        m = P.ConditionalUNet(3, 3, nf, depth=depth)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        m.engine_flags = flags
+        m = m.to("cuda:0").eval()
+        for hw in (32, 16):
+            lq, xT = O.synth_inputs(77, 2, hw, hw)
+            outs.append(m(torch.from_numpy(xT).cuda(), torch.from_numpy(lq).cuda(), 33).cpu().numpy())
+    for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+        e = relerr(b, a)
+        note("%s + NO_FUSED_ATTN nf=32 depth=3 %dx%d vs f32 plan: %.3g" % (mode, a.shape[-1], a.shape[-1], e))
+        assert e < (2e-4 if mode == "fp32_split" else 2e-5)
+    lq, xT = O.synth_inputs(77, 2, 32, 32)
+    want = O.unet_forward(params, xT, lq, 33, depth=depth)          # float64 oracle: the split plan itself is right, not just close to f32
+    assert relerr(outs[2], want) < (2e-4 if mode == "fp32_split" else 2e-5)
+
+
+@pytest.mark.parametrize("mode", ["fp32_split", "fp32_split_f16"])
 def test_split_mode_samplers_T100_vs_reference_golden(golden, mode):
     """Full T=100 reverse_ode and reverse_sde at 256 x 256 in the split modes vs the REAL reference (fp32), through a
     batch of 4 (so that every deep layer, also the 32 x 32 level with 4 x 64 = 256 Winograd tiles, runs the pair GEMM as in the

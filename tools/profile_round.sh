@@ -19,11 +19,11 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 F=$(find "$OUT/pmc_FETCH_SIZE" -name "*counter_collection.csv" | head -1)
 W=$(find "$OUT/pmc_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
-[ -n "$F" ] && [ -n "$W" ] && python "$REPO/tools/pmc_summary.py" "$F" "$W" 3 "$OUT/bench_pmc_hbm" > /dev/null 2> "$OUT/pmc_summary.err"
+[ -n "$F" ] && [ -n "$W" ] && python "$REPO/tools/pmc_summary.py" "$F" "$W" 5 "$OUT/bench_pmc_hbm" > /dev/null 2> "$OUT/pmc_summary.err"
 # 3. MFMA-pipe busy fraction per kernel
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o pmc -- $BENCH --steps 1 --warmup 0 --T 3 --no-profile > /dev/null 2> "$OUT/pmc_mfma.err"
 M=$(find "$OUT/pmc_mfma" -name "*counter_collection.csv" | head -1)
-[ -n "$M" ] && python "$REPO/tools/pmc_mfma_summary.py" "$M" "bench.py default workload ($*), 3 network evaluations" > "$OUT/bench_pmc_mfma.txt" 2>> "$OUT/pmc_mfma.err"
+[ -n "$M" ] && python "$REPO/tools/pmc_mfma_summary.py" "$M" "bench.py default workload ($*), 5 network evaluations (2-step setup call + T=3)" > "$OUT/bench_pmc_mfma.txt" 2>> "$OUT/pmc_mfma.err"
 # keep the merged-back volume small: summaries only
 rm -rf "$OUT/kt" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_mfma"
 ls -la "$OUT"
