@@ -564,7 +564,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             launch_wino_output(sp.out, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dU); (void)hipFree(dUs); (void)hipFree(dVs); (void)hipFree(dM);
-        } else if (naive == 35 || naive == 37) {  // the 64-cout fused Winograd kernel on fp16 hi + lo operand pairs (IRSDE_FLAG_SPLIT_F16X2's big-feature-map path)
+        } else if (naive == 35 || naive == 37 || naive == 39) {  // the 64-cout fused Winograd kernel on fp16 hi + lo operand pairs (IRSDE_FLAG_SPLIT_F16X2's big-feature-map path)
             if (!wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -579,10 +579,10 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             launch_wino_fused64_split_weights(dUf, dUp, Uf.size(), usc, s);
             p.pair_scale = 1.0f / (kWinoFused64PairVScale * usc);
-            launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, naive == 37 ? 4 + 16 : 4);   // 37: + cout block by XCD where legal
+            launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, naive == 39 ? 9 : naive == 37 ? 4 + 64 : 4);   // 37: + cout block by XCD where legal; 39: r03's one-block-per-tile-group kernel
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf); (void)hipFree(dUp);
-        } else if (naive == 33 || naive == 34 || naive == 36) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
+        } else if (naive == 33 || naive == 34 || naive == 36 || naive == 38) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
             if (naive == 33 ? !wino_fused_eligible(p) : !wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -592,7 +592,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dUf, Uf.size() * 4));
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             if (naive == 33) launch_wino_fused(p, dUf, s);
-            else launch_wino_fused64(p, dUf, s, naive == 36 ? 16 : 0);   // 36: + cout block by XCD where legal
+            else launch_wino_fused64(p, dUf, s, naive == 38 ? 10 : naive == 36 ? 64 : 0);   // 36: + cout block by XCD where legal; 38: r03's one-block-per-tile-group kernel
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf);
         } else if (wino_tile) {  // naive / 10: 0 = production dispatch, 1 / 2 = force the batch-loop GEMM kernel (all / 2 components per block)
@@ -815,13 +815,13 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         const bool split_v = variant == 412 || variant == 413 || variant == 422 || variant == 423;  // split-operand GEMMs: 41x whole three-launch layer, 42x the GEMM alone; x = planes
         unsigned short *dUs = nullptr, *dVs = nullptr;
         WinoSplitPlan sp{};
-        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410)) {
+        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410) || (variant >= 430 && variant <= 435)) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
             if (variant != 81 && variant != 421 && !split_v && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
             if (variant >= 400 && !wino_fused64_eligible(p)) throw HipError("bench_conv: shape not eligible for the 64-cout fused Winograd kernel");
-            if (variant == 404 || variant == 405) {  // the fp16-pair twin: the random weights as hi / lo halves
+            if (variant == 404 || variant == 405 || variant == 434) {  // the fp16-pair twin: the random weights as hi / lo halves
                 float* dUp = nullptr;
                 IRSDE_HIP_CHECK(hipMalloc(&dUp, (size_t)36 * nw / 9 * 4));
                 launch_wino_fused64_split_weights(dU, reinterpret_cast<unsigned short*>(dUp), (size_t)36 * nw / 9, 256.0f, s);
@@ -888,12 +888,53 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
             (void)hipStreamDestroy(s);
             return;
         }
+        if (variant == 435) {  // the persistent fused Winograd kernel once with per-wave cycle stamps: prints the averaged budget
+            const int nbp = 256;
+            unsigned long long* dd = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dd, (size_t)nbp * 64 * 8));
+            launch_wino_fused64(p, dU, s, 20);  // warm
+            IRSDE_HIP_CHECK(hipMemsetAsync(dd, 0, (size_t)nbp * 64 * 8, s));
+            wino_fused64_set_debug(dd);
+            launch_wino_fused64(p, dU, s, 25);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            wino_fused64_set_debug(nullptr);
+            std::vector<unsigned long long> hd((size_t)nbp * 64);
+            IRSDE_HIP_CHECK(hipMemcpy(hd.data(), dd, hd.size() * 8, hipMemcpyDeviceToHost));
+            double acc[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+            int nw[2] = {0, 0};
+            for (int bi = 0; bi < nbp; ++bi)
+                for (int w = 0; w < 8; ++w) {
+                    const unsigned long long* t = &hd[((size_t)bi * 8 + w) * 8];
+                    if (!t[3]) continue;
+                    for (int k = 0; k < 5; ++k) acc[w >= 4][k] += (double)t[k];
+                    nw[w >= 4]++;
+                }
+            const int nchk = Cin / 32;
+            const double items = acc[0][4] / std::max(nw[0], 1), chunks = acc[1][4] / std::max(nw[1], 1);
+            printf("wino4_fused64p stamps B=%d %dx%d Cin=%d Cout=%d: %.1f items x %d chunks per block; shader cycles per wave (mean over %d + %d waves)\n", B, p.Ho, p.Wo,
+                   Cin, Cout, items, nchk, nw[0], nw[1]);
+            printf("  MFMA waves    : kernel %.0f = K-loop compute %.0f (%.0f per chunk; MFMA floor 9216) + barrier wait %.0f (%.0f per chunk) + epilogue %.0f (%.0f per item)\n",
+                   acc[0][3] / nw[0], acc[0][0] / nw[0], acc[0][0] / nw[0] / (items * nchk), acc[0][1] / nw[0], acc[0][1] / nw[0] / (items * nchk), acc[0][2] / nw[0],
+                   acc[0][2] / nw[0] / items);
+            printf("  producer waves: kernel %.0f = load issue %.0f (%.0f per chunk) + data wait, transform, LDS writes %.0f (%.0f per chunk) + barrier wait %.0f (%.0f per chunk)\n",
+                   acc[1][3] / nw[1], acc[1][0] / nw[1], acc[1][0] / nw[1] / chunks, acc[1][1] / nw[1], acc[1][1] / nw[1] / chunks, acc[1][2] / nw[1], acc[1][2] / nw[1] / chunks);
+            fflush(stdout);
+            (void)hipFree(dd);
+            (void)hipFree(dU);
+            dU = nullptr;
+            *ms_out = 0.0;
+            (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
+            (void)hipStreamDestroy(s);
+            return;
+        }
         auto run = [&] {
             if (variant == 80) {
                 launch_wino_fused(p, dU, s);
             } else if (variant >= 400 && variant <= 410) {  // 406 / 407 / 408: non-temporal epilogue traffic / + patch loads / no hint at all
                  // 64-cout fused Winograd kernel: 400 production, 401 no weight traffic, 402 no patch traffic, 403 short U ring, 404 / 405 fp16 pairs (ring 12 / 18)
                 launch_wino_fused64(p, dU, s, variant - 400);
+            } else if (variant >= 430 && variant <= 434) {  // r04 persistent kernel: 430 production, 431 / 432 weight fragments / patch loads read zeros, 433 no nt hint, 434 fp16 pairs
+                launch_wino_fused64(p, dU, s, variant - 410);
             } else if (variant >= 83 && variant <= 82 + 255) {  // tuning aids: dflags = variant - 82 (1 no patch traffic, 2 no weight traffic, 4 / 8 producer / MFMA waves at s_setprio 2)
                 launch_wino_fused(p, dU, s, nullptr, variant - 82);
             } else if (variant == 81) {

@@ -647,6 +647,351 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64_kernel(const ConvParam
     }
 }
 
+
+// ================================================================================================================
+// r04: wino4_fused64p_kernel — the 64-cout kernel as a PERSISTENT block with the output transform in registers.
+//
+// r03's kernel spent ~11 us per block outside its K loop (first patch fetch + transform before the first MFMA, then
+// accumulators -> LDS -> output transform -> stores) with ONE block per CU, so nothing overlapped it: 0.35 of the MFMA roof on
+// the 2-chunk 64 -> 64 layers, 0.54 on 4-chunk layers (profiles/r03_wino_fused64_notes.md).  Two changes remove it:
+//  * wave = 16-cout block (not 9 components): MFMA wave w owns couts 16 w .. 16 w + 15 of the block's 64 and ALL 36 components
+//    (36 accumulators of 4 registers = the same 144).  With A = U (16 couts x 4 k) and B = V (4 k x 16 tiles) a lane (tile =
+//    l & 15, g = l >> 4) ends up holding M_z[tile][4 g .. 4 g + 3] for every component z — everything A^T M A needs for its
+//    (tile, 4 couts).  The output transform is lane-local: no LDS staging, no barrier, and the V buffers are never aliased.
+//    Cost: every wave reads all of V from LDS (4 x the ds_read_b128 traffic: 288 KB per chunk and CU, ~30 B/clk of the 256 the
+//    LDS delivers) and a store instruction covers 16 segments of 64 B (the four waves fill the other quarters of the same lines).
+//  * one block per CU walks its tile groups (virtual block id = blockIdx.x + k gridDim.x, the same XCD-aware item map as
+//    before): the producer waves run straight on into the next tile group — its chunk 0 is transformed while the MFMA waves
+//    finish the last chunk, chunk 1 during their epilogue — and the weight-fragment ring prefetches across the boundary.
+// V double buffer, one barrier per 32-channel chunk, exactly as in wino4_fused64_kernel; producer code unchanged.
+// ================================================================================================================
+struct W6Item { int nblk, gx, gy, b; };
+
+__device__ __forceinline__ W6Item w6_item(const int v, const int total, const int NB, const int GX, const int GY, const int xcd_nb) {
+    int nblk, g_;
+    if (xcd_nb) {
+        const int xcd = v & 7;
+        nblk = xcd % NB;
+        g_ = (xcd / NB) * (total / 8) + (v >> 3);
+    } else {
+        const int xcd = v & 7, q = total >> 3, r = total & 7;
+        const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        nblk = wgid % NB;
+        g_ = wgid / NB;
+    }
+    W6Item it;
+    it.nblk = nblk;
+    it.gx = g_ % GX; g_ /= GX;
+    it.gy = g_ % GY;
+    it.b = g_ / GY;
+    return it;
+}
+
+// lane-local output transform + epilogue of the persistent kernel: acc[z] = M_z[tile][n .. n + 3].
+// Branch-free and address-arithmetic-free: residual / output go through buffer descriptors (lane offset in one VGPR, the pixel (i, j) of the
+// 4 x 4 tile in the scalar offset; tiles past the edge of a ragged group carry an out-of-range offset: loads return 0, stores are dropped).
+// The residual rows 0 / 1 are requested before the first transform stage, rows 2 / 3 behind it (the accumulators are dead by then), so
+// their latency hides under the ~400 vector instructions of A^T M A instead of being paid once per output row.
+// Between the two stages (the accumulators are dead, 144 registers free) the weight-fragment ring is primed with the next tile group's first units:
+// the ring is NOT live across the first stage (accumulators + ring + residual rows would not fit in 256 registers).
+template <bool NT, bool PAIR, bool RES, bool SILU, int RING>
+__device__ __forceinline__ void wf64p_epilogue(const ConvParams& p, floatx4 (&acc)[36], const unsigned lane_off_out, const unsigned lane_off_res,
+                                               const __amdgpu_buffer_rsrc_t rs_out, const __amdgpu_buffer_rsrc_t rs_res, const floatx4 bias,
+                                               const floatx4 fsc, const floatx4 fsh, floatx4 (&ring)[RING], const __amdgpu_buffer_rsrc_t rsrc_u,
+                                               const int uv_lane, const int nubase, const int zstride) {
+    constexpr int AUX = NT ? 2 : 0;
+    const int orow = p.Wo * p.out_stride * 4, opix = p.out_stride * 4;
+    const int rrow = p.Wo * p.res_stride * 4, rpix = p.res_stride * 4;
+    floatx4 rv[4][4];
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rv[i][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)lane_off_res, i * rrow + j * rpix, AUX));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // rows: u[i][s] = sum_r A^T[i][r] M[r][s]
+    floatx4 u[4][6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const floatx4 m0 = acc[s], m1 = acc[6 + s], m2 = acc[12 + s], m3 = acc[18 + s], m4 = acc[24 + s], m5 = acc[30 + s];
+        const floatx4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        u[0][s] = m0 + s12 + s34;
+        u[1][s] = d12 + 2.0f * d34;
+        u[2][s] = s12 + 4.0f * s34;
+        u[3][s] = d12 + 8.0f * d34 + m5;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RING; ++i)   // unit i of the next tile group's first chunk (r = 0, component i)
+        ring[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uv_lane, nubase + i * zstride, 0));
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 2; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rv[i][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)lane_off_res, i * rrow + j * rpix, AUX));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const floatx4 s12 = u[i][1] + u[i][2], d12 = u[i][1] - u[i][2], s34 = u[i][3] + u[i][4], d34 = u[i][3] - u[i][4];
+        floatx4 y[4];
+        y[0] = u[i][0] + s12 + s34;
+        y[1] = d12 + 2.0f * d34;
+        y[2] = s12 + 4.0f * s34;
+        y[3] = d12 + 8.0f * d34 + u[i][5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            floatx4 v = ((PAIR ? y[j] * p.pair_scale : y[j]) + bias) * fsc + fsh;   // (pair_scale: the operand scales, powers of two, undone exactly)
+            if constexpr (SILU) {
+                v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w);
+            }
+            if constexpr (RES) v = v + rv[i][j];
+            // The pixel offset goes into the VECTOR offset (one v_add), not the scalar one: with an SGPR soffset hipcc (ROCm 7.2) pads no wait state
+            // between a buffer_store_dwordx4 and the next VALU write of its data registers, and on gfx950 the store's last lanes (12-15 of every
+            // row of 16) then read the NEW value of the later dwords — measured: component .y of tile row 3 came out shifted by one pixel.
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), rs_out,
+                                                   (int)(lane_off_out + (unsigned)(i * orow + j * opix)), 0, AUX);
+        }
+    }
+}
+
+// STAMP (irsde_bench_conv 435): per-wave cycle totals into dbg[(block * 8 + wave) * 8 ..]: MFMA waves { K-loop compute, barrier wait, epilogue, whole
+// kernel, items }, producer waves { load issue, wait + transform + LDS writes, barrier wait, whole kernel, chunks }
+// EPI: the epilogue this instance is compiled for — bit 0 SiLU, bit 1 residual (0 .. 3: the production instances; four epilogue bodies behind
+// run-time branches in ONE kernel cost 250 spilled registers); -1: all four behind run-time branches (the measurement twins only)
+template <int RING, bool NOWT, bool NOPATCH, bool PAIR, bool NT, int EPI, bool STAMP = false>
+__global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX, const int GY,
+                                                                   const int NB, const unsigned in0_bytes, const unsigned in1_bytes,
+                                                                   const unsigned uf_bytes, const unsigned out_bytes, const unsigned res_bytes,
+                                                                   const int xcd_nb, const int total, unsigned long long* __restrict__ dbg) {
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_n = 0, st_t0 = 0, st_t = 0;
+    if constexpr (STAMP) st_t0 = st_t = __builtin_amdgcn_s_memtime();
+#define W6P_STAMP(ACC)                                                    \
+    if constexpr (STAMP) {                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        ACC += now_ - st_t;                                               \
+        st_t = now_;                                                      \
+    }
+    static_assert(72 % RING == 0 && RING % 4 == 0, "the ring must divide the 72 (component, k group) units of a chunk, in whole groups of 4");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int TH = p.Ho >> 2, TW = p.Wo >> 2;
+    const int Ctot = p.C0 + p.C1;
+    const int nch = Ctot / W6_KC;
+    const int nsub = Ctot / 16;   // 16-channel k groups (one U unit each)
+    const int nblocks = gridDim.x;
+
+    if (wave < 4) {
+        // =============================== MFMA waves: wave = 16-cout block ===============================
+        const int l15 = lane & 15, g = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Uf), 0, NOWT ? 0u : uf_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.out), 0, p.res ? res_bytes : 0u, 0x00020000);
+        floatx4 acc[36];
+#pragma unroll
+        for (int z = 0; z < 36; ++z) acc[z] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // unit (component z, k group s) of this wave's 16-cout block: 1 KB at Uf + (((z NB + nblk) nsub + s) 4 + wave) KB; lane reads 16 B
+        const int uv_lane = lane * 16;
+        const int zstride = NB * nsub * 4096;                       // bytes between components
+        int v = blockIdx.x;
+        W6Item it = w6_item(v, total, NB, GX, GY, xcd_nb);
+        int ubase = it.nblk * nsub * 4096 + wave * 1024;
+        // unit K of a chunk (0 .. 71; r = K / 36 major, component K % 36 minor) relative to the chunk's first k group
+        auto unit_rel = [&](const int K) { return (K % 36) * zstride + (K / 36) * 4096; };
+        floatx4 ring[RING];
+#pragma unroll
+        for (int i = 0; i < RING; ++i)
+            ring[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uv_lane, ubase + unit_rel(i), 0));
+        const int v_lane = g * 64 + ((l15 ^ g) * 4);
+        __syncthreads();  // the producers have filled V[0] of the first tile group
+        W6P_STAMP(st_b)
+        while (v < total) {
+            const int nv = v + nblocks;
+            const W6Item nit = w6_item(nv < total ? nv : v, total, NB, GX, GY, xcd_nb);
+            const int nubase = nit.nblk * nsub * 4096 + wave * 1024;
+            for (int c = 0; c < nch; ++c) {
+                const float* vb = smem + (c & 1) * W6_VBUF + v_lane;
+                const int cur_off = ubase + c * 8192;
+                const int nxt_off = (c + 1 < nch) ? cur_off + 8192 : nubase;   // units past this chunk: the next chunk / the next tile group's first
+                floatx4 vq[2][4];   // V fragments of the current / next group (ping-pong by group parity: no register copies)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vq[0][i] = *reinterpret_cast<const floatx4*>(vb + i * W6_ZS);
+                // 18 groups (r major) of 4 components: { V fragments of the next group, 16 MFMAs (k step outer, component inner: consecutive
+                // MFMAs hit different accumulators), refill of the 4 ring slots RING units ahead }.  The scheduling barriers pin that order.
+#pragma unroll
+                for (int gi = 0; gi < 18; ++gi) {
+                    const int zq = gi % 9, cu = gi & 1, nx = cu ^ 1;
+                    if (gi + 1 < 18) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            vq[nx][i] = *reinterpret_cast<const floatx4*>(vb + (4 * ((gi + 1) % 9) + i) * W6_ZS + ((gi + 1) / 9) * W6_RS);
+                    }
+                    if constexpr (PAIR) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[4 * zq + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wf_f16x8, ring[(gi * 4 + i) % RING]),
+                                                                                     __builtin_bit_cast(wf_f16x8, vq[cu][i]), acc[4 * zq + i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const floatx4 v_sw = {vq[cu][i][1], vq[cu][i][0], vq[cu][i][3], vq[cu][i][2]};
+                            acc[4 * zq + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wf_f16x8, ring[(gi * 4 + i) % RING]),
+                                                                                     __builtin_bit_cast(wf_f16x8, v_sw), acc[4 * zq + i], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc[4 * zq + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(gi * 4 + i) % RING][j], vq[cu][i][j], acc[4 * zq + i], 0, 0, 0);
+                            // without this the scheduler regroups a group's MFMAs by accumulator (4 dependent MFMAs in a row: 40 instead of 32 cycles each)
+                            if (j < 3) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ul = gi * 4 + i, K = ul + RING;   // 72 % RING == 0: the slot is static
+                        const int off = K < 72 ? cur_off + unit_rel(K) : nxt_off + unit_rel(K - 72);
+                        ring[ul % RING] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uv_lane, off, 0));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                W6P_STAMP(st_a)
+                __syncthreads();
+                W6P_STAMP(st_b)
+            }
+            // the producers are already transforming the next tile group; this wave's accumulators hold everything its output needs
+            {
+                const int n = it.nblk * 64 + wave * 16 + 4 * g;
+                const int tyy = it.gy * 4 + (l15 >> 2), txx = it.gx * 4 + (l15 & 3);
+                const bool ok = tyy < TH && txx < TW;
+                const unsigned pix = (unsigned)((it.b * p.Ho + 4 * tyy) * p.Wo + 4 * txx);
+                const unsigned off_out = ok ? (pix * (unsigned)p.out_stride + (unsigned)n) * 4u : WF_OOB;
+                const unsigned off_res = ok ? (pix * (unsigned)p.res_stride + (unsigned)n) * 4u : WF_OOB;
+                floatx4 bias = {0.f, 0.f, 0.f, 0.f}, fsc = {1.f, 1.f, 1.f, 1.f}, fsh = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bias = *reinterpret_cast<const floatx4*>(p.bias + n);
+                if (p.film) {
+                    const float* f = p.film + (size_t)it.b * p.film_bstride;
+                    fsc = *reinterpret_cast<const floatx4*>(f + n) + 1.0f;
+                    fsh = *reinterpret_cast<const floatx4*>(f + p.Cout + n);
+                }
+#define W6P_EPI(RES_, SILU_) wf64p_epilogue<NT, PAIR, RES_, SILU_, RING>(p, acc, off_out, off_res, rs_out, rs_res, bias, fsc, fsh, ring, rsrc_u, uv_lane, nubase, zstride)
+                if constexpr (EPI >= 0) {
+                    W6P_EPI((EPI & 2) != 0, (EPI & 1) != 0);
+                } else if (p.res) {
+                    if (p.silu) W6P_EPI(true, true); else W6P_EPI(true, false);
+                } else {
+                    if (p.silu) W6P_EPI(false, true); else W6P_EPI(false, false);
+                }
+#undef W6P_EPI
+            }
+#pragma unroll
+            for (int z = 0; z < 36; ++z) acc[z] = floatx4{0.f, 0.f, 0.f, 0.f};
+            v = nv; it = nit; ubase = nubase;
+            if constexpr (STAMP) st_n += 1;
+            W6P_STAMP(st_c)
+        }
+    } else {
+        // =============================== producer waves (as in wino4_fused64_kernel, running on across tile groups) ===============================
+        const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc1 =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1 ? p.in1 : p.in0), 0, p.in1 ? in1_bytes : 0u, 0x00020000);
+        const int cp = lane & 15;                          // channel pair of the chunk: channels 2cp, 2cp+1
+        const int tile = (wave - 4) * 4 + (lane >> 4);     // tile inside the 4 x 4 group
+        const int trow = tile >> 2, tcol = tile & 3;
+        const int kg = (cp >> 1) & 3;
+        // LDS float offset of (tile, channel pair): [r = cp >> 3][g = (cp >> 1) & 3][tile ^ g][j = 2 (cp & 1)]
+        const int vw_base = (cp >> 3) * W6_RS + kg * 64 + ((tile ^ kg) * 4) + 2 * (cp & 1);
+        const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
+        int rowpix[6], colpix[6];
+        unsigned voff[36];
+        floatx2 rawA[36], rawB[36];
+        int v = blockIdx.x;
+#define W6P_SET_ITEM(VID)                                                                                                    \
+    {                                                                                                                        \
+        const bool live_ = (VID) < total && !NOPATCH;                                                                        \
+        const W6Item pi_ = w6_item(live_ ? (VID) : 0, total, NB, GX, GY, xcd_nb);                                            \
+        const int tyy_ = pi_.gy * 4 + trow, txx_ = pi_.gx * 4 + tcol;                                                        \
+        const bool tile_ok_ = live_ && tyy_ < TH && txx_ < TW;                                                               \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                                      \
+            const int y = 4 * tyy_ - 1 + r, x = 4 * txx_ - 1 + r;                                                            \
+            rowpix[r] = (tile_ok_ && (unsigned)y < (unsigned)Hv) ? (pi_.b * p.Hin + (y >> p.in_shift)) * p.Win : -1;         \
+            colpix[r] = (tile_ok_ && (unsigned)x < (unsigned)Wv) ? (x >> p.in_shift) : -1;                                   \
+        }                                                                                                                    \
+    }
+#define W6P_BUILD_VOFF(PIXF)                                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 6; ++r) _Pragma("unroll") for (int s = 0; s < 6; ++s) voff[r * 6 + s] =            \
+        (rowpix[r] >= 0 && colpix[s] >= 0) ? (unsigned)(rowpix[r] + colpix[s]) * (unsigned)((PIXF)*4) + (unsigned)(cp * 8) : WF_OOB;
+#define W6P_LOAD_RAW(RAW, CI)                                                                                                \
+    {                                                                                                                        \
+        const int cc_ = (CI)*W6_KC;                                                                                          \
+        const bool second_ = cc_ >= p.C0;                                                                                    \
+        const int soff_ = (second_ ? cc_ - p.C0 : cc_) * 4;                                                                  \
+        const __amdgpu_buffer_rsrc_t rs_ = second_ ? rsrc1 : rsrc0;                                                          \
+        _Pragma("unroll") for (int e = 0; e < 36; ++e) RAW[e] =                                                              \
+            __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[e], soff_, 0));                  \
+    }
+// one chunk: loads of the NEXT chunk (the next tile group's chunk 0 behind the last one), transform of the current one into V[IT & 1]
+#define W6P_CHUNK(CUR, NXT, IT)                                                                                              \
+    {                                                                                                                        \
+        if ((IT) + 1 == nch) {                                                                                               \
+            W6P_SET_ITEM(v + nblocks)                                                                                        \
+            W6P_BUILD_VOFF(p.pix0)                                                                                           \
+            W6P_LOAD_RAW(NXT, 0)                                                                                             \
+        } else {                                                                                                             \
+            if (((IT) + 1) * W6_KC == p.C0) { W6P_BUILD_VOFF(p.pix1) }                                                       \
+            W6P_LOAD_RAW(NXT, (IT) + 1)                                                                                      \
+        }                                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        W6P_STAMP(st_a)                                                                                                      \
+        floatx2 w[6][6];                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 6; ++s) {                                                                      \
+            floatx2 col[6], tc[6];                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) col[r] = CUR[r * 6 + s];                                           \
+            bt6(col, tc);                                                                                                    \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) w[r][s] = tc[r];                                                   \
+        }                                                                                                                    \
+        float* vw = smem + ((IT)&1) * W6_VBUF + vw_base;                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                                      \
+            floatx2 o[6];                                                                                                    \
+            bt6(w[r], o);                                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < 6; ++s)                                                                    \
+                *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * W6_ZS) = PAIR ? wf_split_pair(o[s]) : o[s];                  \
+        }                                                                                                                    \
+        if constexpr (STAMP) st_n += 1;                                                                                      \
+        W6P_STAMP(st_b)                                                                                                      \
+        __syncthreads();                                                                                                     \
+        W6P_STAMP(st_c)                                                                                                      \
+    }
+        W6P_SET_ITEM(v)
+        W6P_BUILD_VOFF(p.pix0)
+        W6P_LOAD_RAW(rawA, 0)
+        while (v < total) {
+            for (int it = 0; it < nch; it += 2) {   // Ctot is a multiple of 64: the chunk count is even
+                W6P_CHUNK(rawA, rawB, it)
+                W6P_CHUNK(rawB, rawA, it + 1)
+            }
+            v += nblocks;
+        }
+#undef W6P_CHUNK
+#undef W6P_BUILD_VOFF
+#undef W6P_LOAD_RAW
+#undef W6P_SET_ITEM
+        __syncthreads();  // the MFMA waves' last chunk
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && dbg) {
+            unsigned long long* d = dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+            d[0] = st_a; d[1] = st_b; d[2] = st_c; d[3] = __builtin_amdgcn_s_memtime() - st_t0; d[4] = st_n;
+        }
+    }
+#undef W6P_STAMP
+}
+
 }  // namespace
 
 // Blocks the launch of launch_wino_fused(p, ...) creates (the size of the variant-82 stamp buffer: 64 stamps per block)
@@ -671,6 +1016,17 @@ void wino_fused_global_init() {
     W6_ATTR(W6_RING_ALT, false, false, true, 1);
     W6_ATTR(W6_RING_ALT, false, false, false, 1);
 #undef W6_ATTR
+#define W6P_ATTR(...) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused64p_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define W6P_ATTR4(...) W6P_ATTR(__VA_ARGS__, 0); W6P_ATTR(__VA_ARGS__, 1); W6P_ATTR(__VA_ARGS__, 2); W6P_ATTR(__VA_ARGS__, 3)
+    W6P_ATTR4(W6_RING_ALT, false, false, false, true);
+    W6P_ATTR4(W6_RING_ALT, false, false, true, true);
+    W6P_ATTR4(W6_RING_ALT, true, false, false, true);
+    W6P_ATTR4(W6_RING_ALT, false, true, false, true);
+    W6P_ATTR4(W6_RING_ALT, false, false, false, false);
+    W6P_ATTR(W6_RING_ALT, false, false, false, true, 0, true); W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, true);
+    W6P_ATTR(W6_RING_ALT, false, false, false, true, 2, true); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, true);
+#undef W6P_ATTR4
+#undef W6P_ATTR
 }
 
 // Geometry / feature check only (the plan decides where the fused kernel pays)
@@ -722,7 +1078,10 @@ void launch_wino_fused(const ConvParams& p, const float* Uf, hipStream_t s, unsi
 
 // ---- the 64-cout variant (r03) ----
 bool wino_fused64_eligible(const ConvParams& p) {
-    return wino_fused_eligible(p) && p.Cout % 64 == 0 && (p.C0 + p.C1) % 64 == 0;   // 32-channel chunks, processed in pairs
+    if (!wino_fused_eligible(p) || p.Cout % 64 || (p.C0 + p.C1) % 64) return false;   // 32-channel chunks, processed in pairs
+    // r04: the persistent kernel's epilogue addresses the output / residual through 32-bit buffer offsets too
+    const double lim = 2147483648.0 - 65536.0, npix = (double)p.B * p.Ho * p.Wo;
+    return 4.0 * npix * p.out_stride < lim && (!p.res || 4.0 * npix * p.res_stride < lim);
 }
 
 // U[z][n][c] -> Uf[z][n >> 6][c >> 4][(n >> 4) & 3][(c >> 2) & 3][n & 15][c & 3]: the fragment of one (component, 16-cout
@@ -757,6 +1116,10 @@ bool wino_fused64_xcd_nb(const ConvParams& p) {
     return b < 0.75 * a;
 }
 
+// tuning aid (irsde_bench_conv 435): the stamp buffer of the STAMP twin, 8 waves x 8 counters per persistent block
+static unsigned long long* g_w6p_dbg = nullptr;
+void wino_fused64_set_debug(unsigned long long* buf) { g_w6p_dbg = buf; }
+
 int wino_fused64_num_blocks(const ConvParams& p) {
     return p.B * ((p.Ho / 4 + 3) / 4) * ((p.Wo / 4 + 3) / 4) * (p.Cout / 64);
 }
@@ -783,13 +1146,62 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
     const unsigned in1_bytes = p.C1 ? (unsigned)((size_t)p.B * p.Hin * p.Win * p.pix1 * 4) : 0u;
     const unsigned uf_bytes = (unsigned)((size_t)36 * p.Cout * (p.C0 + p.C1) * 4);
     const dim3 grid((unsigned)(p.B * GY * GX * NB));
-    // variant + 16: the cout-block-by-XCD mapping wherever it is legal (test hook: the production choice follows the traffic model)
-    const bool force_xnb = (variant & 16) != 0;
-    variant &= 15;
+    // variant + 64: the cout-block-by-XCD mapping wherever it is legal (test hook: the production choice follows the traffic model)
+    const bool force_xnb = (variant & 64) != 0;
+    variant &= 63;
     const long long G_ = (long long)p.B * GY * GX;
     const int xcd_nb = (force_xnb ? (NB >= 2 && 8 % NB == 0 && G_ % (8 / NB) == 0) : wino_fused64_xcd_nb(p)) ? 1 : 0;
 #define W6_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64_kernel<__VA_ARGS__>), grid, dim3(WF_NT), W6_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, xcd_nb)
     static const bool nt = tuning_env_int("IRSDE_WINO_FUSED64_NT", 1) != 0;
+    // r04: the persistent kernel (one block per CU walks its tile groups, output transform in registers) is production;
+    // IRSDE_WINO_FUSED64_PERSIST=0 under IRSDE_TUNING=1 selects r03's one-block-per-tile-group kernel
+    static const bool persist = tuning_env_int("IRSDE_WINO_FUSED64_PERSIST", 1) != 0;
+    if (persist && (variant == 0 || variant == 4)) variant = variant == 0 ? 20 : 24;
+    if (variant >= 20) {   // 20 production f32, 21 weight fragments read zeros, 22 patch loads read zeros, 23 no non-temporal hint, 24 fp16 pairs
+        static const int ncu = [] {
+            int dev = 0, n = 0;
+            IRSDE_HIP_CHECK(hipGetDevice(&dev));
+            IRSDE_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+            return n > 0 ? n : 256;
+        }();
+        const int total = (int)grid.x;
+        const size_t npix_out = (size_t)p.B * p.Ho * p.Wo;
+        const size_t ob = npix_out * p.out_stride * 4, rb = p.res ? npix_out * p.res_stride * 4 : 0;
+        if (ob >= 0x7fff0000ull || rb >= 0x7fff0000ull) throw HipError("launch_wino_fused64: output / residual tensor too large for 32-bit buffer offsets");
+        const unsigned out_bytes = (unsigned)ob, res_bytes = (unsigned)rb;
+        // one block per CU; a multiple of 8 so that virtual block id % 8 stays the XCD of the block that runs it
+        const dim3 pgrid((unsigned)std::min(total, std::max(8, ncu & ~7)));
+#define W6P_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64p_kernel<__VA_ARGS__>), pgrid, dim3(WF_NT), W6_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, out_bytes, res_bytes, xcd_nb, total, g_w6p_dbg)
+        const int epi = (p.silu ? 1 : 0) | (p.res ? 2 : 0);   // one kernel instance per epilogue (see the EPI template parameter)
+#define W6P_LAUNCH_EPI(...)                                          \
+    switch (epi) {                                                   \
+        case 0: W6P_LAUNCH(W6_RING_ALT, __VA_ARGS__, 0); break;      \
+        case 1: W6P_LAUNCH(W6_RING_ALT, __VA_ARGS__, 1); break;      \
+        case 2: W6P_LAUNCH(W6_RING_ALT, __VA_ARGS__, 2); break;      \
+        default: W6P_LAUNCH(W6_RING_ALT, __VA_ARGS__, 3); break;     \
+    }
+#define W6P_LAUNCH_EPI_STAMP()                                                          \
+    switch (epi) {                                                                      \
+        case 0: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 0, true); break;     \
+        case 1: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 1, true); break;     \
+        case 2: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 2, true); break;     \
+        default: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 3, true); break;    \
+    }
+        switch (variant) {
+            case 20: W6P_LAUNCH_EPI(false, false, false, true) break;
+            case 21: W6P_LAUNCH_EPI(true, false, false, true) break;    // weight fragments read zeros
+            case 22: W6P_LAUNCH_EPI(false, true, false, true) break;    // patch loads read zeros
+            case 23: W6P_LAUNCH_EPI(false, false, false, false) break;  // no non-temporal hint
+            case 24: W6P_LAUNCH_EPI(false, false, true, true) break;    // fp16 pairs
+            case 25: W6P_LAUNCH_EPI_STAMP() break;                      // cycle stamps into the buffer of wino_fused64_set_debug()
+            default: throw HipError("launch_wino_fused64: bad variant");
+        }
+#undef W6P_LAUNCH_EPI_STAMP
+#undef W6P_LAUNCH_EPI
+#undef W6P_LAUNCH
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (variant == 0 && nt) variant = 10;   // 12 units in flight: with the epilogue hint the weights hit L2 more often, and the shorter ring has no spills (237 VGPRs)
     if (variant == 4 && nt) variant = 9;
     switch (variant) {

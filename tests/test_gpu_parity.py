@@ -208,6 +208,33 @@ def test_conv_wino_fused64_edges(shape):
     assert np.array_equal(got, run_conv(x0, x1, w, None, 1, 1, up, None, 0, None, naive=36)), shape
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 0, 96, 128, 128, 0), (6, 32, 32, 32, 32, 192, 1), (6, 64, 64, 96, 128, 64, 0)])
+def test_conv_wino_fused64_persistent_rounds(shape):
+    """r04: wino4_fused64p_kernel is one block per CU walking its tile groups (288 items each: more than the 256 CUs, ragged last
+    round): the producers run on into the next tile group (concat source / upsample offsets rebuilt at the boundary), the weight ring
+    prefetches across it, the output transform is lane-local.  Against the float64 oracle, r03's one-block-per-tile-group kernel (38 / 39),
+    the cout-block-by-XCD item map (bit-exact), and the fp16-pair twin."""
+    B, C0, C1, H, W, Cout, up = shape
+    rs = np.random.RandomState(B * 131 + Cout)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, 3, 3)) / np.sqrt((C0 + C1) * 9)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32)
+    film = (0.3 * rs.standard_normal((B, 2 * Cout))).astype(np.float32)
+    res = rs.standard_normal((B, Cout, H << up, W << up)).astype(np.float32)
+    ref = oracle_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, film_bstride=2 * Cout)
+    got = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=34, film_bstride=2 * Cout)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert relerr(got, ref) < 5e-5, shape
+    old = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=38, film_bstride=2 * Cout)
+    assert relerr(old, ref) < 5e-5 and relerr(got, old) < 2e-5, shape
+    assert np.array_equal(got, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=36, film_bstride=2 * Cout)), shape
+    pair = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=35, film_bstride=2 * Cout)
+    assert relerr(pair, ref) < 5e-5, shape
+    assert relerr(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=39, film_bstride=2 * Cout)) < 2e-5, shape
+    assert np.array_equal(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=37, film_bstride=2 * Cout)), shape
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 0, 32, 32, 128, 0), (1, 64, 64, 16, 16, 256, 1), (4, 64, 0, 16, 32, 512, 0), (3, 64, 0, 16, 16, 128, 0)])
 def test_conv_wino_fused64_xcd_mapping(shape):
     """wino4_fused64_kernel with cout block = XCD % NB (NB = 2 / 4 / 8; the last shape has 3 x 16 tile groups... an odd count the mapping
