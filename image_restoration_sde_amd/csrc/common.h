@@ -159,6 +159,7 @@ bool wino_fused64_eligible(const ConvParams& p);
 void wino_fused64_pack_weights(const float* U, int Cout, int Cin, float* Uf);
 void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, int variant = 0);
 void wino_fused64_set_debug(unsigned long long* buf);   // stamp buffer of launch variant 25 (irsde_bench_conv 435)
+void wino_fused64_set_opt(int opt);                     // OPT value of the tuning twins (launch variants 26 / 27; irsde_bench_conv 436 / 437)
 // the fp16-pair twin (variant 4): V is split as V / 16, the weights as scale * U (scale a power of two), p.pair_scale undoes both
 constexpr float kWinoFused64PairVScale = 0.0625f;
 void launch_wino_fused64_split_weights(const float* Uf, unsigned short* out, size_t nfloats, float scale, hipStream_t s);

@@ -582,7 +582,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, naive == 39 ? 9 : naive == 37 ? 4 + 64 : 4);   // 37: + cout block by XCD where legal; 39: r03's one-block-per-tile-group kernel
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf); (void)hipFree(dUp);
-        } else if (naive == 33 || naive == 34 || naive == 36 || naive == 38) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
+        } else if (naive == 33 || naive == 34 || naive == 36 || naive == 38 || (naive >= 40 && naive <= 44)) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
             if (naive == 33 ? !wino_fused_eligible(p) : !wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -592,7 +592,11 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dUf, Uf.size() * 4));
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             if (naive == 33) launch_wino_fused(p, dUf, s);
-            else launch_wino_fused64(p, dUf, s, naive == 38 ? 10 : naive == 36 ? 64 : 0);   // 36: + cout block by XCD where legal; 38: r03's one-block-per-tile-group kernel
+            else if (naive >= 40) {   // r04 tuning twins of the persistent kernel: OPT = 15 / 1 / 2 / 4 / 8
+                static const int opts[5] = {15, 1, 2, 4, 8};
+                wino_fused64_set_opt(opts[naive - 40]);
+                launch_wino_fused64(p, dUf, s, 26);
+            } else launch_wino_fused64(p, dUf, s, naive == 38 ? 10 : naive == 36 ? 64 : 0);   // 36: + cout block by XCD where legal; 38: r03's one-block-per-tile-group kernel
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf);
         } else if (wino_tile) {  // naive / 10: 0 = production dispatch, 1 / 2 = force the batch-loop GEMM kernel (all / 2 components per block)
@@ -815,7 +819,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         const bool split_v = variant == 412 || variant == 413 || variant == 422 || variant == 423;  // split-operand GEMMs: 41x whole three-launch layer, 42x the GEMM alone; x = planes
         unsigned short *dUs = nullptr, *dVs = nullptr;
         WinoSplitPlan sp{};
-        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410) || (variant >= 430 && variant <= 435)) {
+        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410) || (variant >= 430 && variant <= 435) || (variant >= 1000 && variant < 1064) || (variant >= 2000 && variant <= 2004)) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
@@ -888,14 +892,16 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
             (void)hipStreamDestroy(s);
             return;
         }
-        if (variant == 435) {  // the persistent fused Winograd kernel once with per-wave cycle stamps: prints the averaged budget
+        if (variant == 435 || (variant >= 2000 && variant <= 2004)) {  // the persistent fused Winograd kernel once with per-wave cycle stamps: prints the averaged budget
+            // 2000 + k: the stamp twins (k = 0 every r04 OPT bit, 1 no weight traffic, 2 no patch traffic, 3 patches from an L2-resident window, 4 = 435)
+            const int stamp_variant = variant == 435 || variant == 2004 ? 25 : 27 + (variant - 2000);
             const int nbp = 256;
             unsigned long long* dd = nullptr;
             IRSDE_HIP_CHECK(hipMalloc(&dd, (size_t)nbp * 64 * 8));
             launch_wino_fused64(p, dU, s, 20);  // warm
             IRSDE_HIP_CHECK(hipMemsetAsync(dd, 0, (size_t)nbp * 64 * 8, s));
             wino_fused64_set_debug(dd);
-            launch_wino_fused64(p, dU, s, 25);
+            launch_wino_fused64(p, dU, s, stamp_variant);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             wino_fused64_set_debug(nullptr);
             std::vector<unsigned long long> hd((size_t)nbp * 64);
@@ -933,6 +939,9 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
             } else if (variant >= 400 && variant <= 410) {  // 406 / 407 / 408: non-temporal epilogue traffic / + patch loads / no hint at all
                  // 64-cout fused Winograd kernel: 400 production, 401 no weight traffic, 402 no patch traffic, 403 short U ring, 404 / 405 fp16 pairs (ring 12 / 18)
                 launch_wino_fused64(p, dU, s, variant - 400);
+            } else if (variant >= 1000 && variant < 1064) {  // r04 tuning twins of the persistent kernel: OPT = variant - 1000 (see wino4_fused64p_kernel)
+                wino_fused64_set_opt(variant - 1000);
+                launch_wino_fused64(p, dU, s, 26);
             } else if (variant >= 430 && variant <= 434) {  // r04 persistent kernel: 430 production, 431 / 432 weight fragments / patch loads read zeros, 433 no nt hint, 434 fp16 pairs
                 launch_wino_fused64(p, dU, s, variant - 410);
             } else if (variant >= 83 && variant <= 82 + 255) {  // tuning aids: dflags = variant - 82 (1 no patch traffic, 2 no weight traffic, 4 / 8 producer / MFMA waves at s_setprio 2)

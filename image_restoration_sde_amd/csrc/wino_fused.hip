@@ -58,6 +58,17 @@ __device__ __forceinline__ void bt6(const floatx2* d, floatx2* t) {
     t[4] = fma2(-2.0f, a, b);                                  // 2 (d1 - d3) + (d4 - d2)
     t[5] = fma2(-5.0f, d[3], fma2(4.0f, d[1], d[5]));          // 4 d1 - 5 d3 + d5
 }
+// r04: the same transform in 12 operations (t1 / t2 share p = d4 - 4 d2, q = d3 - 4 d1); same number of roundings per output
+__device__ __forceinline__ void bt6_12(const floatx2* d, floatx2* t) {
+    t[0] = fma2(-5.0f, d[2], fma2(4.0f, d[0], d[4]));
+    const floatx2 p = fma2(-4.0f, d[2], d[4]), q = fma2(-4.0f, d[1], d[3]);
+    t[1] = p + q;                                              // (d3 + d4) - 4 (d1 + d2)
+    t[2] = p - q;                                              // 4 (d1 - d2) + (d4 - d3)
+    const floatx2 a = d[3] - d[1], b = d[4] - d[2];
+    t[3] = fma2(2.0f, a, b);
+    t[4] = fma2(-2.0f, a, b);
+    t[5] = fma2(-5.0f, d[3], fma2(4.0f, d[1], d[5]));
+}
 // A^T of F(4x4,3x3) along one axis
 __device__ __forceinline__ void at6(const float* m, float* y) {
     const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
@@ -762,7 +773,17 @@ __device__ __forceinline__ void wf64p_epilogue(const ConvParams& p, floatx4 (&ac
 // kernel, items }, producer waves { load issue, wait + transform + LDS writes, barrier wait, whole kernel, chunks }
 // EPI: the epilogue this instance is compiled for — bit 0 SiLU, bit 1 residual (0 .. 3: the production instances; four epilogue bodies behind
 // run-time branches in ONE kernel cost 250 spilled registers); -1: all four behind run-time branches (the measurement twins only)
-template <int RING, bool NOWT, bool NOPATCH, bool PAIR, bool NT, int EPI, bool STAMP = false>
+// OPT (r04 tuning bits; the production instances carry W6P_OPT_PROD):
+//   1  the ring refills of a tile group's LAST chunk that would fetch units past it read out of range (zeros, no traffic): the ring is not live across
+//      the epilogue (it is primed between the two transform stages), so those 12 KB per wave and tile group were fetched twice, and the epilogue began
+//      by draining them (s_waitcnt vmcnt(0) before their registers could be reused)
+//   2  bt6_12 instead of bt6 in the producers
+//   4  the producers issue the next chunk's 36 patch loads in six groups between the column passes instead of up front (the issue of a load blocks
+//      for ~280 cycles on the shared, saturated vector-memory queue: up front that is ~10k cycles during which the wave cannot transform)
+//   8  residual tile warmed into L2 during the last chunk (two LDS-DMA dword loads per MFMA lane into a scratch corner of LDS: no registers)
+//  16  measurement twin: every patch load reads from the first 512 KB of the input (L2-resident patches)
+//  32  bias / FiLM rows of the epilogue requested before the last chunk's barrier
+template <int RING, bool NOWT, bool NOPATCH, bool PAIR, bool NT, int EPI, bool STAMP = false, int OPT = 0>
 __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX, const int GY,
                                                                    const int NB, const unsigned in0_bytes, const unsigned in1_bytes,
                                                                    const unsigned uf_bytes, const unsigned out_bytes, const unsigned res_bytes,
@@ -814,10 +835,13 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
             const int nv = v + nblocks;
             const W6Item nit = w6_item(nv < total ? nv : v, total, NB, GX, GY, xcd_nb);
             const int nubase = nit.nblk * nsub * 4096 + wave * 1024;
+            floatx4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_fsc = {1.f, 1.f, 1.f, 1.f}, e_fsh = {0.f, 0.f, 0.f, 0.f};
             for (int c = 0; c < nch; ++c) {
                 const float* vb = smem + (c & 1) * W6_VBUF + v_lane;
                 const int cur_off = ubase + c * 8192;
-                const int nxt_off = (c + 1 < nch) ? cur_off + 8192 : nubase;   // units past this chunk: the next chunk / the next tile group's first
+                // units past this chunk: the next chunk / the next tile group's first (OPT & 1: the latter are re-fetched by the epilogue anyway: read out of range)
+                const int nxt_off = ((OPT & 1) || c + 1 < nch) ? cur_off + 8192 : nubase;
+                const int uv_nx = ((OPT & 1) && c + 1 == nch) ? (int)WF_OOB : uv_lane;
                 floatx4 vq[2][4];   // V fragments of the current / next group (ping-pong by group parity: no register copies)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) vq[0][i] = *reinterpret_cast<const floatx4*>(vb + i * W6_ZS);
@@ -856,11 +880,20 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
                     for (int i = 0; i < 4; ++i) {
                         const int ul = gi * 4 + i, K = ul + RING;   // 72 % RING == 0: the slot is static
                         const int off = K < 72 ? cur_off + unit_rel(K) : nxt_off + unit_rel(K - 72);
-                        ring[ul % RING] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uv_lane, off, 0));
+                        ring[ul % RING] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, K < 72 ? uv_lane : uv_nx, off, 0));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 W6P_STAMP(st_a)
+                if ((OPT & 32) && c + 1 == nch) {   // the epilogue's bias / FiLM rows: their latency hides under the barrier wait
+                    const int n = it.nblk * 64 + wave * 16 + 4 * g;
+                    if (p.bias) e_bias = *reinterpret_cast<const floatx4*>(p.bias + n);
+                    if (p.film) {
+                        const float* f = p.film + (size_t)it.b * p.film_bstride;
+                        e_fsc = *reinterpret_cast<const floatx4*>(f + n);
+                        e_fsh = *reinterpret_cast<const floatx4*>(f + p.Cout + n);
+                    }
+                }
                 __syncthreads();
                 W6P_STAMP(st_b)
             }
@@ -872,12 +905,16 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
                 const unsigned pix = (unsigned)((it.b * p.Ho + 4 * tyy) * p.Wo + 4 * txx);
                 const unsigned off_out = ok ? (pix * (unsigned)p.out_stride + (unsigned)n) * 4u : WF_OOB;
                 const unsigned off_res = ok ? (pix * (unsigned)p.res_stride + (unsigned)n) * 4u : WF_OOB;
-                floatx4 bias = {0.f, 0.f, 0.f, 0.f}, fsc = {1.f, 1.f, 1.f, 1.f}, fsh = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bias = *reinterpret_cast<const floatx4*>(p.bias + n);
-                if (p.film) {
-                    const float* f = p.film + (size_t)it.b * p.film_bstride;
-                    fsc = *reinterpret_cast<const floatx4*>(f + n) + 1.0f;
-                    fsh = *reinterpret_cast<const floatx4*>(f + p.Cout + n);
+                floatx4 bias = e_bias, fsc = e_fsc, fsh = e_fsh;
+                if constexpr (OPT & 32) {
+                    if (p.film) fsc = fsc + 1.0f;
+                } else {
+                    if (p.bias) bias = *reinterpret_cast<const floatx4*>(p.bias + n);
+                    if (p.film) {
+                        const float* f = p.film + (size_t)it.b * p.film_bstride;
+                        fsc = *reinterpret_cast<const floatx4*>(f + n) + 1.0f;
+                        fsh = *reinterpret_cast<const floatx4*>(f + p.Cout + n);
+                    }
                 }
 #define W6P_EPI(RES_, SILU_) wf64p_epilogue<NT, PAIR, RES_, SILU_, RING>(p, acc, off_out, off_res, rs_out, rs_res, bias, fsc, fsh, ring, rsrc_u, uv_lane, nubase, zstride)
                 if constexpr (EPI >= 0) {
@@ -925,40 +962,64 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
     }
 #define W6P_BUILD_VOFF(PIXF)                                                                                                 \
     _Pragma("unroll") for (int r = 0; r < 6; ++r) _Pragma("unroll") for (int s = 0; s < 6; ++s) voff[r * 6 + s] =            \
-        (rowpix[r] >= 0 && colpix[s] >= 0) ? (unsigned)(rowpix[r] + colpix[s]) * (unsigned)((PIXF)*4) + (unsigned)(cp * 8) : WF_OOB;
-#define W6P_LOAD_RAW(RAW, CI)                                                                                                \
-    {                                                                                                                        \
-        const int cc_ = (CI)*W6_KC;                                                                                          \
-        const bool second_ = cc_ >= p.C0;                                                                                    \
-        const int soff_ = (second_ ? cc_ - p.C0 : cc_) * 4;                                                                  \
-        const __amdgpu_buffer_rsrc_t rs_ = second_ ? rsrc1 : rsrc0;                                                          \
-        _Pragma("unroll") for (int e = 0; e < 36; ++e) RAW[e] =                                                              \
-            __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[e], soff_, 0));                  \
+        (rowpix[r] >= 0 && colpix[s] >= 0)                                                                                   \
+            ? (((unsigned)(rowpix[r] + colpix[s]) * (unsigned)((PIXF)*4) + (unsigned)(cp * 8)) & ((OPT & 16) ? 0x7ffffu : 0xffffffffu)) : WF_OOB;
+// OPT & 8: the residual tile of tile group VID (the one the MFMA waves are finishing) into L2: lane = (pixel row wave - 4, pixel column lane >> 4) of
+// tile lane & 15, the two 128-byte lines of its 64 output channels; the data lands in a scratch corner of LDS and is never read
+#define W6P_TOUCH(VID)                                                                                                       \
+    if ((VID) >= (int)blockIdx.x) {                                                                                          \
+        const W6Item ti_ = w6_item((VID), total, NB, GX, GY, xcd_nb);                                                        \
+        const int ty_ = ti_.gy * 4 + ((lane & 15) >> 2), tx_ = ti_.gx * 4 + (lane & 3);                                      \
+        if (ty_ < TH && tx_ < TW) {                                                                                          \
+            const size_t pix_ = ((size_t)ti_.b * p.Ho + 4 * ty_ + (wave - 4)) * p.Wo + 4 * tx_ + (lane >> 4);                \
+            const float* rp_ = p.res + pix_ * p.res_stride + ti_.nblk * 64;                                                  \
+            __attribute__((address_space(3))) void* sc_ = (__attribute__((address_space(3))) void*)(smem + 2 * W6_VBUF + (wave - 4) * 64); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rp_, sc_, 4, 0, 0);              \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rp_ + 32), sc_, 4, 0, 0);       \
+        }                                                                                                                    \
     }
+#define W6P_BT6(D, T) { if constexpr (OPT & 2) bt6_12(D, T); else bt6(D, T); }
 // one chunk: loads of the NEXT chunk (the next tile group's chunk 0 behind the last one), transform of the current one into V[IT & 1]
 #define W6P_CHUNK(CUR, NXT, IT)                                                                                              \
     {                                                                                                                        \
+        if constexpr ((OPT & 8) != 0 && EPI != 0 && EPI != 1) {                                                              \
+            if ((IT) == 0 && p.res) { W6P_TOUCH(v - nblocks) }                                                               \
+        }                                                                                                                    \
+        int ci_ = (IT) + 1;                                                                                                  \
         if ((IT) + 1 == nch) {                                                                                               \
             W6P_SET_ITEM(v + nblocks)                                                                                        \
             W6P_BUILD_VOFF(p.pix0)                                                                                           \
-            W6P_LOAD_RAW(NXT, 0)                                                                                             \
-        } else {                                                                                                             \
-            if (((IT) + 1) * W6_KC == p.C0) { W6P_BUILD_VOFF(p.pix1) }                                                       \
-            W6P_LOAD_RAW(NXT, (IT) + 1)                                                                                      \
+            ci_ = 0;                                                                                                         \
+        } else if (((IT) + 1) * W6_KC == p.C0) {                                                                             \
+            W6P_BUILD_VOFF(p.pix1)                                                                                           \
+        }                                                                                                                    \
+        const int cc_ = ci_ * W6_KC;                                                                                         \
+        const bool second_ = cc_ >= p.C0;                                                                                    \
+        const int soff_ = (second_ ? cc_ - p.C0 : cc_) * 4;                                                                  \
+        const __amdgpu_buffer_rsrc_t rs_ = second_ ? rsrc1 : rsrc0;                                                          \
+        if constexpr (!(OPT & 4)) {                                                                                          \
+            _Pragma("unroll") for (int e = 0; e < 36; ++e) NXT[e] =                                                          \
+                __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[e], soff_, 0));              \
         }                                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         W6P_STAMP(st_a)                                                                                                      \
         floatx2 w[6][6];                                                                                                     \
         _Pragma("unroll") for (int s = 0; s < 6; ++s) {                                                                      \
+            if constexpr ((OPT & 4) != 0) {                                                                                  \
+                _Pragma("unroll") for (int e = 6 * s; e < 6 * s + 6; ++e) NXT[e] =                                           \
+                    __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[e], soff_, 0));          \
+                __builtin_amdgcn_sched_barrier(0);                                                                           \
+            }                                                                                                                \
             floatx2 col[6], tc[6];                                                                                           \
             _Pragma("unroll") for (int r = 0; r < 6; ++r) col[r] = CUR[r * 6 + s];                                           \
-            bt6(col, tc);                                                                                                    \
+            W6P_BT6(col, tc)                                                                                                 \
             _Pragma("unroll") for (int r = 0; r < 6; ++r) w[r][s] = tc[r];                                                   \
+            if constexpr ((OPT & 4) != 0) __builtin_amdgcn_sched_barrier(0);                                                 \
         }                                                                                                                    \
         float* vw = smem + ((IT)&1) * W6_VBUF + vw_base;                                                                     \
         _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                                      \
             floatx2 o[6];                                                                                                    \
-            bt6(w[r], o);                                                                                                    \
+            W6P_BT6(w[r], o)                                                                                                 \
             _Pragma("unroll") for (int s = 0; s < 6; ++s)                                                                    \
                 *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * W6_ZS) = PAIR ? wf_split_pair(o[s]) : o[s];                  \
         }                                                                                                                    \
@@ -969,7 +1030,8 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
     }
         W6P_SET_ITEM(v)
         W6P_BUILD_VOFF(p.pix0)
-        W6P_LOAD_RAW(rawA, 0)
+        _Pragma("unroll") for (int e = 0; e < 36; ++e) rawA[e] =
+            __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rsrc0, (int)voff[e], 0, 0));
         while (v < total) {
             for (int it = 0; it < nch; it += 2) {   // Ctot is a multiple of 64: the chunk count is even
                 W6P_CHUNK(rawA, rawB, it)
@@ -977,9 +1039,13 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
             }
             v += nblocks;
         }
+        if constexpr ((OPT & 8) != 0 && EPI != 0 && EPI != 1) {
+            if (p.res) { W6P_TOUCH(v - nblocks) }
+        }
 #undef W6P_CHUNK
+#undef W6P_BT6
+#undef W6P_TOUCH
 #undef W6P_BUILD_VOFF
-#undef W6P_LOAD_RAW
 #undef W6P_SET_ITEM
         __syncthreads();  // the MFMA waves' last chunk
     }
@@ -1025,6 +1091,14 @@ void wino_fused_global_init() {
     W6P_ATTR4(W6_RING_ALT, false, false, false, false);
     W6P_ATTR(W6_RING_ALT, false, false, false, true, 0, true); W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, true);
     W6P_ATTR(W6_RING_ALT, false, false, false, true, 2, true); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, true);
+    // r04 tuning twins (irsde_bench_conv 436 .. 440): timed instances per OPT value, stamp instances for OPT = all / no weights / no patches / hot patches
+#define W6P_OPT_TIMED(O) W6P_ATTR(W6_RING_ALT, false, false, false, true, 0, false, O); W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, false, O); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, false, O)
+    W6P_OPT_TIMED(1); W6P_OPT_TIMED(2); W6P_OPT_TIMED(4); W6P_OPT_TIMED(8); W6P_OPT_TIMED(15);
+#undef W6P_OPT_TIMED
+    W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, true, 15); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, true, 15);
+    W6P_ATTR(W6_RING_ALT, true, false, false, true, 1, true, 0); W6P_ATTR(W6_RING_ALT, true, false, false, true, 3, true, 0);
+    W6P_ATTR(W6_RING_ALT, false, true, false, true, 1, true, 0); W6P_ATTR(W6_RING_ALT, false, true, false, true, 3, true, 0);
+    W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, true, 16); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, true, 16);
 #undef W6P_ATTR4
 #undef W6P_ATTR
 }
@@ -1119,6 +1193,9 @@ bool wino_fused64_xcd_nb(const ConvParams& p) {
 // tuning aid (irsde_bench_conv 435): the stamp buffer of the STAMP twin, 8 waves x 8 counters per persistent block
 static unsigned long long* g_w6p_dbg = nullptr;
 void wino_fused64_set_debug(unsigned long long* buf) { g_w6p_dbg = buf; }
+// tuning aid: the OPT value of launch variants 26 (timed) / 27 (stamps)
+static int g_w6p_opt = 0;
+void wino_fused64_set_opt(int opt) { g_w6p_opt = opt; }
 
 int wino_fused64_num_blocks(const ConvParams& p) {
     return p.B * ((p.Ho / 4 + 3) / 4) * ((p.Wo / 4 + 3) / 4) * (p.Cout / 64);
@@ -1171,7 +1248,7 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
         const unsigned out_bytes = (unsigned)ob, res_bytes = (unsigned)rb;
         // one block per CU; a multiple of 8 so that virtual block id % 8 stays the XCD of the block that runs it
         const dim3 pgrid((unsigned)std::min(total, std::max(8, ncu & ~7)));
-#define W6P_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64p_kernel<__VA_ARGS__>), pgrid, dim3(WF_NT), W6_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, out_bytes, res_bytes, xcd_nb, total, g_w6p_dbg)
+#define W6P_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64p_kernel<__VA_ARGS__>), pgrid, dim3(WF_NT), W6_LDS_BYTES + 1024, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, out_bytes, res_bytes, xcd_nb, total, g_w6p_dbg)
         const int epi = (p.silu ? 1 : 0) | (p.res ? 2 : 0);   // one kernel instance per epilogue (see the EPI template parameter)
 #define W6P_LAUNCH_EPI(...)                                          \
     switch (epi) {                                                   \
@@ -1194,6 +1271,34 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
             case 23: W6P_LAUNCH_EPI(false, false, false, false) break;  // no non-temporal hint
             case 24: W6P_LAUNCH_EPI(false, false, true, true) break;    // fp16 pairs
             case 25: W6P_LAUNCH_EPI_STAMP() break;                      // cycle stamps into the buffer of wino_fused64_set_debug()
+            case 26: {   // timed tuning twins: OPT = wino_fused64_set_opt() (epilogues 0 / 1 / 3 only)
+#define W6P_LAUNCH_OPT(O)                                                                  \
+    switch (epi) {                                                                         \
+        case 0: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 0, false, O); break;    \
+        case 1: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 1, false, O); break;    \
+        case 3: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 3, false, O); break;    \
+        default: throw HipError("launch_wino_fused64: tuning twins exist for epilogues 0 / 1 / 3");  \
+    }
+                switch (g_w6p_opt) {
+                    case 1: W6P_LAUNCH_OPT(1) break;
+                    case 2: W6P_LAUNCH_OPT(2) break;
+                    case 4: W6P_LAUNCH_OPT(4) break;
+                    case 8: W6P_LAUNCH_OPT(8) break;
+                    
+                    case 15: W6P_LAUNCH_OPT(15) break;
+                    default: throw HipError("launch_wino_fused64: no timed twin for this OPT");
+                }
+#undef W6P_LAUNCH_OPT
+                break;
+            }
+            case 27: case 28: case 29: case 30: {   // stamp twins: 27 OPT = all, 28 no weight traffic, 29 no patch traffic, 30 hot patches
+                if (epi != 1 && epi != 3) throw HipError("launch_wino_fused64: stamp twins exist for epilogues 1 / 3");
+                if (variant == 27) { if (epi == 1) W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 1, true, 15); else W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 3, true, 15); }
+                if (variant == 28) { if (epi == 1) W6P_LAUNCH(W6_RING_ALT, true, false, false, true, 1, true, 0); else W6P_LAUNCH(W6_RING_ALT, true, false, false, true, 3, true, 0); }
+                if (variant == 29) { if (epi == 1) W6P_LAUNCH(W6_RING_ALT, false, true, false, true, 1, true, 0); else W6P_LAUNCH(W6_RING_ALT, false, true, false, true, 3, true, 0); }
+                if (variant == 30) { if (epi == 1) W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 1, true, 16); else W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 3, true, 16); }
+                break;
+            }
             default: throw HipError("launch_wino_fused64: bad variant");
         }
 #undef W6P_LAUNCH_EPI_STAMP

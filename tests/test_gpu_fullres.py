@@ -581,7 +581,7 @@ def test_bench_single_gpu_line_small():
     assert res["n_gpus"] == 1 and res["unit"] == "images/s" and res["vs_baseline"] is None and res["dtype"] == "f32"
     r = res["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] <= 1 and r["unit"] == "TFLOP/s" and r["algorithmic_equiv_TFLOPs"] > 0
-    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-12
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3   # (the compact line rounds both to 4 significant digits)
 
 
 def _shard_worker(rank, world, port, q):

@@ -229,6 +229,11 @@ def test_conv_wino_fused64_persistent_rounds(shape):
     old = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=38, film_bstride=2 * Cout)
     assert relerr(old, ref) < 5e-5 and relerr(got, old) < 2e-5, shape
     assert np.array_equal(got, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=36, film_bstride=2 * Cout)), shape
+    for nv in (40, 41, 42, 43, 44):   # r04 tuning twins (OPT = 15 / 1 / 2 / 4 / 8): 41 / 43 / 44 change no arithmetic
+        tw = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout)
+        assert relerr(tw, ref) < 5e-5, (shape, nv)
+        if nv in (41, 43, 44):
+            assert np.array_equal(tw, got), (shape, nv)
     pair = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=35, film_bstride=2 * Cout)
     assert relerr(pair, ref) < 5e-5, shape
     assert relerr(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=39, film_bstride=2 * Cout)) < 2e-5, shape
