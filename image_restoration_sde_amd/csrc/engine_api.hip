@@ -564,7 +564,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             launch_wino_output(sp.out, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dU); (void)hipFree(dUs); (void)hipFree(dVs); (void)hipFree(dM);
-        } else if (naive == 35 || naive == 37 || naive == 39) {  // the 64-cout fused Winograd kernel on fp16 hi + lo operand pairs (IRSDE_FLAG_SPLIT_F16X2's big-feature-map path)
+        } else if (naive == 35 || naive == 37 || naive == 39 || naive == 46) {  // the 64-cout fused Winograd kernel on fp16 hi + lo operand pairs (IRSDE_FLAG_SPLIT_F16X2's big-feature-map path)
             if (!wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -579,10 +579,10 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             launch_wino_fused64_split_weights(dUf, dUp, Uf.size(), usc, s);
             p.pair_scale = 1.0f / (kWinoFused64PairVScale * usc);
-            launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, naive == 39 ? 9 : naive == 37 ? 4 + 64 : 4);   // 37: + cout block by XCD where legal; 39: r03's one-block-per-tile-group kernel
+            launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, naive == 46 ? 24 : naive == 39 ? 9 : naive == 37 ? 4 + 64 : 4);   // 37: + cout block by XCD where legal; 39: r03's one-block-per-tile-group kernel
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf); (void)hipFree(dUp);
-        } else if (naive == 33 || naive == 34 || naive == 36 || naive == 38 || (naive >= 40 && naive <= 44)) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
+        } else if (naive == 33 || naive == 34 || naive == 36 || naive == 38 || (naive >= 40 && naive <= 45)) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
             if (naive == 33 ? !wino_fused_eligible(p) : !wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -592,6 +592,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dUf, Uf.size() * 4));
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             if (naive == 33) launch_wino_fused(p, dUf, s);
+            else if (naive == 45) launch_wino_fused64(p, dUf, s, 20);   // r04's register-patch persistent kernel (production is the halo kernel)
             else if (naive >= 40) {   // r04 tuning twins of the persistent kernel: OPT = 15 / 1 / 2 / 4 / 8
                 static const int opts[5] = {15, 1, 2, 4, 8};
                 wino_fused64_set_opt(opts[naive - 40]);
@@ -819,13 +820,13 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         const bool split_v = variant == 412 || variant == 413 || variant == 422 || variant == 423;  // split-operand GEMMs: 41x whole three-launch layer, 42x the GEMM alone; x = planes
         unsigned short *dUs = nullptr, *dVs = nullptr;
         WinoSplitPlan sp{};
-        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410) || (variant >= 430 && variant <= 435) || (variant >= 1000 && variant < 1064) || (variant >= 2000 && variant <= 2004)) {
+        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410) || (variant >= 430 && variant <= 435) || (variant >= 440 && variant <= 444) || (variant >= 1000 && variant < 1064) || (variant >= 2000 && variant <= 2004)) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
             if (variant != 81 && variant != 421 && !split_v && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
             if (variant >= 400 && !wino_fused64_eligible(p)) throw HipError("bench_conv: shape not eligible for the 64-cout fused Winograd kernel");
-            if (variant == 404 || variant == 405 || variant == 434) {  // the fp16-pair twin: the random weights as hi / lo halves
+            if (variant == 404 || variant == 405 || variant == 434 || variant == 444) {  // the fp16-pair twin: the random weights as hi / lo halves
                 float* dUp = nullptr;
                 IRSDE_HIP_CHECK(hipMalloc(&dUp, (size_t)36 * nw / 9 * 4));
                 launch_wino_fused64_split_weights(dU, reinterpret_cast<unsigned short*>(dUp), (size_t)36 * nw / 9, 256.0f, s);
@@ -938,6 +939,8 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
                 launch_wino_fused(p, dU, s);
             } else if (variant >= 400 && variant <= 410) {  // 406 / 407 / 408: non-temporal epilogue traffic / + patch loads / no hint at all
                  // 64-cout fused Winograd kernel: 400 production, 401 no weight traffic, 402 no patch traffic, 403 short U ring, 404 / 405 fp16 pairs (ring 12 / 18)
+                launch_wino_fused64(p, dU, s, variant - 400);
+            } else if (variant >= 440 && variant <= 444) {  // r04 halo kernel: 440 production, 441 / 442 weight fragments / halo fetches read zeros, 444 fp16 pairs
                 launch_wino_fused64(p, dU, s, variant - 400);
             } else if (variant >= 1000 && variant < 1064) {  // r04 tuning twins of the persistent kernel: OPT = variant - 1000 (see wino4_fused64p_kernel)
                 wino_fused64_set_opt(variant - 1000);

@@ -1058,6 +1058,250 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
 #undef W6P_STAMP
 }
 
+
+// ================================================================================================================
+// r04: wino4_fused64h_kernel — the persistent 64-cout kernel with the input patches staged through LDS ("halo" kernel).
+//
+// What the cycle stamps of wino4_fused64p_kernel said (profiles/r04_wino_fused64p_stamps_b.txt): its MFMA waves run a 32-channel chunk in
+// ~10.1k cycles (floor 9216) and then wait ~5.5k cycles at the barrier for the producers, whose 36 buffer_load_dwordx2 per chunk take 15 - 20k
+// cycles to ISSUE (~430 cycles per instruction with four producer waves in the queue).  Patches served from an L2-resident window: no change;
+// no weight traffic: no change; patch loads out of range (no data): kernel -25 ... -30 %.  The cost is the number of small gather
+// instructions through the CU's vector-memory path, not bytes, L2 or HBM.  So:
+//  * the 18 x 18 pixel halo of a 4 x 4 tile group (the 16 overlapping 6 x 6 patches: 324 instead of 576 pixels) is fetched once per 16-channel
+//    chunk by LDS-DMA (buffer_load_dwordx4 ... lds: 16 pixels x 64 B per instruction, 23 instead of 144 / 2 instructions, no registers) into a
+//    ring of three halo buffers, two chunks ahead of its use;
+//  * the producers read their 6 x 6 patches from LDS (36 ds_read_b64), transform, and write V as before;
+//  * K chunk = 16 channels (V double buffer 2 x 39 KB + halos 3 x 23 KB = 146 KB); one barrier per chunk; the four producer waves work as two
+//    pairs on alternate chunks (pair = chunk parity = V buffer), so every producer wave has two chunk periods for one transform.
+// Halo layout (bytes): [row 18][slot 20][64 B = 16 channels]; pixel column col sits in slot (col & 3) * 5 + (col >> 2): the four tiles of a
+// tile row read four CONSECUTIVE slots (one 256-byte bank window) whatever the patch position, so the ds_read_b64 of 32 lanes (4 tiles x 8 channel
+// pairs) is conflict-free; lanes are ordered so that every 16-lane group of the V writes holds two tiles from different tile rows (their
+// tile ^ g columns fall into different halves of the 128-byte write window).
+// Pixels outside the image carry an out-of-range buffer offset: the DMA writes zeros.  The fused nearest x2 upsample reads input pixel
+// (y >> 1, x >> 1) for halo pixel (y, x).
+// MFMA waves, item walk, weight ring and the lane-local output transform are wino4_fused64p_kernel's (OPT bit 1: no double-fetched units).
+// ================================================================================================================
+constexpr int W7_KC = 16;
+constexpr int W7_ZS = 272;                        // floats per component plane of a V buffer: [g 4][tile ^ g 16][j 4] + 16 pad
+constexpr int W7_VBUF = 36 * W7_ZS;               // 39 168 B
+constexpr int W7_HROW = 20;                       // pixel slots per halo row (18 used)
+constexpr int W7_NDMA = 23;                       // 1 KB LDS-DMA instructions per halo: 368 slots >= 18 x 20
+constexpr int W7_HBUF_BYTES = W7_NDMA * 1024;
+constexpr int W7_NH = 3;
+constexpr int W7_LDS_BYTES = 2 * W7_VBUF * 4 + W7_NH * W7_HBUF_BYTES;   // 148 992 B
+
+template <int RING, bool NOWT, bool NOPATCH, bool PAIR, bool NT, int EPI>
+__global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX, const int GY,
+                                                                   const int NB, const unsigned in0_bytes, const unsigned in1_bytes,
+                                                                   const unsigned uf_bytes, const unsigned out_bytes, const unsigned res_bytes,
+                                                                   const int xcd_nb, const int total) {
+    static_assert(36 % RING == 0 && RING % 4 == 0, "the ring must divide the 36 units of a chunk, in whole groups of 4");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int TH = p.Ho >> 2, TW = p.Wo >> 2;
+    const int Ctot = p.C0 + p.C1;
+    const int nch = Ctot / W7_KC;      // a multiple of 4
+    const int nsub = nch;              // 16-channel k groups = chunks
+    const int nblocks = gridDim.x;
+
+    if (wave < 4) {
+        // =============================== MFMA waves: wave = 16-cout block ===============================
+        const int l15 = lane & 15, g = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Uf), 0, NOWT ? 0u : uf_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.out), 0, p.res ? res_bytes : 0u, 0x00020000);
+        floatx4 acc[36];
+#pragma unroll
+        for (int z = 0; z < 36; ++z) acc[z] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // unit (component z, k group s) of this wave's 16-cout block: 1 KB at Uf + (((z NB + nblk) nsub + s) 4 + wave) KB; lane reads 16 B
+        const int uv_lane = lane * 16;
+        const int zstride = NB * nsub * 4096;                       // bytes between components
+        int v = blockIdx.x;
+        W6Item it = w6_item(v, total, NB, GX, GY, xcd_nb);
+        int ubase = it.nblk * nsub * 4096 + wave * 1024;
+        floatx4 ring[RING];
+#pragma unroll
+        for (int i = 0; i < RING; ++i)
+            ring[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uv_lane, ubase + i * zstride, 0));
+        const int v_lane = g * 64 + ((l15 ^ g) * 4);
+        __syncthreads();  // P: the first two halos have landed
+        __syncthreads();  // B_0: V[0] of the first tile group is ready
+        while (v < total) {
+            const int nv = v + nblocks;
+            const W6Item nit = w6_item(nv < total ? nv : v, total, NB, GX, GY, xcd_nb);
+            const int nubase = nit.nblk * nsub * 4096 + wave * 1024;
+            for (int c = 0; c < nch; ++c) {
+                const float* vb = smem + (c & 1) * W7_VBUF + v_lane;
+                const int cur_off = ubase + c * 4096;
+                // units past this chunk belong to the next chunk; past the tile group's last chunk nothing is fetched (out-of-range lane offset: zeros, no traffic):
+                // the ring is primed for the next tile group between the two stages of the output transform
+                const int uv_nx = (c + 1 == nch) ? (int)WF_OOB : uv_lane;
+                floatx4 vq[2][4];   // V fragments of the current / next group of 4 components
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vq[0][i] = *reinterpret_cast<const floatx4*>(vb + i * W7_ZS);
+#pragma unroll
+                for (int gi = 0; gi < 9; ++gi) {
+                    const int cu = gi & 1, nx = cu ^ 1;
+                    if (gi + 1 < 9) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) vq[nx][i] = *reinterpret_cast<const floatx4*>(vb + (4 * (gi + 1) + i) * W7_ZS);
+                    }
+                    if constexpr (PAIR) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[4 * gi + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wf_f16x8, ring[(gi * 4 + i) % RING]),
+                                                                                     __builtin_bit_cast(wf_f16x8, vq[cu][i]), acc[4 * gi + i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const floatx4 v_sw = {vq[cu][i][1], vq[cu][i][0], vq[cu][i][3], vq[cu][i][2]};
+                            acc[4 * gi + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wf_f16x8, ring[(gi * 4 + i) % RING]),
+                                                                                     __builtin_bit_cast(wf_f16x8, v_sw), acc[4 * gi + i], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc[4 * gi + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(gi * 4 + i) % RING][j], vq[cu][i][j], acc[4 * gi + i], 0, 0, 0);
+                            if (j < 3) __builtin_amdgcn_sched_barrier(0);   // (keeps consecutive MFMAs on different accumulators)
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ul = gi * 4 + i, K = ul + RING;   // 36 % RING == 0: the slot is static
+                        const int off = K < 36 ? cur_off + K * zstride : cur_off + 4096 + (K - 36) * zstride;
+                        ring[ul % RING] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, K < 36 ? uv_lane : uv_nx, off, 0));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+            }
+            {
+                const int n = it.nblk * 64 + wave * 16 + 4 * g;
+                const int tyy = it.gy * 4 + (l15 >> 2), txx = it.gx * 4 + (l15 & 3);
+                const bool ok = tyy < TH && txx < TW;
+                const unsigned pix = (unsigned)((it.b * p.Ho + 4 * tyy) * p.Wo + 4 * txx);
+                const unsigned off_out = ok ? (pix * (unsigned)p.out_stride + (unsigned)n) * 4u : WF_OOB;
+                const unsigned off_res = ok ? (pix * (unsigned)p.res_stride + (unsigned)n) * 4u : WF_OOB;
+                floatx4 bias = {0.f, 0.f, 0.f, 0.f}, fsc = {1.f, 1.f, 1.f, 1.f}, fsh = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bias = *reinterpret_cast<const floatx4*>(p.bias + n);
+                if (p.film) {
+                    const float* f = p.film + (size_t)it.b * p.film_bstride;
+                    fsc = *reinterpret_cast<const floatx4*>(f + n) + 1.0f;
+                    fsh = *reinterpret_cast<const floatx4*>(f + p.Cout + n);
+                }
+                wf64p_epilogue<NT, PAIR, (EPI & 2) != 0, (EPI & 1) != 0, RING>(p, acc, off_out, off_res, rs_out, rs_res, bias, fsc, fsh, ring, rsrc_u, uv_lane, nubase, zstride);
+            }
+#pragma unroll
+            for (int z = 0; z < 36; ++z) acc[z] = floatx4{0.f, 0.f, 0.f, 0.f};
+            v = nv; it = nit; ubase = nubase;
+        }
+    } else {
+        // =============================== producer waves: two pairs on alternate chunks ===============================
+        const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, NOPATCH ? 0u : in0_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc1 =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1 ? p.in1 : p.in0), 0, (p.in1 && !NOPATCH) ? in1_bytes : 0u, 0x00020000);
+        const int pw = wave - 4, pair = pw >> 1, pp = pw & 1;
+        const int q = lane >> 3, cp = lane & 7;
+        const int trl = 2 * pp + (q & 1);                       // tile row / column inside the 4 x 4 group (see the lane order above)
+        const int tc = q < 4 ? q : ((q - 4) ^ 1);
+        const int tile = 4 * trl + tc, kg = cp >> 1;
+        // V float offset of (tile, channel pair) inside a component plane: [g = cp >> 1][tile ^ g][j = 2 (cp & 1)]
+        const int vw_base = kg * 64 + ((tile ^ kg) * 4) + 2 * (cp & 1);
+        const int hrd_base = ((4 * trl) * W7_HROW + tc) * 64 + cp * 8;   // byte offset of this lane's patch origin inside a halo buffer
+        char* const hbase = reinterpret_cast<char*>(smem) + 2 * W7_VBUF * 4;
+        const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
+        unsigned voff0[12], voff1[12];   // this lane's 16 bytes of DMA instruction d = 2 dd + pp: byte offset inside source 0 / 1
+        int vi = blockIdx.x;             // tile group and chunk of this pair's next halo fetch
+        int cd = pair;
+#define W7_SET_ITEM(VID)                                                                                                     \
+    {                                                                                                                        \
+        const bool live_ = (VID) < total;                                                                                    \
+        const W6Item pi_ = w6_item(live_ ? (VID) : 0, total, NB, GX, GY, xcd_nb);                                            \
+        _Pragma("unroll") for (int dd = 0; dd < 12; ++dd) {                                                                  \
+            const int sig_ = 16 * (2 * dd + pp) + (lane >> 2);                                                               \
+            const int hr_ = sig_ / W7_HROW, sc_ = sig_ - hr_ * W7_HROW;                                                      \
+            const int a_ = sc_ / 5, hc_ = 4 * (sc_ - 5 * a_) + a_;                                                           \
+            const int y_ = 16 * pi_.gy - 1 + hr_, x_ = 16 * pi_.gx - 1 + hc_;                                                \
+            const bool ok_ = live_ && hr_ < 18 && hc_ < 18 && (unsigned)y_ < (unsigned)Hv && (unsigned)x_ < (unsigned)Wv;    \
+            const unsigned pidx_ = (unsigned)((pi_.b * p.Hin + (y_ >> p.in_shift)) * p.Win + (x_ >> p.in_shift));           \
+            voff0[dd] = ok_ ? pidx_ * (unsigned)(p.pix0 * 4) + (unsigned)((lane & 3) * 16) : WF_OOB;                         \
+            voff1[dd] = ok_ ? pidx_ * (unsigned)(p.pix1 * 4) + (unsigned)((lane & 3) * 16) : WF_OOB;                         \
+        }                                                                                                                    \
+    }
+// this wave's half of the halo of chunk cd of tile group vi into halo buffer HB, then advance (vi, cd) to the pair's next chunk
+#define W7_DMA(HB)                                                                                                           \
+    {                                                                                                                        \
+        const int cc_ = cd * W7_KC;                                                                                          \
+        const bool second_ = cc_ >= p.C0;                                                                                    \
+        const int soff_ = (second_ ? cc_ - p.C0 : cc_) * 4;                                                                  \
+        char* const hb_ = hbase + (HB) * W7_HBUF_BYTES + pp * 1024;                                                          \
+        if (second_) {                                                                                                       \
+            _Pragma("unroll") for (int dd = 0; dd < 12; ++dd) if (2 * dd + pp < W7_NDMA)                                     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(hb_ + dd * 2048), 16, (int)voff1[dd], soff_, 0, 0); \
+        } else {                                                                                                             \
+            _Pragma("unroll") for (int dd = 0; dd < 12; ++dd) if (2 * dd + pp < W7_NDMA)                                     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)(hb_ + dd * 2048), 16, (int)voff0[dd], soff_, 0, 0); \
+        }                                                                                                                    \
+        cd += 2;                                                                                                             \
+        if (cd >= nch) {                                                                                                     \
+            cd -= nch;                                                                                                       \
+            vi += nblocks;                                                                                                   \
+            W7_SET_ITEM(vi)                                                                                                  \
+        }                                                                                                                    \
+    }
+        W7_SET_ITEM(vi)
+        W7_DMA(pair)   // chunk G = pair into halo buffer G % 3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // P
+        const int nitems = (total - (int)blockIdx.x + nblocks - 1) / nblocks;
+        const int Gtot = nitems * nch;
+        int hcur = 0;   // G % 3
+        for (int G = 0; G < Gtot; ++G) {
+            if ((G & 1) == pair) {
+                if (G + 2 < Gtot) {
+                    const int hn = hcur + 2 >= 3 ? hcur - 1 : hcur + 2;
+                    W7_DMA(hn)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // B^T d B of this lane's (tile, channel pair) from halo G % 3 into V[pair]
+                const char* hp = hbase + hcur * W7_HBUF_BYTES + hrd_base;
+                floatx2 w[6][6];
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    floatx2 col[6], tcv[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) col[r] = *reinterpret_cast<const floatx2*>(hp + (r * W7_HROW + (s & 3) * 5 + (s >> 2)) * 64);
+                    bt6(col, tcv);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) w[r][s] = tcv[r];
+                }
+                float* vw = smem + pair * W7_VBUF + vw_base;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    floatx2 o[6];
+                    bt6(w[r], o);
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * W7_ZS) = PAIR ? wf_split_pair(o[s]) : o[s];
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the halo this pair requested one step ago has landed
+            }
+            hcur = hcur == 2 ? 0 : hcur + 1;
+            // B_G as a raw barrier: __syncthreads() would drain vmcnt(0) here (the LDS-DMA counts as a pending LDS store), i.e. make every halo land
+            // inside the step that requested it; only this wave's V writes have to be complete
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+#undef W7_DMA
+#undef W7_SET_ITEM
+        __syncthreads();  // the MFMA waves' last chunk
+    }
+}
+
 }  // namespace
 
 // Blocks the launch of launch_wino_fused(p, ...) creates (the size of the variant-82 stamp buffer: 64 stamps per block)
@@ -1101,6 +1345,14 @@ void wino_fused_global_init() {
     W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, true, 16); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, true, 16);
 #undef W6P_ATTR4
 #undef W6P_ATTR
+#define W7_ATTR(...) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused64h_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define W7_ATTR4(...) W7_ATTR(__VA_ARGS__, 0); W7_ATTR(__VA_ARGS__, 1); W7_ATTR(__VA_ARGS__, 2); W7_ATTR(__VA_ARGS__, 3)
+    W7_ATTR4(W6_RING_ALT, false, false, false, true);
+    W7_ATTR4(W6_RING_ALT, false, false, true, true);
+    W7_ATTR4(W6_RING_ALT, true, false, false, true);
+    W7_ATTR4(W6_RING_ALT, false, true, false, true);
+#undef W7_ATTR4
+#undef W7_ATTR
 }
 
 // Geometry / feature check only (the plan decides where the fused kernel pays)
@@ -1232,8 +1484,10 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
     static const bool nt = tuning_env_int("IRSDE_WINO_FUSED64_NT", 1) != 0;
     // r04: the persistent kernel (one block per CU walks its tile groups, output transform in registers) is production;
     // IRSDE_WINO_FUSED64_PERSIST=0 under IRSDE_TUNING=1 selects r03's one-block-per-tile-group kernel
-    static const bool persist = tuning_env_int("IRSDE_WINO_FUSED64_PERSIST", 1) != 0;
-    if (persist && (variant == 0 || variant == 4)) variant = variant == 0 ? 20 : 24;
+    // (r04, later) 2 = the halo kernel (patches staged through LDS by LDS-DMA) is production; 1 selects the register-patch persistent kernel
+    static const int persist = tuning_env_int("IRSDE_WINO_FUSED64_PERSIST", 2);
+    if (persist == 1 && (variant == 0 || variant == 4)) variant = variant == 0 ? 20 : 24;
+    if (persist >= 2 && (variant == 0 || variant == 4)) variant = variant == 0 ? 40 : 44;
     if (variant >= 20) {   // 20 production f32, 21 weight fragments read zeros, 22 patch loads read zeros, 23 no non-temporal hint, 24 fp16 pairs
         static const int ncu = [] {
             int dev = 0, n = 0;
@@ -1264,6 +1518,27 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
         case 2: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 2, true); break;     \
         default: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 3, true); break;    \
     }
+        if (variant >= 40 && variant <= 44) {   // the halo kernel: 40 production f32, 41 weight fragments read zeros, 42 halo fetches read zeros, 44 fp16 pairs
+#define W7_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64h_kernel<W6_RING_ALT, __VA_ARGS__>), pgrid, dim3(WF_NT), W7_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, out_bytes, res_bytes, xcd_nb, total)
+#define W7_LAUNCH_EPI(...)                                  \
+    switch (epi) {                                          \
+        case 0: W7_LAUNCH(__VA_ARGS__, 0); break;           \
+        case 1: W7_LAUNCH(__VA_ARGS__, 1); break;           \
+        case 2: W7_LAUNCH(__VA_ARGS__, 2); break;           \
+        default: W7_LAUNCH(__VA_ARGS__, 3); break;          \
+    }
+            switch (variant) {
+                case 40: W7_LAUNCH_EPI(false, false, false, true) break;
+                case 41: W7_LAUNCH_EPI(true, false, false, true) break;
+                case 42: W7_LAUNCH_EPI(false, true, false, true) break;
+                case 44: W7_LAUNCH_EPI(false, false, true, true) break;
+                default: throw HipError("launch_wino_fused64: bad variant");
+            }
+#undef W7_LAUNCH_EPI
+#undef W7_LAUNCH
+            IRSDE_HIP_CHECK(hipGetLastError());
+            return;
+        }
         switch (variant) {
             case 20: W6P_LAUNCH_EPI(false, false, false, true) break;
             case 21: W6P_LAUNCH_EPI(true, false, false, true) break;    // weight fragments read zeros
