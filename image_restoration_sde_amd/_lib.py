@@ -27,6 +27,7 @@ FLAG_NAF_LENS = 512
 FLAG_FP16 = 1024
 FLAG_NO_WINOGRAD_FUSED = 2048
 FLAG_NO_FUSED_ATTN = 4096
+FLAG_NO_NAF_CHAIN = 8192
 FLAG_SPLIT_BF16X2 = 16384
 FLAG_SPLIT_F16X2 = 32768
 SAMPLE_GRAPH = 1

@@ -166,6 +166,13 @@ void launch_wino_fused64_split_weights(const float* Uf, unsigned short* out, siz
 int wino_fused64_num_blocks(const ConvParams& p);
 bool wino_fused64_xcd_nb(const ConvParams& p);   // the launch maps cout blocks to XCDs (layers whose input is small next to U x rounds)
 void wino_fused_global_init();
+// fused NAFBlock chain (naf_chain.hip): consecutive 512-channel NAFBlocks on an 8 x 8 feature map, one work-group per image
+void naf_chain_global_init();
+bool naf_chain_shape_ok(int H, int W, int c);
+size_t naf_chain_weight_halves(int nblocks);   // fp16 fragment streams [8 waves][nblocks][448 fragments][512]
+size_t naf_chain_vec_floats(int nblocks);      // fp32 per-channel vectors [nblocks][15872]
+void launch_naf_chain(const float* x, float* out, const unsigned short* w, const float* vecs, int nblocks, int B, const float* film, int film_bstride,
+                      int film_off, const float* cam, int cam_bstride, int cam_off, hipStream_t s);
 void attention_global_init();
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)

@@ -1289,6 +1289,7 @@ void conv_set_variant(int v) { g_variant = v; }
 void conv_global_init() {
     conv_halo_global_init();
     wino_fused_global_init();
+    naf_chain_global_init();
     attention_global_init();
     gemm_split_global_init();
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<128, 128, 2, 2, 2>),

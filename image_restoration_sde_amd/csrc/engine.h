@@ -107,6 +107,13 @@ struct NafBlockW {
     int cam_off = 0;                             // [cam_scale | cam_shift] inside a row of the lens table
 };
 
+// a run of consecutive 512-channel NAFBlocks packed for naf_chain_kernel (fp16 mode): fragment streams + fp32 vectors
+struct NafChainW {
+    unsigned short* w = nullptr;
+    float* vecs = nullptr;
+    int nblocks = 0, film_off = 0, cam_off = 0;
+};
+
 enum OpKind { OP_CONV = 0, OP_LN = 1, OP_ATTN = 2, OP_OTHER = 3, OP_WINO = 4, OP_NKINDS = 5 };
 
 struct Op {
@@ -299,6 +306,8 @@ struct irsde_engine {
     std::vector<ConvW> naf_downs, naf_ups;
     ConvW naf_intro, naf_ending;
     std::vector<NafBlockW*> naf_all;
+    std::vector<NafChainW> naf_chain_enc, naf_chain_dec;   // per level (nblocks == 0: none)
+    NafChainW naf_chain_mid;
     // latent-bokeh variant (IRSDE_FLAG_NAF_LENS): lens-information FiLM, one row per image of the batch
     float *cm_w1 = nullptr, *cm_b1 = nullptr, *cm_w3 = nullptr, *cm_b3 = nullptr;  // cam_mlp.0 / cam_mlp.2
     int cam_row = 0;            // sum over blocks of 2c

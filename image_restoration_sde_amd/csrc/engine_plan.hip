@@ -313,6 +313,33 @@ struct Builder {
         return out;
     }
 
+    // a run of NAFBlocks as one launch (naf_chain.hip): one work-group per image walks the whole run
+    bool naf_chain_ok(const NafChainW& cw, const Tensor& x) const {
+        return cw.nblocks > 0 && !naive && !x.bf16 && naf_chain_shape_ok(x.H, x.W, x.C);
+    }
+    Tensor nafchain(const NafChainW& cw, const Tensor& x) {
+        Tensor out = talloc(x.B, x.H, x.W, x.C);
+        const float *xp = x.p, *film = e->film_cur, *cam = naf_lens(e) ? e->cam_cur : nullptr;
+        float* op = out.p;
+        const int B = x.B, fb = film_bstride, cb = e->cam_row;
+        const NafChainW c = cw;
+        Op o;
+        o.kind = OP_CONV;
+        // 1x1 convolutions of the run: conv1 + conv4 (512 -> 1024), conv3 + conv5 + sca.1 on the pooled vector (512 -> 512)
+        o.flops = 2.0 * (double)c.nblocks * B * ((double)x.H * x.W * 512.0 * (1024.0 + 512.0 + 1024.0 + 512.0) + 512.0 * 512.0);
+        o.exec_flops = o.flops;
+        o.bytes = (double)c.nblocks * (3.5 * 1024 * 1024 + 4.0 * 15872) + 2.0 * 4.0 * (double)x.numel();
+        pl->conv_flops += o.flops;
+        pl->conv_exec_flops += o.exec_flops;
+        pl->conv_bytes += o.bytes;
+        char buf[160];
+        snprintf(buf, sizeof buf, "naf_chain(fp16) blocks=%d B=%d c=%d hw=%dx%d flops=%.4g", c.nblocks, B, x.C, x.H, x.W, o.flops);
+        o.desc = buf;
+        o.fn = [=](hipStream_t s) { launch_naf_chain(xp, op, c.w, c.vecs, c.nblocks, B, film, fb, c.film_off, cam, cb, c.cam_off, s); };
+        pl->net_ops.push_back(std::move(o));
+        return out;
+    }
+
     // ResBlock.forward — module_util.py:136-146
     Tensor resblock(const ResW& w, const Tensor& in0, const Tensor* in1) {
         Tensor R;
@@ -495,6 +522,11 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
     const Tensor intro = x;
     std::vector<Tensor> encs;
     for (size_t i = 0; i < e->naf_enc.size(); ++i) {
+        if (b.naf_chain_ok(e->naf_chain_enc[i], x)) {
+            Tensor y = b.nafchain(e->naf_chain_enc[i], x);
+            if (!(intro_skip && x.p == intro.p)) b.tfree(x);
+            x = y;
+        } else
         for (auto& blk : e->naf_enc[i]) {
             Tensor y = b.nafblock(blk, x);
             if (!(intro_skip && x.p == intro.p)) b.tfree(x);
@@ -507,6 +539,11 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
         x = b.conv_naf(e->naf_downs[i], x, od);  // Conv2d(chan, 2 chan, 2, 2)
         b.tap("downs." + std::to_string(i), x);
     }
+    if (b.naf_chain_ok(e->naf_chain_mid, x)) {
+        Tensor y = b.nafchain(e->naf_chain_mid, x);
+        b.tfree(x);
+        x = y;
+    } else
     for (auto& blk : e->naf_mid) {
         Tensor y = b.nafblock(blk, x);
         b.tfree(x);
@@ -522,6 +559,11 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
         b.tfree(skip);
         x = y;
         b.tap("ups." + std::to_string(i), x);
+        if (b.naf_chain_ok(e->naf_chain_dec[i], x)) {
+            Tensor z = b.nafchain(e->naf_chain_dec[i], x);
+            b.tfree(x);
+            x = z;
+        } else
         for (auto& blk : e->naf_dec[i]) {
             Tensor z = b.nafblock(blk, x);
             b.tfree(x);

@@ -313,6 +313,80 @@ NafBlockW pack_nafblock(irsde_engine* e, const std::string& p, int c) {
     return b;
 }
 
+
+// The fp16 weight streams + fp32 vectors of naf_chain_kernel (csrc/naf_chain.hip) for the blocks `prefixes` (consecutive 512-channel NAFBlocks).
+// Stream of wave w, block i: [conv1: 4 passes x 16 k steps x (lo tile, hi tile)] [sca.1: 2 passes x 16 x 2 tiles] [conv3: same] [conv4: as conv1]
+// [conv5: as conv3]; a fragment = 64 lanes x 8 halves: lane l holds W[tile channel base + (l & 15)][32 ks + 8 (l >> 4) + 0 .. 7].
+NafChainW pack_naf_chain(irsde_engine* e, const std::vector<std::string>& prefixes, const NafBlockW& first) {
+    constexpr int C = 512, FR = 448;
+    const int nb = (int)prefixes.size();
+    std::vector<unsigned short> w(naf_chain_weight_halves(nb));
+    std::vector<float> vecs(naf_chain_vec_floats(nb));
+    const size_t NV = vecs.size() / nb;
+    auto h16 = [](float v) {
+        const _Float16 h = (_Float16)v;   // round to nearest even
+        unsigned short u;
+        memcpy(&u, &h, 2);
+        return u;
+    };
+    for (int i = 0; i < nb; ++i) {
+        const std::string& p = prefixes[i];
+        const float* w1 = need(e, p + "conv1.weight").data.data();
+        const float* ws = need(e, p + "sca.1.weight").data.data();
+        const float* w3 = need(e, p + "conv3.weight").data.data();
+        const float* w4 = need(e, p + "conv4.weight").data.data();
+        const float* w5 = need(e, p + "conv5.weight").data.data();
+        for (int wave = 0; wave < 8; ++wave) {
+            unsigned short* dst = w.data() + ((size_t)wave * nb + i) * FR * 512;
+            auto frag = [&](const float* W, int chbase, int ks) {
+                for (int l = 0; l < 64; ++l)
+                    for (int k = 0; k < 8; ++k) dst[l * 8 + k] = h16(W[(size_t)(chbase + (l & 15)) * C + 32 * ks + 8 * (l >> 4) + k]);
+                dst += 512;
+            };
+            auto gated = [&](const float* W) {   // 1024 outputs: gate pairs (j, j + 512)
+                for (int ps = 0; ps < 4; ++ps)
+                    for (int ks = 0; ks < 16; ++ks) {
+                        frag(W, 64 * wave + 16 * ps, ks);
+                        frag(W, C + 64 * wave + 16 * ps, ks);
+                    }
+            };
+            auto plain = [&](const float* W) {   // 512 outputs
+                for (int ps = 0; ps < 2; ++ps)
+                    for (int ks = 0; ks < 16; ++ks) {
+                        frag(W, 64 * wave + 32 * ps, ks);
+                        frag(W, 64 * wave + 32 * ps + 16, ks);
+                    }
+            };
+            gated(w1); plain(ws); plain(w3); gated(w4); plain(w5);
+            if (dst != w.data() + ((size_t)wave * nb + i + 1) * FR * 512) throw HipError("pack_naf_chain: stream length mismatch");
+        }
+        float* v = vecs.data() + (size_t)i * NV;
+        auto put = [&](int off, const std::string& name, size_t nexp) {
+            const HostTensor& t = need(e, p + name);
+            if (t.data.size() != nexp) throw HipError("pack_naf_chain: unexpected size of " + p + name);
+            std::copy(t.data.begin(), t.data.end(), v + off);
+        };
+        // offsets: naf_chain.hip NV_*
+        put(0, "norm1.g", C); put(512, "norm2.g", C); put(1024, "conv1.bias", 2 * C); put(2048, "conv2.bias", 2 * C);
+        {
+            const HostTensor& t = need(e, p + "conv2.weight");   // [2c][1][3][3] -> [9][2c]
+            for (int ch = 0; ch < 2 * C; ++ch)
+                for (int k = 0; k < 9; ++k) v[3072 + (size_t)k * 2 * C + ch] = t.data[(size_t)ch * 9 + k];
+        }
+        put(12288, "sca.1.bias", C); put(12800, "conv3.bias", C); put(13312, "beta", C); put(13824, "conv4.bias", 2 * C); put(14848, "conv5.bias", C);
+        put(15360, "gamma", C);
+    }
+    NafChainW cw;
+    unsigned short* dw = reinterpret_cast<unsigned short*>(e->dmalloc((w.size() + 1) / 2));
+    IRSDE_HIP_CHECK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    cw.w = dw;
+    cw.vecs = e->upload(vecs);
+    cw.nblocks = nb;
+    cw.film_off = first.film_off;
+    cw.cam_off = first.cam_off;
+    return cw;
+}
+
 void finalize_naf(irsde_engine* e) {
     const int width = e->cfg.nf, ic = e->cfg.in_nc;
     const std::string t1 = naf_lens(e) ? "time_mlp.0." : "time_mlp.1.", t3 = naf_lens(e) ? "time_mlp.2." : "time_mlp.3.";
@@ -384,6 +458,24 @@ void finalize_naf(irsde_engine* e) {
     }
     e->film_row = off;
     e->cam_row = coff;
+    // fused NAFBlock chains (fp16 mode): every group of blocks with 512 channels; the plan uses one where the feature map is 8 x 8
+    e->naf_chain_enc.assign(e->naf_enc.size(), NafChainW());
+    e->naf_chain_dec.assign(e->naf_dec.size(), NafChainW());
+    e->naf_chain_mid = NafChainW();
+    if ((e->cfg.flags & IRSDE_FLAG_FP16) && !(e->cfg.flags & (IRSDE_FLAG_NO_NAF_CHAIN | IRSDE_FLAG_NAIVE_CONV))) {
+        auto names = [](const std::string& base, size_t n) {
+            std::vector<std::string> v;
+            for (size_t j = 0; j < n; ++j) v.push_back(base + std::to_string(j) + ".");
+            return v;
+        };
+        for (size_t i = 0; i < e->naf_enc.size(); ++i)
+            if (!e->naf_enc[i].empty() && e->naf_enc[i][0].c == 512)
+                e->naf_chain_enc[i] = pack_naf_chain(e, names("encoders." + std::to_string(i) + ".", e->naf_enc[i].size()), e->naf_enc[i][0]);
+        if (!e->naf_mid.empty() && e->naf_mid[0].c == 512) e->naf_chain_mid = pack_naf_chain(e, names("middle_blks.", e->naf_mid.size()), e->naf_mid[0]);
+        for (size_t i = 0; i < e->naf_dec.size(); ++i)
+            if (!e->naf_dec[i].empty() && e->naf_dec[i][0].c == 512)
+                e->naf_chain_dec[i] = pack_naf_chain(e, names("decoders." + std::to_string(i) + ".", e->naf_dec[i].size()), e->naf_dec[i][0]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,399 @@
+// naf_chain_kernel — a run of consecutive NAFBlocks of the latent score network as ONE launch: one work-group per image walks the whole chain
+// (NAFBlock.forward, codes/config/latent-bokeh/models/modules/DenoisingNAFNet_arch.py:56-83 and the deraining / latent-dehazing twins) with the
+// activations resident in registers + LDS and the 16-bit weights streamed from L2.
+//
+// Why (profiles/r04_latent_bench_kernel_trace_stats.txt): BASELINE configs[4] samples 64 x 64 x 4 latents, so 28 of the 36 NAFBlocks run on
+// 8 x 8 pixels x 512 channels.  Per image that is 64 x 512 activations: every op of the block (LayerNorm, 1x1 convolutions, depthwise 3x3, SimpleGate,
+// the SCA pool, the beta / gamma residuals) is per image, and the block took ~190 us in 8 - 11 launches of 4 - 25 us each (GEMMs of M = 4096, K = 512:
+// launch- and ramp-bound at 0.04 of the fp16 MFMA roof) for ~20 us of MFMA work.
+//
+// Work-group = 512 threads = 8 waves, image b = blockIdx.x.  Wave w owns output channels [64 w, 64 w + 64) of every 512-wide tensor and the gate pairs
+// (j, j + 512), j in that range, of the two 1024-wide ones.  All GEMMs run on v_mfma_f32_16x16x32_f16 with A = weights (16 output channels x 32 k),
+// B = activations (32 k x 16 pixels): a lane (n = lane & 15, q = lane >> 4) ends with 4 consecutive channels (4 q .. 4 q + 3 of the 16-channel tile) of
+// pixel n of the 16-pixel tile.
+//   registers  x[4 channel tiles][4 pixel tiles] (64): the fp32 residual stream of the block chain; acc (64); the weight ring (16 fragments = 64)
+//   LDS        bufA, bufB: [64 px][512 k] fp16 operand images (LayerNorm output / gated tensors), 16-byte chunks XOR-swizzled by the pixel so that both the
+//              B-fragment reads (ds_read_b128) and the accumulator write-back (ds_write_b64) are conflict-free; a 10 x 10 zero-bordered fp16 staging
+//              grid per wave for the depthwise 3x3; LayerNorm partials; the SCA mean / scale vectors
+//   weights    one contiguous fp16 stream per wave in exactly the order of use (pack_naf_chain in engine_weights.hip), 448 fragments of 1 KB per block:
+//              a lane's 16 bytes of fragment (tile, k step) are W[tile * 16 + n][32 ks + 8 q .. + 7]; ring of 16 fragments, refilled 16 ahead.
+// Arithmetic: the 16-bit operand mode's (IRSDE_FLAG_FP16): fp16 operands, fp32 accumulation, fp32 residual stream / LayerNorm / depthwise conv / gates.
+// Differences to the per-layer path, all at operand-rounding level: the conv1 output passes through fp16 before the depthwise conv (staging grid),
+// and the SCA 1x1 conv runs on the MFMA pipe with fp16 operands.
+#include "common.h"
+
+namespace irsde {
+
+typedef float nc_f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 nc_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 nc_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 nc_h2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int NC_C = 512;                 // channels
+constexpr int NC_PX = 64;                 // pixels per image (8 x 8)
+constexpr int NC_RING = 8;                // weight fragments in flight per wave (x 4 registers; 16 spills 55 registers)
+constexpr int NC_ROW = NC_C * 2;          // bytes per pixel row of an operand image
+constexpr int NC_BUF = NC_PX * NC_ROW;    // 65 536
+constexpr int NC_GRID = 100 * 32;         // staging grid per wave: 10 x 10 positions x 16 channels fp16
+constexpr int NC_OFF_B = NC_BUF;
+constexpr int NC_OFF_GRID = 2 * NC_BUF;
+constexpr int NC_OFF_RED1 = NC_OFF_GRID + 8 * NC_GRID;     // [64 px][8 waves] f32
+constexpr int NC_OFF_RED2 = NC_OFF_RED1 + 2048;
+constexpr int NC_OFF_MEAN = NC_OFF_RED2 + 2048;            // [512] fp16
+constexpr int NC_OFF_S = NC_OFF_MEAN + 1024;               // [512] fp16
+constexpr int NC_LDS_BYTES = NC_OFF_S + 1024;              // 162 816
+static_assert(NC_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// fp32 vectors of a block (floats): pack_naf_chain writes them in this order
+constexpr int NV_G1 = 0, NV_G2 = 512, NV_B1 = 1024, NV_DWB = 2048, NV_DWW = 3072, NV_SCAB = 12288, NV_B3 = 12800, NV_BETA = 13312, NV_B4 = 13824,
+              NV_B5 = 14848, NV_GAMMA = 15360, NV_TOTAL = 15872;
+constexpr int NC_FRAGS_PER_BLOCK = 448;   // per wave: conv1 128, sca 64, conv3 64, conv4 128, conv5 64
+
+struct NafChainArgs {
+    const float* x;            // [B][64][512] fp32 in
+    float* out;                // [B][64][512]
+    const unsigned short* w;   // fp16 fragment streams: [8 waves][nblocks][448][512 halves]
+    const float* vecs;         // [nblocks][NV_TOTAL]
+    const float* film;         // FiLM rows of the step: row of image b at film + b * film_bstride; block i at + film_off + i * 2048: [shift_att | scale_att | shift_ffn | scale_ffn]
+    const float* cam;          // latent-bokeh lens FiLM (or nullptr): row b at cam + b * cam_bstride; block i at + cam_off + i * 1024: [scale | shift]
+    int film_bstride, film_off, cam_bstride, cam_off;
+    int nblocks;
+    unsigned w_bytes;
+};
+
+__device__ __forceinline__ nc_h4 cvt4(const nc_f4 v) {
+    nc_h4 h;
+    h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+    return h;
+}
+
+// ---- the weight stream of one wave: ring[i] holds fragment (pos + i); slot i is refilled with fragment pos + 16 + i right after its last use ----
+struct WStream {
+    __amdgpu_buffer_rsrc_t rs;
+    int lane_off;   // wave region + lane * 16 (bytes)
+    int pos;        // fragment index of ring slot 0 (bytes / 1024), multiple of 16
+};
+
+// One GEMM pass: acc[t][pt] += sum_k W_t[., k] B[k, pixel tile pt] over K = 512 for the 2 weight tiles t the stream delivers per k step (32 fragments: 16 / (NC_RING / 2)
+// rounds of the fragment ring).  NPT: pixel tiles (4: the image; 1: the SCA matvec, every column carries the same vector).  SCALE: B fragments are
+// multiplied by the fp16 vector at sv (the SCA scale per input channel, DenoisingNAFNet_arch.py:68) on their way into the MFMA.
+// bsrc[c]: LDS address of this lane's B fragment of k steps ks with (ks & 3) == c (see the swizzle); + (ks >> 2) * 256, pixel tile stride 16 rows.
+template <int NPT, bool SCALE>
+__device__ __forceinline__ void gemm_pass(nc_f4 (&acc)[2][NPT], const char* const* bsrc, const char* sv, nc_f4 (&ring)[NC_RING], WStream& ws) {
+    constexpr int KSU = NC_RING / 2;   // k steps per round of the ring (a multiple of 4)
+#pragma unroll 1
+    for (int ko = 0; ko < 16 / KSU; ++ko) {
+#pragma unroll
+        for (int kk = 0; kk < KSU; ++kk) {
+            nc_h8 bq[NPT];
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) bq[pt] = *reinterpret_cast<const nc_h8*>(bsrc[kk & 3] + ((KSU / 4) * ko + (kk >> 2)) * 256 + pt * (16 * NC_ROW));
+            if constexpr (SCALE) {
+                const nc_h8 s8 = *reinterpret_cast<const nc_h8*>(sv + (ko * KSU + kk) * 64);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) bq[pt] = bq[pt] * s8;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt)
+                    acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nc_h8, ring[kk * 2 + t]), bq[pt], acc[t][pt], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                ring[kk * 2 + t] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, ws.lane_off, (ws.pos + NC_RING + kk * 2 + t) * 1024, 0));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ws.pos += NC_RING;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+
+    // ---- LDS addressing ----
+    // operand image element (px, k): byte px * 1024 + (((k >> 3) ^ (px & 15)) << 4) + (k & 7) * 2   (the XOR touches the low 4 bits of the chunk index only)
+    // B fragment of k step ks = 4 k4 + kk, pixel tile pt: lane reads chunk (4 ks + q) of pixel 16 pt + n: chunk' = (k4 << 4) | (((kk << 2) | q) ^ n)
+    const char* bsrcA[4];
+    const char* bsrcB[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {   // (kk = ks & 3)
+        const int off = n * NC_ROW + ((((kk << 2) | q) ^ n) << 4);
+        bsrcA[kk] = lds + off;
+        bsrcB[kk] = lds + NC_OFF_B + off;
+    }
+    // accumulator write-back: this lane's 4 channels (tile channel base cb, + 4 q) of pixel 16 pt + n: 8 bytes at chunk (cb >> 3) + (q >> 1), half (q & 1)
+    auto wr_off = [&](const int cb, const int pt) {
+        const int chunk = ((cb >> 3) + (q >> 1)) ^ n;   // cb is a multiple of 16: (cb >> 3) has bit 0 clear, adding q >> 1 cannot carry
+        return (16 * pt + n) * NC_ROW + (chunk << 4) + ((q & 1) << 3);
+    };
+    char* const grid = lds + NC_OFF_GRID + wave * NC_GRID;
+    float* const red1 = reinterpret_cast<float*>(lds + NC_OFF_RED1);
+    float* const red2 = reinterpret_cast<float*>(lds + NC_OFF_RED2);
+    // zero the staging grid once: its border is never written again
+    for (int i = lane; i < NC_GRID / 4; i += 64) reinterpret_cast<unsigned*>(grid)[i] = 0u;
+    // grid position of pixel (16 pt + n): (y + 1) * 10 + x + 1 with y = 2 pt + (n >> 3), x = n & 7; the 3 x 3 window starts one row / column earlier
+    const int gpos0 = ((n >> 3) * 10 + (n & 7)) * 32 + q * 8;   // byte offset of the window origin for pt = 0 (pt adds 20 positions)
+
+    // ---- weight stream ----
+    WStream ws;
+    ws.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, a.w_bytes, 0x00020000);
+    ws.lane_off = wave * (a.nblocks * NC_FRAGS_PER_BLOCK * 1024) + lane * 16;
+    ws.pos = 0;
+    nc_f4 ring[NC_RING];
+#pragma unroll
+    for (int i = 0; i < NC_RING; ++i) ring[i] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, ws.lane_off, i * 1024, 0));
+
+    // ---- residual stream: x[ct][pt] = channels 64 w + 16 ct + 4 q .. + 3 of pixel 16 pt + n ----
+    nc_f4 x[4][4];
+    const float* xin = a.x + (size_t)b * NC_PX * NC_C;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) x[ct][pt] = *reinterpret_cast<const nc_f4*>(xin + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q);
+    const int chl = 64 * wave + 4 * q;   // + 16 ct: this lane's channels of a 512-wide tensor
+
+    // LayerNorm over the channels (module_util.py:20-26: biased variance, eps 1e-5) * g, then the block's FiLM x * (scale + 1) + shift
+    // (DenoisingNAFNet_arch.py:63-64,74-75), result as the fp16 operand image in bufA.  Two passes like layernorm_kernel.
+    auto layernorm_to_A = [&](const float* g, const float* fscale, const float* fshift) {
+        float s[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            float t = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) t += (x[ct][pt][0] + x[ct][pt][1]) + (x[ct][pt][2] + x[ct][pt][3]);
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            s[pt] = t;
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) red1[(16 * pt + n) * 8 + wave] = s[pt];
+        }
+        __syncthreads();
+        float mean[4], rstd[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const nc_f4 r0 = *reinterpret_cast<const nc_f4*>(red1 + (16 * pt + n) * 8), r1 = *reinterpret_cast<const nc_f4*>(red1 + (16 * pt + n) * 8 + 4);
+            mean[pt] = (((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3]))) * (1.0f / NC_C);
+            float t = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const nc_f4 d = x[ct][pt] - mean[pt];
+                t += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            s[pt] = t;
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) red2[(16 * pt + n) * 8 + wave] = s[pt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const nc_f4 r0 = *reinterpret_cast<const nc_f4*>(red2 + (16 * pt + n) * 8), r1 = *reinterpret_cast<const nc_f4*>(red2 + (16 * pt + n) * 8 + 4);
+            const float var = (((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3]))) * (1.0f / NC_C);
+            rstd[pt] = 1.0f / sqrtf(var + 1e-5f);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const nc_f4 gg = *reinterpret_cast<const nc_f4*>(g + chl + 16 * ct);
+            const nc_f4 fs = *reinterpret_cast<const nc_f4*>(fscale + chl + 16 * ct) + 1.0f;
+            const nc_f4 fh = *reinterpret_cast<const nc_f4*>(fshift + chl + 16 * ct);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const nc_f4 v = ((x[ct][pt] - mean[pt]) * rstd[pt] * gg) * fs + fh;
+                *reinterpret_cast<nc_h4*>(lds + wr_off(64 * wave + 16 * ct, pt)) = cvt4(v);
+            }
+        }
+        __syncthreads();
+    };
+
+    for (int blk = 0; blk < a.nblocks; ++blk) {
+        const float* vec = a.vecs + (size_t)blk * NV_TOTAL;
+        const float* film = a.film + (size_t)b * a.film_bstride + a.film_off + blk * (4 * NC_C);
+        // ===== norm1 + time FiLM -> bufA =====
+        layernorm_to_A(vec + NV_G1, film + NC_C, film);
+
+        // ===== conv1 (1x1, 512 -> 1024) + conv2 (depthwise 3x3) + SimpleGate -> bufB; channel means for the SCA pool =====
+        // four passes of one gate pair of 16-channel tiles: lo = channels j = 64 w + 16 ps (+ 4 q + i), hi = j + 512
+#pragma unroll 1
+        for (int ps = 0; ps < 4; ++ps) {
+            nc_f4 acc[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
+            gemm_pass<4, false>(acc, bsrcA, nullptr, ring, ws);
+            nc_f4 dwlo[4];
+            nc_f4 cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int ch = (hi ? NC_C : 0) + 64 * wave + 16 * ps + 4 * q;
+                const nc_f4 b1 = *reinterpret_cast<const nc_f4*>(vec + NV_B1 + ch);
+                const nc_f4 db = *reinterpret_cast<const nc_f4*>(vec + NV_DWB + ch);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) *reinterpret_cast<nc_h4*>(grid + gpos0 + pt * 640 + 11 * 32) = cvt4(acc[hi][pt] + b1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                nc_f4 o[4] = {db, db, db, db};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {   // one row of taps at a time: 12 weight registers live instead of 36
+                    nc_f4 wk[3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) wk[kx] = *reinterpret_cast<const nc_f4*>(vec + NV_DWW + (ky * 3 + kx) * 1024 + ch);
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const nc_h4 u = *reinterpret_cast<const nc_h4*>(grid + gpos0 + pt * 640 + (ky * 10 + kx) * 32);
+                            const nc_f4 uf = {(float)u[0], (float)u[1], (float)u[2], (float)u[3]};
+                            o[pt] = __builtin_elementwise_fma(uf, wk[kx], o[pt]);
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    if (hi == 0) {
+                        dwlo[pt] = o[pt];
+                    } else {
+                        const nc_f4 gv = dwlo[pt] * o[pt];
+                        cs += gv;
+                        *reinterpret_cast<nc_h4*>(lds + NC_OFF_B + wr_off(64 * wave + 16 * ps, pt)) = cvt4(gv);
+                    }
+                }
+            }
+            // SCA pool (AdaptiveAvgPool2d(1)): the lane's 4 pixels are in cs; sum the 16 pixel lanes of the channel group
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                cs[0] += __shfl_xor(cs[0], m, 64); cs[1] += __shfl_xor(cs[1], m, 64);
+                cs[2] += __shfl_xor(cs[2], m, 64); cs[3] += __shfl_xor(cs[3], m, 64);
+            }
+            if (n == 0) *reinterpret_cast<nc_h4*>(lds + NC_OFF_MEAN + (64 * wave + 16 * ps + 4 * q) * 2) = cvt4(cs * (1.0f / NC_PX));
+        }
+        __syncthreads();
+        // ===== sca.1 (1x1 conv on the pooled vector): s = W mean + b for this wave's 64 channels -> the fp16 scale vector =====
+        {
+            const char* msrc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) msrc[c] = lds + NC_OFF_MEAN + (c * 32 + 8 * q) * 2;   // every column reads the same 8 k values of its k step
+#pragma unroll 1
+            for (int ps = 0; ps < 2; ++ps) {
+                nc_f4 as[2][1];
+                as[0][0] = nc_f4{0.f, 0.f, 0.f, 0.f};
+                as[1][0] = nc_f4{0.f, 0.f, 0.f, 0.f};
+                gemm_pass<1, false>(as, msrc, nullptr, ring, ws);
+                if (n == 0) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const nc_f4 sb = *reinterpret_cast<const nc_f4*>(vec + NV_SCAB + chl + 16 * (2 * ps + t));
+                        *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + (chl + 16 * (2 * ps + t)) * 2) = cvt4(as[t][0] + sb);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ===== conv3 (1x1, 512 -> 512) on x * sca(x); y = inp + conv3 * beta =====
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            nc_f4 acc[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
+            gemm_pass<4, true>(acc, bsrcB, lds + NC_OFF_S + 8 * q * 2, ring, ws);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ct = 2 * ps + t;
+                const nc_f4 b3 = *reinterpret_cast<const nc_f4*>(vec + NV_B3 + chl + 16 * ct);
+                const nc_f4 be = *reinterpret_cast<const nc_f4*>(vec + NV_BETA + chl + 16 * ct);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) x[ct][pt] = x[ct][pt] + (acc[t][pt] + b3) * be;
+            }
+        }
+        // ===== norm2 + time FiLM -> bufA (its barriers also fence conv3's reads of bufB) =====
+        layernorm_to_A(vec + NV_G2, film + 3 * NC_C, film + 2 * NC_C);
+        // ===== conv4 (1x1, 512 -> 1024) + SimpleGate (+ lens FiLM) -> bufB =====
+#pragma unroll 1
+        for (int ps = 0; ps < 4; ++ps) {
+            nc_f4 acc[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
+            gemm_pass<4, false>(acc, bsrcA, nullptr, ring, ws);
+            const int ch = 64 * wave + 16 * ps + 4 * q;
+            const nc_f4 blo = *reinterpret_cast<const nc_f4*>(vec + NV_B4 + ch), bhi = *reinterpret_cast<const nc_f4*>(vec + NV_B4 + NC_C + ch);
+            nc_f4 cs = {1.f, 1.f, 1.f, 1.f}, cf = {0.f, 0.f, 0.f, 0.f};
+            if (a.cam) {
+                const float* cam = a.cam + (size_t)b * a.cam_bstride + a.cam_off + blk * (2 * NC_C);
+                cs = *reinterpret_cast<const nc_f4*>(cam + ch) + 1.0f;
+                cf = *reinterpret_cast<const nc_f4*>(cam + NC_C + ch);
+            }
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const nc_f4 v = ((acc[0][pt] + blo) * (acc[1][pt] + bhi)) * cs + cf;
+                *reinterpret_cast<nc_h4*>(lds + NC_OFF_B + wr_off(64 * wave + 16 * ps, pt)) = cvt4(v);
+            }
+        }
+        __syncthreads();
+        // ===== conv5 (1x1, 512 -> 512); out = y + conv5 * gamma =====
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            nc_f4 acc[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
+            gemm_pass<4, false>(acc, bsrcB, nullptr, ring, ws);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ct = 2 * ps + t;
+                const nc_f4 b5 = *reinterpret_cast<const nc_f4*>(vec + NV_B5 + chl + 16 * ct);
+                const nc_f4 ga = *reinterpret_cast<const nc_f4*>(vec + NV_GAMMA + chl + 16 * ct);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) x[ct][pt] = x[ct][pt] + (acc[t][pt] + b5) * ga;
+            }
+        }
+        // (the next block's norm1 writes bufA: every wave has passed the barrier behind conv4; its barriers fence conv5's reads of bufB)
+    }
+    float* xout = a.out + (size_t)b * NC_PX * NC_C;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) *reinterpret_cast<nc_f4*>(xout + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q) = x[ct][pt];
+}
+
+}  // namespace
+
+bool naf_chain_shape_ok(int H, int W, int c) { return H * W == NC_PX && H == 8 && c == NC_C; }
+size_t naf_chain_weight_halves(int nblocks) { return (size_t)8 * nblocks * NC_FRAGS_PER_BLOCK * 512; }
+size_t naf_chain_vec_floats(int nblocks) { return (size_t)nblocks * NV_TOTAL; }
+
+void naf_chain_global_init() {
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+
+void launch_naf_chain(const float* x, float* out, const unsigned short* w, const float* vecs, int nblocks, int B, const float* film, int film_bstride,
+                      int film_off, const float* cam, int cam_bstride, int cam_off, hipStream_t s) {
+    NafChainArgs a;
+    a.x = x; a.out = out; a.w = w; a.vecs = vecs; a.film = film; a.cam = cam;
+    a.film_bstride = film_bstride; a.film_off = film_off; a.cam_bstride = cam_bstride; a.cam_off = cam_off;
+    a.nblocks = nblocks;
+    const size_t wb = naf_chain_weight_halves(nblocks) * 2;
+    if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain: weight stream too large for 32-bit buffer offsets");
+    a.w_bytes = (unsigned)wb;
+    hipLaunchKernelGGL(naf_chain_kernel, dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace irsde

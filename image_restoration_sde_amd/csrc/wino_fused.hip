@@ -1068,15 +1068,17 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
 // no weight traffic: no change; patch loads out of range (no data): kernel -25 ... -30 %.  The cost is the number of small gather
 // instructions through the CU's vector-memory path, not bytes, L2 or HBM.  So:
 //  * the 18 x 18 pixel halo of a 4 x 4 tile group (the 16 overlapping 6 x 6 patches: 324 instead of 576 pixels) is fetched once per 16-channel
-//    chunk by LDS-DMA (buffer_load_dwordx4 ... lds: 16 pixels x 64 B per instruction, 23 instead of 144 / 2 instructions, no registers) into a
-//    ring of three halo buffers, two chunks ahead of its use;
+//    chunk by LDS-DMA (buffer_load_dwordx4 ... lds: 16 pixels x 64 B per instruction, 21 instead of 144 / 2 instructions, no registers) into a
+//    ring of four halo buffers, three chunks ahead of its use;
 //  * the producers read their 6 x 6 patches from LDS (36 ds_read_b64), transform, and write V as before;
-//  * K chunk = 16 channels (V double buffer 2 x 39 KB + halos 3 x 23 KB = 146 KB); one barrier per chunk; the four producer waves work as two
-//    pairs on alternate chunks (pair = chunk parity = V buffer), so every producer wave has two chunk periods for one transform.
-// Halo layout (bytes): [row 18][slot 20][64 B = 16 channels]; pixel column col sits in slot (col & 3) * 5 + (col >> 2): the four tiles of a
-// tile row read four CONSECUTIVE slots (one 256-byte bank window) whatever the patch position, so the ds_read_b64 of 32 lanes (4 tiles x 8 channel
-// pairs) is conflict-free; lanes are ordered so that every 16-lane group of the V writes holds two tiles from different tile rows (their
-// tile ^ g columns fall into different halves of the 128-byte write window).
+//  * K chunk = 16 channels (V double buffer 2 x 39 KB + halos 4 x 20 KB = 158 KB); one barrier per chunk ("step"); the four producer waves work as
+//    two pairs on alternate chunks (pair = chunk parity = V buffer): in its own step a pair only transforms (at raised wave priority: its ~250 vector
+//    instructions otherwise wait for gaps between the MFMAs of the wave that shares the SIMD and the transform takes a whole step,
+//    profiles/r04_wino_fused64h_stamps_a.txt), in the other step it waits for the halo of its next chunk and requests the one after.
+// Halo layout (bytes): [row 18][slot 18][64 B = 16 channels]; pixel column col < 16 sits in slot (col & 3) * 4 + (col >> 2), columns 16 / 17 in
+// slots 16 / 17: the four tiles of a tile row read four slots that are distinct mod 4 (one 256-byte bank window; the one exception, the last
+// patch column, is a 2-way conflict), so the ds_read_b64 of 32 lanes (4 tiles x 8 channel pairs) is conflict-free; lanes are ordered so that every
+// 16-lane group of the V writes holds two tiles from different tile rows (their tile ^ g columns fall into different halves of the 128-byte write window).
 // Pixels outside the image carry an out-of-range buffer offset: the DMA writes zeros.  The fused nearest x2 upsample reads input pixel
 // (y >> 1, x >> 1) for halo pixel (y, x).
 // MFMA waves, item walk, weight ring and the lane-local output transform are wino4_fused64p_kernel's (OPT bit 1: no double-fetched units).
@@ -1084,17 +1086,27 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
 constexpr int W7_KC = 16;
 constexpr int W7_ZS = 272;                        // floats per component plane of a V buffer: [g 4][tile ^ g 16][j 4] + 16 pad
 constexpr int W7_VBUF = 36 * W7_ZS;               // 39 168 B
-constexpr int W7_HROW = 20;                       // pixel slots per halo row (18 used)
-constexpr int W7_NDMA = 23;                       // 1 KB LDS-DMA instructions per halo: 368 slots >= 18 x 20
-constexpr int W7_HBUF_BYTES = W7_NDMA * 1024;
-constexpr int W7_NH = 3;
-constexpr int W7_LDS_BYTES = 2 * W7_VBUF * 4 + W7_NH * W7_HBUF_BYTES;   // 148 992 B
+constexpr int W7_HROW = 18;                       // pixel slots per halo row
+constexpr int W7_NDMA = 21;                       // 1 KB LDS-DMA instructions per halo: 324 slots (the last instruction: 4 slots = 16 lanes)
+constexpr int W7_HBUF_BYTES = 18 * W7_HROW * 64;  // 20 736 B
+constexpr int W7_NH = 4;
+constexpr int W7_LDS_BYTES = 2 * W7_VBUF * 4 + W7_NH * W7_HBUF_BYTES;   // 161 280 B
 
-template <int RING, bool NOWT, bool NOPATCH, bool PAIR, bool NT, int EPI>
+// STAMP: per-wave cycle totals (irsde_bench_conv 2010 ..): MFMA waves { K loop, barrier wait, epilogue, kernel, items }, producer waves { halo DMA issue,
+// transform, barrier wait, wait for the halo in the off step, kernel }
+template <int RING, bool NOWT, bool NOPATCH, bool PAIR, bool NT, int EPI, bool STAMP = false>
 __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX, const int GY,
                                                                    const int NB, const unsigned in0_bytes, const unsigned in1_bytes,
                                                                    const unsigned uf_bytes, const unsigned out_bytes, const unsigned res_bytes,
-                                                                   const int xcd_nb, const int total) {
+                                                                   const int xcd_nb, const int total, unsigned long long* __restrict__ dbg) {
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_n = 0, st_t0 = 0, st_t = 0;
+    if constexpr (STAMP) st_t0 = st_t = __builtin_amdgcn_s_memtime();
+#define W7_STAMP(ACC)                                                     \
+    if constexpr (STAMP) {                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        ACC += now_ - st_t;                                               \
+        st_t = now_;                                                      \
+    }
     static_assert(36 % RING == 0 && RING % 4 == 0, "the ring must divide the 36 units of a chunk, in whole groups of 4");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -1128,6 +1140,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
         const int v_lane = g * 64 + ((l15 ^ g) * 4);
         __syncthreads();  // P: the first two halos have landed
         __syncthreads();  // B_0: V[0] of the first tile group is ready
+        W7_STAMP(st_b)
         while (v < total) {
             const int nv = v + nblocks;
             const W6Item nit = w6_item(nv < total ? nv : v, total, NB, GX, GY, xcd_nb);
@@ -1176,7 +1189,9 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                W7_STAMP(st_a)
                 __syncthreads();
+                W7_STAMP(st_b)
             }
             {
                 const int n = it.nblk * 64 + wave * 16 + 4 * g;
@@ -1197,6 +1212,8 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
 #pragma unroll
             for (int z = 0; z < 36; ++z) acc[z] = floatx4{0.f, 0.f, 0.f, 0.f};
             v = nv; it = nit; ubase = nubase;
+            if constexpr (STAMP) st_n += 1;
+            W7_STAMP(st_c)
         }
     } else {
         // =============================== producer waves: two pairs on alternate chunks ===============================
@@ -1210,28 +1227,35 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
         const int tile = 4 * trl + tc, kg = cp >> 1;
         // V float offset of (tile, channel pair) inside a component plane: [g = cp >> 1][tile ^ g][j = 2 (cp & 1)]
         const int vw_base = kg * 64 + ((tile ^ kg) * 4) + 2 * (cp & 1);
-        const int hrd_base = ((4 * trl) * W7_HROW + tc) * 64 + cp * 8;   // byte offset of this lane's patch origin inside a halo buffer
+        // byte offsets of this lane's patch origin inside a halo buffer: patch columns 0 .. 3 (slot 4 s + tc), column 4 and column 5
+        const int hrd0 = ((4 * trl) * W7_HROW + tc) * 64 + cp * 8;
+        const int hrd4 = ((4 * trl) * W7_HROW + (tc < 3 ? tc + 1 : 16)) * 64 + cp * 8;
+        const int hrd5 = ((4 * trl) * W7_HROW + (tc < 3 ? tc + 5 : 17)) * 64 + cp * 8;
         char* const hbase = reinterpret_cast<char*>(smem) + 2 * W7_VBUF * 4;
         const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
-        unsigned voff0[12], voff1[12];   // this lane's 16 bytes of DMA instruction d = 2 dd + pp: byte offset inside source 0 / 1
+        unsigned voff0[11], voff1[11];   // this lane's 16 bytes of DMA instruction d = 2 dd + pp: byte offset inside source 0 / 1
         int vi = blockIdx.x;             // tile group and chunk of this pair's next halo fetch
         int cd = pair;
 #define W7_SET_ITEM(VID)                                                                                                     \
     {                                                                                                                        \
         const bool live_ = (VID) < total;                                                                                    \
         const W6Item pi_ = w6_item(live_ ? (VID) : 0, total, NB, GX, GY, xcd_nb);                                            \
-        _Pragma("unroll") for (int dd = 0; dd < 12; ++dd) {                                                                  \
+        _Pragma("unroll") for (int dd = 0; dd < 11; ++dd) {                                                                  \
             const int sig_ = 16 * (2 * dd + pp) + (lane >> 2);                                                               \
             const int hr_ = sig_ / W7_HROW, sc_ = sig_ - hr_ * W7_HROW;                                                      \
-            const int a_ = sc_ / 5, hc_ = 4 * (sc_ - 5 * a_) + a_;                                                           \
+            const int hc_ = sc_ < 16 ? 4 * (sc_ & 3) + (sc_ >> 2) : sc_;                                                     \
             const int y_ = 16 * pi_.gy - 1 + hr_, x_ = 16 * pi_.gx - 1 + hc_;                                                \
-            const bool ok_ = live_ && hr_ < 18 && hc_ < 18 && (unsigned)y_ < (unsigned)Hv && (unsigned)x_ < (unsigned)Wv;    \
+            const bool ok_ = live_ && sig_ < 18 * W7_HROW && (unsigned)y_ < (unsigned)Hv && (unsigned)x_ < (unsigned)Wv;     \
             const unsigned pidx_ = (unsigned)((pi_.b * p.Hin + (y_ >> p.in_shift)) * p.Win + (x_ >> p.in_shift));           \
             voff0[dd] = ok_ ? pidx_ * (unsigned)(p.pix0 * 4) + (unsigned)((lane & 3) * 16) : WF_OOB;                         \
             voff1[dd] = ok_ ? pidx_ * (unsigned)(p.pix1 * 4) + (unsigned)((lane & 3) * 16) : WF_OOB;                         \
         }                                                                                                                    \
     }
 // this wave's half of the halo of chunk cd of tile group vi into halo buffer HB, then advance (vi, cd) to the pair's next chunk
+// (the 21st instruction covers 4 slots: lanes 0 .. 15 only, the others would write past the buffer)
+#define W7_DMA_ONE(RS, VOFF, DD)                                                                                             \
+    if (2 * (DD) + pp < W7_NDMA - 1 || (2 * (DD) + pp == W7_NDMA - 1 && lane < 16))                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(hb_ + (DD) * 2048), 16, (int)VOFF[DD], soff_, 0, 0);
 #define W7_DMA(HB)                                                                                                           \
     {                                                                                                                        \
         const int cc_ = cd * W7_KC;                                                                                          \
@@ -1239,11 +1263,9 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
         const int soff_ = (second_ ? cc_ - p.C0 : cc_) * 4;                                                                  \
         char* const hb_ = hbase + (HB) * W7_HBUF_BYTES + pp * 1024;                                                          \
         if (second_) {                                                                                                       \
-            _Pragma("unroll") for (int dd = 0; dd < 12; ++dd) if (2 * dd + pp < W7_NDMA)                                     \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(hb_ + dd * 2048), 16, (int)voff1[dd], soff_, 0, 0); \
+            _Pragma("unroll") for (int dd = 0; dd < 11; ++dd) { W7_DMA_ONE(rsrc1, voff1, dd) }                               \
         } else {                                                                                                             \
-            _Pragma("unroll") for (int dd = 0; dd < 12; ++dd) if (2 * dd + pp < W7_NDMA)                                     \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)(hb_ + dd * 2048), 16, (int)voff0[dd], soff_, 0, 0); \
+            _Pragma("unroll") for (int dd = 0; dd < 11; ++dd) { W7_DMA_ONE(rsrc0, voff0, dd) }                               \
         }                                                                                                                    \
         cd += 2;                                                                                                             \
         if (cd >= nch) {                                                                                                     \
@@ -1252,28 +1274,28 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
             W7_SET_ITEM(vi)                                                                                                  \
         }                                                                                                                    \
     }
+        // prologue: the pair's chunks before its first off step (off step G requests chunk G + 3): pair 0 chunks 0 and 2, pair 1 chunk 1
         W7_SET_ITEM(vi)
-        W7_DMA(pair)   // chunk G = pair into halo buffer G % 3
+        W7_DMA(pair)
+        if (pair == 0) { W7_DMA(2) }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // P
+        W7_STAMP(st_c)
         const int nitems = (total - (int)blockIdx.x + nblocks - 1) / nblocks;
         const int Gtot = nitems * nch;
-        int hcur = 0;   // G % 3
         for (int G = 0; G < Gtot; ++G) {
             if ((G & 1) == pair) {
-                if (G + 2 < Gtot) {
-                    const int hn = hcur + 2 >= 3 ? hcur - 1 : hcur + 2;
-                    W7_DMA(hn)
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // B^T d B of this lane's (tile, channel pair) from halo G % 3 into V[pair]
-                const char* hp = hbase + hcur * W7_HBUF_BYTES + hrd_base;
+                // own step: B^T d B of this lane's (tile, channel pair) from halo G % 4 into V[pair].  Raised priority: the transform's vector
+                // instructions and the f32 MFMAs of the other wave on this SIMD share one pipe; left at equal priority they only get the gaps
+                __builtin_amdgcn_s_setprio(3);
+                const char* hq = hbase + (G & 3) * W7_HBUF_BYTES;
                 floatx2 w[6][6];
 #pragma unroll
                 for (int s = 0; s < 6; ++s) {
+                    const char* hp = hq + (s < 4 ? hrd0 + s * 256 : s == 4 ? hrd4 : hrd5);
                     floatx2 col[6], tcv[6];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) col[r] = *reinterpret_cast<const floatx2*>(hp + (r * W7_HROW + (s & 3) * 5 + (s >> 2)) * 64);
+                    for (int r = 0; r < 6; ++r) col[r] = *reinterpret_cast<const floatx2*>(hp + r * (W7_HROW * 64));
                     bt6(col, tcv);
 #pragma unroll
                     for (int r = 0; r < 6; ++r) w[r][s] = tcv[r];
@@ -1286,20 +1308,34 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
 #pragma unroll
                     for (int s = 0; s < 6; ++s) *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * W7_ZS) = PAIR ? wf_split_pair(o[s]) : o[s];
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_setprio(0);
+                W7_STAMP(st_b)
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the halo this pair requested one step ago has landed
+                // off step: the halo of the next own chunk (requested two steps ago, or in the prologue) has landed; request chunk G + 3
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                W7_STAMP(st_d)
+                if (G + 3 < Gtot) { W7_DMA((G + 3) & 3) }
+                W7_STAMP(st_a)
             }
-            hcur = hcur == 2 ? 0 : hcur + 1;
-            // B_G as a raw barrier: __syncthreads() would drain vmcnt(0) here (the LDS-DMA counts as a pending LDS store), i.e. make every halo land
-            // inside the step that requested it; only this wave's V writes have to be complete
+            // B_G as a raw barrier: __syncthreads() would drain vmcnt(0) here (the LDS-DMA counts as a pending LDS store)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            W7_STAMP(st_c)
         }
 #undef W7_DMA
+#undef W7_DMA_ONE
 #undef W7_SET_ITEM
         __syncthreads();  // the MFMA waves' last chunk
     }
+    if constexpr (STAMP) {
+        if (lane == 0 && dbg) {
+            unsigned long long* d = dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+            d[0] = st_a; d[1] = st_b; d[2] = st_c; d[3] = __builtin_amdgcn_s_memtime() - st_t0; d[4] = st_n; d[5] = st_d;
+        }
+    }
+#undef W7_STAMP
 }
 
 }  // namespace
@@ -1351,6 +1387,9 @@ void wino_fused_global_init() {
     W7_ATTR4(W6_RING_ALT, false, false, true, true);
     W7_ATTR4(W6_RING_ALT, true, false, false, true);
     W7_ATTR4(W6_RING_ALT, false, true, false, true);
+    W7_ATTR(W6_RING_ALT, false, false, false, true, 1, true); W7_ATTR(W6_RING_ALT, false, false, false, true, 3, true);
+    W7_ATTR(W6_RING_ALT, true, false, false, true, 1, true); W7_ATTR(W6_RING_ALT, true, false, false, true, 3, true);
+    W7_ATTR(W6_RING_ALT, false, true, false, true, 1, true); W7_ATTR(W6_RING_ALT, false, true, false, true, 3, true);
 #undef W7_ATTR4
 #undef W7_ATTR
 }
@@ -1484,8 +1523,8 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
     static const bool nt = tuning_env_int("IRSDE_WINO_FUSED64_NT", 1) != 0;
     // r04: the persistent kernel (one block per CU walks its tile groups, output transform in registers) is production;
     // IRSDE_WINO_FUSED64_PERSIST=0 under IRSDE_TUNING=1 selects r03's one-block-per-tile-group kernel
-    // (r04, later) 2 = the halo kernel (patches staged through LDS by LDS-DMA) is production; 1 selects the register-patch persistent kernel
-    static const int persist = tuning_env_int("IRSDE_WINO_FUSED64_PERSIST", 2);
+    // (r04, later) 2 selects the halo kernel (patches staged through LDS by LDS-DMA); 1 = the register-patch persistent kernel is production
+    static const int persist = tuning_env_int("IRSDE_WINO_FUSED64_PERSIST", 1);
     if (persist == 1 && (variant == 0 || variant == 4)) variant = variant == 0 ? 20 : 24;
     if (persist >= 2 && (variant == 0 || variant == 4)) variant = variant == 0 ? 40 : 44;
     if (variant >= 20) {   // 20 production f32, 21 weight fragments read zeros, 22 patch loads read zeros, 23 no non-temporal hint, 24 fp16 pairs
@@ -1518,8 +1557,8 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
         case 2: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 2, true); break;     \
         default: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 3, true); break;    \
     }
-        if (variant >= 40 && variant <= 44) {   // the halo kernel: 40 production f32, 41 weight fragments read zeros, 42 halo fetches read zeros, 44 fp16 pairs
-#define W7_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64h_kernel<W6_RING_ALT, __VA_ARGS__>), pgrid, dim3(WF_NT), W7_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, out_bytes, res_bytes, xcd_nb, total)
+        if (variant >= 40 && variant <= 47) {   // the halo kernel: 40 production f32, 41 weight fragments read zeros, 42 halo fetches read zeros, 44 fp16 pairs
+#define W7_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64h_kernel<W6_RING_ALT, __VA_ARGS__>), pgrid, dim3(WF_NT), W7_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, out_bytes, res_bytes, xcd_nb, total, g_w6p_dbg)
 #define W7_LAUNCH_EPI(...)                                  \
     switch (epi) {                                          \
         case 0: W7_LAUNCH(__VA_ARGS__, 0); break;           \
@@ -1532,6 +1571,12 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
                 case 41: W7_LAUNCH_EPI(true, false, false, true) break;
                 case 42: W7_LAUNCH_EPI(false, true, false, true) break;
                 case 44: W7_LAUNCH_EPI(false, false, true, true) break;
+                case 45: case 46: case 47:   // stamp twins (epilogues 1 / 3): production / no weight traffic / no halo traffic
+                    if (epi != 1 && epi != 3) throw HipError("launch_wino_fused64: stamp twins exist for epilogues 1 / 3");
+                    if (variant == 45) { if (epi == 1) W7_LAUNCH(false, false, false, true, 1, true); else W7_LAUNCH(false, false, false, true, 3, true); }
+                    if (variant == 46) { if (epi == 1) W7_LAUNCH(true, false, false, true, 1, true); else W7_LAUNCH(true, false, false, true, 3, true); }
+                    if (variant == 47) { if (epi == 1) W7_LAUNCH(false, true, false, true, 1, true); else W7_LAUNCH(false, true, false, true, 3, true); }
+                    break;
                 default: throw HipError("launch_wino_fused64: bad variant");
             }
 #undef W7_LAUNCH_EPI

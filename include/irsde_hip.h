@@ -19,6 +19,7 @@
  *   101  irsde_sample: T == 0 runs NO step and copies xT to out (the reference's `range(1, T + 1)` is empty); only T < 0
  *        selects the full schedule.  (Version 100 treated T <= 0 as "full schedule".)
  *   102  IRSDE_FLAG_SPLIT_BF16X2 / IRSDE_FLAG_SPLIT_F16X2 (split-operand GEMMs on the 16-bit MFMA pipe for the deep Winograd layers).
+ *   103  IRSDE_FLAG_NO_NAF_CHAIN (the fused NAFBlock chain of the fp16 ConditionalNAFNet on 8 x 8 feature maps is on by default).
  */
 #ifndef IRSDE_HIP_H
 #define IRSDE_HIP_H
@@ -97,6 +98,11 @@ enum {
                                         magnitude >~ 0.1 — the network's O(1) activations; a layer fed |x| ~ 0.02 is at 3e-5 instead of 5e-6
                                         (tests/test_gpu_split.py), |x| ~ 1e-3 at 4e-4: use IRSDE_FLAG_SPLIT_BF16X2 (f32 exponent range) or the
                                         native mode for data scaled that far from unit range.  Wins over IRSDE_FLAG_SPLIT_BF16X2 when both are set. */
+    IRSDE_FLAG_NO_NAF_CHAIN = 8192,  /* r04: keep every NAFBlock on the per-layer path.  Default with IRSDE_FLAG_FP16: a run of consecutive 512-channel
+                                        NAFBlocks on an 8 x 8 feature map (the 28-block level of BASELINE configs[4]'s 64 x 64 latents) runs as ONE
+                                        launch, one work-group per image, activations in registers + LDS, fp16 weights streamed from L2
+                                        (csrc/naf_chain.hip).  Same operand mode; the conv1 output additionally passes through fp16 before the
+                                        depthwise conv and the SCA 1x1 conv runs with fp16 operands */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };

@@ -50,7 +50,7 @@ def test_native_library_is_loaded():
     """The HIP extension (in-tree .so) is what runs; there is no eager/PyTorch fallback."""
     assert torch.cuda.is_available()
     L = _lib.lib()
-    assert L.irsde_version() == 102
+    assert L.irsde_version() == 103
     maps = open("/proc/self/maps").read()
     assert "libirsde_hip.so" in maps
 
@@ -229,15 +229,19 @@ def test_conv_wino_fused64_persistent_rounds(shape):
     old = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=38, film_bstride=2 * Cout)
     assert relerr(old, ref) < 5e-5 and relerr(got, old) < 2e-5, shape
     assert np.array_equal(got, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=36, film_bstride=2 * Cout)), shape
-    # production (34 / 35) is the halo kernel (patches through LDS); 45 / 46: the register-patch persistent kernel, 41 / 43: its tuning twins
-    # (no double-fetched ring units / interleaved patch-load issue) - the same arithmetic in the same order everywhere
-    for nv in (45, 41, 43):
+    # 55 / 56: r04's register-patch persistent kernel (f32 / fp16 pairs); 34 / 35: production; 57 / 58: the halo kernel (patches through LDS);
+    # 51 / 53: tuning twins of the persistent kernel (no double-fetched ring units / interleaved patch-load issue).  Same arithmetic in the
+    # same order everywhere: bit-identical.  52 (12-operation B^T) and 50 (every tuning bit) re-associate the input transform.
+    for nv in (55, 57, 51, 53):
         assert np.array_equal(got, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout)), (shape, nv)
+    for nv in (52, 50):
+        assert relerr(run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout), ref) < 5e-5, (shape, nv)
     pair = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=35, film_bstride=2 * Cout)
     assert relerr(pair, ref) < 5e-5, shape
     assert relerr(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=39, film_bstride=2 * Cout)) < 2e-5, shape
     assert np.array_equal(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=37, film_bstride=2 * Cout)), shape
-    assert np.array_equal(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=46, film_bstride=2 * Cout)), shape
+    for nv in (56, 58):
+        assert np.array_equal(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout)), (shape, nv)
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 0, 32, 32, 128, 0), (1, 64, 64, 16, 16, 256, 1), (4, 64, 0, 16, 32, 512, 0), (3, 64, 0, 16, 16, 128, 0)])
@@ -1029,6 +1033,40 @@ def test_latent_pipeline_vs_reference_golden(golden):
         model.test(sde, hidden, perform_ode=(mode == "ode"))
         out = model.get_current_visuals(need_GT=False)["Output"].numpy()[None]
         assert relerr(out, g["pipe/out_" + mode]) < 2e-3, mode
+
+
+
+def test_naf_chain_vs_per_layer_path():
+    """r04: in the fp16 mode a run of 512-channel NAFBlocks on an 8 x 8 feature map (the 28-block level of BASELINE configs[4]) is ONE launch
+    (csrc/naf_chain.hip: one work-group per image, activations in registers + LDS).  Against the per-layer path of the same mode
+    (IRSDE_FLAG_NO_NAF_CHAIN) and the fp32 engine, on the latent-bokeh network (per-image lens FiLM, [B] timesteps) and the plain one."""
+    from image_restoration_sde_amd import _lib
+    rs = np.random.RandomState(5)
+    for lens in (True, False):
+        cls = P.latent_bokeh.ConditionalNAFNet if lens else P.ConditionalNAFNet
+        kw = dict(img_channel=4, width=64, enc_blk_nums=[1, 1, 1, 3], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+        bp = O.naf_synth_params(seed=11, img_channel=4, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 3), dec_blk_nums=(1, 1, 1, 1), lens=lens)
+        for k in bp:   # default-init beta / gamma are zero (the blocks would be identities): give every branch weight
+            if k.endswith(".beta") or k.endswith(".gamma"):
+                bp[k] = (0.5 * rs.standard_normal(bp[k].shape)).astype(np.float32)
+        xt = torch.from_numpy(rs.standard_normal((3, 4, 64, 64)).astype(np.float32)).to(DEV)
+        cond = torch.from_numpy(rs.standard_normal((3, 4, 64, 64)).astype(np.float32)).to(DEV)
+        li = [torch.from_numpy(rs.uniform(0.1, 1.0, 3).astype(np.float32)) for _ in range(3)]
+        outs = {}
+        for tag, flags in (("fp32", 0), ("chain", _lib.FLAG_FP16), ("layers", _lib.FLAG_FP16 | _lib.FLAG_NO_NAF_CHAIN)):
+            m = cls(**kw)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in bp.items()}, strict=True)
+            m.engine_flags = flags
+            m = m.to(DEV).eval()
+            t = torch.tensor([5, 60, 33])
+            outs[tag] = (m(xt, cond, t, lens_info=li) if lens else m(xt, cond, t)).cpu().numpy()
+            if tag == "chain":
+                one = (m(xt[1:2], cond[1:2], 60, lens_info=[v[1:2] for v in li]) if lens else m(xt[1:2], cond[1:2], 60)).cpu().numpy()
+                assert relerr(one, outs[tag][1:2]) < 1e-6   # an image's result does not depend on the batch around it
+        e_cl, e_c32, e_l32 = relerr(outs["chain"], outs["layers"]), relerr(outs["chain"], outs["fp32"]), relerr(outs["layers"], outs["fp32"])
+        print("naf chain (lens=%s): chain vs layers %.3g, chain vs fp32 %.3g, layers vs fp32 %.3g" % (lens, e_cl, e_c32, e_l32))
+        assert np.isfinite(outs["chain"]).all()
+        assert e_cl < 3e-3 and e_c32 < 3e-3 and e_c32 < 2.0 * e_l32 + 1e-4
 
 
 def test_latent_bokeh_nafnet_vs_reference_golden(golden):

@@ -9,7 +9,7 @@ cases = [("L0  64->64  film", 256, 64, 64, 0, 1), ("L0  64->64  res", 256, 64, 6
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 # stamp twins (r04): 435 production; 2000 every OPT bit; 2001 / 2002 no weight / patch traffic; 2003 patches from an L2-resident window (epilogues 1 / 2 of this list only)
 variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "435").split(",")]
-NAMES = {435: "production", 2000: "OPT = 15", 2001: "no weight traffic", 2002: "no patch traffic", 2003: "hot patches", 2004: "production"}
+NAMES = {2010: "halo kernel", 2011: "halo kernel, no weight traffic", 2012: "halo kernel, no halo traffic", 435: "production", 2000: "OPT = 15", 2001: "no weight traffic", 2002: "no patch traffic", 2003: "hot patches", 2004: "production"}
 for name, H, Cin, Cout, up, epi in cases:
     if flt not in name:
         continue
