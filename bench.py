@@ -118,9 +118,9 @@ def cpu_baseline(size, T, budget_s=20.0):
 # kernel classes of the event pass: description prefix (engine_plan.hip `op.desc`) -> the HIP kernel behind it (short names: the
 # whole JSON line has to fit the driver's 8 KB record; what each kernel does is in DESIGN.md section 3)
 KERNEL_CLASSES = [
-    ("conv(winograd F4 fused)", "wino4_fused64_kernel"),
+    ("conv(winograd F4 fused)", "wino4_fused64p_kernel"),
     ("conv(winograd", "gemm_zloop_kernel (Winograd component GEMMs)"),
-    ("conv(split f16x2 winograd F4 fused)", "wino4_fused64_kernel<PAIR>"),
+    ("conv(split f16x2 winograd F4 fused)", "wino4_fused64p_kernel<PAIR>"),
     ("conv(split f16x2) M=", "conv_igemm_kernel<PAIR>"),
     ("conv(split bf16x2) M=", "conv_igemm_kernel<PAIR>"),
     ("conv(split", "gemm_split2i_kernel"),
@@ -196,7 +196,7 @@ def roofline_object(prof, op_text, w):
     def products(n):   # 16-bit MFMA products a split-mode kernel issues per f32 product (0: the kernel runs at `peak`)
         if w["dtype"] not in ("fp32_split", "fp32_split_f16"):
             return 0.0
-        return 4.0 if n.startswith("wino4_fused64_kernel<PAIR>") else 3.0 if (n.startswith("gemm_split2i") or "<PAIR>" in n) else 0.0
+        return 4.0 if n.startswith("wino4_fused64p_kernel<PAIR>") else 3.0 if (n.startswith("gemm_split2i") or "<PAIR>" in n) else 0.0
 
     def kfrac(n, v):
         tf = v[1] / (v[0] * 1e-3) / 1e12

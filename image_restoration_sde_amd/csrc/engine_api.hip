@@ -726,6 +726,47 @@ int irsde_debug_split_gemm(const float* A, const float* Bm, float* C, int M, int
     });
 }
 
+int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out) {
+    return guard([&] {
+        if (!ms_out || nblocks < 1 || nblocks > 64 || B < 1 || iters < 1) throw HipError("bench_naf_chain: bad argument");
+        conv_global_init();
+        hipStream_t s;
+        IRSDE_HIP_CHECK(hipStreamCreate(&s));
+        const size_t nx = (size_t)B * 64 * 512, nw = naf_chain_weight_halves(nblocks), nv = naf_chain_vec_floats(nblocks);
+        float *dx = nullptr, *dout = nullptr, *dwf = nullptr, *dvec = nullptr, *dfilm = nullptr;
+        unsigned short* dw = nullptr;
+        IRSDE_HIP_CHECK(hipMalloc(&dx, nx * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dout, nx * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dvec, nv * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dfilm, (size_t)nblocks * 2048 * 4));
+        IRSDE_HIP_CHECK(hipMalloc(&dw, nw * 2));
+        const size_t chunk = (size_t)64 << 20;   // f32 staging of the random weights, converted to fp16 piecewise
+        IRSDE_HIP_CHECK(hipMalloc(&dwf, chunk * 4));
+        launch_fill_random(dx, nx, 1, 1.0f, s);
+        launch_fill_random(dvec, nv, 2, 0.1f, s);
+        launch_fill_random(dfilm, (size_t)nblocks * 2048, 3, 0.1f, s);
+        for (size_t o = 0; o < nw; o += chunk) {
+            const size_t n = std::min(chunk, nw - o);
+            launch_fill_random(dwf, n, 4 + (unsigned)(o / chunk), 0.04f, s);
+            launch_f32_to_f16(dwf, dw + o, n, s);
+        }
+        launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant);   // warm
+        hipEvent_t e0, e1;
+        IRSDE_HIP_CHECK(hipEventCreate(&e0));
+        IRSDE_HIP_CHECK(hipEventCreate(&e1));
+        IRSDE_HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant);
+        IRSDE_HIP_CHECK(hipEventRecord(e1, s));
+        IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0.f;
+        IRSDE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(dx); (void)hipFree(dout); (void)hipFree(dwf); (void)hipFree(dvec); (void)hipFree(dfilm); (void)hipFree(dw);
+        (void)hipStreamDestroy(s);
+    });
+}
+
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out) {
     return guard([&] {

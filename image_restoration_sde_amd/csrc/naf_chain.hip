@@ -33,7 +33,6 @@ namespace {
 
 constexpr int NC_C = 512;                 // channels
 constexpr int NC_PX = 64;                 // pixels per image (8 x 8)
-constexpr int NC_RING = 8;                // weight fragments in flight per wave (x 4 registers; 16 spills 55 registers)
 constexpr int NC_ROW = NC_C * 2;          // bytes per pixel row of an operand image
 constexpr int NC_BUF = NC_PX * NC_ROW;    // 65 536
 constexpr int NC_GRID = 100 * 32;         // staging grid per wave: 10 x 10 positions x 16 channels fp16
@@ -80,7 +79,7 @@ struct WStream {
 // rounds of the fragment ring).  NPT: pixel tiles (4: the image; 1: the SCA matvec, every column carries the same vector).  SCALE: B fragments are
 // multiplied by the fp16 vector at sv (the SCA scale per input channel, DenoisingNAFNet_arch.py:68) on their way into the MFMA.
 // bsrc[c]: LDS address of this lane's B fragment of k steps ks with (ks & 3) == c (see the swizzle); + (ks >> 2) * 256, pixel tile stride 16 rows.
-template <int NPT, bool SCALE>
+template <int NPT, bool SCALE, int NC_RING>
 __device__ __forceinline__ void gemm_pass(nc_f4 (&acc)[2][NPT], const char* const* bsrc, const char* sv, nc_f4 (&ring)[NC_RING], WStream& ws) {
     constexpr int KSU = NC_RING / 2;   // k steps per round of the ring (a multiple of 4)
 #pragma unroll 1
@@ -109,6 +108,11 @@ __device__ __forceinline__ void gemm_pass(nc_f4 (&acc)[2][NPT], const char* cons
     }
 }
 
+// NC_RING: weight fragments in flight per wave (x 4 registers).  XG: the fp32 residual stream lives in the output tensor (L2) instead of 64 registers —
+// every lane re-reads / updates exactly the elements it wrote itself — which frees the registers for a ring of 32 fragments (a whole GEMM pass):
+// with 64 work-groups streaming the same weights in lock-step nearly every line is a first touch for its XCD (MALL / HBM latency, not an L2 hit),
+// and a ring of 8 covers only ~0.5k cycles of it.
+template <int NC_RING, bool XG>
 __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -151,23 +155,51 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
     for (int i = 0; i < NC_RING; ++i) ring[i] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, ws.lane_off, i * 1024, 0));
 
     // ---- residual stream: x[ct][pt] = channels 64 w + 16 ct + 4 q .. + 3 of pixel 16 pt + n ----
-    nc_f4 x[4][4];
+    nc_f4 x[XG ? 1 : 4][XG ? 1 : 4];
     const float* xin = a.x + (size_t)b * NC_PX * NC_C;
+    float* const xg = a.out + (size_t)b * NC_PX * NC_C + 64 * wave + 4 * q + n * NC_C;   // + 16 ct + pt * 16 * NC_C
+    if constexpr (XG) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) x[ct][pt] = *reinterpret_cast<const nc_f4*>(xin + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q);
+            for (int pt = 0; pt < 4; ++pt)
+                *reinterpret_cast<nc_f4*>(xg + 16 * ct + pt * 16 * NC_C) = *reinterpret_cast<const nc_f4*>(xin + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q);
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) x[ct][pt] = *reinterpret_cast<const nc_f4*>(xin + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q);
+    }
     const int chl = 64 * wave + 4 * q;   // + 16 ct: this lane's channels of a 512-wide tensor
 
     // LayerNorm over the channels (module_util.py:20-26: biased variance, eps 1e-5) * g, then the block's FiLM x * (scale + 1) + shift
     // (DenoisingNAFNet_arch.py:63-64,74-75), result as the fp16 operand image in bufA.  Two passes like layernorm_kernel.
+    // (the epilogue vectors of the GEMM passes are requested BEFORE the pass and return under it: a load issued where it is used waits for its own L2
+    // latency behind the weight ring's loads — ~45 such waits per block were most of the kernel's time, profiles/r04_naf_chain_bench_a.txt.  The LayerNorm's
+    // own vectors are not: 48 more live registers across a GEMM pass spill the residual stream)
+    struct LnVec { nc_f4 g[4], fs[4], fh[4]; };
+    auto ln_prefetch = [&](LnVec& v, const float* g, const float* fscale, const float* fshift) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            v.g[ct] = *reinterpret_cast<const nc_f4*>(g + chl + 16 * ct);
+            v.fs[ct] = *reinterpret_cast<const nc_f4*>(fscale + chl + 16 * ct);
+            v.fh[ct] = *reinterpret_cast<const nc_f4*>(fshift + chl + 16 * ct);
+        }
+    };
     auto layernorm_to_A = [&](const float* g, const float* fscale, const float* fshift) {
+        LnVec lv;
+        ln_prefetch(lv, g, fscale, fshift);
+        // XG: every pass re-reads the lane's 16 vectors from L2 instead of holding them (the ring of 32 fragments owns the registers)
+        auto X = [&](const int ct, const int pt) -> nc_f4 {
+            if constexpr (XG) return *reinterpret_cast<const nc_f4*>(xg + 16 * ct + pt * 16 * NC_C);
+            else return x[ct][pt];
+        };
         float s[4];
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
             float t = 0.f;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) t += (x[ct][pt][0] + x[ct][pt][1]) + (x[ct][pt][2] + x[ct][pt][3]);
+            for (int ct = 0; ct < 4; ++ct) { const nc_f4 v = X(ct, pt); t += (v[0] + v[1]) + (v[2] + v[3]); }
             t += __shfl_xor(t, 16, 64);
             t += __shfl_xor(t, 32, 64);
             s[pt] = t;
@@ -185,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             float t = 0.f;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                const nc_f4 d = x[ct][pt] - mean[pt];
+                const nc_f4 d = X(ct, pt) - mean[pt];
                 t += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
             t += __shfl_xor(t, 16, 64);
@@ -205,12 +237,10 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            const nc_f4 gg = *reinterpret_cast<const nc_f4*>(g + chl + 16 * ct);
-            const nc_f4 fs = *reinterpret_cast<const nc_f4*>(fscale + chl + 16 * ct) + 1.0f;
-            const nc_f4 fh = *reinterpret_cast<const nc_f4*>(fshift + chl + 16 * ct);
+            const nc_f4 gg = lv.g[ct], fs = lv.fs[ct] + 1.0f, fh = lv.fh[ct];
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
-                const nc_f4 v = ((x[ct][pt] - mean[pt]) * rstd[pt] * gg) * fs + fh;
+                const nc_f4 v = ((X(ct, pt) - mean[pt]) * rstd[pt] * gg) * fs + fh;
                 *reinterpret_cast<nc_h4*>(lds + wr_off(64 * wave + 16 * ct, pt)) = cvt4(v);
             }
         }
@@ -232,14 +262,24 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
-            gemm_pass<4, false>(acc, bsrcA, nullptr, ring, ws);
+            // the lo half's epilogue vectors (conv1 bias, depthwise bias and 9 taps) are requested before the GEMM and return under it (the hi half's
+            // too would spill the residual stream: they are fetched row by row where they are used)
+            const int chlo = 64 * wave + 16 * ps + 4 * q;
+            const nc_f4 b1lo = *reinterpret_cast<const nc_f4*>(vec + NV_B1 + chlo), dblo = *reinterpret_cast<const nc_f4*>(vec + NV_DWB + chlo);
+            nc_f4 wklo[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wklo[k] = *reinterpret_cast<const nc_f4*>(vec + NV_DWW + k * 1024 + chlo);
+            gemm_pass<4, false, NC_RING>(acc, bsrcA, nullptr, ring, ws);
             nc_f4 dwlo[4];
             nc_f4 cs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hi = 0; hi < 2; ++hi) {
-                const int ch = (hi ? NC_C : 0) + 64 * wave + 16 * ps + 4 * q;
-                const nc_f4 b1 = *reinterpret_cast<const nc_f4*>(vec + NV_B1 + ch);
-                const nc_f4 db = *reinterpret_cast<const nc_f4*>(vec + NV_DWB + ch);
+                const int ch = (hi ? NC_C : 0) + chlo;
+                nc_f4 b1 = b1lo, db = dblo;
+                if (hi) {
+                    b1 = *reinterpret_cast<const nc_f4*>(vec + NV_B1 + ch);
+                    db = *reinterpret_cast<const nc_f4*>(vec + NV_DWB + ch);
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) *reinterpret_cast<nc_h4*>(grid + gpos0 + pt * 640 + 11 * 32) = cvt4(acc[hi][pt] + b1);
@@ -247,10 +287,10 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 __builtin_amdgcn_wave_barrier();
                 nc_f4 o[4] = {db, db, db, db};
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {   // one row of taps at a time: 12 weight registers live instead of 36
+                for (int ky = 0; ky < 3; ++ky) {
                     nc_f4 wk[3];
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) wk[kx] = *reinterpret_cast<const nc_f4*>(vec + NV_DWW + (ky * 3 + kx) * 1024 + ch);
+                    for (int kx = 0; kx < 3; ++kx) wk[kx] = hi ? *reinterpret_cast<const nc_f4*>(vec + NV_DWW + (ky * 3 + kx) * 1024 + ch) : wklo[ky * 3 + kx];
 #pragma unroll
                     for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
@@ -291,13 +331,11 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 nc_f4 as[2][1];
                 as[0][0] = nc_f4{0.f, 0.f, 0.f, 0.f};
                 as[1][0] = nc_f4{0.f, 0.f, 0.f, 0.f};
-                gemm_pass<1, false>(as, msrc, nullptr, ring, ws);
+                const nc_f4 sb0 = *reinterpret_cast<const nc_f4*>(vec + NV_SCAB + chl + 16 * (2 * ps)), sb1 = *reinterpret_cast<const nc_f4*>(vec + NV_SCAB + chl + 16 * (2 * ps + 1));
+                gemm_pass<1, false, NC_RING>(as, msrc, nullptr, ring, ws);
                 if (n == 0) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const nc_f4 sb = *reinterpret_cast<const nc_f4*>(vec + NV_SCAB + chl + 16 * (2 * ps + t));
-                        *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + (chl + 16 * (2 * ps + t)) * 2) = cvt4(as[t][0] + sb);
-                    }
+                    *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + (chl + 16 * (2 * ps)) * 2) = cvt4(as[0][0] + sb0);
+                    *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + (chl + 16 * (2 * ps + 1)) * 2) = cvt4(as[1][0] + sb1);
                 }
             }
         }
@@ -310,14 +348,26 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
-            gemm_pass<4, true>(acc, bsrcB, lds + NC_OFF_S + 8 * q * 2, ring, ws);
+            nc_f4 b3v[2], bev[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                b3v[t] = *reinterpret_cast<const nc_f4*>(vec + NV_B3 + chl + 16 * (2 * ps + t));
+                bev[t] = *reinterpret_cast<const nc_f4*>(vec + NV_BETA + chl + 16 * (2 * ps + t));
+            }
+            gemm_pass<4, true, NC_RING>(acc, bsrcB, lds + NC_OFF_S + 8 * q * 2, ring, ws);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ct = 2 * ps + t;
-                const nc_f4 b3 = *reinterpret_cast<const nc_f4*>(vec + NV_B3 + chl + 16 * ct);
-                const nc_f4 be = *reinterpret_cast<const nc_f4*>(vec + NV_BETA + chl + 16 * ct);
+                const nc_f4 b3 = b3v[t], be = bev[t];
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) x[ct][pt] = x[ct][pt] + (acc[t][pt] + b3) * be;
+                for (int pt = 0; pt < 4; ++pt) {
+                    if constexpr (XG) {
+                        nc_f4* xp = reinterpret_cast<nc_f4*>(xg + 16 * ct + pt * 16 * NC_C);
+                        *xp = *xp + (acc[t][pt] + b3) * be;
+                    } else {
+                        x[ct][pt] = x[ct][pt] + (acc[t][pt] + b3) * be;
+                    }
+                }
             }
         }
         // ===== norm2 + time FiLM -> bufA (its barriers also fence conv3's reads of bufB) =====
@@ -330,15 +380,16 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
-            gemm_pass<4, false>(acc, bsrcA, nullptr, ring, ws);
             const int ch = 64 * wave + 16 * ps + 4 * q;
             const nc_f4 blo = *reinterpret_cast<const nc_f4*>(vec + NV_B4 + ch), bhi = *reinterpret_cast<const nc_f4*>(vec + NV_B4 + NC_C + ch);
-            nc_f4 cs = {1.f, 1.f, 1.f, 1.f}, cf = {0.f, 0.f, 0.f, 0.f};
+            nc_f4 cs = {0.f, 0.f, 0.f, 0.f}, cf = {0.f, 0.f, 0.f, 0.f};
             if (a.cam) {
                 const float* cam = a.cam + (size_t)b * a.cam_bstride + a.cam_off + blk * (2 * NC_C);
-                cs = *reinterpret_cast<const nc_f4*>(cam + ch) + 1.0f;
+                cs = *reinterpret_cast<const nc_f4*>(cam + ch);
                 cf = *reinterpret_cast<const nc_f4*>(cam + NC_C + ch);
             }
+            gemm_pass<4, false, NC_RING>(acc, bsrcA, nullptr, ring, ws);
+            cs = cs + 1.0f;
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 const nc_f4 v = ((acc[0][pt] + blo) * (acc[1][pt] + bhi)) * cs + cf;
@@ -354,23 +405,37 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
-            gemm_pass<4, false>(acc, bsrcB, nullptr, ring, ws);
+            nc_f4 b5v[2], gav[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                b5v[t] = *reinterpret_cast<const nc_f4*>(vec + NV_B5 + chl + 16 * (2 * ps + t));
+                gav[t] = *reinterpret_cast<const nc_f4*>(vec + NV_GAMMA + chl + 16 * (2 * ps + t));
+            }
+            gemm_pass<4, false, NC_RING>(acc, bsrcB, nullptr, ring, ws);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ct = 2 * ps + t;
-                const nc_f4 b5 = *reinterpret_cast<const nc_f4*>(vec + NV_B5 + chl + 16 * ct);
-                const nc_f4 ga = *reinterpret_cast<const nc_f4*>(vec + NV_GAMMA + chl + 16 * ct);
+                const nc_f4 b5 = b5v[t], ga = gav[t];
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) x[ct][pt] = x[ct][pt] + (acc[t][pt] + b5) * ga;
+                for (int pt = 0; pt < 4; ++pt) {
+                    if constexpr (XG) {
+                        nc_f4* xp = reinterpret_cast<nc_f4*>(xg + 16 * ct + pt * 16 * NC_C);
+                        *xp = *xp + (acc[t][pt] + b5) * ga;
+                    } else {
+                        x[ct][pt] = x[ct][pt] + (acc[t][pt] + b5) * ga;
+                    }
+                }
             }
         }
         // (the next block's norm1 writes bufA: every wave has passed the barrier behind conv4; its barriers fence conv5's reads of bufB)
     }
-    float* xout = a.out + (size_t)b * NC_PX * NC_C;
+    if constexpr (!XG) {
+        float* xout = a.out + (size_t)b * NC_PX * NC_C;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) *reinterpret_cast<nc_f4*>(xout + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q) = x[ct][pt];
+            for (int pt = 0; pt < 4; ++pt) *reinterpret_cast<nc_f4*>(xout + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q) = x[ct][pt];
+    }
 }
 
 }  // namespace
@@ -380,11 +445,14 @@ size_t naf_chain_weight_halves(int nblocks) { return (size_t)8 * nblocks * NC_FR
 size_t naf_chain_vec_floats(int nblocks) { return (size_t)nblocks * NV_TOTAL; }
 
 void naf_chain_global_init() {
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
+// variant: 0 production (= 1); 1 residual stream in registers + ring of 8 weight fragments; 2 residual stream in L2 + ring of 16: measured 1.4x slower
+// (profiles/r04_naf_chain_bench_a.txt; the ring of 32 was 1.55x slower): kept as the measurement twin  (IRSDE_NAF_CHAIN_VARIANT under IRSDE_TUNING=1)
 void launch_naf_chain(const float* x, float* out, const unsigned short* w, const float* vecs, int nblocks, int B, const float* film, int film_bstride,
-                      int film_off, const float* cam, int cam_bstride, int cam_off, hipStream_t s) {
+                      int film_off, const float* cam, int cam_bstride, int cam_off, hipStream_t s, int variant) {
     NafChainArgs a;
     a.x = x; a.out = out; a.w = w; a.vecs = vecs; a.film = film; a.cam = cam;
     a.film_bstride = film_bstride; a.film_off = film_off; a.cam_bstride = cam_bstride; a.cam_off = cam_off;
@@ -392,7 +460,14 @@ void launch_naf_chain(const float* x, float* out, const unsigned short* w, const
     const size_t wb = naf_chain_weight_halves(nblocks) * 2;
     if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain: weight stream too large for 32-bit buffer offsets");
     a.w_bytes = (unsigned)wb;
-    hipLaunchKernelGGL(naf_chain_kernel, dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a);
+    static const int env_variant = tuning_env_int("IRSDE_NAF_CHAIN_VARIANT", 0);
+    if (variant == 0) variant = env_variant ? env_variant : 1;
+    if (x == out && variant != 1) throw HipError("launch_naf_chain: in-place call needs the register variant");
+    switch (variant) {
+        case 1: hipLaunchKernelGGL((naf_chain_kernel<8, false>), dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a); break;
+        case 2: hipLaunchKernelGGL((naf_chain_kernel<16, true>), dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a); break;
+        default: throw HipError("launch_naf_chain: bad variant");
+    }
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 

@@ -783,6 +783,7 @@ __device__ __forceinline__ void wf64p_epilogue(const ConvParams& p, floatx4 (&ac
 //   8  residual tile warmed into L2 during the last chunk (two LDS-DMA dword loads per MFMA lane into a scratch corner of LDS: no registers)
 //  16  measurement twin: every patch load reads from the first 512 KB of the input (L2-resident patches)
 //  32  bias / FiLM rows of the epilogue requested before the last chunk's barrier
+//  64  producer waves at s_setprio 3 (the MFMA waves stay at 0)
 template <int RING, bool NOWT, bool NOPATCH, bool PAIR, bool NT, int EPI, bool STAMP = false, int OPT = 0>
 __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX, const int GY,
                                                                    const int NB, const unsigned in0_bytes, const unsigned in1_bytes,
@@ -934,6 +935,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64p_kernel(const ConvPara
         }
     } else {
         // =============================== producer waves (as in wino4_fused64_kernel, running on across tile groups) ===============================
+        if constexpr ((OPT & 64) != 0) __builtin_amdgcn_s_setprio(3);   // OPT 64: the producers' vector-memory / vector instructions win the SIMD's issue arbitration
         const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc1 =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1 ? p.in1 : p.in0), 0, p.in1 ? in1_bytes : 0u, 0x00020000);
@@ -1220,6 +1222,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
         const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, NOPATCH ? 0u : in0_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc1 =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1 ? p.in1 : p.in0), 0, (p.in1 && !NOPATCH) ? in1_bytes : 0u, 0x00020000);
+        __builtin_amdgcn_s_setprio(3);   // the producers' few instructions go first: their halo requests queue behind the weight loads of the MFMA waves otherwise
         const int pw = wave - 4, pair = pw >> 1, pp = pw & 1;
         const int q = lane >> 3, cp = lane & 7;
         const int trl = 2 * pp + (q & 1);                       // tile row / column inside the 4 x 4 group (see the lane order above)
@@ -1285,17 +1288,23 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
         const int Gtot = nitems * nch;
         for (int G = 0; G < Gtot; ++G) {
             if ((G & 1) == pair) {
-                // own step: B^T d B of this lane's (tile, channel pair) from halo G % 4 into V[pair].  Raised priority: the transform's vector
-                // instructions and the f32 MFMAs of the other wave on this SIMD share one pipe; left at equal priority they only get the gaps
-                __builtin_amdgcn_s_setprio(3);
+                // own step: B^T d B of this lane's (tile, channel pair) from halo G % 4 into V[pair]
                 const char* hq = hbase + (G & 3) * W7_HBUF_BYTES;
-                floatx2 w[6][6];
+                // all 36 patch reads first (one LDS latency instead of one per column: the LDS queue is busy with the V reads of four MFMA waves)
+                floatx2 raw[36];
 #pragma unroll
                 for (int s = 0; s < 6; ++s) {
                     const char* hp = hq + (s < 4 ? hrd0 + s * 256 : s == 4 ? hrd4 : hrd5);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) raw[r * 6 + s] = *reinterpret_cast<const floatx2*>(hp + r * (W7_HROW * 64));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                floatx2 w[6][6];
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
                     floatx2 col[6], tcv[6];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) col[r] = *reinterpret_cast<const floatx2*>(hp + r * (W7_HROW * 64));
+                    for (int r = 0; r < 6; ++r) col[r] = raw[r * 6 + s];
                     bt6(col, tcv);
 #pragma unroll
                     for (int r = 0; r < 6; ++r) w[r][s] = tcv[r];
@@ -1309,7 +1318,6 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
                     for (int s = 0; s < 6; ++s) *reinterpret_cast<floatx2*>(vw + (r * 6 + s) * W7_ZS) = PAIR ? wf_split_pair(o[s]) : o[s];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_setprio(0);
                 W7_STAMP(st_b)
             } else {
                 // off step: the halo of the next own chunk (requested two steps ago, or in the prologue) has landed; request chunk G + 3
@@ -1373,7 +1381,7 @@ void wino_fused_global_init() {
     W6P_ATTR(W6_RING_ALT, false, false, false, true, 2, true); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, true);
     // r04 tuning twins (irsde_bench_conv 436 .. 440): timed instances per OPT value, stamp instances for OPT = all / no weights / no patches / hot patches
 #define W6P_OPT_TIMED(O) W6P_ATTR(W6_RING_ALT, false, false, false, true, 0, false, O); W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, false, O); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, false, O)
-    W6P_OPT_TIMED(1); W6P_OPT_TIMED(2); W6P_OPT_TIMED(4); W6P_OPT_TIMED(8); W6P_OPT_TIMED(15);
+    W6P_OPT_TIMED(1); W6P_OPT_TIMED(2); W6P_OPT_TIMED(4); W6P_OPT_TIMED(8); W6P_OPT_TIMED(15); W6P_OPT_TIMED(64); W6P_OPT_TIMED(65);
 #undef W6P_OPT_TIMED
     W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, true, 15); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, true, 15);
     W6P_ATTR(W6_RING_ALT, true, false, false, true, 1, true, 0); W6P_ATTR(W6_RING_ALT, true, false, false, true, 3, true, 0);
@@ -1606,6 +1614,8 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
                     case 8: W6P_LAUNCH_OPT(8) break;
                     
                     case 15: W6P_LAUNCH_OPT(15) break;
+                    case 64: W6P_LAUNCH_OPT(64) break;
+                    case 65: W6P_LAUNCH_OPT(65) break;
                     default: throw HipError("launch_wino_fused64: no timed twin for this OPT");
                 }
 #undef W6P_LAUNCH_OPT

@@ -52,6 +52,10 @@ int irsde_debug_split_gemm(const float* A, const float* B, float* C, int M, int 
  * engine's pair-interleaved two-plane GEMM alone (473 / 475 / 476: without its global loads / MFMAs / output stores); epi: 0 none, 1 FiLM+SiLU, 2 SiLU+residual. */
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out);
+/* Times naf_chain_kernel (csrc/naf_chain.hip) alone on synthetic data: `nblocks` consecutive 512-channel NAFBlocks on B images of 8 x 8 pixels,
+ * `iters` launches; variant 1 residual stream in registers + ring of 8 weight fragments (= 0, production), 2 residual stream in L2 + ring of 16.
+ * *ms_out = milliseconds per launch.  (tools/naf_chain_bench.py) */
+int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,36 @@ def test_sample_sharded_world2_gloo(n):
     assert np.array_equal(res[0], want) and np.array_equal(res[1], want)
 
 
+@pytest.mark.parametrize("n", [16, 13, 5])
+def test_sample_sharded_world8_gloo(n):
+    """The real world size of the node (8 ranks): BASELINE configs[1]'s 16 images (2 per rank), a ragged 13 (five ranks with 2, three with 1)
+    and 5 images (three ranks with an EMPTY shard: they skip the sampler and still take part in the gather)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 3, 4, 5, generator=g)
+    mu = torch.rand(n, 3, 4, 5, generator=g)
+    z = torch.randn(4, n, 3, 4, 5, generator=g)
+    ref = FakeSDE()
+    ref.injected_noise = z
+    ref.set_mu(mu)
+    want = ref.reverse_posterior(x).numpy()
+    for r in range(world):
+        assert np.array_equal(res[r], want), r
+    bounds = [P.dist.shard_bounds(n, world, r) for r in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == n and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+    assert max(hi - lo for lo, hi in bounds) - min(hi - lo for lo, hi in bounds) <= 1
+
+
 def test_single_process_passthrough():
     sde = FakeSDE()
     x = torch.ones(3, 3, 2, 2)

@@ -302,7 +302,7 @@ def test_bench_roofline_object_from_an_op_profile():
             "   0.0200 ms  layernorm\n")
     cls = bench.op_classes(text)
     assert len(cls) == 8 and abs(sum(v[0] for v in cls.values()) - 2.5484) < 1e-9
-    fused = [k for k in cls if k.startswith("wino4_fused64_kernel")][0]
+    fused = [k for k in cls if k.startswith("wino4_fused64")][0]
     assert cls[fused] == [1.0, 8.0e10, 1]
     assert any(k.startswith("gemm_split2i_kernel") for k in cls)
     prof = {"conv_ms": 2.15, "wino_ms": 0.05, "conv_exec_flops": 2.7e11, "conv_flops": 1.01e12, "conv_launches": 4.0, "net_evals": 1.0,
