@@ -168,6 +168,7 @@ bool wino_fused64_xcd_nb(const ConvParams& p);   // the launch maps cout blocks 
 void wino_fused_global_init();
 // fused NAFBlock chain (naf_chain.hip): consecutive 512-channel NAFBlocks on an 8 x 8 feature map, one work-group per image
 void naf_chain_global_init();
+void naf_chain_set_debug(unsigned long long* buf);   // stamp buffer of launch variant 11: [B][8 waves][16]
 bool naf_chain_shape_ok(int H, int W, int c);
 size_t naf_chain_weight_halves(int nblocks);   // fp16 fragment streams [8 waves][nblocks][448 fragments][512]
 size_t naf_chain_vec_floats(int nblocks);      // fp32 per-channel vectors [nblocks][15872]

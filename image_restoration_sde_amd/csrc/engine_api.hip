@@ -750,12 +750,32 @@ int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms
             launch_fill_random(dwf, n, 4 + (unsigned)(o / chunk), 0.04f, s);
             launch_f32_to_f16(dwf, dw + o, n, s);
         }
-        launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant);   // warm
+        launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant == 11 ? 1 : variant);   // warm
+        if (variant == 11) {   // the stamp twin once: per-phase cycle budget per block, averaged over all waves
+            unsigned long long* dd = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dd, (size_t)B * 8 * 16 * 8));
+            IRSDE_HIP_CHECK(hipMemsetAsync(dd, 0, (size_t)B * 8 * 16 * 8, s));
+            naf_chain_set_debug(dd);
+            launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, 11);
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            naf_chain_set_debug(nullptr);
+            std::vector<unsigned long long> hd((size_t)B * 8 * 16);
+            IRSDE_HIP_CHECK(hipMemcpy(hd.data(), dd, hd.size() * 8, hipMemcpyDeviceToHost));
+            double acc[16] = {0};
+            for (size_t i = 0; i < hd.size(); ++i) acc[i % 16] += (double)hd[i];
+            const double nwv = (double)B * 8, nb = nblocks;
+            static const char* names[10] = {"norm1", "conv1 GEMM passes", "depthwise 3x3 + gate + pool", "barrier (pool)", "sca.1 GEMM", "conv3 GEMM + residual", "norm2", "conv4 GEMM + gate", "conv5 GEMM + residual", "barriers (sca, conv4)"};
+            printf("naf_chain stamps: %d blocks, B=%d; shader cycles per wave and block (mean over %d waves); MFMA floor per wave: conv1 / conv4 512 x 16, conv3 / conv5 256 x 16, sca 64 x 16\n", nblocks, B, B * 8);
+            for (int k = 0; k < 10; ++k) printf("  %-30s %9.0f\n", names[k], acc[k] / nwv / nb);
+            printf("  %-30s %9.0f\n", "whole kernel / blocks", acc[15] / nwv / nb);
+            fflush(stdout);
+            (void)hipFree(dd);
+        }
         hipEvent_t e0, e1;
         IRSDE_HIP_CHECK(hipEventCreate(&e0));
         IRSDE_HIP_CHECK(hipEventCreate(&e1));
         IRSDE_HIP_CHECK(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant);
+        for (int i = 0; i < iters; ++i) launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant == 11 ? 1 : variant);
         IRSDE_HIP_CHECK(hipEventRecord(e1, s));
         IRSDE_HIP_CHECK(hipStreamSynchronize(s));
         float ms = 0.f;

@@ -368,13 +368,15 @@ NafChainW pack_naf_chain(irsde_engine* e, const std::vector<std::string>& prefix
         };
         // offsets: naf_chain.hip NV_*
         put(0, "norm1.g", C); put(512, "norm2.g", C); put(1024, "conv1.bias", 2 * C); put(2048, "conv2.bias", 2 * C);
-        {
-            const HostTensor& t = need(e, p + "conv2.weight");   // [2c][1][3][3] -> [9][2c]
+        {   // NV_TAP = 3072: conv2.weight [2c][1][3][3] as fp16 rows of 16 halves per channel (taps 0 .. 8, then zeros)
+            const HostTensor& t = need(e, p + "conv2.weight");
+            if (t.data.size() != (size_t)18 * C) throw HipError("pack_naf_chain: unexpected conv2.weight size");
+            unsigned short* hd = reinterpret_cast<unsigned short*>(v + 3072);
             for (int ch = 0; ch < 2 * C; ++ch)
-                for (int k = 0; k < 9; ++k) v[3072 + (size_t)k * 2 * C + ch] = t.data[(size_t)ch * 9 + k];
+                for (int k = 0; k < 16; ++k) hd[ch * 16 + k] = k < 9 ? h16(t.data[(size_t)ch * 9 + k]) : (unsigned short)0;
         }
-        put(12288, "sca.1.bias", C); put(12800, "conv3.bias", C); put(13312, "beta", C); put(13824, "conv4.bias", 2 * C); put(14848, "conv5.bias", C);
-        put(15360, "gamma", C);
+        put(11264, "sca.1.bias", C); put(11776, "conv3.bias", C); put(12288, "beta", C); put(12800, "conv4.bias", 2 * C); put(13824, "conv5.bias", C);
+        put(14336, "gamma", C);
     }
     NafChainW cw;
     unsigned short* dw = reinterpret_cast<unsigned short*>(e->dmalloc((w.size() + 1) / 2));

@@ -46,8 +46,9 @@ constexpr int NC_LDS_BYTES = NC_OFF_S + 1024;              // 162 816
 static_assert(NC_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // fp32 vectors of a block (floats): pack_naf_chain writes them in this order
-constexpr int NV_G1 = 0, NV_G2 = 512, NV_B1 = 1024, NV_DWB = 2048, NV_DWW = 3072, NV_SCAB = 12288, NV_B3 = 12800, NV_BETA = 13312, NV_B4 = 13824,
-              NV_B5 = 14848, NV_GAMMA = 15360, NV_TOTAL = 15872;
+// NV_TAP: the depthwise 3x3 taps as fp16, [1024 channels][16 halves] (taps 0 .. 8 = ky * 3 + kx, then zeros): the rows of the depthwise MFMAs' A operand
+constexpr int NV_G1 = 0, NV_G2 = 512, NV_B1 = 1024, NV_DWB = 2048, NV_TAP = 3072, NV_SCAB = 11264, NV_B3 = 11776, NV_BETA = 12288, NV_B4 = 12800,
+              NV_B5 = 13824, NV_GAMMA = 14336, NV_TOTAL = 14848;
 constexpr int NC_FRAGS_PER_BLOCK = 448;   // per wave: conv1 128, sca 64, conv3 64, conv4 128, conv5 64
 
 struct NafChainArgs {
@@ -60,6 +61,7 @@ struct NafChainArgs {
     int film_bstride, film_off, cam_bstride, cam_off;
     int nblocks;
     unsigned w_bytes;
+    unsigned long long* dbg;   // STAMP twin only
 };
 
 __device__ __forceinline__ nc_h4 cvt4(const nc_f4 v) {
@@ -112,8 +114,19 @@ __device__ __forceinline__ void gemm_pass(nc_f4 (&acc)[2][NPT], const char* cons
 // every lane re-reads / updates exactly the elements it wrote itself — which frees the registers for a ring of 32 fragments (a whole GEMM pass):
 // with 64 work-groups streaming the same weights in lock-step nearly every line is a first touch for its XCD (MALL / HBM latency, not an L2 hit),
 // and a ring of 8 covers only ~0.5k cycles of it.
-template <int NC_RING, bool XG>
+// STAMP (irsde_bench_naf_chain variant 11): per-wave cycle totals per phase into a.dbg[(block * 8 + wave) * 16 ..]: 0 norm1, 1 conv1 GEMM passes,
+// 2 depthwise conv + gate, 3 SCA pool barrier, 4 sca.1 GEMM, 5 conv3 GEMM + residual, 6 norm2, 7 conv4 GEMM + gate, 8 conv5 GEMM + residual, 9 barriers
+// behind sca / conv4, 15 whole kernel
+template <int NC_RING, bool XG, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a) {
+    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_t0 = 0;
+    if constexpr (STAMP) st_t0 = st_t = __builtin_amdgcn_s_memtime();
+#define NC_STAMP(K)                                                       \
+    if constexpr (STAMP) {                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        st[K] += now_ - st_t;                                             \
+        st_t = now_;                                                      \
+    }
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -144,6 +157,17 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
     for (int i = lane; i < NC_GRID / 4; i += 64) reinterpret_cast<unsigned*>(grid)[i] = 0u;
     // grid position of pixel (16 pt + n): (y + 1) * 10 + x + 1 with y = 2 pt + (n >> 3), x = n & 7; the 3 x 3 window starts one row / column earlier
     const int gpos0 = ((n >> 3) * 10 + (n & 7)) * 32 + q * 8;   // byte offset of the window origin for pt = 0 (pt adds 20 positions)
+    // depthwise conv as MFMAs (see conv1): B fragment of k step ks = 8 channels (8 (q & 1) ..) of the neighbour for tap t = 2 ks + (q >> 1) of pixel n
+    const int gposB = ((n >> 3) * 10 + (n & 7)) * 32 + (q & 1) * 16;
+    int dw_toff[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int t = min(2 * ks + (q >> 1), 8);   // (tap 9 does not exist: its A column is zero, read tap 8's data)
+        dw_toff[ks] = ((t / 3) * 10 + (t % 3)) * 32;
+    }
+    // A fragment: row = channel n of the tile; its single non-zero half sits at k = channel n - 8 (q & 1) of the lane's 8, if that is this quarter's range
+    const bool dw_row_active = (n >> 3) == (q & 1);
+    const int dw_widx = (n & 7) >> 1, dw_wsh = (n & 1) * 16;
 
     // ---- weight stream ----
     WStream ws;
@@ -252,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
         const float* film = a.film + (size_t)b * a.film_bstride + a.film_off + blk * (4 * NC_C);
         // ===== norm1 + time FiLM -> bufA =====
         layernorm_to_A(vec + NV_G1, film + NC_C, film);
+        NC_STAMP(0)
 
         // ===== conv1 (1x1, 512 -> 1024) + conv2 (depthwise 3x3) + SimpleGate -> bufB; channel means for the SCA pool =====
         // four passes of one gate pair of 16-channel tiles: lo = channels j = 64 w + 16 ps (+ 4 q + i), hi = j + 512
@@ -262,43 +287,52 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
-            // the lo half's epilogue vectors (conv1 bias, depthwise bias and 9 taps) are requested before the GEMM and return under it (the hi half's
-            // too would spill the residual stream: they are fetched row by row where they are used)
-            const int chlo = 64 * wave + 16 * ps + 4 * q;
-            const nc_f4 b1lo = *reinterpret_cast<const nc_f4*>(vec + NV_B1 + chlo), dblo = *reinterpret_cast<const nc_f4*>(vec + NV_DWB + chlo);
-            nc_f4 wklo[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) wklo[k] = *reinterpret_cast<const nc_f4*>(vec + NV_DWW + k * 1024 + chlo);
+            // the pass's epilogue vectors (conv1 bias, depthwise bias in the accumulator layout; the 9 fp16 taps of tile row channel n): the lo half's are
+            // requested before the GEMM and return under it, the hi half's in one batch right behind the GEMM and return under the lo half's depthwise conv
+            // (loaded where they are used they cost ~7 exposed L2 latencies per half: 24k of the block's 135k cycles, profiles/r04_naf_chain_stamps_a.txt)
+            typedef unsigned nc_u4 __attribute__((ext_vector_type(4)));
+            nc_f4 b1v[2], dbv[2];
+            nc_u4 tapa[2], tapb[2];
+            auto dw_prefetch = [&](const int hi) {
+                const int cb = (hi ? NC_C : 0) + 64 * wave + 16 * ps;
+                b1v[hi] = *reinterpret_cast<const nc_f4*>(vec + NV_B1 + cb + 4 * q);
+                dbv[hi] = *reinterpret_cast<const nc_f4*>(vec + NV_DWB + cb + 4 * q);
+                tapa[hi] = *reinterpret_cast<const nc_u4*>(vec + NV_TAP + (cb + n) * 8);
+                tapb[hi] = *reinterpret_cast<const nc_u4*>(vec + NV_TAP + (cb + n) * 8 + 4);
+            };
+            dw_prefetch(0);
             gemm_pass<4, false, NC_RING>(acc, bsrcA, nullptr, ring, ws);
+            NC_STAMP(1)
+            dw_prefetch(1);
+            __builtin_amdgcn_sched_barrier(0);
             nc_f4 dwlo[4];
             nc_f4 cs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hi = 0; hi < 2; ++hi) {
-                const int ch = (hi ? NC_C : 0) + chlo;
-                nc_f4 b1 = b1lo, db = dblo;
-                if (hi) {
-                    b1 = *reinterpret_cast<const nc_f4*>(vec + NV_B1 + ch);
-                    db = *reinterpret_cast<const nc_f4*>(vec + NV_DWB + ch);
-                }
+                const nc_f4 b1 = b1v[hi], db = dbv[hi];
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) *reinterpret_cast<nc_h4*>(grid + gpos0 + pt * 640 + 11 * 32) = cvt4(acc[hi][pt] + b1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+                // The depthwise conv on the MFMA pipe (idle in this phase; on the vector pipe it was 1152 multiply-adds per lane and block, a fifth of the
+                // kernel): out[ch][px] = sum over k = (tap, ch') of A[ch][k] B[k][px] with A[ch][(tap, ch')] = w[ch][tap] if ch' == ch else 0 and
+                // B[(tap, ch')][px] = the staged tile at the tap's neighbour of px — an im2col read of 8 channels = one ds_read_b128.  K = 9 taps x 16 channels,
+                // k step ks = taps 2 ks, 2 ks + 1 (lane quarter q: tap 2 ks + (q >> 1), channels 8 (q & 1) .. + 7); the 10th tap has zero weights.
+                // Products fp16 x fp16, accumulation f32: what v_fma_mix_f32 computed.  The result lands in the accumulator layout of the GEMMs.
                 nc_f4 o[4] = {db, db, db, db};
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    nc_f4 wk[3];
+                for (int ks = 0; ks < 5; ++ks) {
+                    const unsigned word = ks < 4 ? tapa[hi][ks] : tapb[hi][0];        // taps 2 ks (low half) and 2 ks + 1 (high half) of channel n
+                    const unsigned w16 = (q >> 1) ? (word >> 16) : (word & 0xffffu);
+                    const unsigned wv = (dw_row_active && 2 * ks + (q >> 1) < 9) ? (w16 << dw_wsh) : 0u;
+                    nc_u4 af;
+                    af[0] = dw_widx == 0 ? wv : 0u; af[1] = dw_widx == 1 ? wv : 0u; af[2] = dw_widx == 2 ? wv : 0u; af[3] = dw_widx == 3 ? wv : 0u;
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) wk[kx] = hi ? *reinterpret_cast<const nc_f4*>(vec + NV_DWW + (ky * 3 + kx) * 1024 + ch) : wklo[ky * 3 + kx];
-#pragma unroll
-                    for (int pt = 0; pt < 4; ++pt)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const nc_h4 u = *reinterpret_cast<const nc_h4*>(grid + gpos0 + pt * 640 + (ky * 10 + kx) * 32);
-                            const nc_f4 uf = {(float)u[0], (float)u[1], (float)u[2], (float)u[3]};
-                            o[pt] = __builtin_elementwise_fma(uf, wk[kx], o[pt]);
-                        }
+                    for (int pt = 0; pt < 4; ++pt) {
+                        const nc_h8 bf = *reinterpret_cast<const nc_h8*>(grid + gposB + pt * 640 + dw_toff[ks]);
+                        o[pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nc_h8, af), bf, o[pt], 0, 0, 0);
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -319,8 +353,10 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 cs[2] += __shfl_xor(cs[2], m, 64); cs[3] += __shfl_xor(cs[3], m, 64);
             }
             if (n == 0) *reinterpret_cast<nc_h4*>(lds + NC_OFF_MEAN + (64 * wave + 16 * ps + 4 * q) * 2) = cvt4(cs * (1.0f / NC_PX));
+            NC_STAMP(2)
         }
         __syncthreads();
+        NC_STAMP(3)
         // ===== sca.1 (1x1 conv on the pooled vector): s = W mean + b for this wave's 64 channels -> the fp16 scale vector =====
         {
             const char* msrc[4];
@@ -339,7 +375,9 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 }
             }
         }
+        NC_STAMP(4)
         __syncthreads();
+        NC_STAMP(9)
         // ===== conv3 (1x1, 512 -> 512) on x * sca(x); y = inp + conv3 * beta =====
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
@@ -370,8 +408,10 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 }
             }
         }
+        NC_STAMP(5)
         // ===== norm2 + time FiLM -> bufA (its barriers also fence conv3's reads of bufB) =====
         layernorm_to_A(vec + NV_G2, film + 3 * NC_C, film + 2 * NC_C);
+        NC_STAMP(6)
         // ===== conv4 (1x1, 512 -> 1024) + SimpleGate (+ lens FiLM) -> bufB =====
 #pragma unroll 1
         for (int ps = 0; ps < 4; ++ps) {
@@ -396,7 +436,9 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 *reinterpret_cast<nc_h4*>(lds + NC_OFF_B + wr_off(64 * wave + 16 * ps, pt)) = cvt4(v);
             }
         }
+        NC_STAMP(7)
         __syncthreads();
+        NC_STAMP(9)
         // ===== conv5 (1x1, 512 -> 512); out = y + conv5 * gamma =====
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
@@ -427,6 +469,7 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 }
             }
         }
+        NC_STAMP(8)
         // (the next block's norm1 writes bufA: every wave has passed the barrier behind conv4; its barriers fence conv5's reads of bufB)
     }
     if constexpr (!XG) {
@@ -436,6 +479,14 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) *reinterpret_cast<nc_f4*>(xout + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q) = x[ct][pt];
     }
+    if constexpr (STAMP) {
+        if (lane == 0 && a.dbg) {
+            unsigned long long* d = a.dbg + ((size_t)b * 8 + wave) * 16;
+            for (int i = 0; i < 10; ++i) d[i] = st[i];
+            d[15] = __builtin_amdgcn_s_memtime() - st_t0;
+        }
+    }
+#undef NC_STAMP
 }
 
 }  // namespace
@@ -444,7 +495,11 @@ bool naf_chain_shape_ok(int H, int W, int c) { return H * W == NC_PX && H == 8 &
 size_t naf_chain_weight_halves(int nblocks) { return (size_t)8 * nblocks * NC_FRAGS_PER_BLOCK * 512; }
 size_t naf_chain_vec_floats(int nblocks) { return (size_t)nblocks * NV_TOTAL; }
 
+static unsigned long long* g_nc_dbg = nullptr;
+void naf_chain_set_debug(unsigned long long* buf) { g_nc_dbg = buf; }
+
 void naf_chain_global_init() {
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
@@ -457,6 +512,7 @@ void launch_naf_chain(const float* x, float* out, const unsigned short* w, const
     a.x = x; a.out = out; a.w = w; a.vecs = vecs; a.film = film; a.cam = cam;
     a.film_bstride = film_bstride; a.film_off = film_off; a.cam_bstride = cam_bstride; a.cam_off = cam_off;
     a.nblocks = nblocks;
+    a.dbg = g_nc_dbg;
     const size_t wb = naf_chain_weight_halves(nblocks) * 2;
     if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain: weight stream too large for 32-bit buffer offsets");
     a.w_bytes = (unsigned)wb;
@@ -465,6 +521,7 @@ void launch_naf_chain(const float* x, float* out, const unsigned short* w, const
     if (x == out && variant != 1) throw HipError("launch_naf_chain: in-place call needs the register variant");
     switch (variant) {
         case 1: hipLaunchKernelGGL((naf_chain_kernel<8, false>), dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a); break;
+        case 11: hipLaunchKernelGGL((naf_chain_kernel<8, false, true>), dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a); break;
         case 2: hipLaunchKernelGGL((naf_chain_kernel<16, true>), dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a); break;
         default: throw HipError("launch_naf_chain: bad variant");
     }

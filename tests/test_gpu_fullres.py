@@ -37,22 +37,33 @@ def sub3(y):
 _CACHE = {}
 
 
-def unet64():
-    if "unet" not in _CACHE:
+def unet64(prec="fp32"):
+    key = "unet" if prec == "fp32" else "unet_" + prec
+    if key not in _CACHE:
         params = O.synth_params(seed=0, nf=64, depth=4)
         m = P.ConditionalUNet(3, 3, 64, depth=4)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
-        _CACHE["unet"] = m.to(DEV).eval()
-    return _CACHE["unet"]
+        if prec != "fp32":
+            m.set_compute_dtype(prec)
+        _CACHE[key] = m.to(DEV).eval()
+    return _CACHE[key]
 
 
-def refusion_net():
-    if "naf" not in _CACHE:
+def refusion_net(prec="fp32"):
+    key = "naf" if prec == "fp32" else "naf_" + prec
+    if key not in _CACHE:
         params = O.naf_synth_params(seed=0, img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 28), dec_blk_nums=(1, 1, 1, 1))
         m = P.ConditionalNAFNet(img_channel=3, width=64, enc_blk_nums=[1, 1, 1, 28], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
         m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
-        _CACHE["naf"] = m.to(DEV).eval()
-    return _CACHE["naf"]
+        if prec != "fp32":
+            m.set_compute_dtype(prec)
+        _CACHE[key] = m.to(DEV).eval()
+    return _CACHE[key]
+
+
+# the plan-level checks below also run in the opt-in fp32_split_f16 mode (fp16 hi + lo operand pairs on the 16-bit MFMA pipe) inside the
+# default `-m gpu` run, at the native tolerances
+PRECS = ["fp32", "fp32_split_f16"]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -192,10 +203,11 @@ def test_latent_pipeline_256_reduced_precision(golden, dtype, tol):
 # ---------------------------------------------------------------------------------------------
 # production plan: batch independence, reduced precision at 256x256
 # ---------------------------------------------------------------------------------------------
-def test_batch16_256_equals_single_images():
+@pytest.mark.parametrize("prec", PRECS)
+def test_batch16_256_equals_single_images(prec):
     """The plan at B=16 256x256 (tile-loop component GEMMs, 1x1 tile-loop path, 256-wide tiles) differs from the B=1 plan
     (64-row tiles, split-K): image b of the batch-16 evaluation must equal the single-image evaluation to fp32 noise."""
-    m = unet64()
+    m = unet64(prec)
     lq, xT = O.synth_inputs(77, 16, 256, 256)
     x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
     yb = m(x, c, 63).cpu().numpy()
@@ -318,12 +330,13 @@ def test_reduced_precision_ode_256_T100(golden, dtype):
         assert _CACHE["ode_err_fp16"] < _CACHE["ode_err_bf16"]   # 11 vs 8 significand bits
 
 
-def test_unet_forward_512_vs_reference_golden_and_batch_plan(golden):
+@pytest.mark.parametrize("prec", PRECS)
+def test_unet_forward_512_vs_reference_golden_and_batch_plan(golden, prec):
     """ConditionalUNet.forward at 512x512 (north_star: "256x256 and 512x512 batches"): the single-image plan vs the REAL
     reference, then the 4 x 512 x 512 batch plan (1M-pixel level 0, 262 144 Winograd tiles per layer: other tile-loop /
     components-per-block choices than 16 x 256 x 256) vs four single-image evaluations and vs the golden through one slot."""
     g = golden.fullres2
-    m = unet64()
+    m = unet64(prec)
     lq1, xT1 = O.synth_inputs(1234, 1, 512, 512)
     x1, c1 = torch.from_numpy(xT1).to(DEV), torch.from_numpy(lq1).to(DEV)
     for t in (100, 23):
@@ -347,12 +360,13 @@ def test_unet_forward_512_vs_reference_golden_and_batch_plan(golden):
     assert float(np.abs(sub3(yb[2:3]) - g["unet_1x512x512/t23_sub3"]).max() / np.abs(g["unet_1x512x512/t23_sub3"]).max()) < 1e-4
 
 
-def test_nafnet_batch8_512_equals_single_images(golden):
+@pytest.mark.parametrize("prec", PRECS)
+def test_nafnet_batch8_512_equals_single_images(golden, prec):
     """BASELINE configs[3] plan: Refusion NAFNet at 8 x 512 x 512 vs eight single-image evaluations (deterministic pooled
     sums of the SCA branch are per image; the batch plan picks other GEMM tilings), and vs the reference golden through
     one slot of the batch."""
     g = golden.fullres
-    m = refusion_net()
+    m = refusion_net(prec)
     lq1, xT1 = O.synth_inputs(1234, 1, 512, 512, max_sigma=50)
     lq, xT = O.synth_inputs(79, 8, 512, 512, max_sigma=50)
     x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
