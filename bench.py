@@ -275,6 +275,8 @@ class Workload:
             model = P.latent_bokeh.ConditionalNAFNet(img_channel=4, **ncfg)   # lens-conditioned (lens_info kwargs)
             lm = P.latent.UNet(in_ch=3, out_ch=3, ch=64, ch_mult=[1, 2, 4], embed_dim=4)
             lm.load_state_dict(synth_state_dict(lm, 1))
+            if w["dtype"] == "fp16":   # configs[4] names fp16: the encode / decode convolutions run on fp16 operands too (tests/test_gpu_fullres.py::test_latent_pipeline_256_all_fp16)
+                lm.engine_flags = P._lib.FLAG_FP16
             self.latent_model = lm.to(dev).eval()
         elif model_kind == "dsde":  # denoising-sde/options/test/ir-sde.yml: unconditional UNet + DenoisingSDE(max_sigma=75, T=100)
             model = P.denoising_sde.ConditionalUNet(3, 3, 64, depth=4)

@@ -152,10 +152,13 @@ def _latent_256_models():
     return um.to(DEV).eval(), bm.to(DEV).eval()
 
 
-def _latent_256_run(golden, dtype):
+def _latent_256_run(golden, dtype, unet_fp16=False):
+    from image_restoration_sde_amd import _lib
     g = golden.fullres
     um, bm = _latent_256_models()
     bm.set_compute_dtype(dtype)
+    if unet_fp16:
+        um.engine_flags = _lib.FLAG_FP16   # the latent UNet's convolutions on fp16 operands too (encode / decode once per image)
     lq, _ = O.synth_inputs(1234, 1, 256, 256)
     lat, hid = um.encode(torch.from_numpy(lq).to(DEV))
     assert tuple(lat.shape) == (1, 4, 64, 64)
@@ -198,6 +201,18 @@ def test_latent_pipeline_256_reduced_precision(golden, dtype, tol):
     _CACHE["latent_err_" + dtype] = e_x0
     if "latent_err_fp16" in _CACHE and "latent_err_bf16" in _CACHE:
         assert _CACHE["latent_err_fp16"] < _CACHE["latent_err_bf16"]
+
+
+def test_latent_pipeline_256_all_fp16(golden):
+    """configs[4] with BOTH networks in the fp16 operand mode (bench.py's latent workload): the latent UNet's encode / decode convolutions on fp16 operands
+    as well as the score network.  Same 2e-2 bar as the score-network-only mode on the sampled latent and the decoded image; the encoder alone within 2e-3."""
+    g = golden.fullres
+    lat, x0, rec = _latent_256_run(golden, "fp16", unet_fp16=True)
+    e_lat = relerr(lat, g["latent_1x256x256/latent"])
+    e_x0 = relerr(x0, g["latent_1x256x256/latent_sde"])
+    e_rec = relerr(sub3(rec), g["latent_1x256x256/out_sde_sub3"])
+    print("latent 256 all-fp16: encode %.3g, latent sampler %.3g, decoded %.3g" % (e_lat, e_x0, e_rec))
+    assert np.isfinite(rec).all() and e_lat < 2e-3 and e_x0 < 2e-2 and e_rec < 2e-2
 
 
 # ---------------------------------------------------------------------------------------------
