@@ -517,7 +517,8 @@ def main():
             traffic, traffic_src = None, None
             try:
                 if is_default:
-                    pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc_hbm.json"))
+                    import re as _re   # the headline workload's file only: r<NN>_final_bench_pmc_hbm.json (not the latent / NAFNet / split-mode ones)
+                    pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if _re.fullmatch(r"r\d+_final_bench_pmc_hbm\.json", f))
                     traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"]
                     traffic_src = "profiles/%s (builder's rocprofv3 PMC passes of this command; not measured in this run)" % pm[-1]
             except (OSError, IndexError, KeyError, ValueError):
