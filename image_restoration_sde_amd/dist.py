@@ -4,7 +4,10 @@ Every image's reverse trajectory is independent (no cross-batch op in the score 
 batch is split over ranks with NO collective inside the T-step loop; one all_gather of the final
 [B,3,H,W] tensors (RCCL over xGMI when the backend is "nccl", gloo in the CPU tests) reassembles the batch.
 Noise streams are keyed by the GLOBAL image index (`sde.image_offset`), so the gathered result does
-not depend on the number of ranks.
+not depend on the number of ranks — to fp32 summation-order level, not bit for bit: the engine plans per
+local batch size (GEMM tilings, split-K, and the chunking of the LinearAttention softmax / context partials
+all depend on it), so an image sampled in a shard of 2 and in a batch of 16 differs by ~1e-6 relative per
+network evaluation (tests: batch-plan invariance at 5e-5, `tests/test_gpu_fullres.py`).
 """
 import torch
 import torch.distributed as dist
@@ -40,7 +43,7 @@ def sample_shard(sde, mode, x_local, mu_local, lo, n_items, group=None, **kwargs
     """Run `sde.reverse_<mode>` on THIS rank's shard (images [lo, lo + len(x_local)) of a global batch of `n_items`)
     and all_gather the restored global batch.  Only the shard has to be resident on the rank.  The noise streams are
     keyed by the global image index (`sde.image_offset` is set to its current value + lo for the call), so the result
-    equals one single-GPU call on the whole batch.  This is the one N>1 sampling path: `sample_sharded` and
+    equals one single-GPU call on the whole batch up to fp32 summation order (see the module docstring).  This is the one N>1 sampling path: `sample_sharded` and
     `bench.py --gpus N` go through it (`tools/eval_folder.py --gpus N` shards its FILE LIST over the ranks instead and only
     all_reduces the metric sums)."""
     fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[mode]
