@@ -773,7 +773,7 @@ __device__ __forceinline__ void wf64p_epilogue(const ConvParams& p, floatx4 (&ac
 // kernel, items }, producer waves { load issue, wait + transform + LDS writes, barrier wait, whole kernel, chunks }
 // EPI: the epilogue this instance is compiled for — bit 0 SiLU, bit 1 residual (0 .. 3: the production instances; four epilogue bodies behind
 // run-time branches in ONE kernel cost 250 spilled registers); -1: all four behind run-time branches (the measurement twins only)
-// OPT (r04 tuning bits; the production instances carry W6P_OPT_PROD):
+// OPT (r04 tuning bits, measurement twins only — irsde_bench_conv 1000 + OPT; production is OPT = 0: none of them paid, profiles/r04_wino_fused64_notes.md):
 //   1  the ring refills of a tile group's LAST chunk that would fetch units past it read out of range (zeros, no traffic): the ring is not live across
 //      the epilogue (it is primed between the two transform stages), so those 12 KB per wave and tile group were fetched twice, and the epilogue began
 //      by draining them (s_waitcnt vmcnt(0) before their registers could be reused)
