@@ -564,7 +564,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             launch_wino_output(sp.out, s);
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dU); (void)hipFree(dUs); (void)hipFree(dVs); (void)hipFree(dM);
-        } else if (naive == 35 || naive == 37 || naive == 39 || naive == 56 || naive == 58) {  // the 64-cout fused Winograd kernel on fp16 hi + lo operand pairs (IRSDE_FLAG_SPLIT_F16X2's big-feature-map path)
+        } else if (naive == 35 || naive == 37 || naive == 39 || naive == 56 || naive == 58 || naive == 61) {  // the 64-cout fused Winograd kernel on fp16 hi + lo operand pairs (IRSDE_FLAG_SPLIT_F16X2's big-feature-map path)
             if (!wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -579,10 +579,10 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             launch_wino_fused64_split_weights(dUf, dUp, Uf.size(), usc, s);
             p.pair_scale = 1.0f / (kWinoFused64PairVScale * usc);
-            launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, naive == 58 ? 44 : naive == 56 ? 24 : naive == 39 ? 9 : naive == 37 ? 4 + 64 : 4);   // 37: + cout block by XCD where legal; 39: r03's one-block-per-tile-group kernel
+            launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, naive == 61 ? 52 : naive == 58 ? 44 : naive == 56 ? 24 : naive == 39 ? 9 : naive == 37 ? 4 + 64 : 4);   // 37: + cout block by XCD where legal; 39: r03's one-block-per-tile-group kernel
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf); (void)hipFree(dUp);
-        } else if (naive == 33 || naive == 34 || naive == 36 || naive == 38 || (naive >= 50 && naive <= 55) || naive == 57) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
+        } else if (naive == 33 || naive == 34 || naive == 36 || naive == 38 || (naive >= 50 && naive <= 55) || naive == 57 || naive == 60) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
             if (naive == 33 ? !wino_fused_eligible(p) : !wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -592,6 +592,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMalloc(&dUf, Uf.size() * 4));
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             if (naive == 33) launch_wino_fused(p, dUf, s);
+            else if (naive == 60) launch_wino_fused64(p, dUf, s, 48);   // r04's single-stream kernel (61: its fp16-pair twin)
             else if (naive == 55 || naive == 57) launch_wino_fused64(p, dUf, s, naive == 55 ? 20 : 40);   // r04's register-patch persistent kernel (production is the halo kernel)
             else if (naive >= 50) {   // r04 tuning twins of the persistent kernel: 50 .. 54 = OPT 15 / 1 / 2 / 4 / 8
                 static const int opts[5] = {15, 1, 2, 4, 8};
@@ -881,13 +882,13 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         const bool split_v = variant == 412 || variant == 413 || variant == 422 || variant == 423;  // split-operand GEMMs: 41x whole three-launch layer, 42x the GEMM alone; x = planes
         unsigned short *dUs = nullptr, *dVs = nullptr;
         WinoSplitPlan sp{};
-        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410) || (variant >= 430 && variant <= 435) || (variant >= 440 && variant <= 444) || (variant >= 1000 && variant < 1064) || (variant >= 2000 && variant <= 2004) || (variant >= 2010 && variant <= 2012)) {
+        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410) || (variant >= 430 && variant <= 435) || (variant >= 440 && variant <= 454) || (variant >= 1000 && variant < 1064) || (variant >= 2000 && variant <= 2004) || (variant >= 2010 && variant <= 2012) || variant == 2020) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
             if (variant != 81 && variant != 421 && !split_v && !wino_fused_eligible(p)) throw HipError("bench_conv: shape not eligible for the fused Winograd kernel");
             if (variant >= 400 && !wino_fused64_eligible(p)) throw HipError("bench_conv: shape not eligible for the 64-cout fused Winograd kernel");
-            if (variant == 404 || variant == 405 || variant == 434 || variant == 444) {  // the fp16-pair twin: the random weights as hi / lo halves
+            if (variant == 404 || variant == 405 || variant == 434 || variant == 444 || variant == 452) {  // the fp16-pair twin: the random weights as hi / lo halves
                 float* dUp = nullptr;
                 IRSDE_HIP_CHECK(hipMalloc(&dUp, (size_t)36 * nw / 9 * 4));
                 launch_wino_fused64_split_weights(dU, reinterpret_cast<unsigned short*>(dUp), (size_t)36 * nw / 9, 256.0f, s);
@@ -954,11 +955,12 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
             (void)hipStreamDestroy(s);
             return;
         }
-        if (variant == 435 || (variant >= 2000 && variant <= 2004) || (variant >= 2010 && variant <= 2012)) {  // the persistent fused Winograd kernel once with per-wave cycle stamps: prints the averaged budget
+        if (variant == 435 || (variant >= 2000 && variant <= 2004) || (variant >= 2010 && variant <= 2012) || variant == 2020) {  // the persistent fused Winograd kernel once with per-wave cycle stamps: prints the averaged budget
             // 2000 + k: the stamp twins (k = 0 every r04 OPT bit, 1 no weight traffic, 2 no patch traffic, 3 patches from an L2-resident window, 4 = 435)
             // 2010 + k: the halo kernel's stamp twins (k = 0 production, 1 no weight traffic, 2 no halo traffic)
-            const bool halo = variant >= 2010;
-            const int stamp_variant = halo ? 45 + (variant - 2010) : variant == 435 || variant == 2004 ? 25 : 27 + (variant - 2000);
+            const bool halo = variant >= 2010 && variant <= 2012;
+            const bool single = variant == 2020;   // the single-stream kernel: 4 waves per block, every wave both roles
+            const int stamp_variant = single ? 53 : halo ? 45 + (variant - 2010) : variant == 435 || variant == 2004 ? 25 : 27 + (variant - 2000);
             const int nbp = 256;
             unsigned long long* dd = nullptr;
             IRSDE_HIP_CHECK(hipMalloc(&dd, (size_t)nbp * 64 * 8));
@@ -979,6 +981,14 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
                     for (int k = 0; k < 5; ++k) acc[w >= 4][k] += (double)t[k];
                     nw[w >= 4]++;
                 }
+            if (single) {
+                const int nst = Cin / 32;
+                const double items = acc[0][4] / std::max(nw[0], 1);
+                const double chunks = items * nst;
+                printf("wino4_fused64s stamps B=%d %dx%d Cin=%d Cout=%d: %.1f items x %d chunks per block; shader cycles per wave (mean over %d waves)\n", B, p.Ho, p.Wo, Cin, Cout, items, nst, nw[0]);
+                printf("  kernel %.0f = K loop incl. transform slices %.0f (%.0f per chunk; MFMA floor 9216) + barrier wait %.0f (%.0f per chunk) + epilogue %.0f (%.0f per item)\n",
+                       acc[0][3] / nw[0], acc[0][0] / nw[0], acc[0][0] / nw[0] / chunks, acc[0][1] / nw[0], acc[0][1] / nw[0] / chunks, acc[0][2] / nw[0], acc[0][2] / nw[0] / items);
+            } else
             if (halo) {   // per 16-channel step; producer columns: DMA issue, transform, barrier wait (both kinds of step), halo wait (off step)
                 double pa[6] = {0, 0, 0, 0, 0, 0};
                 int pn = 0;
@@ -1030,6 +1040,8 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
                 launch_wino_fused(p, dU, s);
             } else if (variant >= 400 && variant <= 410) {  // 406 / 407 / 408: non-temporal epilogue traffic / + patch loads / no hint at all
                  // 64-cout fused Winograd kernel: 400 production, 401 no weight traffic, 402 no patch traffic, 403 short U ring, 404 / 405 fp16 pairs (ring 12 / 18)
+                launch_wino_fused64(p, dU, s, variant - 400);
+            } else if (variant >= 448 && variant <= 454) {  // r04 single-stream kernel: 448 f32, 450 patch loads read zeros, 452 fp16 pairs; 449 / 451 / 454 measurement twins
                 launch_wino_fused64(p, dU, s, variant - 400);
             } else if (variant >= 440 && variant <= 444) {  // r04 halo kernel: 440 production, 441 / 442 weight fragments / halo fetches read zeros, 444 fp16 pairs
                 launch_wino_fused64(p, dU, s, variant - 400);

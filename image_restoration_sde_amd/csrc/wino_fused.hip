@@ -1346,6 +1346,245 @@ __global__ __launch_bounds__(WF_NT, 2) void wino4_fused64h_kernel(const ConvPara
 #undef W7_STAMP
 }
 
+// ================================================================================================================
+// r04 (late): wino4_fused64s_kernel — the persistent 64-cout kernel with ONE role per wave ("single-stream" kernel).
+//
+// What the two experiments after the halo kernel said (profiles/r04_wino_fused64_notes.md): an instruction of a producer wave —
+// vector, LDS or vector-memory — waits for a gap between the back-to-back f32 MFMAs of the wave that shares its SIMD (~27 cycles per vector
+// instruction, ~430 per gather), while the MFMA waves' own weight-fragment loads issue without any such wait (their K loop runs at 10.0-10.4k
+// cycles per chunk against a floor of 9.2k).  So the producer's work moves INTO the MFMA waves' instruction stream:
+//  * block = 4 waves, one per SIMD (the whole 512-register file of the SIMD: accumulators in the AccVGPR half);
+//    wave w = couts 16 w .. 16 w + 15 of the block's 64, all 36 components (as in wino4_fused64p_kernel) AND the input transform of tiles
+//    4 w .. 4 w + 3 (lane = (tile, channel pair), as the producer wave w + 4 did);
+//  * one register set of 36 patch pairs.  During the K loop of chunk q the wave transforms chunk q + 1 into the other V buffer between its
+//    MFMA groups: groups 6-11 the column pass (in place), groups 12-17 the row pass of row r, its six ds_write_b64, and — into the registers
+//    that row just freed — the six gathers of row r of chunk q + 2 (>= 7 groups, ~3.5k cycles, before the column pass needs them; packing the
+//    passes into groups 12-17 to give them 13 was slower: twelve gathers in a row from all four waves queue up in the CU's one address unit).
+//  * item walk, weight ring, V layout, lane-local output transform: wino4_fused64p_kernel's.  Same arithmetic in the same order: bit-identical.
+// ================================================================================================================
+template <int RING, bool NOPATCH, bool PAIR, bool NT, int EPI, bool STAMP = false, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void wino4_fused64s_kernel(const ConvParams p, const float* __restrict__ Uf, const int GX, const int GY, const int NB, const unsigned in0_bytes,
+                           const unsigned in1_bytes, const unsigned uf_bytes, const unsigned out_bytes, const unsigned res_bytes, const int xcd_nb,
+                           const int total, unsigned long long* __restrict__ dbg) {
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_n = 0, st_t0 = 0, st_t = 0;
+    if constexpr (STAMP) st_t0 = st_t = __builtin_amdgcn_s_memtime();
+#define W8_STAMP(ACC)                                                     \
+    if constexpr (STAMP) {                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        ACC += now_ - st_t;                                               \
+        st_t = now_;                                                      \
+    }
+    static_assert(72 % RING == 0 && RING % 4 == 0, "the ring must divide the 72 (component, k group) units of a chunk, in whole groups of 4");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int TH = p.Ho >> 2, TW = p.Wo >> 2;
+    const int Ctot = p.C0 + p.C1;
+    const int nch = Ctot / W6_KC;
+    const int nsub = Ctot / 16;
+    const int nblocks = gridDim.x;
+    // ---- matrix role
+    const int l15 = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Uf), 0, uf_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.out), 0, p.res ? res_bytes : 0u, 0x00020000);
+    floatx4 acc[36];
+#pragma unroll
+    for (int z = 0; z < 36; ++z) acc[z] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int uv_lane = lane * 16;
+    const int zstride = NB * nsub * 4096;
+    int v = blockIdx.x;
+    W6Item it = w6_item(v, total, NB, GX, GY, xcd_nb);
+    int ubase = it.nblk * nsub * 4096 + wave * 1024;
+    auto unit_rel = [&](const int K) { return (K % 36) * zstride + (K / 36) * 4096; };
+    floatx4 ring[RING];
+    const int v_lane = g * 64 + ((l15 ^ g) * 4);
+    // ---- transform role: lane = (tile 4 wave + (lane >> 4), channel pair lane & 15)
+    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, in0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1 ? p.in1 : p.in0), 0, p.in1 ? in1_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0), 0, 0u, 0x00020000);
+    const int cp = lane & 15;
+    const int tile = wave * 4 + (lane >> 4);
+    const int trow = tile >> 2, tcol = tile & 3;
+    const int kg = (cp >> 1) & 3;
+    const int vw_base = (cp >> 3) * W6_RS + kg * 64 + ((tile ^ kg) * 4) + 2 * (cp & 1);
+    const int Hv = p.Hin << p.in_shift, Wv = p.Win << p.in_shift;
+    const int N = (((total - 1 - (int)blockIdx.x) / nblocks) + 1) * nch;   // chunks of this block over all its tile groups (even)
+    unsigned voff[36];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) voff[e] = WF_OOB;
+    floatx2 raw[36];
+    int gq = 0, gv = blockIdx.x, gc = 0;        // the next chunk to gather: global index, tile group, chunk of the group
+    int go_v = -1, go_second = -1;              // what rowoff / coloff were built for
+    int g_soff = 0, g_second = 0;
+    unsigned g_dead = 0;
+// offsets / descriptor choice of chunk gq (the 36 gather offsets are rebuilt when the tile group or the concat source changes)
+#define W8_SETUP()                                                                                                           \
+    {                                                                                                                        \
+        const bool live_ = gq < N;                                                                                           \
+        const int cc_ = gc * W6_KC;                                                                                          \
+        g_second = cc_ >= p.C0 ? 1 : 0;                                                                                      \
+        if (live_ && (gv != go_v || g_second != go_second)) {                                                                \
+            const W6Item pi_ = w6_item(gv, total, NB, GX, GY, xcd_nb);                                                       \
+            const int tyy_ = pi_.gy * 4 + trow, txx_ = pi_.gx * 4 + tcol;                                                    \
+            const bool tile_ok_ = !NOPATCH && tyy_ < TH && txx_ < TW;                                                        \
+            const unsigned pixb_ = (unsigned)((g_second ? p.pix1 : p.pix0) * 4);                                             \
+            unsigned rowoff_[6], coloff_[6];                                                                                 \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                                  \
+                const int y = 4 * tyy_ - 1 + r, x = 4 * txx_ - 1 + r;                                                        \
+                rowoff_[r] = (tile_ok_ && (unsigned)y < (unsigned)Hv) ? (unsigned)((pi_.b * p.Hin + (y >> p.in_shift)) * p.Win) * pixb_ + (unsigned)(cp * 8) : WF_OOB; \
+                coloff_[r] = (tile_ok_ && (unsigned)x < (unsigned)Wv) ? (unsigned)(x >> p.in_shift) * pixb_ : WF_OOB;        \
+            }                                                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) _Pragma("unroll") for (int s = 0; s < 6; ++s)                      \
+                voff[r * 6 + s] = ((rowoff_[r] | coloff_[s]) & WF_OOB) ? WF_OOB : rowoff_[r] + coloff_[s];                   \
+            go_v = gv; go_second = g_second;                                                                                 \
+        }                                                                                                                    \
+        g_dead = live_ ? 0u : 1u;                                                                                            \
+        g_soff = (g_second ? cc_ - p.C0 : cc_) * 4;                                                                          \
+    }
+#define W8_GATHER_ROW(R)                                                                                                     \
+    {                                                                                                                        \
+        const __amdgpu_buffer_rsrc_t rs_ = g_dead ? rsrc_null : (g_second ? rsrc1 : rsrc0);   /* past the block's last chunk: out of range */ \
+        _Pragma("unroll") for (int s = 0; s < 6; ++s) raw[(R)*6 + s] =                                                       \
+            __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)voff[(R)*6 + s], g_soff, 0));         \
+    }
+#define W8_ADVANCE() { gq += 1; gc += 1; if (gc == nch) { gc = 0; gv += nblocks; } }
+#define W8_COLPASS(S)                                                                                                        \
+    {                                                                                                                        \
+        floatx2 col_[6], tc_[6];                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) col_[r] = raw[r * 6 + (S)];                                            \
+        bt6(col_, tc_);                                                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) raw[r * 6 + (S)] = tc_[r];                                             \
+    }
+#define W8_ROWPASS_WRITE(R, BUF)                                                                                             \
+    {                                                                                                                        \
+        floatx2 o_[6];                                                                                                       \
+        bt6(&raw[(R)*6], o_);                                                                                                \
+        float* vw_ = smem + (BUF)*W6_VBUF + vw_base;                                                                         \
+        _Pragma("unroll") for (int s = 0; s < 6; ++s)                                                                        \
+            *reinterpret_cast<floatx2*>(vw_ + ((R)*6 + s) * W6_ZS) = PAIR ? wf_split_pair(o_[s]) : o_[s];                    \
+    }
+    // prologue: chunk 0 of the first tile group into V[0], chunk 1 requested, the ring primed
+    W8_SETUP()
+#pragma unroll
+    for (int r = 0; r < 6; ++r) W8_GATHER_ROW(r)
+    W8_ADVANCE()
+#pragma unroll
+    for (int i = 0; i < RING; ++i)
+        ring[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uv_lane, ubase + unit_rel(i), 0));
+#pragma unroll
+    for (int s = 0; s < 6; ++s) W8_COLPASS(s)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) W8_ROWPASS_WRITE(r, 0)
+    W8_SETUP()
+#pragma unroll
+    for (int r = 0; r < 6; ++r) W8_GATHER_ROW(r)
+    W8_ADVANCE()
+    __syncthreads();
+    W8_STAMP(st_b)
+    while (v < total) {
+        const int nv = v + nblocks;
+        const W6Item nit = w6_item(nv < total ? nv : v, total, NB, GX, GY, xcd_nb);
+        const int nubase = nit.nblk * nsub * 4096 + wave * 1024;
+        for (int c = 0; c < nch; ++c) {
+            // (the chunk count of a tile group is even: the parity of the global chunk index is the parity of c)
+            const float* vb = smem + (c & 1) * W6_VBUF + v_lane;
+            const int wbuf = (c & 1) ^ 1;
+            const int cur_off = ubase + c * 8192;
+            const int nxt_off = c + 1 < nch ? cur_off + 8192 : nubase;
+            W8_SETUP()   // chunk (this + 2): its rows are gathered in groups 12 .. 17
+            floatx4 vq[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vq[0][i] = *reinterpret_cast<const floatx4*>(vb + i * W6_ZS);
+#pragma unroll
+            for (int gi = 0; gi < 18; ++gi) {
+                const int zq = gi % 9, cu = gi & 1, nx = cu ^ 1;
+                if (gi + 1 < 18) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        vq[nx][i] = *reinterpret_cast<const floatx4*>(vb + (4 * ((gi + 1) % 9) + i) * W6_ZS + ((gi + 1) / 9) * W6_RS);
+                }
+                if constexpr (PAIR) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[4 * zq + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wf_f16x8, ring[(gi * 4 + i) % RING]),
+                                                                                 __builtin_bit_cast(wf_f16x8, vq[cu][i]), acc[4 * zq + i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const floatx4 v_sw = {vq[cu][i][1], vq[cu][i][0], vq[cu][i][3], vq[cu][i][2]};
+                        acc[4 * zq + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wf_f16x8, ring[(gi * 4 + i) % RING]),
+                                                                                 __builtin_bit_cast(wf_f16x8, v_sw), acc[4 * zq + i], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[4 * zq + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(gi * 4 + i) % RING][j], vq[cu][i][j], acc[4 * zq + i], 0, 0, 0);
+                        if (j < 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the transform slice of this group (chunk + 1 -> V[wbuf]; rows of chunk + 2 into the registers the row pass freed)
+                // (DBG, measurement twins: 1 no column pass, 2 no row pass / V writes, 8 no gathers inside the K loop)
+                if constexpr (!(DBG & 1)) { if (gi >= 6 && gi < 12) W8_COLPASS(gi - 6) }
+                if (gi >= 12) {
+                    if constexpr (!(DBG & 2)) W8_ROWPASS_WRITE(gi - 12, wbuf)
+                    if constexpr (!(DBG & 8)) W8_GATHER_ROW(gi - 12)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ul = gi * 4 + i, K = ul + RING;
+                    const int off = K < 72 ? cur_off + unit_rel(K) : nxt_off + unit_rel(K - 72);
+                    ring[ul % RING] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, uv_lane, off, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            W8_ADVANCE()
+            W8_STAMP(st_a)
+            __syncthreads();
+            W8_STAMP(st_b)
+        }
+        {
+            const int n = it.nblk * 64 + wave * 16 + 4 * g;
+            const int tyy = it.gy * 4 + (l15 >> 2), txx = it.gx * 4 + (l15 & 3);
+            const bool ok = tyy < TH && txx < TW;
+            const unsigned pix = (unsigned)((it.b * p.Ho + 4 * tyy) * p.Wo + 4 * txx);
+            const unsigned off_out = ok ? (pix * (unsigned)p.out_stride + (unsigned)n) * 4u : WF_OOB;
+            const unsigned off_res = ok ? (pix * (unsigned)p.res_stride + (unsigned)n) * 4u : WF_OOB;
+            floatx4 bias = {0.f, 0.f, 0.f, 0.f}, fsc = {1.f, 1.f, 1.f, 1.f}, fsh = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bias = *reinterpret_cast<const floatx4*>(p.bias + n);
+            if (p.film) {
+                const float* f = p.film + (size_t)it.b * p.film_bstride;
+                fsc = *reinterpret_cast<const floatx4*>(f + n) + 1.0f;
+                fsh = *reinterpret_cast<const floatx4*>(f + p.Cout + n);
+            }
+            wf64p_epilogue<NT, PAIR, (EPI & 2) != 0, (EPI & 1) != 0, RING>(p, acc, off_out, off_res, rs_out, rs_res, bias, fsc, fsh, ring, rsrc_u, uv_lane, nubase, zstride);
+        }
+#pragma unroll
+        for (int z = 0; z < 36; ++z) acc[z] = floatx4{0.f, 0.f, 0.f, 0.f};
+        v = nv; it = nit; ubase = nubase;
+        if constexpr (STAMP) st_n += 1;
+        W8_STAMP(st_c)
+    }
+#undef W8_ROWPASS_WRITE
+#undef W8_COLPASS
+#undef W8_ADVANCE
+#undef W8_GATHER_ROW
+#undef W8_SETUP
+    if constexpr (STAMP) {
+        if (lane == 0 && dbg) {
+            unsigned long long* d = dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+            d[0] = st_a; d[1] = st_b; d[2] = st_c; d[3] = __builtin_amdgcn_s_memtime() - st_t0; d[4] = st_n;
+        }
+    }
+#undef W8_STAMP
+}
+
 }  // namespace
 
 // Blocks the launch of launch_wino_fused(p, ...) creates (the size of the variant-82 stamp buffer: 64 stamps per block)
@@ -1389,6 +1628,17 @@ void wino_fused_global_init() {
     W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, true, 16); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, true, 16);
 #undef W6P_ATTR4
 #undef W6P_ATTR
+#define W8_ATTR(...) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused64s_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define W8_ATTR4(...) W8_ATTR(__VA_ARGS__, 0); W8_ATTR(__VA_ARGS__, 1); W8_ATTR(__VA_ARGS__, 2); W8_ATTR(__VA_ARGS__, 3)
+    W8_ATTR4(W6_RING_ALT, false, false, true);
+    W8_ATTR4(W6_RING_ALT, true, false, true);
+    W8_ATTR4(W6_RING_ALT, false, true, true);
+    W8_ATTR(W6_RING_ALT, false, false, true, 1, true); W8_ATTR(W6_RING_ALT, false, false, true, 3, true);
+    W8_ATTR(W6_RING_ALT, false, false, true, 1, false, 11); W8_ATTR(W6_RING_ALT, false, false, true, 3, false, 11);
+    W8_ATTR(W6_RING_ALT, false, false, true, 1, false, 3); W8_ATTR(W6_RING_ALT, false, false, true, 3, false, 3);
+    W8_ATTR(W6_RING_ALT, false, false, true, 1, false, 8); W8_ATTR(W6_RING_ALT, false, false, true, 3, false, 8);
+#undef W8_ATTR4
+#undef W8_ATTR
 #define W7_ATTR(...) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused64h_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
 #define W7_ATTR4(...) W7_ATTR(__VA_ARGS__, 0); W7_ATTR(__VA_ARGS__, 1); W7_ATTR(__VA_ARGS__, 2); W7_ATTR(__VA_ARGS__, 3)
     W7_ATTR4(W6_RING_ALT, false, false, false, true);
@@ -1565,6 +1815,36 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
         case 2: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 2, true); break;     \
         default: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 3, true); break;    \
     }
+        if (variant >= 48 && variant <= 54) {   // the single-stream kernel: 48 f32, 50 patch loads read zeros, 52 fp16 pairs, 53 cycle stamps (epilogues 1 / 3)
+#define W8_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64s_kernel<W6_RING_ALT, __VA_ARGS__>), pgrid, dim3(256), W6_LDS_BYTES + 1024, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, out_bytes, res_bytes, xcd_nb, total, g_w6p_dbg)
+#define W8_LAUNCH_EPI(...)                                  \
+    switch (epi) {                                          \
+        case 0: W8_LAUNCH(__VA_ARGS__, 0); break;           \
+        case 1: W8_LAUNCH(__VA_ARGS__, 1); break;           \
+        case 2: W8_LAUNCH(__VA_ARGS__, 2); break;           \
+        default: W8_LAUNCH(__VA_ARGS__, 3); break;          \
+    }
+            switch (variant) {
+                case 48: W8_LAUNCH_EPI(false, false, true) break;
+                case 50: W8_LAUNCH_EPI(true, false, true) break;
+                case 52: W8_LAUNCH_EPI(false, true, true) break;
+                case 53:
+                    if (epi != 1 && epi != 3) throw HipError("launch_wino_fused64: stamp twins exist for epilogues 1 / 3");
+                    if (epi == 1) W8_LAUNCH(false, false, true, 1, true); else W8_LAUNCH(false, false, true, 3, true);
+                    break;
+                case 49: case 51: case 54:   // measurement twins (results are garbage): 49 MFMAs + ring + V reads only, 51 + gathers, 54 everything but the gathers
+                    if (epi != 1 && epi != 3) throw HipError("launch_wino_fused64: measurement twins exist for epilogues 1 / 3");
+                    if (variant == 49) { if (epi == 1) W8_LAUNCH(false, false, true, 1, false, 11); else W8_LAUNCH(false, false, true, 3, false, 11); }
+                    if (variant == 51) { if (epi == 1) W8_LAUNCH(false, false, true, 1, false, 3); else W8_LAUNCH(false, false, true, 3, false, 3); }
+                    if (variant == 54) { if (epi == 1) W8_LAUNCH(false, false, true, 1, false, 8); else W8_LAUNCH(false, false, true, 3, false, 8); }
+                    break;
+                default: throw HipError("launch_wino_fused64: bad variant");
+            }
+#undef W8_LAUNCH_EPI
+#undef W8_LAUNCH
+            IRSDE_HIP_CHECK(hipGetLastError());
+            return;
+        }
         if (variant >= 40 && variant <= 47) {   // the halo kernel: 40 production f32, 41 weight fragments read zeros, 42 halo fetches read zeros, 44 fp16 pairs
 #define W7_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64h_kernel<W6_RING_ALT, __VA_ARGS__>), pgrid, dim3(WF_NT), W7_LDS_BYTES, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, out_bytes, res_bytes, xcd_nb, total, g_w6p_dbg)
 #define W7_LAUNCH_EPI(...)                                  \

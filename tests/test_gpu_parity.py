@@ -232,7 +232,7 @@ def test_conv_wino_fused64_persistent_rounds(shape):
     # 55 / 56: r04's register-patch persistent kernel (f32 / fp16 pairs); 34 / 35: production; 57 / 58: the halo kernel (patches through LDS);
     # 51 / 53: tuning twins of the persistent kernel (no double-fetched ring units / interleaved patch-load issue).  Same arithmetic in the
     # same order everywhere: bit-identical.  52 (12-operation B^T) and 50 (every tuning bit) re-associate the input transform.
-    for nv in (55, 57, 51, 53):
+    for nv in (55, 57, 51, 53, 60):   # 60: the single-stream kernel (every wave both roles)
         assert np.array_equal(got, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout)), (shape, nv)
     for nv in (52, 50):
         assert relerr(run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout), ref) < 5e-5, (shape, nv)
@@ -240,7 +240,7 @@ def test_conv_wino_fused64_persistent_rounds(shape):
     assert relerr(pair, ref) < 5e-5, shape
     assert relerr(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=39, film_bstride=2 * Cout)) < 2e-5, shape
     assert np.array_equal(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=37, film_bstride=2 * Cout)), shape
-    for nv in (56, 58):
+    for nv in (56, 58, 61):
         assert np.array_equal(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout)), (shape, nv)
 
 
