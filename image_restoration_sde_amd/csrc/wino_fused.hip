@@ -1781,10 +1781,11 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
     static const bool nt = tuning_env_int("IRSDE_WINO_FUSED64_NT", 1) != 0;
     // r04: the persistent kernel (one block per CU walks its tile groups, output transform in registers) is production;
     // IRSDE_WINO_FUSED64_PERSIST=0 under IRSDE_TUNING=1 selects r03's one-block-per-tile-group kernel
-    // (r04, later) 2 selects the halo kernel (patches staged through LDS by LDS-DMA); 1 = the register-patch persistent kernel is production
+    // (r04, later) 2 selects the halo kernel (patches staged through LDS by LDS-DMA), 3 the single-stream kernel; 1 = the register-patch persistent kernel is production
     static const int persist = tuning_env_int("IRSDE_WINO_FUSED64_PERSIST", 1);
     if (persist == 1 && (variant == 0 || variant == 4)) variant = variant == 0 ? 20 : 24;
-    if (persist >= 2 && (variant == 0 || variant == 4)) variant = variant == 0 ? 40 : 44;
+    if (persist == 2 && (variant == 0 || variant == 4)) variant = variant == 0 ? 40 : 44;
+    if (persist >= 3 && (variant == 0 || variant == 4)) variant = variant == 0 ? 48 : 52;   // 3: the single-stream kernel (one role per wave)
     if (variant >= 20) {   // 20 production f32, 21 weight fragments read zeros, 22 patch loads read zeros, 23 no non-temporal hint, 24 fp16 pairs
         static const int ncu = [] {
             int dev = 0, n = 0;
