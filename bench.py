@@ -260,6 +260,9 @@ def workload_text(w, n_evals):
     return "IR-SDE deraining ConditionalUNet nf=64 depth=4, reverse_%s, batch=%d/GPU %dx%d, T=%d (BASELINE.json configs[1])" % fmt
 
 
+DIST_ON = False   # a process group is up (world > 1, or the one-rank RCCL test hook): barriers, gathers and all_reduces are live
+
+
 class Workload:
     """One synthetic workload on this rank: models, schedule, resident inputs, `one_step()` = one pass of the hot path over
     this rank's share of the batch (+ the final gather when world > 1), `profile_pass(T)` = the event-instrumented pass."""
@@ -338,7 +341,7 @@ class Workload:
         P, sde = self.P, self.sde
         if self.fn is not None:
             out = self.fn(self.x_T)
-            return P.gather_batch(out, self.nglobal) if self.world > 1 else out
+            return P.gather_batch(out, self.nglobal) if DIST_ON else out
         # the product's N>1 path: sample this rank's shard, then the final all_gather (the only collective)
         sde.image_offset = 0
         return P.sample_shard(sde, self.w["mode"], self.x_T, self.mu, self.lo, self.nglobal)
@@ -379,7 +382,7 @@ def timed(wl, steps, warmup, world, dev):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if DIST_ON:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -395,7 +398,7 @@ def timed(wl, steps, warmup, world, dev):
     fence()
     dt = time.perf_counter() - t0
     per_rank = [mine]
-    if world > 1:
+    if DIST_ON:
         tt = torch.tensor([dt, mine], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
         parts = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(parts, tt)
@@ -457,7 +460,17 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if oversub else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # IRSDE_BENCH_FORCE_RCCL=1 (tests/test_gpu_fullres.py, 1-GPU box): a process group of ONE rank over RCCL, so that the N > 1 code path —
+    # init_process_group("nccl", device_id=...), barrier, the device-side all_gather of gather_batch, the all_reduce of all_ok — runs on the hardware there is
+    global DIST_ON
+    force_rccl = world == 1 and os.environ.get("IRSDE_BENCH_FORCE_RCCL") == "1"
+    if force_rccl:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    DIST_ON = world > 1 or force_rccl
+    if DIST_ON:
         if oversub:
             dist.init_process_group("gloo")
         else:
@@ -469,7 +482,7 @@ def main():
     def all_ok(ok):
         """True only if EVERY rank says ok (so a failure on one rank makes all ranks skip the phase together instead of leaving the
         others blocked in the next collective)."""
-        if world == 1:
+        if not DIST_ON:
             return ok
         t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -483,7 +496,7 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
     setup_s = [t_setup]
-    if world > 1:
+    if DIST_ON:
         parts = [None] * world
         dist.all_gather_object(parts, t_setup)
         setup_s = [float(x) for x in parts]
@@ -575,7 +588,7 @@ def main():
             except Exception as ex:  # the GPU number must not be lost to a host-side problem
                 res["cpu_baseline"] = {"value": None, "error": repr(ex)}
         print(json.dumps(res, separators=(",", ":")))
-    if world > 1:
+    if DIST_ON:
         dist.destroy_process_group()
 
 

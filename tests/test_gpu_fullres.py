@@ -634,6 +634,42 @@ def _shard_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def test_sample_sharded_one_rank_over_rccl():
+    """The RCCL branch on the hardware a 1-GPU box has: a process group of ONE rank with backend "nccl" (= RCCL), `init_process_group(..., device_id=)`,
+    `sample_sharded` -> `sample_shard` -> the device-side `all_gather` of `gather_batch`.  Result == the plain single-GPU call, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_shard_worker, args=(0, 1, port, q))
+    pr.start()
+    rank, got = q.get(timeout=600)
+    pr.join(timeout=120)
+    assert pr.exitcode == 0 and rank == 0
+    params = O.synth_params(seed=0, nf=32, depth=2)
+    m = P.ConditionalUNet(3, 3, 32, depth=2)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.to(DEV).eval()
+    lq, xT = O.synth_inputs(4, 5, 24, 20)
+    sde = P.IRSDE(10, 8, "cosine", 0.005, device=DEV)
+    sde.set_model(m)
+    sde.seed = 11
+    sde.set_mu(torch.from_numpy(lq).to(DEV))
+    ref = sde.reverse_sde(torch.from_numpy(xT).to(DEV)).cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_bench_one_rank_over_rccl():
+    """bench.py's N > 1 code path (RCCL group, barrier fences, gather_batch, all_reduce'd phase agreement, max over ranks) with a group of one rank."""
+    res = _run_bench(["--steps", "1", "--warmup", "1", "--batch", "3", "--size", "64", "--T", "6", "--no-cpu-baseline"], {"IRSDE_BENCH_FORCE_RCCL": "1"})
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["global_batch"] == 3
+    assert 0 < res["rank_ms_per_step"]["min"] <= res["rank_ms_per_step"]["max"]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
 def test_sample_sharded_two_real_gpus():
     """2-rank `sample_sharded` on real devices over RCCL: ragged split (5 images), Philox noise keyed by the global image
