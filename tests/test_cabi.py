@@ -43,6 +43,14 @@ def _create(nf=64, depth=4, in_nc=3, out_nc=3):
     return L, rc, h
 
 
+def test_graft_entry_build_passes():
+    """The driver's "does it build" check: __graft_entry__.build() compiles (or finds) the library and checks that its ABI version is the
+    last entry of the header's changelog (a stale literal there failed the check once the ABI moved to 103)."""
+    import __graft_entry__ as g
+    path = g.build()
+    assert os.path.exists(path) and path.endswith("libirsde_hip.so")
+
+
 def test_engine_inventory_matches_reference_state_dict():
     """irsde_create is host-only: the weight inventory must be the reference's 151 state_dict tensors."""
     L, rc, h = _create()
