@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .sde import _save_state, _unwrap
+from .sde import _check_fp16_range, _save_state, _unwrap
 from .unet import ConditionalUNet as _CondUNet, _Gain, _ResBlock, _Residual, _upsample
 
 
@@ -176,6 +176,7 @@ class DenoisingSDE:
                 _lib.check(L.irsde_sample(eng.h, mode, ctypes.c_void_p(x_in.data_ptr()), None,
                                           ctypes.c_void_p(z.data_ptr()) if z is not None else None, self.seed,
                                           self.image_offset, B, H, W, T, 0, ctypes.c_void_p(out.data_ptr()), stream, flags))
+                _check_fp16_range(self.model, out)
                 return out
             out.copy_(x_in)
             for t in reversed(range(1, T + 1)):

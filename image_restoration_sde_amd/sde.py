@@ -35,6 +35,18 @@ from . import _lib
 from .unet import ConditionalUNet
 
 
+def _check_fp16_range(model, out):
+    """The fp16-operand modes ('fp32_split_f16', 'fp16') are range-limited (|activation| below ~1e4, include/irsde_hip.h): leaving that
+    window shows up as inf / NaN in the sampler's output.  Fail loudly instead of handing it on (costs one stream synchronisation, in
+    these opt-in modes only; `model.check_fp16_range = False` switches it off)."""
+    m = _unwrap(model)
+    flags = int(getattr(m, "engine_flags", 0))
+    if flags & (_lib.FLAG_SPLIT_F16X2 | _lib.FLAG_FP16) and getattr(m, "check_fp16_range", True):
+        if not bool(torch.isfinite(out).all()):
+            raise _lib.IrsdeError("non-finite sampler output in an fp16-operand mode: the activations left fp16's range "
+                                  "(|x| < ~1e4 is required) — use compute dtype 'fp32' or 'fp32_split' (bf16 pieces, f32's range)")
+
+
 def _unwrap(model):
     m = model
     while hasattr(m, "module") and isinstance(getattr(m, "module"), torch.nn.Module):
@@ -187,6 +199,7 @@ class IRSDE:
                         if d >= 1:
                             _save_state(out, save_dir, d // interval)
                         cur, t = out, t_stop
+                _check_fp16_range(self.model, out)
                 return out
             # foreign score model: reference-style loop, fused HIP state update per step
             out.copy_(x_in)

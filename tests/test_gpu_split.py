@@ -197,6 +197,32 @@ def test_split_f16_large_activations_stay_finite():
         assert relerr(got, ref) < (3e-5 if naive == 44 else 2e-4), naive
 
 
+def test_split_f16_out_of_range_input_fails_loudly():
+    """fp16 pairs are range-limited (|activation| below ~1e4).  Inputs six orders of magnitude above an image drive the activations out of
+    fp16's range: the fp32 engine still returns finite numbers, fp32_split (bf16 pieces, f32's exponent range) too, fp32_split_f16 must RAISE
+    instead of handing inf / NaN on (image_restoration_sde_amd/sde.py::_check_fp16_range)."""
+    params = O.synth_params(seed=0, nf=64, depth=2)
+    lq, xT = O.synth_inputs(7, 1, 32, 32)
+    lq_t, xT_t = torch.from_numpy(lq * 3e6).to("cuda:0"), torch.from_numpy(xT * 3e6).to("cuda:0")
+    outs = {}
+    for prec in ("fp32", "fp32_split", "fp32_split_f16"):
+        m = P.ConditionalUNet(3, 3, 64, depth=2)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        m = m.to("cuda:0").eval()
+        m.set_compute_dtype(prec)
+        sde = P.IRSDE(10, 4, "cosine", 0.005, device="cuda:0")
+        sde.set_model(m)
+        sde.set_mu(lq_t)
+        if prec == "fp32_split_f16":
+            with pytest.raises(P._lib.IrsdeError, match="fp16's range"):
+                sde.reverse_ode(xT_t)
+            m.check_fp16_range = False   # the switch: the same call now returns whatever the arithmetic produced
+            assert not bool(torch.isfinite(sde.reverse_ode(xT_t)).all())
+        else:
+            outs[prec] = sde.reverse_ode(xT_t)
+            assert bool(torch.isfinite(outs[prec]).all()), prec
+
+
 # ---------------------------------------------------------------------------------------------
 # the PAIR instance of the fused Winograd kernel (wino4_fused64_kernel<.., PAIR = true>): the big-feature-map layers of fp32_split_f16
 # ---------------------------------------------------------------------------------------------
