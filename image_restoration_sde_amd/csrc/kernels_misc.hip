@@ -1201,14 +1201,18 @@ constexpr int kDwRows = 4;
 constexpr int kDwRun = 16;
 
 struct DwGeom {
-    int gpp, PP, tiles_x, tiles_y;
+    int gpp, PP, run, tiles_x, tiles_y;
 };
 static inline DwGeom dw_geom(int H, int W, int c) {
     DwGeom g;
     const int G = c >> 2;
     g.gpp = G < 256 ? G : 256;
     g.PP = 256 / g.gpp;
-    g.tiles_x = (W + g.PP * kDwRun - 1) / (g.PP * kDwRun);
+    // columns a lane walks: kDwRun, but no more than it takes the block's pixel lanes to cover the image width (r04: on the latent feature maps,
+    // 64 .. 16 columns wide, a run of 16 left three of four lanes without work); at least 4, so that the two window columns a walk starts with stay < 50 % extra
+    g.run = (W + g.PP - 1) / g.PP;
+    g.run = g.run < 4 ? 4 : g.run > kDwRun ? kDwRun : g.run;
+    g.tiles_x = (W + g.PP * g.run - 1) / (g.PP * g.run);
     g.tiles_y = (H + kDwRows - 1) / kDwRows;
     return g;
 }
@@ -1216,7 +1220,7 @@ static inline DwGeom dw_geom(int H, int W, int c) {
 __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restrict__ u, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           float* __restrict__ partial, const int H, const int W,
-                                                          const int c, const int tiles_x, const int ntiles) {
+                                                          const int c, const int tiles_x, const int ntiles, const int run) {
     __shared__ float4 red[256];
     constexpr int R = kDwRows;
     const int tile = blockIdx.x, b = blockIdx.y;
@@ -1230,7 +1234,7 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restric
         const int g = gc + (int)(threadIdx.x % gpp);
         const int pl = threadIdx.x / gpp;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int y0 = ty * R, x0 = (tx * PP + pl) * kDwRun;
+        const int y0 = ty * R, x0 = (tx * PP + pl) * run;
         if (g < G && pl < PP && x0 < W) {
             const int ch = g * 4;
             const float4 b1 = *reinterpret_cast<const float4*>(bias + ch);
@@ -1287,7 +1291,7 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(const float* __restric
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>;
-            const int xe = x0 + kDwRun < W ? x0 + kDwRun : W;
+            const int xe = x0 + run < W ? x0 + run : W;
             for (int x = x0; x < xe; x += 3) {  // three steps per iteration: the slot roles rotate at compile time
                 step(x, I0{}, I1{}, I2{});
                 if (x + 1 < xe) step(x + 1, I1{}, I2{}, I0{});
@@ -1394,7 +1398,7 @@ void launch_dwconv_gate(const float* u, const float* w, const float* bias, float
     if (c % 4) throw HipError("dwconv_gate: channel count must be a multiple of 4");
     const DwGeom g = dw_geom(H, W, c);
     const int nt = g.tiles_x * g.tiles_y;
-    hipLaunchKernelGGL(dwconv_gate_kernel, dim3(nt, B), dim3(256), 0, s, u, w, bias, out, partial, H, W, c, g.tiles_x, nt);
+    hipLaunchKernelGGL(dwconv_gate_kernel, dim3(nt, B), dim3(256), 0, s, u, w, bias, out, partial, H, W, c, g.tiles_x, nt, g.run);
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
