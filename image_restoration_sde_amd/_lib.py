@@ -40,7 +40,7 @@ SYMBOLS = [
     "irsde_set_schedule", "irsde_unet_forward", "irsde_sample", "irsde_sde_step", "irsde_philox_normal",
     "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv", "irsde_plan_describe", "irsde_bench_conv", "irsde_op_profile", "irsde_debug_split_gemm", "irsde_bench_naf_chain",
     "irsde_eval_metrics", "irsde_tensor2img",
-    "irsde_set_lens_info", "irsde_create_latent_unet", "irsde_latent_shapes", "irsde_latent_encode", "irsde_latent_decode",
+    "irsde_set_lens_info", "irsde_create_latent_unet", "irsde_latent_shapes", "irsde_latent_encode", "irsde_latent_decode", "irsde_latent_hidden",
 ]
 
 
@@ -125,6 +125,7 @@ def _declare(lib):
     lib.irsde_latent_shapes.argtypes = [P, c.c_int, c.c_int, c.POINTER(c.c_int64), c.POINTER(c.c_int64), c.POINTER(c.c_int)]
     lib.irsde_latent_encode.argtypes = [P, P, c.c_int, c.c_int, c.c_int, P, c.POINTER(P), P]
     lib.irsde_latent_decode.argtypes = [P, P, c.POINTER(P), c.c_int, c.c_int, c.c_int, P, P]
+    lib.irsde_latent_hidden.argtypes = [P, c.c_int, c.c_int, c.c_int, c.c_int, P, P]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError here = the .so does not export what the header declares
     return lib

@@ -268,6 +268,7 @@ struct LatentPlan {
     Tensor latent;               // NHWC latent (channels padded to 32)
     std::vector<Tensor> hidden;  // NHWC skips in the reference's list order h[0..2*depth]
     std::vector<int> hidden_c;   // logical channel counts
+    bool resident = false;       // encode plan: the skips of the last encode are in place (decode plan: it SHARES the encode plan's skip tensors)
 };
 
 }  // namespace irsde

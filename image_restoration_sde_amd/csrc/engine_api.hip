@@ -89,7 +89,7 @@ int guard(const std::function<void()>& f) {
 extern "C" {
 
 const char* irsde_last_error(void) { return g_last_error.c_str(); }
-int irsde_version(void) { return 103; }  // changelog: include/irsde_hip.h
+int irsde_version(void) { return 104; }  // changelog: include/irsde_hip.h
 
 int irsde_create(const irsde_config* cfg, irsde_engine** out) {
     return guard([&] {
@@ -1135,7 +1135,7 @@ int irsde_latent_shapes(irsde_engine* e, int H, int W, int64_t latent_chw[3], in
 int irsde_latent_encode(irsde_engine* e, const float* x, int B, int H, int W, float* latent, float* const* hidden,
                         void* stream) {
     return guard([&] {
-        if (!e || e->arch != 2 || !x || !latent || !hidden) throw HipError("latent_encode: not a latent UNet engine / null argument");
+        if (!e || e->arch != 2 || !x || !latent) throw HipError("latent_encode: not a latent UNet engine / null argument");
         if (!e->finalized) throw HipError("latent_encode: weights not finalized");
         if (B < 1 || H < 2 || W < 2) throw HipError("latent_encode: bad shape");
         std::lock_guard<std::mutex> lk(e->mu);
@@ -1149,7 +1149,8 @@ int irsde_latent_encode(irsde_engine* e, const float* x, int B, int H, int W, fl
         run_net(pl, s);
         const Tensor& L = lp->latent;
         launch_unpack_pred(L.p, latent, B, e->lat_embed, L.H, L.W, L.H, L.W, L.C, s);
-        for (size_t k = 0; k < lp->hidden.size(); ++k) {
+        lp->resident = true;   // the skips stay in place for irsde_latent_decode(hidden = NULL) / irsde_latent_hidden
+        for (size_t k = 0; hidden && k < lp->hidden.size(); ++k) {
             const Tensor& h = lp->hidden[k];
             if (!hidden[k]) throw HipError("latent_encode: null hidden pointer");
             launch_unpack_pred(h.p, hidden[k], B, lp->hidden_c[k], h.H, h.W, h.H, h.W, h.C, s);
@@ -1162,24 +1163,47 @@ int irsde_latent_encode(irsde_engine* e, const float* x, int B, int H, int W, fl
 int irsde_latent_decode(irsde_engine* e, const float* latent, const float* const* hidden, int B, int H, int W, float* out,
                         void* stream) {
     return guard([&] {
-        if (!e || e->arch != 2 || !latent || !hidden || !out) throw HipError("latent_decode: not a latent UNet engine / null argument");
+        if (!e || e->arch != 2 || !latent || !out) throw HipError("latent_decode: not a latent UNet engine / null argument");
         if (!e->finalized) throw HipError("latent_decode: weights not finalized");
         std::lock_guard<std::mutex> lk(e->mu);
         DeviceScope dev_scope(e->cfg.device);
         hipStream_t user = reinterpret_cast<hipStream_t>(stream), s = e->stream;
         LatentPlan* lp = get_latent_plan(e, B, H, W, true);
         Plan* pl = lp->plan.get();
+        LatentPlan* enc = get_latent_plan(e, B, H, W, false);   // (exists: the decode plan was built on it)
+        if (!hidden && !enc->resident) throw HipError("latent_decode: hidden == NULL needs a preceding irsde_latent_encode of the same B x H x W on this engine");
+        if (hidden) enc->resident = false;   // the caller's skips overwrite the shared storage
         IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
         IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
         const Tensor& L = lp->latent;
         launch_nchw_to_nhwc_pad(latent, L.p, B, e->lat_embed, L.H, L.W, L.H, L.W, L.C, 0, s);
-        for (size_t k = 0; k < lp->hidden.size(); ++k) {
+        for (size_t k = 0; hidden && k < lp->hidden.size(); ++k) {
             const Tensor& h = lp->hidden[k];
             if (!hidden[k]) throw HipError("latent_decode: null hidden pointer");
             launch_nchw_to_nhwc_pad(hidden[k], h.p, B, lp->hidden_c[k], h.H, h.W, h.H, h.W, h.C, 0, s);
         }
         run_net(pl, s);
         launch_unpack_pred(lp->image.p, out, B, e->lat_out, H, W, pl->Hp, pl->Wp, 4, s);  // x[..., :H, :W]
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+    });
+}
+
+int irsde_latent_hidden(irsde_engine* e, int B, int H, int W, int k, float* out, void* stream) {
+    return guard([&] {
+        if (!e || e->arch != 2 || !out) throw HipError("latent_hidden: not a latent UNet engine / null argument");
+        std::lock_guard<std::mutex> lk(e->mu);
+        DeviceScope dev_scope(e->cfg.device);
+        hipStream_t user = reinterpret_cast<hipStream_t>(stream), s = e->stream;
+        LatentPlan* enc = nullptr;
+        for (auto& lp : e->lat_plans)
+            if (!lp->decode && lp->plan->B == B && lp->plan->H == H && lp->plan->W == W) enc = lp.get();
+        if (!enc || !enc->resident) throw HipError("latent_hidden: no resident skips of an irsde_latent_encode with this B x H x W");
+        if (k < 0 || k >= (int)enc->hidden.size()) throw HipError("latent_hidden: bad skip index");
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+        const Tensor& h = enc->hidden[k];
+        launch_unpack_pred(h.p, out, B, enc->hidden_c[k], h.H, h.W, h.H, h.W, h.C, s);
         IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
         IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
     });

@@ -730,12 +730,20 @@ LatentPlan* get_latent_plan(irsde_engine* e, int B, int H, int W, bool decode) {
             lp->plan->last_use = ++e->use_counter;
             return lp.get();
         }
+    // r04 (ABI 104): a decode plan reads its skips where the encode plan of the same shape leaves them (no NCHW round trip when the caller
+    // passes hidden == NULL), so the two plans of a shape live and die together
+    LatentPlan* enc = decode ? get_latent_plan(e, B, H, W, false) : nullptr;
     if (e->lat_plans.size() >= 4) {
-        size_t lru = 0;
-        for (size_t i = 1; i < e->lat_plans.size(); ++i)
-            if (e->lat_plans[i]->plan->last_use < e->lat_plans[lru]->plan->last_use) lru = i;
+        size_t lru = e->lat_plans.size();
+        for (size_t i = 0; i < e->lat_plans.size(); ++i) {
+            if (e->lat_plans[i].get() == enc) continue;
+            if (lru == e->lat_plans.size() || e->lat_plans[i]->plan->last_use < e->lat_plans[lru]->plan->last_use) lru = i;
+        }
         IRSDE_HIP_CHECK(hipDeviceSynchronize());
-        e->lat_plans.erase(e->lat_plans.begin() + lru);
+        const int vb = e->lat_plans[lru]->plan->B, vh = e->lat_plans[lru]->plan->H, vw = e->lat_plans[lru]->plan->W;
+        for (size_t i = e->lat_plans.size(); i-- > 0;)
+            if (e->lat_plans[i].get() != enc && e->lat_plans[i]->plan->B == vb && e->lat_plans[i]->plan->H == vh && e->lat_plans[i]->plan->W == vw)
+                e->lat_plans.erase(e->lat_plans.begin() + i);
     }
     const int depth = (int)e->lat_mult.size(), ch = e->lat_ch;
     auto dim = [&](int i) { return i == 0 ? ch : ch * e->lat_mult[i - 1]; };
@@ -775,7 +783,10 @@ LatentPlan* get_latent_plan(irsde_engine* e, int B, int H, int W, bool decode) {
         lp->latent = b.conv(e->lat_latent, x, nullptr, 1, 0, 0, nullptr, 0, nullptr);
     } else {
         lp->latent = b.talloc(B, hl, wl, rup32(e->lat_embed));
-        for (auto& g : hgeo) lp->hidden.push_back(b.talloc(B, pl->Hp >> g.first, pl->Wp >> g.first, rup32(g.second)));
+        lp->hidden = enc->hidden;   // shared storage (same NHWC geometry: the skips are conv outputs of 64 .. 256 channels)
+        for (size_t k = 0; k < hgeo.size(); ++k)
+            if (lp->hidden[k].H != (pl->Hp >> hgeo[k].first) || lp->hidden[k].W != (pl->Wp >> hgeo[k].first) || lp->hidden[k].C != rup32(hgeo[k].second))
+                throw HipError("latent plan: encode / decode skip geometry mismatch");
         Tensor x = b.conv(e->lat_post, lp->latent, nullptr, 1, 0, 0, nullptr, 0, nullptr);
         const int nh = (int)lp->hidden.size();
         for (int j = 0; j < depth; ++j) {

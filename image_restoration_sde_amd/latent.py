@@ -12,6 +12,7 @@ Reference: /root/reference/codes/config/latent-dehazing/
 Modules only own parameters under the reference's state_dict names; the arithmetic runs in libirsde_hip.so.
 """
 import ctypes
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -28,6 +29,44 @@ class _PlainResBlock(nn.Module):  # module_util.ResBlock with time_emb_dim=None 
         self.block1 = _Block(ci, co)
         self.block2 = _Block(co, co)
         self.res_conv = nn.Conv2d(ci, co, 1, bias=False) if ci != co else nn.Identity()
+
+
+class _ResidentHidden(list):
+    """The `hidden` list of UNet.encode (UNet_arch.py:59-77) while its tensors still sit in the engine's working layout.  The reference only
+    hands the list on to decode; touching it (indexing, iterating, len-independent operations) materialises the NCHW tensors first, and so do a
+    second encode or a decode with other skips on the same model — the object never dangles."""
+
+    def __init__(self, eng, B, H, W, shapes, device):
+        super().__init__()
+        self._eng, self._geom, self._shapes, self._device = eng, (B, H, W), list(shapes), device
+        self._mat = False
+
+    def in_place(self, eng, B, H, W):
+        return not self._mat and eng is self._eng and self._geom == (B, H, W)
+
+    def materialize(self):
+        if self._mat:
+            return self
+        B, H, W = self._geom
+        with torch.cuda.device(self._device):
+            for k, shp in enumerate(self._shapes):
+                t = torch.empty((B,) + tuple(shp), device=self._device, dtype=torch.float32)
+                _lib.check(_lib.lib().irsde_latent_hidden(self._eng.h, B, H, W, k, ctypes.c_void_p(t.data_ptr()), _lib.stream_ptr()))
+                super().append(t)
+        self._mat = True
+        return self
+
+    def __len__(self):
+        return len(self._shapes)
+
+    def __getitem__(self, i):
+        return list.__getitem__(self.materialize(), i)
+
+    def __iter__(self):
+        return list.__iter__(self.materialize())
+
+    def __repr__(self):
+        return "<hidden states of UNet.encode: %d skips, %s>" % (len(self._shapes), "NCHW tensors" if self._mat else "resident in the engine")
 
 
 class UNet(nn.Module):
@@ -55,6 +94,7 @@ class UNet(nn.Module):
         self._engine_key = None
         self.engine_flags = 0
         self.H = self.W = None
+        self._live_hidden = None   # weakref to the lazy hidden list of the last encode (resident skips)
 
     # ---- engine management (as ConditionalUNet) ----------------------------------------------
     def _create_handle(self, L, device_index, flags):
@@ -75,6 +115,9 @@ class UNet(nn.Module):
         key = (device.index if device.index is not None else torch.cuda.current_device(), self.engine_flags,
                tuple((p.data_ptr(), p._version) for p in self.parameters()))
         if self._engine is None or self._engine_key != key:
+            old = self._live_hidden() if self._live_hidden is not None else None
+            if old is not None:
+                old.materialize()   # (the old engine, which the list keeps alive, still holds its skips)
             self._engine = _Engine(self, key[0], self.engine_flags)
             self._engine_key = key
         return self._engine
@@ -88,6 +131,8 @@ class UNet(nn.Module):
         return tuple(lat), [tuple(hid[3 * k:3 * k + 3]) for k in range(n.value)]
 
     # ---- reference interface (UNet_arch.py:59-96) ---------------------------------------------
+    resident_hidden = True   # encode() leaves the skips in the engine and returns a lazy list (ABI 104); False: NCHW tensors right away
+
     def encode(self, x):
         if x.device.type != "cuda":
             raise _lib.IrsdeError("UNet.encode needs CUDA(HIP) tensors; got %s" % x.device)
@@ -97,6 +142,18 @@ class UNet(nn.Module):
         lat_s, hid_s = self._shapes(eng, self.H, self.W)
         xin = x.detach().to(torch.float32).contiguous()
         latent = torch.empty((B,) + lat_s, device=x.device, dtype=torch.float32)
+        # a lazy list of an earlier encode still points at the engine's skip storage: give it its tensors before they are overwritten
+        old = self._live_hidden() if self._live_hidden is not None else None
+        if old is not None:
+            old.materialize()
+        if self.resident_hidden:
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().irsde_latent_encode(eng.h, ctypes.c_void_p(xin.data_ptr()), B, self.H, self.W,
+                                                          ctypes.c_void_p(latent.data_ptr()), None, _lib.stream_ptr()))
+            hidden = _ResidentHidden(eng, B, self.H, self.W, hid_s, x.device)
+            self._live_hidden = weakref.ref(hidden)
+            return latent, hidden
+        self._live_hidden = None
         hidden = [torch.empty((B,) + s, device=x.device, dtype=torch.float32) for s in hid_s]
         ptrs = (ctypes.c_void_p * len(hidden))(*[h.data_ptr() for h in hidden])
         with torch.cuda.device(x.device):
@@ -112,8 +169,21 @@ class UNet(nn.Module):
         B = x.shape[0]
         eng = self.engine(x.device)
         lat_s, hid_s = self._shapes(eng, self.H, self.W)
+        if isinstance(h, _ResidentHidden) and h.in_place(eng, B, self.H, self.W):
+            # the reference only threads `hidden` from encode to decode (latent_denoising_model.py:177-189): the skips never left the engine
+            if tuple(x.shape[1:]) != lat_s:
+                raise _lib.IrsdeError("latent shape does not belong to the encoded %dx%d image" % (self.H, self.W))
+            lat = x.detach().to(torch.float32).contiguous()
+            out = torch.empty((B, self.out_ch, self.H, self.W), device=x.device, dtype=torch.float32)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().irsde_latent_decode(eng.h, ctypes.c_void_p(lat.data_ptr()), None, B, self.H, self.W,
+                                                          ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()))
+            return out
         if tuple(x.shape[1:]) != lat_s or len(h) != len(hid_s) or any(tuple(t.shape[1:]) != s for t, s in zip(h, hid_s)):
             raise _lib.IrsdeError("latent / hidden shapes do not belong to the encoded %dx%d image" % (self.H, self.W))
+        live = self._live_hidden() if self._live_hidden is not None else None
+        if live is not None and live is not h:
+            live.materialize()   # this decode overwrites the engine's skip storage with the caller's tensors
         lat = x.detach().to(torch.float32).contiguous()
         hid = [t.detach().to(torch.float32).contiguous() for t in h]
         ptrs = (ctypes.c_void_p * len(hid))(*[t.data_ptr() for t in hid])

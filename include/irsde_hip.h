@@ -20,6 +20,8 @@
  *        selects the full schedule.  (Version 100 treated T <= 0 as "full schedule".)
  *   102  IRSDE_FLAG_SPLIT_BF16X2 / IRSDE_FLAG_SPLIT_F16X2 (split-operand GEMMs on the 16-bit MFMA pipe for the deep Winograd layers).
  *   103  IRSDE_FLAG_NO_NAF_CHAIN (the fused NAFBlock chain of the fp16 ConditionalNAFNet on 8 x 8 feature maps is on by default).
+ *   104  irsde_latent_encode / irsde_latent_decode accept hidden == NULL (the skips stay resident in the engine between the two calls: no
+ *        NCHW round trip of 4.8 GB per 64 images); irsde_latent_hidden exports one resident skip.
  */
 #ifndef IRSDE_HIP_H
 #define IRSDE_HIP_H
@@ -252,6 +254,11 @@ int irsde_latent_encode(irsde_engine* e, const float* x, int B, int H, int W, fl
                         void* stream);
 int irsde_latent_decode(irsde_engine* e, const float* latent, const float* const* hidden, int B, int H, int W, float* out,
                         void* stream);
+/* ABI 104: `hidden` may be NULL in both calls.  encode(hidden = NULL) leaves the skips in the engine's working layout; decode(hidden = NULL)
+ * reads them there — valid until the next irsde_latent_encode / irsde_latent_decode(hidden != NULL) of the same B x H x W on this engine (error
+ * otherwise).  The reference only threads `hidden` through (latent-dehazing/test.py:90-95, latent_denoising_model.py:177-189).
+ * irsde_latent_hidden writes resident skip k (reference list order) as a device NCHW tensor [B][C_k][h_k][w_k]. */
+int irsde_latent_hidden(irsde_engine* e, int B, int H, int W, int k, float* out, void* stream);
 
 /* latent-bokeh only (IRSDE_FLAG_NAF_LENS): replaces the `lens_info` kwargs of ConditionalNAFNet.forward(inp, cond, time,
  * lens_info=[src_lens, tgt_lens, disparity]) that latent_denoising_model.py:183-189 threads through sde.reverse_sde(**kwargs).

@@ -50,7 +50,7 @@ def test_native_library_is_loaded():
     """The HIP extension (in-tree .so) is what runs; there is no eager/PyTorch fallback."""
     assert torch.cuda.is_available()
     L = _lib.lib()
-    assert L.irsde_version() == 103
+    assert L.irsde_version() == 104
     maps = open("/proc/self/maps").read()
     assert "libirsde_hip.so" in maps
 
@@ -1002,6 +1002,41 @@ def test_latent_unet_vs_reference_golden(golden, tag, cfg):
     hid_ref = [torch.from_numpy(g[tag + "/hidden%d" % i]).to(DEV) for i in range(len(hid))]
     rec2 = m.decode(torch.from_numpy(g[tag + "/latent2"]).to(DEV), hid_ref)
     assert tuple(rec2.shape) == (B, 3, H, W) and relerr(rec2.cpu().numpy(), g[tag + "/decode2"]) < 1e-4
+
+
+def test_latent_hidden_stays_resident_and_never_dangles():
+    """ABI 104: UNet.encode leaves the skips in the engine and returns a lazy list; decode(latent, that list) reads them in place.  Same bits as
+    the NCHW round trip; touching the list, a second encode, or a decode with other skips materialises it first (the reference semantics: `hidden`
+    is a plain list of tensors, UNet_arch.py:59-91)."""
+    cfg = dict(ch=16, ch_mult=(1, 2, 4), embed_dim=4)
+    m, _ = latent_unet(cfg)
+    a = torch.from_numpy(O.synth_inputs(11, 2, 24, 32)[0]).to(DEV)
+    b = torch.from_numpy(O.synth_inputs(12, 2, 24, 32)[0]).to(DEV)
+    m.resident_hidden = False
+    lat_a, hid_a = m.encode(a)
+    rec_a = m.decode(lat_a, hid_a)
+    lat_b, hid_b = m.encode(b)
+    rec_b = m.decode(lat_b, hid_b)
+    m.resident_hidden = True
+    l1, h1 = m.encode(a)
+    assert "resident" in repr(h1) and len(h1) == len(hid_a) and torch.equal(l1, lat_a)
+    assert torch.equal(m.decode(l1, h1), rec_a)                     # in place: no NCHW tensors were made
+    assert "resident" in repr(h1)
+    l2, h2 = m.encode(b)                                            # overwrites the engine's skips: h1 gets its tensors first
+    assert "NCHW" in repr(h1) and "resident" in repr(h2)
+    assert all(torch.equal(x, y) for x, y in zip(h1, hid_a))
+    assert torch.equal(m.decode(l1, h1), rec_a)                     # decode with OTHER skips: h2 is materialised before they are overwritten
+    assert "NCHW" in repr(h2) and all(torch.equal(x, y) for x, y in zip(h2, hid_b))
+    assert torch.equal(m.decode(l2, h2), rec_b)
+    l3, h3 = m.encode(a)
+    assert torch.equal(h3[1], hid_a[1]) and "NCHW" in repr(h3)      # indexing materialises
+    # the C ABI refuses a decode without skips when none are resident (the decode above put the caller's skips in place)
+    out = torch.empty_like(rec_a)
+    rc = P._lib.lib().irsde_latent_decode(m.engine(a.device).h, ctypes.c_void_p(l3.data_ptr()), None, 2, 24, 32, ctypes.c_void_p(out.data_ptr()), P._lib.stream_ptr())
+    assert rc == 0   # (encode(a) just made them resident again)
+    assert torch.equal(out, rec_a)
+    rc = P._lib.lib().irsde_latent_decode(m.engine(a.device).h, ctypes.c_void_p(l3.data_ptr()), None, 3, 24, 32, ctypes.c_void_p(out.data_ptr()), P._lib.stream_ptr())
+    assert rc != 0 and b"preceding irsde_latent_encode" in P._lib.lib().irsde_last_error()
 
 
 def test_latent_pipeline_vs_reference_golden(golden):
