@@ -14,6 +14,7 @@ Modules only own parameters under the reference's state_dict names; the arithmet
 import ctypes
 import weakref
 from collections import OrderedDict
+from collections.abc import Sequence
 
 import torch
 import torch.nn as nn
@@ -31,39 +32,43 @@ class _PlainResBlock(nn.Module):  # module_util.ResBlock with time_emb_dim=None 
         self.res_conv = nn.Conv2d(ci, co, 1, bias=False) if ci != co else nn.Identity()
 
 
-class _ResidentHidden(list):
+class _ResidentHidden(Sequence):
     """The `hidden` list of UNet.encode (UNet_arch.py:59-77) while its tensors still sit in the engine's working layout.  The reference only
-    hands the list on to decode; touching it (indexing, iterating, len-independent operations) materialises the NCHW tensors first, and so do a
-    second encode or a decode with other skips on the same model — the object never dangles."""
+    hands the list on to decode; touching it (indexing, iterating, list(...)) materialises the NCHW tensors first, and so do a second encode or a
+    decode with other skips on the same model — the object never dangles.  (A Sequence, not a list subclass: C-level list fast paths would read
+    the empty base storage of an unmaterialised subclass.)"""
 
     def __init__(self, eng, B, H, W, shapes, device):
-        super().__init__()
         self._eng, self._geom, self._shapes, self._device = eng, (B, H, W), list(shapes), device
-        self._mat = False
+        self._items = None
+
+    @property
+    def _mat(self):
+        return self._items is not None
 
     def in_place(self, eng, B, H, W):
-        return not self._mat and eng is self._eng and self._geom == (B, H, W)
+        return self._items is None and eng is self._eng and self._geom == (B, H, W)
 
     def materialize(self):
-        if self._mat:
-            return self
-        B, H, W = self._geom
-        with torch.cuda.device(self._device):
-            for k, shp in enumerate(self._shapes):
-                t = torch.empty((B,) + tuple(shp), device=self._device, dtype=torch.float32)
-                _lib.check(_lib.lib().irsde_latent_hidden(self._eng.h, B, H, W, k, ctypes.c_void_p(t.data_ptr()), _lib.stream_ptr()))
-                super().append(t)
-        self._mat = True
-        return self
+        if self._items is None:
+            B, H, W = self._geom
+            items = []
+            with torch.cuda.device(self._device):
+                for k, shp in enumerate(self._shapes):
+                    t = torch.empty((B,) + tuple(shp), device=self._device, dtype=torch.float32)
+                    _lib.check(_lib.lib().irsde_latent_hidden(self._eng.h, B, H, W, k, ctypes.c_void_p(t.data_ptr()), _lib.stream_ptr()))
+                    items.append(t)
+            self._items = items
+        return self._items
 
     def __len__(self):
         return len(self._shapes)
 
     def __getitem__(self, i):
-        return list.__getitem__(self.materialize(), i)
+        return self.materialize()[i]
 
     def __iter__(self):
-        return list.__iter__(self.materialize())
+        return iter(self.materialize())
 
     def __repr__(self):
         return "<hidden states of UNet.encode: %d skips, %s>" % (len(self._shapes), "NCHW tensors" if self._mat else "resident in the engine")

@@ -1030,6 +1030,11 @@ def test_latent_hidden_stays_resident_and_never_dangles():
     assert torch.equal(m.decode(l2, h2), rec_b)
     l3, h3 = m.encode(a)
     assert torch.equal(h3[1], hid_a[1]) and "NCHW" in repr(h3)      # indexing materialises
+    l4, h4 = m.encode(b)
+    as_list = list(h4)                                              # so does list(...) (a Sequence, not a list subclass)
+    assert len(as_list) == len(hid_b) and all(torch.equal(x, y) for x, y in zip(as_list, hid_b))
+    assert torch.equal(m.decode(l4, as_list), rec_b)
+    l3, h3 = m.encode(a)
     # the C ABI refuses a decode without skips when none are resident (the decode above put the caller's skips in place)
     out = torch.empty_like(rec_a)
     rc = P._lib.lib().irsde_latent_decode(m.engine(a.device).h, ctypes.c_void_p(l3.data_ptr()), None, 2, 24, 32, ctypes.c_void_p(out.data_ptr()), P._lib.stream_ptr())
