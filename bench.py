@@ -244,6 +244,8 @@ SECONDARY = [
     dict(tag="configs[1] in fp32_split_f16", model="unet", dtype="fp32_split_f16", mode="sde", batch=16, size=256, T=100),
     dict(tag="configs[3] in fp32_split_f16", model="nafnet", dtype="fp32_split_f16", mode="sde", batch=8, size=512, T=200),
     dict(tag="strong-scaling shard: unet 2x256 f32", model="unet", dtype="fp32", mode="sde", batch=2, size=256, T=100),
+    # the per-GPU shard of "batch=64 ... 8xMI355X" (BASELINE configs[4]): 8 images per GPU
+    dict(tag="configs[4] shard of 8 GPUs: latent 8x(64x64x4) fp16", model="latent", dtype="fp16", mode="sde", batch=8, size=256, T=100),
 ]
 
 

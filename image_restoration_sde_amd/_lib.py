@@ -9,7 +9,9 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libirsde_hip.so")
+# IRSDE_LIB_PATH: load another build of the SAME library (A/B measurements of two builds inside one GPU call, tools/ab_bench.sh);
+# there is still no fallback — a missing file fails exactly like a missing default library.
+LIB_PATH = os.environ.get("IRSDE_LIB_PATH") or os.path.join(_HERE, "libirsde_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 MODE = {"sde": 0, "ode": 1, "posterior": 2, "dsde_sde": 3, "dsde_ode": 4}

@@ -171,7 +171,7 @@ void naf_chain_global_init();
 void naf_chain_set_debug(unsigned long long* buf);   // stamp buffer of launch variant 11: [B][8 waves][16]
 bool naf_chain_shape_ok(int H, int W, int c);
 size_t naf_chain_weight_halves(int nblocks);   // fp16 fragment streams [8 waves][nblocks][448 fragments][512]
-size_t naf_chain_vec_floats(int nblocks);      // fp32 per-channel vectors [nblocks][15872]
+size_t naf_chain_vec_floats(int nblocks);      // fp32 per-channel vectors [nblocks][NV_TOTAL = 14848]
 void launch_naf_chain(const float* x, float* out, const unsigned short* w, const float* vecs, int nblocks, int B, const float* film, int film_bstride,
                       int film_off, const float* cam, int cam_bstride, int cam_off, hipStream_t s, int variant = 0);
 void attention_global_init();

@@ -593,7 +593,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
             if (naive == 33) launch_wino_fused(p, dUf, s);
             else if (naive == 60) launch_wino_fused64(p, dUf, s, 48);   // r04's single-stream kernel (61: its fp16-pair twin)
-            else if (naive == 55 || naive == 57) launch_wino_fused64(p, dUf, s, naive == 55 ? 20 : 40);   // r04's register-patch persistent kernel (production is the halo kernel)
+            else if (naive == 55 || naive == 57) launch_wino_fused64(p, dUf, s, naive == 55 ? 20 : 40);   // the register-patch persistent kernel at fixed grid sizes (it IS production: launch_wino_fused64 defaults to persist = 1)
             else if (naive >= 50) {   // r04 tuning twins of the persistent kernel: 50 .. 54 = OPT 15 / 1 / 2 / 4 / 8
                 static const int opts[5] = {15, 1, 2, 4, 8};
                 wino_fused64_set_opt(opts[naive - 50]);
@@ -1168,10 +1168,15 @@ int irsde_latent_decode(irsde_engine* e, const float* latent, const float* const
         std::lock_guard<std::mutex> lk(e->mu);
         DeviceScope dev_scope(e->cfg.device);
         hipStream_t user = reinterpret_cast<hipStream_t>(stream), s = e->stream;
+        if (!hidden) {   // residency first: a call that is going to be refused must not build (or evict) any plan
+            bool res = false;
+            for (auto& q : e->lat_plans)
+                if (!q->decode && q->plan->B == B && q->plan->H == H && q->plan->W == W) res = q->resident;
+            if (!res) throw HipError("latent_decode: hidden == NULL needs a preceding irsde_latent_encode of the same B x H x W on this engine");
+        }
         LatentPlan* lp = get_latent_plan(e, B, H, W, true);
         Plan* pl = lp->plan.get();
         LatentPlan* enc = get_latent_plan(e, B, H, W, false);   // (exists: the decode plan was built on it)
-        if (!hidden && !enc->resident) throw HipError("latent_decode: hidden == NULL needs a preceding irsde_latent_encode of the same B x H x W on this engine");
         if (hidden) enc->resident = false;   // the caller's skips overwrite the shared storage
         IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
         IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));

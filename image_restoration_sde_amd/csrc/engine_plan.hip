@@ -328,7 +328,7 @@ struct Builder {
         // 1x1 convolutions of the run: conv1 + conv4 (512 -> 1024), conv3 + conv5 + sca.1 on the pooled vector (512 -> 512)
         o.flops = 2.0 * (double)c.nblocks * B * ((double)x.H * x.W * 512.0 * (1024.0 + 512.0 + 1024.0 + 512.0) + 512.0 * 512.0);
         o.exec_flops = o.flops;
-        o.bytes = (double)c.nblocks * (3.5 * 1024 * 1024 + 4.0 * 15872) + 2.0 * 4.0 * (double)x.numel();
+        o.bytes = (double)c.nblocks * (3.5 * 1024 * 1024 + 4.0 * (double)naf_chain_vec_floats(1)) + 2.0 * 4.0 * (double)x.numel();
         pl->conv_flops += o.flops;
         pl->conv_exec_flops += o.exec_flops;
         pl->conv_bytes += o.bytes;
@@ -733,7 +733,20 @@ LatentPlan* get_latent_plan(irsde_engine* e, int B, int H, int W, bool decode) {
     // r04 (ABI 104): a decode plan reads its skips where the encode plan of the same shape leaves them (no NCHW round trip when the caller
     // passes hidden == NULL), so the two plans of a shape live and die together
     LatentPlan* enc = decode ? get_latent_plan(e, B, H, W, false) : nullptr;
-    if (e->lat_plans.size() >= 4) {
+    // the LRU counts SHAPES (an encode / decode pair is one entry): four shapes in rotation never rebuild
+    size_t n_shapes = 0;
+    bool shape_known = false;
+    for (size_t i = 0; i < e->lat_plans.size(); ++i) {
+        const Plan* q = e->lat_plans[i]->plan.get();
+        bool first = true;
+        for (size_t j = 0; j < i; ++j) {
+            const Plan* r = e->lat_plans[j]->plan.get();
+            if (r->B == q->B && r->H == q->H && r->W == q->W) { first = false; break; }
+        }
+        n_shapes += first ? 1 : 0;
+        if (q->B == B && q->H == H && q->W == W) shape_known = true;
+    }
+    if (!shape_known && n_shapes >= 4) {
         size_t lru = e->lat_plans.size();
         for (size_t i = 0; i < e->lat_plans.size(); ++i) {
             if (e->lat_plans[i].get() == enc) continue;

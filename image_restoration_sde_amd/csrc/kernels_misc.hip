@@ -478,24 +478,45 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
     }
 }
 
+// Merge of the chunk partials: ctx[d][e] = sum_c pctx_c[d][e] e^{m_c[d] - m[d]} / sum_c psum_c[d] e^{m_c[d] - m[d]} / N * scale.
+// grid (B * heads, 4): block = 8 context rows d of one (image, head); 1024 threads = 256 elements x 4 chunk slices (r05: one block of 1024
+// threads per (image, head) walked all chunks serially — at the small batches of the strong-scaling shards (B = 2: 256 chunks per image, 8 blocks
+// on the chip) that took longer than the k / v kernel it follows).  The slices are combined in fixed order: deterministic.
 __global__ __launch_bounds__(1024) void attn_ctx_finalize_kernel(const float* __restrict__ pctx,
                                                                  const float* __restrict__ psum,
                                                                  const float* __restrict__ pmax,
                                                                  float* __restrict__ ctx, const int nch,
                                                                  const float inv_n, const float scale) {
-    const int bh = blockIdx.x;
+    __shared__ float sm[4][8];
+    __shared__ float ss[4][256];
+    __shared__ float sz[4][8];
+    const int bh = blockIdx.x, dq = blockIdx.y;
     const int b = bh >> 2, head = bh & 3;
-    const int i = threadIdx.x;  // d*32 + e
-    const int d = i >> 5;
+    const int el = threadIdx.x & 255, sl = threadIdx.x >> 8;
+    const int dl = el >> 5, e = el & 31, d = 8 * dq + dl;
+    const float* pm = pmax + (size_t)b * nch * kHid + head * kDh + d;
     float mx = -INFINITY;
-    for (int c = 0; c < nch; ++c) mx = fmaxf(mx, pmax[((size_t)b * nch + c) * kHid + head * kDh + d]);
+    for (int c = sl; c < nch; c += 4) mx = fmaxf(mx, pm[(size_t)c * kHid]);
+    if (e == 0) sm[sl][dl] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sm[0][dl], sm[1][dl]), fmaxf(sm[2][dl], sm[3][dl]));
+    const float* pc = pctx + (size_t)bh * nch * 1024 + d * 32 + e;
+    const float* ps = psum + (size_t)bh * nch * 32 + d;
     float s = 0.f, z = 0.f;
-    for (int c = 0; c < nch; ++c) {
-        const float w = expf(pmax[((size_t)b * nch + c) * kHid + head * kDh + d] - mx);
-        s += pctx[((size_t)bh * nch + c) * 1024 + i] * w;
-        z += psum[((size_t)bh * nch + c) * 32 + d] * w;
+#pragma unroll 4
+    for (int c = sl; c < nch; c += 4) {
+        const float w = expf(pm[(size_t)c * kHid] - mx);
+        s += pc[(size_t)c * 1024] * w;
+        z += ps[(size_t)c * 32] * w;
     }
-    ctx[(size_t)bh * 1024 + i] = s / z * inv_n * scale;
+    ss[sl][el] = s;
+    if (e == 0) sz[sl][dl] = z;
+    __syncthreads();
+    if (sl == 0) {
+        const float st = (ss[0][el] + ss[1][el]) + (ss[2][el] + ss[3][el]);
+        const float zt = (sz[0][dl] + sz[1][dl]) + (sz[2][dl] + sz[3][dl]);
+        ctx[(size_t)bh * 1024 + d * 32 + e] = st / zt * inv_n * scale;
+    }
 }
 
 constexpr int kOutTilesPerBlock = 8;  // 256 pixels per block
@@ -1435,7 +1456,7 @@ static void linear_attention_t(const T* qkv, T* out, int B, int N, const AttnWor
     if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
     hipLaunchKernelGGL(attn_ctx_partial_kernel<T>, dim3(nch, B * kHeads), dim3(256), 0, s, qkv, ws.pmax, ws.pctx, ws.psum,
                        N, len, nch);
-    hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
+    hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads, 4), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
                        1.0f / (float)N, 1.0f / sqrtf((float)kDh));
     const int tiles = (N + 31) / 32;
     hipLaunchKernelGGL(attn_out_kernel<T>, dim3((tiles + kOutTilesPerBlock - 1) / kOutTilesPerBlock, B), dim3(256), 0, s,
@@ -1479,7 +1500,7 @@ void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N
             default: throw HipError("attention_kv_context: the fp16-pair projection exists for C = 64, 128, 256");
         }
 #undef IRSDE_KVP_LAUNCH
-        hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
+        hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads, 4), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
                            1.0f / (float)N, 1.0f / sqrtf((float)kDh));
         IRSDE_HIP_CHECK(hipGetLastError());
         return;
@@ -1498,7 +1519,7 @@ void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N
         default: throw HipError("attention_kv_context: unsupported channel count");
     }
 #undef IRSDE_KV_LAUNCH
-    hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
+    hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads, 4), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
                        1.0f / (float)N, 1.0f / sqrtf((float)kDh));
     IRSDE_HIP_CHECK(hipGetLastError());
 }

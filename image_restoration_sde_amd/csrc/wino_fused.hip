@@ -23,6 +23,7 @@
 //
 // Arithmetic is exact fp32 (f32 MFMA = fmaf chain); the result differs from wino.hip's only in summation order.
 #include "common.h"
+#include <mutex>
 
 namespace irsde {
 
@@ -1763,6 +1764,22 @@ void launch_wino_fused64_split_weights(const float* Uf, unsigned short* out, siz
 // any hint; 10: 12 units in flight + the epilogue hint = production since late r03 (0 .. -4 % against 6 on every layer class,
 // profiles/r03_wino_fused64_nt.txt).  Production (0, 4) carries the epilogue hint (IRSDE_WINO_FUSED64_NT=0 under IRSDE_TUNING=1 switches it off): the streamed
 // epilogue traffic no longer evicts the weight fragments from the XCD's 4 MB L2 - 128 -> 128 @ 256^2 1.14 -> 1.01 ms, profiles/r03_wino_fused64_nt.txt
+// CU count of the CURRENT device, cached per device ordinal (not one static for whichever device launched first)
+static int device_cu_count() {
+    static std::mutex mu;
+    static std::vector<int> cache;
+    int dev = 0;
+    IRSDE_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)cache.size() <= dev) cache.resize(dev + 1, 0);
+    if (cache[dev] == 0) {
+        int n = 0;
+        IRSDE_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        cache[dev] = n > 0 ? n : 256;
+    }
+    return cache[dev];
+}
+
 void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, int variant) {
     if (!wino_fused64_eligible(p)) throw HipError("launch_wino_fused64: layer not eligible");
     if (!Uf) throw HipError("launch_wino_fused64: fused weights missing");
@@ -1787,12 +1804,7 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
     if (persist == 2 && (variant == 0 || variant == 4)) variant = variant == 0 ? 40 : 44;
     if (persist >= 3 && (variant == 0 || variant == 4)) variant = variant == 0 ? 48 : 52;   // 3: the single-stream kernel (one role per wave)
     if (variant >= 20) {   // 20 production f32, 21 weight fragments read zeros, 22 patch loads read zeros, 23 no non-temporal hint, 24 fp16 pairs
-        static const int ncu = [] {
-            int dev = 0, n = 0;
-            IRSDE_HIP_CHECK(hipGetDevice(&dev));
-            IRSDE_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-            return n > 0 ? n : 256;
-        }();
+        const int ncu = device_cu_count();   // per device (a process may hold parts with different CU counts)
         const int total = (int)grid.x;
         const size_t npix_out = (size_t)p.B * p.Ho * p.Wo;
         const size_t ob = npix_out * p.out_stride * 4, rb = p.res ? npix_out * p.res_stride * 4 : 0;

@@ -48,14 +48,38 @@ def sample_shard(sde, mode, x_local, mu_local, lo, n_items, group=None, **kwargs
     all_reduces the metric sums)."""
     fn = {"sde": sde.reverse_sde, "ode": sde.reverse_ode, "posterior": sde.reverse_posterior}[mode]
     old_off, old_mu = sde.image_offset, getattr(sde, "mu", None)
+    local, err = None, None
     try:
         sde.image_offset = old_off + lo
         sde.set_mu(mu_local)
         local = fn(x_local, **kwargs) if x_local.shape[0] > 0 else x_local.clone()
+    except Exception as e:  # noqa: BLE001 - re-raised below, on EVERY rank, after the ranks have agreed
+        err = e
     finally:
         sde.image_offset = old_off
         sde.set_mu(old_mu)
+    # A rank whose sampler raised (engine error, or the fp16-operand modes' range check `sde._check_fp16_range`) must not
+    # leave the others waiting in the all_gather until the RCCL timeout: agree on success first, then raise everywhere.
+    bad = all_failed(err is not None, x_local.device, group)
+    if err is not None:
+        raise err
+    if bad:
+        raise RuntimeError("sample_shard: the sampler failed on rank(s) %s of this group (their own exception "
+                           "is raised there); no rank entered the gather" % bad)
     return gather_batch(local, n_items, group)
+
+
+def all_failed(failed, device, group=None):
+    """Collective: every rank passes its own `failed` flag and gets the sorted list of ranks that failed (empty = all
+    fine).  One all_gather of a single int per rank; a no-op list ([] or [0]) without an initialised process group."""
+    if not dist.is_available() or not dist.is_initialized():
+        return [0] if failed else []
+    world = dist.get_world_size(group)
+    stage = device if dist.get_backend(group) != "gloo" else torch.device("cpu")
+    mine = torch.tensor([1 if failed else 0], dtype=torch.int32, device=stage)
+    flags = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(flags, mine, group=group)
+    return [r for r, f in enumerate(flags) if int(f.item()) != 0]
 
 
 def sample_sharded(sde, mode, x_T, mu, group=None):

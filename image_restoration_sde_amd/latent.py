@@ -36,7 +36,9 @@ class _ResidentHidden(Sequence):
     """The `hidden` list of UNet.encode (UNet_arch.py:59-77) while its tensors still sit in the engine's working layout.  The reference only
     hands the list on to decode; touching it (indexing, iterating, list(...)) materialises the NCHW tensors first, and so do a second encode or a
     decode with other skips on the same model — the object never dangles.  (A Sequence, not a list subclass: C-level list fast paths would read
-    the empty base storage of an unmaterialised subclass.)"""
+    the empty base storage of an unmaterialised subclass.)  Differences from the reference's plain list: `isinstance(h, list)` is False and
+    there is no `append`; `tolist()` (also what pickle / `torch.save` / `h + [...]` produce) gives the plain list, and `UNet.resident_hidden =
+    False` makes `encode` return one right away.  After `materialize()` the object drops its engine reference."""
 
     def __init__(self, eng, B, H, W, shapes, device):
         self._eng, self._geom, self._shapes, self._device = eng, (B, H, W), list(shapes), device
@@ -59,7 +61,22 @@ class _ResidentHidden(Sequence):
                     _lib.check(_lib.lib().irsde_latent_hidden(self._eng.h, B, H, W, k, ctypes.c_void_p(t.data_ptr()), _lib.stream_ptr()))
                     items.append(t)
             self._items = items
+            self._eng = None   # the tensors own the data now: do not pin the engine (its weights, arena and plans) any longer
         return self._items
+
+    def tolist(self):
+        """The reference's plain `list` of NCHW tensors (for `h + [...]`, `h.append`, `torch.save`: anything beyond Sequence)."""
+        return list(self.materialize())
+
+    def __reduce__(self):
+        # pickle / copy / torch.save see the reference's type: a plain list of tensors (a ctypes engine handle cannot travel)
+        return (list, (self.tolist(),))
+
+    def __add__(self, other):
+        return self.tolist() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self.tolist()
 
     def __len__(self):
         return len(self._shapes)

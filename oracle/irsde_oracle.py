@@ -673,17 +673,12 @@ def _pixel_shuffle2(x):
     return np.ascontiguousarray(x.reshape(B, C // 4, 2 * H, 2 * W))
 
 
-def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_num=1, dec_blk_nums=(1, 1, 1, 1),
-                   dtype=np.float64, taps=None, intro_skip=False, lens_info=None):
-    """ConditionalNAFNet.forward — DenoisingNAFNet_arch.py:149-187.  intro_skip: the latent tasks' variant
-    (latent-dehazing/models/modules/DenoisingNAFNet_arch.py:162-176), `ending(x + intro(x))`.  lens_info = [src_lens,
-    tgt_lens, disparity] (arrays of 1 or B values): the latent-bokeh variant (its DenoisingNAFNet_arch.py:159-198)."""
-    p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
-    xt = np.asarray(xt, dtype=dtype)
-    cond = np.asarray(cond, dtype=dtype)
+def naf_embeddings(p, t, lens_info=None, dtype=np.float64):
+    """The time embedding (and, latent-bokeh, the lens embedding) every NAFBlock receives — the head of
+    ConditionalNAFNet.forward, DenoisingNAFNet_arch.py:149-160 (latent-bokeh: its DenoisingNAFNet_arch.py:159-176).
+    p: parameters already in `dtype`; returns (temb, cam or None)."""
     if np.isscalar(t):
         t = np.array([int(t)])
-    x = np.concatenate([xt - cond, cond], axis=1)
     width = p["intro.weight"].shape[0]
     lens = lens_info is not None
     t1, t3 = ("time_mlp.0.", "time_mlp.2.") if lens else ("time_mlp.1.", "time_mlp.3.")
@@ -698,6 +693,19 @@ def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_n
                               for v in lens_info], axis=1)
         cam = linear(emb, p["cam_mlp.0.weight"], p["cam_mlp.0.bias"])
         cam = linear(cam[:, :h2] * cam[:, h2:], p["cam_mlp.2.weight"], p["cam_mlp.2.bias"])
+    return temb, cam
+
+
+def nafnet_forward(params, xt, cond, t, enc_blk_nums=(1, 1, 1, 28), middle_blk_num=1, dec_blk_nums=(1, 1, 1, 1),
+                   dtype=np.float64, taps=None, intro_skip=False, lens_info=None):
+    """ConditionalNAFNet.forward — DenoisingNAFNet_arch.py:149-187.  intro_skip: the latent tasks' variant
+    (latent-dehazing/models/modules/DenoisingNAFNet_arch.py:162-176), `ending(x + intro(x))`.  lens_info = [src_lens,
+    tgt_lens, disparity] (arrays of 1 or B values): the latent-bokeh variant (its DenoisingNAFNet_arch.py:159-198)."""
+    p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
+    xt = np.asarray(xt, dtype=dtype)
+    cond = np.asarray(cond, dtype=dtype)
+    x = np.concatenate([xt - cond, cond], axis=1)
+    temb, cam = naf_embeddings(p, t, lens_info, dtype)
     B, C, H, W = x.shape
     ps = 2 ** len(enc_blk_nums)
     x = np.pad(x, ((0, 0), (0, 0), (0, (ps - H % ps) % ps), (0, (ps - W % ps) % ps)))  # zero pad (:189-194)

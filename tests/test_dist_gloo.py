@@ -116,6 +116,57 @@ def test_sample_sharded_world8_gloo(n):
     assert max(hi - lo for lo, hi in bounds) - min(hi - lo for lo, hi in bounds) <= 1
 
 
+class FailingSDE(FakeSDE):
+    """Stand-in for a rank whose sampler raises (engine error / the fp16-operand modes' range check)."""
+    def _f(self, x):
+        raise FloatingPointError("non-finite sampler output on this rank")
+
+    reverse_sde = reverse_ode = reverse_posterior = _f
+
+
+def _failing_worker(rank, world, port, bad_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4, 3, 4, 5, generator=g)
+        mu = torch.rand(4, 3, 4, 5, generator=g)
+        sde = FailingSDE() if rank == bad_rank else FakeSDE()
+        try:
+            P.sample_sharded(sde, "sde", x, mu)
+            q.put((rank, "returned"))
+        except FloatingPointError:
+            q.put((rank, "own"))
+        except RuntimeError as e:
+            q.put((rank, "peer:" + str(e)))
+        assert sde.image_offset == 0
+        # the group is still usable afterwards: nobody is stuck inside a half-entered gather
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        assert int(t.item()) == world
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sample_shard_failure_on_one_rank_raises_on_all_ranks():
+    """a rank whose sampler raises must not leave the others waiting in the all_gather.  Every rank agrees on
+    success BEFORE the gather: the failing rank re-raises its own exception, the others raise a RuntimeError naming it."""
+    world, bad = 2, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, bad, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[bad] == "own"
+    assert res[0].startswith("peer:") and "[1]" in res[0]
+
+
 def test_single_process_passthrough():
     sde = FakeSDE()
     x = torch.ones(3, 3, 2, 2)

@@ -187,10 +187,10 @@ def test_latent_pipeline_256_vs_reference_golden(golden):
     assert e_lat < 1e-4 and e_x0 < 2e-3 and e_rec < 2e-3
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-2), ("bf16", 1e-1)])
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-3), ("bf16", 1e-1)])
 def test_latent_pipeline_256_reduced_precision(golden, dtype, tol):
-    """configs[4] names fp16: the latent score network with IEEE fp16 conv operands (IRSDE_FLAG_FP16) stays within 2e-2
-    of the fp32 reference over the T=100 sampler (relative to max|ref|; the reverse drift expands perturbations ~200x);
+    """configs[4] names fp16: the latent score network with IEEE fp16 conv operands (IRSDE_FLAG_FP16, incl. naf_chain_kernel) stays within
+    2e-3 of the fp32 reference over the T=100 sampler (relative to max|ref|; measured 1.4e-4 in r04 — the bar was 2e-2 until r05, VERDICT r04 weak #1a);
     the bf16 mode, with 8 significand bits, within 1e-1 — and fp16 must be the closer one."""
     g = golden.fullres
     _, x0, rec = _latent_256_run(golden, dtype)
@@ -205,14 +205,14 @@ def test_latent_pipeline_256_reduced_precision(golden, dtype, tol):
 
 def test_latent_pipeline_256_all_fp16(golden):
     """configs[4] with BOTH networks in the fp16 operand mode (bench.py's latent workload): the latent UNet's encode / decode convolutions on fp16 operands
-    as well as the score network.  Same 2e-2 bar as the score-network-only mode on the sampled latent and the decoded image; the encoder alone within 2e-3."""
+    as well as the score network.  Same 2e-3 bar as the score-network-only mode on the sampled latent and the decoded image (r04 measured 1.5e-4 / 3e-4); the encoder alone within 2e-3."""
     g = golden.fullres
     lat, x0, rec = _latent_256_run(golden, "fp16", unet_fp16=True)
     e_lat = relerr(lat, g["latent_1x256x256/latent"])
     e_x0 = relerr(x0, g["latent_1x256x256/latent_sde"])
     e_rec = relerr(sub3(rec), g["latent_1x256x256/out_sde_sub3"])
     print("latent 256 all-fp16: encode %.3g, latent sampler %.3g, decoded %.3g" % (e_lat, e_x0, e_rec))
-    assert np.isfinite(rec).all() and e_lat < 2e-3 and e_x0 < 2e-2 and e_rec < 2e-2
+    assert np.isfinite(rec).all() and e_lat < 2e-3 and e_x0 < 2e-3 and e_rec < 2e-3
 
 
 # ---------------------------------------------------------------------------------------------
@@ -239,6 +239,30 @@ def test_batch16_256_equals_single_images(prec):
     xx[5], cc[5] = torch.from_numpy(xT1[0]).to(DEV), torch.from_numpy(lq1[0]).to(DEV)
     g = np.load(os.path.join(ROOT, "tests", "golden", "fullres.npz"))
     assert relerr(m(xx, cc, 50).cpu().numpy()[5:6], g["unet_1x256x256/t50"]) < 1e-4
+
+
+def test_batch16_plan_sampler_256_vs_reference_golden(golden):
+    """VERDICT r04 weak #1b: the BENCHMARKED plan (B = 16, 256 x 256, T = 100 reverse_sde on the captured step graph) pinned to the REAL reference at
+    sampler level: slot 0 of the batch carries the golden's inputs and injected noise, the other 15 slots other images; slot 0 vs
+    tests/golden/fullres.npz at north_star's 1e-3 max-abs (and 2e-3 relative)."""
+    g = golden.fullres
+    m = unet64()
+    lq, xT = O.synth_inputs(77, 16, 256, 256)
+    lq1, xT1 = O.synth_inputs(1234, 1, 256, 256)
+    lq[0], xT[0] = lq1[0], xT1[0]
+    z = O.synth_noise(7, 100, (1, 3, 256, 256))                       # the golden's noise for slot 0 ...
+    zz = torch.from_numpy(O.synth_noise(8, 100, (16, 3, 256, 256)))    # ... other noise for the rest
+    zz[:, 0] = torch.from_numpy(z[:, 0])
+    sde = P.IRSDE(10, 100, "cosine", 0.005, device=DEV)
+    sde.set_model(m)
+    sde.set_mu(torch.from_numpy(lq).to(DEV))
+    sde.injected_noise = zz.to(DEV)
+    y = sde.reverse_sde(torch.from_numpy(xT).to(DEV)).cpu().numpy()
+    ref = g["unet_1x256x256/sampler_sde"]
+    e = relerr(y[0:1], ref)
+    a = float(np.abs(np.asarray(y[0:1], dtype=np.float64) - ref).max())
+    print("B=16 plan, slot 0, T=100 reverse_sde vs reference: %.3g rel, %.3g max-abs" % (e, a))
+    assert np.isfinite(y).all() and e < 2e-3 and a < 1e-3
 
 
 def test_fused_winograd_plan_vs_three_launch_plan():

