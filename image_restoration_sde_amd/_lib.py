@@ -75,15 +75,21 @@ _lib = None
 _lock = threading.Lock()
 
 
-def build_library(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into libirsde_hip.so (hipcc cross-compiles without a GPU)."""
+PROBES_LIB_PATH = os.path.join(_HERE, "libirsde_hip_probes.so")
+
+
+def build_library(force=False, verbose=False, probes=True):
+    """Compile csrc/*.hip for gfx950 into libirsde_hip.so (hipcc cross-compiles without a GPU) and, with probes=True, the
+    measurement build libirsde_hip_probes.so (`make PROBES=1`: the product library + superseded kernel generations, cycle-stamp /
+    ablation / tuning twins — what tools/ and the kernel-generation A/B tests load; the product never does)."""
     if force:
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
-    r = subprocess.run(["make", "-j8", "-C", CSRC], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise IrsdeLibraryError("building libirsde_hip.so failed:\n" + r.stdout + r.stderr)
-    if verbose:
-        print(r.stdout)
+    for extra in ([], ["PROBES=1"]) if probes else ([],):
+        r = subprocess.run(["make", "-j8", "-C", CSRC] + extra, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise IrsdeLibraryError("building libirsde_hip%s.so failed:\n" % ("_probes" if extra else "") + r.stdout + r.stderr)
+        if verbose:
+            print(r.stdout)
     return LIB_PATH
 
 
@@ -149,9 +155,27 @@ def lib():
         return _lib
 
 
-def check(rc):
+_probes = None
+
+
+def probes_lib():
+    """The measurement build (`make PROBES=1`), for tools/ and the tests that compare kernel generations; raises IrsdeLibraryError when it has not
+    been built.  A second copy of the library in the process: its engines, error string and tuning state are its own."""
+    global _probes
+    with _lock:
+        if _probes is None:
+            if not os.path.exists(PROBES_LIB_PATH):
+                raise IrsdeLibraryError("libirsde_hip_probes.so not found at %s — build it with `make -C %s PROBES=1`" % (PROBES_LIB_PATH, CSRC))
+            try:
+                _probes = _declare(ctypes.CDLL(PROBES_LIB_PATH))
+            except OSError as ex:
+                raise IrsdeLibraryError("failed to load %s: %s" % (PROBES_LIB_PATH, ex)) from ex
+        return _probes
+
+
+def check(rc, L=None):
     if rc != 0:
-        msg = lib().irsde_last_error()
+        msg = (L or lib()).irsde_last_error()
         raise IrsdeError("libirsde_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
 
 

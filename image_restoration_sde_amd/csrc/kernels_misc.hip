@@ -6,6 +6,7 @@
 //   reverse-step update + RNG    sde_utils.py:44-48,175-223
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace irsde {
 
@@ -257,17 +258,48 @@ __global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restri
 
 // LayerNorm of a row whose C/4 16-byte pieces sit in C/4 consecutive (aligned) lanes: two-pass mean / centred variance like
 // layernorm_kernel (and torch.var / torch.mean), then * g.  C4 = C/4 is a power of two <= 64.
+// Sum over an aligned group of W consecutive lanes (W a power of two <= 64), every lane of the group ends with the total.  r05: on the
+// vector pipe only — DPP quad permutes / row mirrors inside a 16-lane row, v_permlane16_swap / v_permlane32_swap (gfx950) across rows —
+// instead of __shfl_xor's ds_bpermute round trips (one LDS latency per butterfly step: 10 dependent steps per staged 16-byte piece put
+// ~4.8k cycles of LDS latency into every 128-pixel tile of the fused attention kernels).  The mirror steps are valid because after the
+// quad steps all lanes of a quad hold the same partial sum (and so on upwards); both operands of every add are the same two numbers in
+// every lane of the group, so all lanes end with bit-identical totals.
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(W >= 1 && W <= 64 && (W & (W - 1)) == 0, "group width must be a power of two <= 64");
+    if constexpr (W >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    if constexpr (W >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    if constexpr (W >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    if constexpr (W >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+    if constexpr (W >= 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+        v = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    }
+    if constexpr (W >= 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+        v = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    }
+    return v;
+}
+
+// lane l and lane l ^ 32 combined (the two halves of a v_mfma_f32_32x32 accumulator column): v_permlane32_swap, no LDS round trip
+__device__ __forceinline__ float half_sum(const float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ float half_max(const float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
 template <int C4>
 __device__ __forceinline__ floatx4 ln_piece(floatx4 v, const floatx4 g, const float eps) {
-    float s = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-    for (int o = C4 >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float s = group_sum<C4>((v.x + v.y) + (v.z + v.w));
     const float mean = s * (1.0f / (float)(4 * C4));
     v -= mean;
-    float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-#pragma unroll
-    for (int o = C4 >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / (float)(4 * C4)) + eps);
+    const float q = group_sum<C4>((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    // v_rsq_f32 (1 ulp) instead of 1 / sqrtf (v_sqrt + a full-precision division: ~15 vector instructions per piece on the pipe the f32 MFMAs share)
+    const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / (float)(4 * C4)) + eps);
     return v * rstd * g;
 }
 
@@ -308,7 +340,10 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
     float ssum = 0.f, mrun = -INFINITY;
     for (int t0 = n0; t0 < n1; t0 += kKvTile) {
         // stage the tile (rows past the chunk repeat its last pixel; they are masked below)
-        {
+        auto stage_tile = [&](auto full_tag) {
+            // r05: a full tile is one contiguous run of 128 * C floats (NHWC): element 4 i of it is piece i — no per-piece row / column / clamp arithmetic
+            constexpr bool FULL = decltype(full_tag)::value;
+            const float* tile = xn + ((size_t)b * N + t0) * C;
             // 4 loads in flight before the first LDS write of a pass (a rolled loop waits for every load in turn; more than 4
             // do not fit next to the 144 accumulator registers)
             constexpr int NP = kKvTile * c4n / 256;
@@ -317,12 +352,17 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
                 floatx4 st[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int i = tid + 256 * (j0 + j), row = i / c4n, c4 = i - row * c4n;
-                    st[j] = *reinterpret_cast<const floatx4*>(xn + ((size_t)b * N + min(t0 + row, n1 - 1)) * C + 4 * c4);
+                    int i = tid + 256 * (j0 + j), row, c4;
+                    if constexpr (256 % c4n == 0) { row = tid / c4n + (256 / c4n) * (j0 + j); c4 = tid % c4n; }   // (no carry: tid < 256 — constants the compiler can fold into offsets)
+                    else { row = i / c4n; c4 = i - row * c4n; }
+                    if constexpr (FULL) st[j] = *reinterpret_cast<const floatx4*>(tile + 4 * i);
+                    else st[j] = *reinterpret_cast<const floatx4*>(xn + ((size_t)b * N + min(t0 + row, n1 - 1)) * C + 4 * c4);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int i = tid + 256 * (j0 + j), row = i / c4n, c4 = i - row * c4n;
+                    int i = tid + 256 * (j0 + j), row, c4;
+                    if constexpr (256 % c4n == 0) { row = tid / c4n + (256 / c4n) * (j0 + j); c4 = tid % c4n; }   // (no carry: tid < 256 — constants the compiler can fold into offsets)
+                    else { row = i / c4n; c4 = i - row * c4n; }
                     // ln_g != nullptr: the input is the block's x and PreNorm's LayerNorm (module_util.py:82-90) runs here,
                     // on the staged pieces (power-of-two C only: a row = C/4 consecutive lanes)
                     if constexpr ((c4n & (c4n - 1)) == 0)
@@ -338,7 +378,8 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
                     }
                 }
             }
-        }
+        };
+        if (t0 + kKvTile <= n1) stage_tile(std::true_type{}); else stage_tile(std::false_type{});
         __syncthreads();
         floatx16 ak[4], av[4];
 #pragma unroll
@@ -435,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
                 if (n >= n1) { ak[rt][r] = -INFINITY; av[rt][r] = 0.f; }
                 mit = fmaxf(mit, ak[rt][r]);
             }
-        mit = fmaxf(mit, __shfl_xor(mit, 32, 64));
+        mit = half_max(mit);
         if (__any(mit > mrun)) {  // wave-uniform; the tile's first pixel exists, so mnew is finite
             const float mnew = fmaxf(mrun, mit);
             const float alpha = expf(mrun - mnew);  // 0 on the first tile (mrun = -inf)
@@ -467,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
             for (int r = 0; r < 16; ++r) ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rt][r], av[rt][r], ctx, 0, 0, 0);
         __syncthreads();  // every wave is done with the tile in LDS
     }
-    ssum += __shfl_xor(ssum, 32, 64);
+    ssum = half_sum(ssum);
     const int bh = b * kHeads + head;
     float* oc = pctx + ((size_t)bh * nch + ch) * 1024;
 #pragma unroll
@@ -620,7 +661,10 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
 
     // ---- A: stage the xn tile (rows past N repeat the last pixel; their results are never stored)
     constexpr int C4 = C / 4;
-    {
+    const bool full_tile = t0 + TP <= N;   // uniform; a full tile is one contiguous run of 128 * C floats (r05: no per-piece index arithmetic)
+    auto stage_tile = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const float* tile = xn + (img + t0) * C;
         // 8 loads in flight before the first LDS write of a pass (a rolled loop waits for every load in turn)
         constexpr int NP = TP * C4 / 256;
 #pragma unroll
@@ -628,12 +672,15 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
             floatx4 st[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = tid + 256 * (j0 + j), row = i / C4, c4 = i - row * C4;
-                st[j] = *reinterpret_cast<const floatx4*>(xn + (img + min(t0 + row, N - 1)) * C + 4 * c4);
+                const int i = tid + 256 * (j0 + j), row = tid / C4 + (256 / C4) * (j0 + j), c4 = tid % C4;   // (C4 divides 256; tid < 256)
+                (void)i;
+                if constexpr (FULL) st[j] = *reinterpret_cast<const floatx4*>(tile + 4 * i);
+                else st[j] = *reinterpret_cast<const floatx4*>(xn + (img + min(t0 + row, N - 1)) * C + 4 * c4);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = tid + 256 * (j0 + j), row = i / C4, c4 = i - row * C4;
+                const int i = tid + 256 * (j0 + j), row = tid / C4 + (256 / C4) * (j0 + j), c4 = tid % C4;   // (C4 divides 256; tid < 256)
+                (void)i;
                 // ln_g != nullptr: xn == the block's x and PreNorm's LayerNorm runs here on the staged pieces
                 if (ln_g) st[j] = ln_piece<C4>(st[j], *reinterpret_cast<const floatx4*>(ln_g + 4 * c4), eps);
                 if constexpr (PAIR) {
@@ -647,7 +694,8 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
                 }
             }
         }
-    }
+    };
+    if (full_tile) stage_tile(std::true_type{}); else stage_tile(std::false_type{});
     // context operand of phase D: ctx[d = (s&3) + 8(s>>2) + 4h][e = l31] of head = wave
     float cb[16];
     {
@@ -721,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
         float m = q[ct][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) m = fmaxf(m, q[ct][r]);
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = half_max(m);
         float z = 0.f;
         const float ml = m * 1.44269504088896341f;
 #pragma unroll
@@ -729,8 +777,8 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
             q[ct][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(q[ct][r], 1.44269504088896341f, -ml));  // (the factor of m's rounding cancels in / z)
             z += q[ct][r];
         }
-        z += __shfl_xor(z, 32, 64);
-        const float iz = 1.0f / z;
+        z = half_sum(z);
+        const float iz = __builtin_amdgcn_rcpf(z);   // v_rcp_f32 (1 ulp): softmax normalisation
         floatx16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -836,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
             yv[rt][r] += bias[32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h];
             sum += yv[rt][r];
         }
-    sum += __shfl_xor(sum, 32, 64);
+    sum = half_sum(sum);
     const float mean = sum * (1.0f / (float)C);
     float sq = 0.f;
 #pragma unroll
@@ -846,8 +894,8 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
             yv[rt][r] -= mean;
             sq += yv[rt][r] * yv[rt][r];
         }
-    sq += __shfl_xor(sq, 32, 64);
-    const float rstd = 1.0f / sqrtf(sq * (1.0f / (float)C) + eps);
+    sq = half_sum(sq);
+    const float rstd = __builtin_amdgcn_rsqf(sq * (1.0f / (float)C) + eps);
     // Ys = this wave's own 32 rows of the region.  C <= 128: row stride LDO, exactly the Os rows only this wave read in phase F.
     // C = 256: the rows are wider than an Os row, so they overlap other waves' Os rows -> wait until every wave has left phase F.
     // PAIR: the fp16 planes put other waves' Os rows inside this wave's Ys rows for every C -> always wait.
@@ -864,22 +912,27 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
         }
     // the wave re-reads only its own rows: LDS operations of one wave complete in order, no block barrier needed
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-    {
+    auto residual_store = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         constexpr int NQ = 32 * C4 / 64;
+        const size_t slab = (img + t0 + wave * 32) * C;   // the wave's 32 rows are contiguous: element 4 i of the slab is piece i
         floatx4 xr[NQ];
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {  // residual loads first, all in flight
-            const int i = lane + 64 * j, row = i / C4, c4 = i - row * C4;
-            xr[j] = *reinterpret_cast<const floatx4*>(xres + (img + min(t0 + wave * 32 + row, N - 1)) * C + 4 * c4);
+            const int i = lane + 64 * j, row = lane / C4 + (64 / C4) * j, c4 = lane % C4;   // (C4 divides 64)
+            if constexpr (FULL) xr[j] = *reinterpret_cast<const floatx4*>(xres + slab + 4 * i);
+            else xr[j] = *reinterpret_cast<const floatx4*>(xres + (img + min(t0 + wave * 32 + row, N - 1)) * C + 4 * c4);
         }
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            const int i = lane + 64 * j, row = i / C4, c4 = i - row * C4;
+            const int i = lane + 64 * j, row = lane / C4 + (64 / C4) * j, c4 = lane % C4;   // (C4 divides 64)
             const int n = t0 + wave * 32 + row;
             const floatx4 v = *reinterpret_cast<const floatx4*>(Os + (wave * 32 + row) * LDY + 4 * c4);
-            if (n < N) *reinterpret_cast<floatx4*>(y + (img + n) * C + 4 * c4) = v + xr[j];
+            if constexpr (FULL) *reinterpret_cast<floatx4*>(y + slab + 4 * i) = v + xr[j];
+            else if (n < N) *reinterpret_cast<floatx4*>(y + (img + n) * C + 4 * c4) = v + xr[j];
         }
-    }
+    };
+    if (full_tile) residual_store(std::true_type{}); else residual_store(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -499,9 +499,11 @@ static unsigned long long* g_nc_dbg = nullptr;
 void naf_chain_set_debug(unsigned long long* buf) { g_nc_dbg = buf; }
 
 void naf_chain_global_init() {
-    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef IRSDE_PROBES
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
 }
 
 // variant: 0 production (= 1); 1 residual stream in registers + ring of 8 weight fragments; 2 residual stream in L2 + ring of 16: measured 1.4x slower
@@ -521,9 +523,11 @@ void launch_naf_chain(const float* x, float* out, const unsigned short* w, const
     if (x == out && variant != 1) throw HipError("launch_naf_chain: in-place call needs the register variant");
     switch (variant) {
         case 1: hipLaunchKernelGGL((naf_chain_kernel<8, false>), dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a); break;
+#ifdef IRSDE_PROBES   // the cycle-stamp twin and the measured-slower residual-stream-in-L2 variant: measurement build only (make PROBES=1)
         case 11: hipLaunchKernelGGL((naf_chain_kernel<8, false, true>), dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a); break;
         case 2: hipLaunchKernelGGL((naf_chain_kernel<16, true>), dim3((unsigned)B), dim3(512), NC_LDS_BYTES, s, a); break;
-        default: throw HipError("launch_naf_chain: bad variant");
+#endif
+        default: throw HipError("launch_naf_chain: bad variant (11 / 2 are measurement variants: make PROBES=1)");
     }
     IRSDE_HIP_CHECK(hipGetLastError());
 }

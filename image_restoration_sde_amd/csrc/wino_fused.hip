@@ -1598,6 +1598,7 @@ void wino_fused_global_init() {
                                         160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         160 * 1024));
+#ifdef IRSDE_PROBES
 #define W6_ATTR(...) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused64_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     W6_ATTR(W6_RING, false, false);
     W6_ATTR(W6_RING, true, false);
@@ -1610,10 +1611,12 @@ void wino_fused_global_init() {
     W6_ATTR(W6_RING_ALT, false, false, true, 1);
     W6_ATTR(W6_RING_ALT, false, false, false, 1);
 #undef W6_ATTR
+#endif
 #define W6P_ATTR(...) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused64p_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
 #define W6P_ATTR4(...) W6P_ATTR(__VA_ARGS__, 0); W6P_ATTR(__VA_ARGS__, 1); W6P_ATTR(__VA_ARGS__, 2); W6P_ATTR(__VA_ARGS__, 3)
     W6P_ATTR4(W6_RING_ALT, false, false, false, true);
     W6P_ATTR4(W6_RING_ALT, false, false, true, true);
+#ifdef IRSDE_PROBES
     W6P_ATTR4(W6_RING_ALT, true, false, false, true);
     W6P_ATTR4(W6_RING_ALT, false, true, false, true);
     W6P_ATTR4(W6_RING_ALT, false, false, false, false);
@@ -1627,8 +1630,10 @@ void wino_fused_global_init() {
     W6P_ATTR(W6_RING_ALT, true, false, false, true, 1, true, 0); W6P_ATTR(W6_RING_ALT, true, false, false, true, 3, true, 0);
     W6P_ATTR(W6_RING_ALT, false, true, false, true, 1, true, 0); W6P_ATTR(W6_RING_ALT, false, true, false, true, 3, true, 0);
     W6P_ATTR(W6_RING_ALT, false, false, false, true, 1, true, 16); W6P_ATTR(W6_RING_ALT, false, false, false, true, 3, true, 16);
+#endif
 #undef W6P_ATTR4
 #undef W6P_ATTR
+#ifdef IRSDE_PROBES
 #define W8_ATTR(...) IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused64s_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
 #define W8_ATTR4(...) W8_ATTR(__VA_ARGS__, 0); W8_ATTR(__VA_ARGS__, 1); W8_ATTR(__VA_ARGS__, 2); W8_ATTR(__VA_ARGS__, 3)
     W8_ATTR4(W6_RING_ALT, false, false, true);
@@ -1651,6 +1656,7 @@ void wino_fused_global_init() {
     W7_ATTR(W6_RING_ALT, false, true, false, true, 1, true); W7_ATTR(W6_RING_ALT, false, true, false, true, 3, true);
 #undef W7_ATTR4
 #undef W7_ATTR
+#endif   // IRSDE_PROBES
 }
 
 // Geometry / feature check only (the plan decides where the fused kernel pays)
@@ -1828,6 +1834,7 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
         case 2: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 2, true); break;     \
         default: W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 3, true); break;    \
     }
+#ifdef IRSDE_PROBES   // superseded / measurement kernels (r04 halo and single-stream kernels, their stamp and ablation twins): not in the product library
         if (variant >= 48 && variant <= 54) {   // the single-stream kernel: 48 f32, 50 patch loads read zeros, 52 fp16 pairs, 53 cycle stamps (epilogues 1 / 3)
 #define W8_LAUNCH(...) hipLaunchKernelGGL((wino4_fused64s_kernel<W6_RING_ALT, __VA_ARGS__>), pgrid, dim3(256), W6_LDS_BYTES + 1024, s, p, Uf, GX, GY, NB, in0_bytes, in1_bytes, uf_bytes, out_bytes, res_bytes, xcd_nb, total, g_w6p_dbg)
 #define W8_LAUNCH_EPI(...)                                  \
@@ -1885,12 +1892,18 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
             IRSDE_HIP_CHECK(hipGetLastError());
             return;
         }
+#else
+        if (variant >= 40) throw HipError("launch_wino_fused64: the halo / single-stream kernels are measurement variants: build with make PROBES=1 (libirsde_hip_probes.so)");
+#endif
         switch (variant) {
             case 20: W6P_LAUNCH_EPI(false, false, false, true) break;
+#ifdef IRSDE_PROBES
             case 21: W6P_LAUNCH_EPI(true, false, false, true) break;    // weight fragments read zeros
             case 22: W6P_LAUNCH_EPI(false, true, false, true) break;    // patch loads read zeros
             case 23: W6P_LAUNCH_EPI(false, false, false, false) break;  // no non-temporal hint
+#endif
             case 24: W6P_LAUNCH_EPI(false, false, true, true) break;    // fp16 pairs
+#ifdef IRSDE_PROBES
             case 25: W6P_LAUNCH_EPI_STAMP() break;                      // cycle stamps into the buffer of wino_fused64_set_debug()
             case 26: {   // timed tuning twins: OPT = wino_fused64_set_opt() (epilogues 0 / 1 / 3 only)
 #define W6P_LAUNCH_OPT(O)                                                                  \
@@ -1922,7 +1935,8 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
                 if (variant == 30) { if (epi == 1) W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 1, true, 16); else W6P_LAUNCH(W6_RING_ALT, false, false, false, true, 3, true, 16); }
                 break;
             }
-            default: throw HipError("launch_wino_fused64: bad variant");
+#endif   // IRSDE_PROBES
+            default: throw HipError("launch_wino_fused64: bad variant (the ablation / stamp / tuning twins need a make PROBES=1 build)");
         }
 #undef W6P_LAUNCH_EPI_STAMP
 #undef W6P_LAUNCH_EPI
@@ -1930,6 +1944,10 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
         IRSDE_HIP_CHECK(hipGetLastError());
         return;
     }
+#ifndef IRSDE_PROBES
+    (void)grid; (void)nt;
+    throw HipError("launch_wino_fused64: r03's one-block-per-tile-group kernel (IRSDE_WINO_FUSED64_PERSIST=0, debug_conv 34 / 35 with persist off) is a superseded variant: build with make PROBES=1");
+#else
     if (variant == 0 && nt) variant = 10;   // 12 units in flight: with the epilogue hint the weights hit L2 more often, and the shorter ring has no spills (237 VGPRs)
     if (variant == 4 && nt) variant = 9;
     switch (variant) {
@@ -1945,8 +1963,9 @@ void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, in
         case 7: W6_LAUNCH(W6_RING, false, false, false, 2); break;
         default: throw HipError("launch_wino_fused64: bad variant");
     }
-#undef W6_LAUNCH
     IRSDE_HIP_CHECK(hipGetLastError());
+#endif   // IRSDE_PROBES
+#undef W6_LAUNCH
 }
 
 }  // namespace irsde

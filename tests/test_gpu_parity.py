@@ -58,9 +58,9 @@ def test_native_library_is_loaded():
 # ---------------------------------------------------------------------------------------------
 # kernel level: implicit-GEMM convolution (every shape class the network uses)
 # ---------------------------------------------------------------------------------------------
-def run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=0, splits=1, film_bstride=0):
-    """x0/x1/res: numpy NCHW.  Returns numpy NCHW."""
-    L = _lib.lib()
+def run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=0, splits=1, film_bstride=0, L=None):
+    """x0/x1/res: numpy NCHW.  Returns numpy NCHW.  L: the library (default: the product build; `probes_lib()` for superseded kernel generations)."""
+    L = L or _lib.lib()
     to_nhwc = lambda a: torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 3, 1))).to(DEV)
     d0 = to_nhwc(x0)
     d1 = to_nhwc(x1) if x1 is not None else None
@@ -78,8 +78,17 @@ def run_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, naive=0, s
     torch.cuda.synchronize()
     _lib.check(L.irsde_debug_conv(p(d0), C0, p(d1), C1, B, Hin, Win, in_shift, wc.ctypes.data_as(ctypes.c_void_p), Cout,
                                   KH, KW, stride, pad, bc.ctypes.data_as(ctypes.c_void_p) if bc is not None else None,
-                                  p(dfilm), film_bstride, silu, p(dres), p(out), naive, splits, None))
+                                  p(dfilm), film_bstride, silu, p(dres), p(out), naive, splits, None), L)
     return out.cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def probes_lib():
+    """libirsde_hip_probes.so (`make PROBES=1`: superseded kernel generations and measurement twins, not part of the product library); the
+    tests that compare kernel generations skip when it has not been built."""
+    try:
+        return _lib.probes_lib()
+    except _lib.IrsdeLibraryError as ex:
+        pytest.skip(str(ex))
 
 
 def oracle_conv(x0, x1, w, bias, stride, pad, in_shift, film, silu, res, film_bstride=0):
@@ -208,12 +217,7 @@ def test_conv_wino_fused64_edges(shape):
     assert np.array_equal(got, run_conv(x0, x1, w, None, 1, 1, up, None, 0, None, naive=36)), shape
 
 
-@pytest.mark.parametrize("shape", [(3, 64, 0, 96, 128, 128, 0), (6, 32, 32, 32, 32, 192, 1), (6, 64, 64, 96, 128, 64, 0)])
-def test_conv_wino_fused64_persistent_rounds(shape):
-    """r04: wino4_fused64p_kernel is one block per CU walking its tile groups (288 items each: more than the 256 CUs, ragged last
-    round): the producers run on into the next tile group (concat source / upsample offsets rebuilt at the boundary), the weight ring
-    prefetches across it, the output transform is lane-local.  Against the float64 oracle, r03's one-block-per-tile-group kernel (38 / 39),
-    the cout-block-by-XCD item map (bit-exact), and the fp16-pair twin."""
+def _persistent_rounds_case(shape):
     B, C0, C1, H, W, Cout, up = shape
     rs = np.random.RandomState(B * 131 + Cout)
     x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
@@ -223,25 +227,53 @@ def test_conv_wino_fused64_persistent_rounds(shape):
     film = (0.3 * rs.standard_normal((B, 2 * Cout))).astype(np.float32)
     res = rs.standard_normal((B, Cout, H << up, W << up)).astype(np.float32)
     ref = oracle_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, film_bstride=2 * Cout)
-    got = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=34, film_bstride=2 * Cout)
+    return (x0, x1, w, bias, 1, 1, up, film, 1, res), ref, 2 * Cout
+
+
+PERSISTENT_SHAPES = [(3, 64, 0, 96, 128, 128, 0), (6, 32, 32, 32, 32, 192, 1), (6, 64, 64, 96, 128, 64, 0)]
+
+
+@pytest.mark.parametrize("shape", PERSISTENT_SHAPES)
+def test_conv_wino_fused64_persistent_rounds(shape):
+    """r04: wino4_fused64p_kernel (production) is one block per CU walking its tile groups (288 items each: more than the 256 CUs, ragged last
+    round): the producers run on into the next tile group (concat source / upsample offsets rebuilt at the boundary), the weight ring
+    prefetches across it, the output transform is lane-local.  Against the float64 oracle; the cout-block-by-XCD item map (36 / 37) and the
+    fixed-grid launches (55 / 56) are the same arithmetic in the same order: bit-exact; the fp16-pair twin (35) within the f32 bar."""
+    args, ref, fb = _persistent_rounds_case(shape)
+    got = run_conv(*args, naive=34, film_bstride=fb)
     assert got.shape == ref.shape and np.isfinite(got).all()
     assert relerr(got, ref) < 5e-5, shape
-    old = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=38, film_bstride=2 * Cout)
-    assert relerr(old, ref) < 5e-5 and relerr(got, old) < 2e-5, shape
-    assert np.array_equal(got, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=36, film_bstride=2 * Cout)), shape
-    # 55 / 56: r04's register-patch persistent kernel (f32 / fp16 pairs); 34 / 35: production; 57 / 58: the halo kernel (patches through LDS);
-    # 51 / 53: tuning twins of the persistent kernel (no double-fetched ring units / interleaved patch-load issue).  Same arithmetic in the
-    # same order everywhere: bit-identical.  52 (12-operation B^T) and 50 (every tuning bit) re-associate the input transform.
-    for nv in (55, 57, 51, 53, 60):   # 60: the single-stream kernel (every wave both roles)
-        assert np.array_equal(got, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout)), (shape, nv)
-    for nv in (52, 50):
-        assert relerr(run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout), ref) < 5e-5, (shape, nv)
-    pair = run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=35, film_bstride=2 * Cout)
+    assert np.array_equal(got, run_conv(*args, naive=36, film_bstride=fb)), shape
+    assert np.array_equal(got, run_conv(*args, naive=55, film_bstride=fb)), shape
+    pair = run_conv(*args, naive=35, film_bstride=fb)
     assert relerr(pair, ref) < 5e-5, shape
-    assert relerr(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=39, film_bstride=2 * Cout)) < 2e-5, shape
-    assert np.array_equal(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=37, film_bstride=2 * Cout)), shape
-    for nv in (56, 58, 61):
-        assert np.array_equal(pair, run_conv(x0, x1, w, bias, 1, 1, up, film, 1, res, naive=nv, film_bstride=2 * Cout)), (shape, nv)
+    assert np.array_equal(pair, run_conv(*args, naive=37, film_bstride=fb)), shape
+    assert np.array_equal(pair, run_conv(*args, naive=56, film_bstride=fb)), shape
+
+
+@pytest.mark.parametrize("shape", PERSISTENT_SHAPES)
+def test_conv_wino_fused64_kernel_generations(shape):
+    """The superseded / measurement kernels of the fused Winograd family live in the PROBES build only (libirsde_hip_probes.so, r05): r03's
+    one-block-per-tile-group kernel (38 / 39), the halo kernel (57 / 58: patches through LDS), the single-stream kernel (60 / 61), the tuning twins of
+    the persistent kernel (51 / 53: no double-fetched ring units / interleaved patch-load issue; 52: 12-operation B^T; 50: every tuning bit).  Same
+    arithmetic in the same order wherever the input transform is not re-associated: bit-identical to the PRODUCT library's production kernel."""
+    PL = probes_lib()
+    args, ref, fb = _persistent_rounds_case(shape)
+    got = run_conv(*args, naive=34, film_bstride=fb)                      # product library, production kernel
+    assert np.array_equal(got, run_conv(*args, naive=34, film_bstride=fb, L=PL)), shape   # the probes build runs the same production kernel
+    old = run_conv(*args, naive=38, film_bstride=fb, L=PL)
+    assert relerr(old, ref) < 5e-5 and relerr(got, old) < 2e-5, shape
+    for nv in (57, 51, 53, 60):
+        assert np.array_equal(got, run_conv(*args, naive=nv, film_bstride=fb, L=PL)), (shape, nv)
+    for nv in (52, 50):
+        assert relerr(run_conv(*args, naive=nv, film_bstride=fb, L=PL), ref) < 5e-5, (shape, nv)
+    pair = run_conv(*args, naive=35, film_bstride=fb)
+    assert relerr(pair, run_conv(*args, naive=39, film_bstride=fb, L=PL)) < 2e-5, shape
+    for nv in (58, 61):
+        assert np.array_equal(pair, run_conv(*args, naive=nv, film_bstride=fb, L=PL)), (shape, nv)
+    # the product library refuses these selectors loudly instead of silently running something else
+    with pytest.raises(P.IrsdeError, match="PROBES"):
+        run_conv(*args, naive=38, film_bstride=fb)
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 0, 32, 32, 128, 0), (1, 64, 64, 16, 16, 256, 1), (4, 64, 0, 16, 32, 512, 0), (3, 64, 0, 16, 16, 128, 0)])

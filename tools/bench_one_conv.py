@@ -6,5 +6,5 @@ from image_restoration_sde_amd import _lib
 a = [int(x) for x in sys.argv[1:]]
 iters = a[10] if len(a) > 10 else 5
 ms = ctypes.c_double()
-rc = _lib.lib().irsde_bench_conv(*a[:10], iters, ctypes.byref(ms))
+rc = _lib.probes_lib().irsde_bench_conv(*a[:10], iters, ctypes.byref(ms))
 print("rc=%d  %.4f ms" % (rc, ms.value))

@@ -3,7 +3,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from image_restoration_sde_amd import _lib
-L = _lib.lib()
+L = _lib.probes_lib()   # measurement variants live in the PROBES build (make -C image_restoration_sde_amd/csrc PROBES=1)
 cases = [("L0  64->64  film", 256, 64, 64, 0, 1), ("L0  64->64  res", 256, 64, 64, 0, 2), ("L0 128->128 res", 256, 128, 128, 0, 2), ("L0 192->128 film", 256, 192, 128, 0, 1),
          ("L0 up 256->128", 128, 256, 128, 1, 0), ("L1 256->256 res", 128, 256, 256, 0, 2), ("L2 512->512 res", 64, 512, 512, 0, 2)]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""

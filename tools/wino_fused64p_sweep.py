@@ -7,7 +7,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from image_restoration_sde_amd import _lib
-L = _lib.lib()
+L = _lib.probes_lib()   # measurement variants live in the PROBES build (make -C image_restoration_sde_amd/csrc PROBES=1)
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] else "410,430,431,432,433,409,434").split(",")]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16

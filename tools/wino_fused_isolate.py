@@ -6,7 +6,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from image_restoration_sde_amd import _lib
-L = _lib.lib()
+L = _lib.probes_lib()   # measurement variants live in the PROBES build (make -C image_restoration_sde_amd/csrc PROBES=1)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 combos = [("fused", 0), ("no patch", 1), ("no weights", 2), ("neither", 3), ("prodprio", 4), ("mfmaprio", 8), ("noVALU", 16), ("noLDSw", 32),
           ("noMFMA", 128), ("noMFMA,VALU", 144), ("noMFMA,LDSw", 160), ("noMFMA,VALU,LDSw", 176), ("onlybarriers", 179)]

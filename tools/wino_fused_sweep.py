@@ -5,7 +5,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from image_restoration_sde_amd import _lib
-L = _lib.lib()
+L = _lib.probes_lib()   # measurement variants live in the PROBES build (make -C image_restoration_sde_amd/csrc PROBES=1)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 # (name, H, W, Cin, Cout, up, epi)

@@ -4,7 +4,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from image_restoration_sde_amd import _lib
-L = _lib.lib()
+L = _lib.probes_lib()   # measurement variants live in the PROBES build (make -C image_restoration_sde_amd/csrc PROBES=1)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 for H, W, Cin, Cout, up, epi in [(256, 256, 64, 64, 0, 1), (256, 256, 192, 128, 0, 1), (128, 128, 256, 128, 1, 0), (128, 128, 384, 256, 0, 1)]:
     ms = ctypes.c_double()
