@@ -315,6 +315,8 @@ struct UpdateParams {
     int B, C, H, W;
     uint64_t seed;
     uint64_t image_offset;  // global index of image 0 of this shard (RNG invariance to sharding)
+    int batch0;          // r05 sub-batch plans: x / mu / pred hold images [batch0, batch0 + B) of the call's batch — the injected noise tensor and the
+                         // Philox image index are addressed with the call-level index b + batch0
 };
 void launch_sde_update(const UpdateParams& p, hipStream_t s);
 // fills out[B][C][H][W] with the Philox N(0,1) draw for step t (test hook for the RNG)

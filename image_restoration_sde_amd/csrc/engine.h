@@ -217,6 +217,8 @@ struct PoolBlock {
 struct Plan {
     int B = 0, H = 0, W = 0, Hp = 0, Wp = 0;
     bool per_sample_film = false;
+    int slot = 0, b0 = 0;     // r05 sub-batch plans: slot >= 1 = part `slot - 1` of a split batch, holding images [b0, b0 + B) of the call (own arena, own state buffers;
+                              // per-image tables — lens FiLM rows, per-sample time rows, noise / Philox index — are addressed from b0)
     std::vector<PoolBlock> pool;
     std::vector<Op> net_ops;  // prep + network (one evaluation)
     float* xin = nullptr;     // [B][in_nc][H][W]  state x / xt
@@ -337,6 +339,10 @@ struct irsde_engine {
     float* zeros = nullptr;        // zero page: the branch-free source of out-of-image conv taps
     hipStream_t stream = nullptr;  // engine stream (graph capture needs a non-default stream)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // r05: concurrent sub-batches of a NAFNet sampler step (engine_api.hip: sample_split): branch i > 0 runs on sub_stream[i - 1] between ev_fork and ev_join[i - 1]
+    static constexpr int kMaxSub = 4;
+    hipStream_t sub_stream[kMaxSub - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSub - 1] = {nullptr, nullptr, nullptr};
     std::vector<std::unique_ptr<Plan>> plans;
     uint64_t use_counter = 0;
     double profile[12] = {0};
@@ -437,7 +443,9 @@ void compute_film_rows(irsde_engine* e, const float* tvals, int rows, float* dst
 void ensure_film_cur(irsde_engine* e, int rows);
 
 // engine_plan.hip: one network evaluation as a static launch list over a static arena
-Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film);
+Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film, int slot = 0, int b0 = 0);
+int naf_subbatches(const irsde_engine* e, int B, int H, int W);
+void set_force_subbatches(int n);                                 // irsde_debug_force_subbatches   // how many concurrent sub-batches the sampler splits a NAFNet batch into (1 = none)
 LatentPlan* get_latent_plan(irsde_engine* e, int B, int H, int W, bool decode);
 
 }  // namespace irsde

@@ -38,6 +38,7 @@ UpdateParams make_update(irsde_engine* e, Plan* pl) {
     u.sb = (int64_t)pl->Hp * pl->Wp * ps; u.sc = 1; u.sy = (int64_t)pl->Wp * ps; u.sx = ps;
     u.st = e->step; u.ctl = e->ctl;
     u.B = pl->B; u.C = e->cfg.in_nc; u.H = pl->H; u.W = pl->W;
+    u.batch0 = pl->b0;
     return u;
 }
 
@@ -45,6 +46,33 @@ void one_step(irsde_engine* e, Plan* pl, hipStream_t s) {
     launch_step_begin(e->step, e->film_table, e->film_row, e->film_cur, e->coef_table, s);
     run_net(pl, s);
     launch_sde_update(make_update(e, pl), s);
+}
+
+// r05: one sampler step of a batch split into concurrent sub-batches (plans sp[0 .. n), images [b0, b0 + B / n) each): the per-step state (step index,
+// FiLM row, coefficient row) is popped once, then part 0 runs on the engine stream and part i > 0 on sub_stream[i - 1] between ev_fork and ev_join[i - 1].
+// Captured, the event record / wait pairs become the fork and join edges of ONE graph; eager, they are real cross-stream dependencies.  Nothing in a
+// part depends on another part (no cross-batch op in the score network), so the result is the un-split one up to the tilings the smaller
+// plans choose.
+void ensure_sub_streams(irsde_engine* e, int n) {
+    if (!e->ev_fork) IRSDE_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i + 1 < n; ++i) {
+        if (!e->sub_stream[i]) IRSDE_HIP_CHECK(hipStreamCreateWithFlags(&e->sub_stream[i], hipStreamNonBlocking));
+        if (!e->ev_join[i]) IRSDE_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+    }
+}
+void one_step_split(irsde_engine* e, const std::vector<Plan*>& sp, hipStream_t s) {
+    launch_step_begin(e->step, e->film_table, e->film_row, e->film_cur, e->coef_table, s);
+    IRSDE_HIP_CHECK(hipEventRecord(e->ev_fork, s));
+    for (size_t i = 1; i < sp.size(); ++i) {
+        hipStream_t t = e->sub_stream[i - 1];
+        IRSDE_HIP_CHECK(hipStreamWaitEvent(t, e->ev_fork, 0));
+        run_net(sp[i], t);
+        launch_sde_update(make_update(e, sp[i]), t);
+        IRSDE_HIP_CHECK(hipEventRecord(e->ev_join[i - 1], t));
+    }
+    run_net(sp[0], s);
+    launch_sde_update(make_update(e, sp[0]), s);
+    for (size_t i = 1; i < sp.size(); ++i) IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_join[i - 1], 0));
 }
 
 // irsde_debug_conv / irsde_bench_conv only: selects a kernel variant for the launches of ONE call and always returns to
@@ -89,7 +117,7 @@ int guard(const std::function<void()>& f) {
 extern "C" {
 
 const char* irsde_last_error(void) { return g_last_error.c_str(); }
-int irsde_version(void) { return 104; }  // changelog: include/irsde_hip.h
+int irsde_version(void) { return 105; }  // changelog: include/irsde_hip.h
 
 int irsde_create(const irsde_config* cfg, irsde_engine** out) {
     return guard([&] {
@@ -155,6 +183,9 @@ void irsde_destroy(irsde_engine* e) {
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (auto ev : e->ev_join) if (ev) (void)hipEventDestroy(ev);
+    for (auto st : e->sub_stream) if (st) (void)hipStreamDestroy(st);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     for (float* p : e->dev_allocs) (void)hipFree(p);
     for (auto& kv : e->bf16_copies) (void)hipFree(kv.second);
@@ -298,13 +329,53 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
             IRSDE_HIP_CHECK(hipMemcpyAsync(out, xT, (size_t)B * e->cfg.in_nc * H * W * 4, hipMemcpyDeviceToDevice, user));
             return;
         }
-        Plan* pl = get_plan(e, B, H, W, false);
         hipStream_t s = e->stream;
         const bool profile = (flags & IRSDE_SAMPLE_PROFILE) != 0;
         const bool graph = (flags & IRSDE_SAMPLE_GRAPH) != 0 && !profile;
+        const size_t img = (size_t)B * e->cfg.in_nc * H * W;
+        const int nsub = profile ? 1 : naf_subbatches(e, B, H, W);   // (the event-instrumented pass times the un-split plan: its kernels are the same)
+        if (nsub > 1) {
+            const int Bs = B / nsub;
+            const size_t simg = img / nsub;
+            std::vector<Plan*> sp(nsub);
+            for (int i = 0; i < nsub; ++i) sp[i] = get_plan(e, Bs, H, W, false, i + 1, i * Bs);
+            for (int i = 0; i < nsub; ++i) (void)get_plan(e, Bs, H, W, false, i + 1, i * Bs);   // (all parts most recently used: none of them is the next eviction victim)
+            ensure_sub_streams(e, nsub);
+            IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
+            IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+            for (int i = 0; i < nsub; ++i) {
+                IRSDE_HIP_CHECK(hipMemcpyAsync(sp[i]->xin, xT + i * simg, simg * 4, hipMemcpyDeviceToDevice, s));
+                if (mu) IRSDE_HIP_CHECK(hipMemcpyAsync(sp[i]->cin, mu + i * simg, simg * 4, hipMemcpyDeviceToDevice, s));
+            }
+            launch_set_ctl(e->ctl, mode, noise, (long long)img, seed, image_offset, s);
+            launch_set_step(e->step, T, s);
+            if (graph) {
+                Plan* holder = sp[0];   // the step graph of the split batch lives (and dies) with part 0
+                if (!holder->graph_exec) {
+                    IRSDE_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                    try {
+                        one_step_split(e, sp, s);
+                    } catch (...) {
+                        hipGraph_t g = nullptr;
+                        (void)hipStreamEndCapture(s, &g);
+                        if (g) (void)hipGraphDestroy(g);
+                        throw;
+                    }
+                    IRSDE_HIP_CHECK(hipStreamEndCapture(s, &holder->graph));
+                    IRSDE_HIP_CHECK(hipGraphInstantiate(&holder->graph_exec, holder->graph, nullptr, nullptr, 0));
+                }
+                for (int i = 0; i < nsteps; ++i) IRSDE_HIP_CHECK(hipGraphLaunch(holder->graph_exec, s));
+            } else {
+                for (int i = 0; i < nsteps; ++i) one_step_split(e, sp, s);
+            }
+            for (int i = 0; i < nsub; ++i) IRSDE_HIP_CHECK(hipMemcpyAsync(out + i * simg, sp[i]->xin, simg * 4, hipMemcpyDeviceToDevice, s));
+            IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
+            IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
+            return;
+        }
+        Plan* pl = get_plan(e, B, H, W, false);
         IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
         IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
-        const size_t img = (size_t)B * e->cfg.in_nc * H * W;
         IRSDE_HIP_CHECK(hipMemcpyAsync(pl->xin, xT, img * 4, hipMemcpyDeviceToDevice, s));
         if (mu) IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, mu, img * 4, hipMemcpyDeviceToDevice, s));
         launch_set_ctl(e->ctl, mode, noise, (long long)img, seed, image_offset, s);
@@ -725,6 +796,11 @@ int irsde_debug_split_gemm(const float* A, const float* Bm, float* C, int M, int
         IRSDE_HIP_CHECK(hipStreamSynchronize(s));
         (void)hipFree(da); (void)hipFree(db);
     });
+}
+
+int irsde_debug_force_subbatches(int n) {
+    set_force_subbatches(n < 0 ? 0 : n);
+    return IRSDE_OK;
 }
 
 int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out) {

@@ -15,6 +15,9 @@ struct Builder {
     bool reuse;
     bool naive;
     int film_bstride;
+    int b0 = 0;   // first image of this plan within the call's batch (sub-batch plans): base of the per-image tables
+    const float* film_base() const { return e->film_cur + (size_t)b0 * film_bstride; }
+    const float* cam_base() const { return e->cam_cur + (size_t)b0 * e->cam_row; }
     const float* fused_ln_g = nullptr;  // set around a conv() call: LayerNorm gain applied in that conv's epilogue
 
     bool act_bf16() const { return (e->cfg.flags & IRSDE_FLAG_BF16_ACT) != 0; }
@@ -262,7 +265,7 @@ struct Builder {
         const int64_t M = (int64_t)x.B * x.H * x.W;
         const int64_t ppi = (int64_t)x.H * x.W;
         const int c = w.c;
-        const float* film = e->film_cur + w.film_off;  // [shift_att | scale_att | shift_ffn | scale_ffn]
+        const float* film = film_base() + w.film_off;  // [shift_att | scale_att | shift_ffn | scale_ffn]
         const int fb = film_bstride;
         Tensor t1 = talloc(x.B, x.H, x.W, c);
         {
@@ -302,7 +305,7 @@ struct Builder {
         }
         ConvOpts o4;
         o4.gate = 1;
-        if (naf_lens(e)) o4.gate_film = e->cam_cur + w.cam_off;  // x * (cam_scale + 1) + cam_shift after the gate (:82-83)
+        if (naf_lens(e)) o4.gate_film = cam_base() + w.cam_off;  // x * (cam_scale + 1) + cam_shift after the gate (:82-83)
         Tensor v = conv_naf(w.conv4, t2, o4);
         tfree(t2);
         ConvOpts o5;
@@ -319,7 +322,7 @@ struct Builder {
     }
     Tensor nafchain(const NafChainW& cw, const Tensor& x) {
         Tensor out = talloc(x.B, x.H, x.W, x.C);
-        const float *xp = x.p, *film = e->film_cur, *cam = naf_lens(e) ? e->cam_cur : nullptr;
+        const float *xp = x.p, *film = film_base(), *cam = naf_lens(e) ? cam_base() : nullptr;
         float* op = out.p;
         const int B = x.B, fb = film_bstride, cb = e->cam_row;
         const NafChainW c = cw;
@@ -348,7 +351,7 @@ struct Builder {
         else
             R = in0;
         // latent UNet ResBlocks have no time MLP (UNet_arch.py:23): plain conv -> SiLU
-        Tensor h1 = conv(w.b1, in0, in1, 1, 1, 0, w.mlp_w ? e->film_cur + w.film_off : nullptr, 1, nullptr);
+        Tensor h1 = conv(w.b1, in0, in1, 1, 1, 0, w.mlp_w ? film_base() + w.film_off : nullptr, 1, nullptr);
         Tensor out = conv(w.b2, h1, nullptr, 1, 1, 0, nullptr, 1, &R);
         tfree(h1);
         if (w.has_res) tfree(R);
@@ -588,23 +591,55 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
     pl->pred = pr.p;
 }
 
-Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
+// Sub-batches of a NAFNet sampler step (engine_api.hip: sample_split).  Why: on small latents most of a NAFNet evaluation is per-image latency, not
+// throughput — naf_chain_kernel keeps ONE CU per image busy for ~45 % of the step (64 of 256 CUs at BASELINE configs[4]'s batch of 64) while the other
+// levels' kernels are bandwidth-bound on all CUs: independent sub-batches on concurrent streams let one part's chain run under the other parts' levels.
+// Only where a level actually runs as a chain, and never below 16 images per part (smaller parts are launch-latency-bound themselves).
+static int g_force_subbatches = 0;   // irsde_debug_force_subbatches (test / measurement hook): 0 = the heuristic below
+void set_force_subbatches(int n) { g_force_subbatches = n; }
+int naf_subbatches(const irsde_engine* e, int B, int H, int W) {
+    if (e->arch != 1 || (e->cfg.flags & (IRSDE_FLAG_NAIVE_CONV | IRSDE_FLAG_KEEP_ACTIVATIONS))) return 1;
+    int n = g_force_subbatches;
+    if (n <= 0) {
+        static const int env = tuning_env_int("IRSDE_NAF_SUBBATCHES", 0);
+        n = env;
+    }
+    if (n <= 0) {
+        bool chain = false;
+        const int nlev = (int)e->naf_enc.size(), ps = 1 << nlev;
+        const int Hp = (H + ps - 1) / ps * ps, Wp = (W + ps - 1) / ps * ps;
+        if ((e->cfg.flags & IRSDE_FLAG_FP16) && !(e->cfg.flags & IRSDE_FLAG_NO_NAF_CHAIN))
+            for (int i = 0; i < nlev; ++i)
+                if (e->naf_chain_enc[i].nblocks > 0 && naf_chain_shape_ok(Hp >> i, Wp >> i, e->naf_intro.Cout << i)) chain = true;
+        n = !chain ? 1 : B >= 64 ? 4 : B >= 32 ? 2 : 1;
+    }
+    n = std::min(n, (int)irsde_engine::kMaxSub);
+    while (n > 1 && B % n) --n;
+    return std::max(n, 1);
+}
+
+Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film, int slot, int b0) {
     for (auto& p : e->plans)
-        if (p->B == B && p->H == H && p->W == W && p->per_sample_film == per_sample_film) {
+        if (p->B == B && p->H == H && p->W == W && p->per_sample_film == per_sample_film && p->slot == slot && p->b0 == b0) {
             p->last_use = ++e->use_counter;
             return p.get();
         }
-    if (e->plans.size() >= 4) {  // LRU eviction
+    if (e->plans.size() >= 8) {  // LRU eviction (8: a split batch holds up to four sub-batch plans)
         size_t lru = 0;
         for (size_t i = 1; i < e->plans.size(); ++i)
             if (e->plans[i]->last_use < e->plans[lru]->last_use) lru = i;
         IRSDE_HIP_CHECK(hipDeviceSynchronize());
-        e->plans.erase(e->plans.begin() + lru);
+        // the parts of a split batch share ONE captured graph (held by part 0): they leave together
+        const int vb = e->plans[lru]->B, vh = e->plans[lru]->H, vw = e->plans[lru]->W;
+        const bool split = e->plans[lru]->slot > 0;
+        for (size_t i = e->plans.size(); i-- > 0;)
+            if (i == lru || (split && e->plans[i]->slot > 0 && e->plans[i]->B == vb && e->plans[i]->H == vh && e->plans[i]->W == vw))
+                e->plans.erase(e->plans.begin() + i);
     }
-    ensure_film_cur(e, per_sample_film ? B : 1);
+    ensure_film_cur(e, per_sample_film ? b0 + B : 1);
     if (naf_lens(e)) {
-        if (e->cam_set < B) throw HipError("latent-bokeh ConditionalNAFNet: irsde_set_lens_info must cover the batch first");
-        if (e->cam_rows < B) throw HipError("internal: lens table smaller than the batch");
+        if (e->cam_set < b0 + B) throw HipError("latent-bokeh ConditionalNAFNet: irsde_set_lens_info must cover the batch first");
+        if (e->cam_rows < b0 + B) throw HipError("internal: lens table smaller than the batch");
     }
 
     const int depth = e->cfg.depth, nf = e->cfg.nf, in_nc = e->cfg.in_nc;
@@ -615,6 +650,7 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
     pl->Hp = (H + sdiv - 1) / sdiv * sdiv;
     pl->Wp = (W + sdiv - 1) / sdiv * sdiv;
     pl->per_sample_film = per_sample_film;
+    pl->slot = slot; pl->b0 = b0;
     pl->pred_stride = (e->cfg.out_nc + 3) & ~3;
     pl->last_use = ++e->use_counter;
     // F.pad 'reflect' needs pad < dim (DenoisingUNet_arch.py:82)
@@ -630,7 +666,7 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film) {
     IRSDE_HIP_CHECK(hipMemset(pl->x0, 0, x0n * sizeof(float)));
 
     Builder b{e, pl, (e->cfg.flags & IRSDE_FLAG_KEEP_ACTIVATIONS) == 0, (e->cfg.flags & IRSDE_FLAG_NAIVE_CONV) != 0,
-              per_sample_film ? e->film_row : 0};
+              per_sample_film ? e->film_row : 0, b0};
     {
         const float *xi = pl->xin, *ci = uncond ? nullptr : pl->cin;
         float* x0 = pl->x0;

@@ -264,6 +264,23 @@ __global__ __launch_bounds__(256) void attn_ctx_partial_kernel(const T* __restri
 // ~4.8k cycles of LDS latency into every 128-pixel tile of the fused attention kernels).  The mirror steps are valid because after the
 // quad steps all lanes of a quad hold the same partial sum (and so on upwards); both operands of every add are the same two numbers in
 // every lane of the group, so all lanes end with bit-identical totals.
+// v_permlane16_swap / v_permlane32_swap (gfx950): rows 1, 3 (lanes 32 - 63) of the first operand change places with rows 0, 2 (lanes 0 - 31) of the second.
+// With x in both operands the two results are [A A C C] / [B B D D] (resp. [lo lo] / [hi hi]): their sum (max) is the xor-16 (xor-32) butterfly step.
+// Inline assembly on purpose (hipcc, ROCm 7.2; found by the parity tests, r05): through __builtin_amdgcn_permlane*_swap the optimiser folds the case
+// "both operands hold the same value" into "both results = result 0" (also when the second operand is an identity DPP copy of the first), and
+// `auto r = builtin(...); r[0], r[1]` reads element 0 twice even for different operands — either way the "sum" silently becomes 2 x one half.
+// s_nop 1 = the two wait states the swap needs behind a VALU write of its operands (LLVM gfx950 hazard rule); the asm is opaque to the hazard recogniser.
+struct SwapPair { float a, b; };
+__device__ __forceinline__ SwapPair swap16(const float v) {
+    SwapPair r{v, v};
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r.a), "+v"(r.b));
+    return r;
+}
+__device__ __forceinline__ SwapPair swap32(const float v) {
+    SwapPair r{v, v};
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r.a), "+v"(r.b));
+    return r;
+}
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
     static_assert(W >= 1 && W <= 64 && (W & (W - 1)) == 0, "group width must be a power of two <= 64");
@@ -272,24 +289,24 @@ __device__ __forceinline__ float group_sum(float v) {
     if constexpr (W >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
     if constexpr (W >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
     if constexpr (W >= 32) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-        v = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+        const SwapPair r = swap16(v);
+        v = r.a + r.b;
     }
     if constexpr (W >= 64) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-        v = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+        const SwapPair r = swap32(v);
+        v = r.a + r.b;
     }
     return v;
 }
 
 // lane l and lane l ^ 32 combined (the two halves of a v_mfma_f32_32x32 accumulator column): v_permlane32_swap, no LDS round trip
 __device__ __forceinline__ float half_sum(const float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    const SwapPair r = swap32(v);
+    return r.a + r.b;
 }
 __device__ __forceinline__ float half_max(const float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    const SwapPair r = swap32(v);
+    return fmaxf(r.a, r.b);
 }
 
 template <int C4>
@@ -1187,7 +1204,8 @@ __global__ __launch_bounds__(256) void sde_update_kernel(const UpdateParams p) {
     }
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     const bool need_z = mode != 1 && mode != 4;
-    if (need_z && !noise) philox_normal4((uint32_t)quad, (uint32_t)t, (uint32_t)(image_offset + b), seed, z);
+    const int bg = b + p.batch0;   // index of this image in the call's batch (sub-batch plans: batch0 > 0)
+    if (need_z && !noise) philox_normal4((uint32_t)quad, (uint32_t)t, (uint32_t)(image_offset + bg), seed, z);
     for (int k = 0; k < 4; ++k) {
         const int e = quad * 4 + k;
         if (e >= CHW) break;
@@ -1195,7 +1213,7 @@ __global__ __launch_bounds__(256) void sde_update_kernel(const UpdateParams p) {
         const int c = e / HW, rem = e - c * HW, y = rem / p.W, xx = rem - y * p.W;
         const float eps_hat = p.pred[(size_t)b * p.sb + (size_t)c * p.sc + (size_t)y * p.sy + (size_t)xx * p.sx];
         const float x = p.x[si], mu = p.mu[si];
-        if (need_z && noise) z[k] = noise[(size_t)t * noise_tstride + si];
+        if (need_z && noise) z[k] = noise[(size_t)t * noise_tstride + (size_t)bg * CHW + e];
         float xn;
         if (mode >= 3) {
             // DenoisingSDE (sde_utils.py:448-457, 44-48): mode 3 reverse_sde, mode 4 reverse_ode; cf[9] = exp(-2 Theta_t dt)

@@ -50,7 +50,7 @@ def test_native_library_is_loaded():
     """The HIP extension (in-tree .so) is what runs; there is no eager/PyTorch fallback."""
     assert torch.cuda.is_available()
     L = _lib.lib()
-    assert L.irsde_version() == 104
+    assert L.irsde_version() == 105
     maps = open("/proc/self/maps").read()
     assert "libirsde_hip.so" in maps
 
@@ -1180,12 +1180,15 @@ def test_naf_chain_blocks_vs_oracle(lens, enc3):
     tvec = np.array([5, 60])
     li = [rs.uniform(0.1, 1.0, B).astype(np.float32) for _ in range(3)]
     if lens:
+        m.set_lens_info([torch.from_numpy(v) for v in li], B, torch.device(DEV))
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine(torch.device(DEV)).h, B, 64, 64, buf, len(buf)))
+    assert buf.value.count(b"naf_chain(fp16)") == 2, buf.value[-600:]     # encoder level 3 and decoder level 0 run as chains
+    # (the forward comes AFTER the describe call: debug_tap reads the most recently used plan, and the [B]-timestep forward has its own)
+    if lens:
         m(xt, cond, torch.from_numpy(tvec), lens_info=[torch.from_numpy(v) for v in li])
     else:
         m(xt, cond, torch.from_numpy(tvec))
-    buf = ctypes.create_string_buffer(1 << 16)
-    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, B, 64, 64, buf, len(buf)))
-    assert buf.value.count(b"naf_chain(fp16)") == 2, buf.value[-600:]     # encoder level 3 and decoder level 0 run as chains
     p64 = {k: np.asarray(v, dtype=np.float64) for k, v in bp.items()}
     temb, cam = O.naf_embeddings(p64, tvec, li if lens else None, np.float64)
     for src, dst, pres in (("downs.2", "encoders.3", ["encoders.3.%d." % j for j in range(enc3)]), ("ups.0", "decoders.0", ["decoders.0.0."])):
@@ -1230,6 +1233,54 @@ def test_nafnet_levels_64_32_16_vs_oracle(B):
     assert not bad, bad
     assert {taps["encoders.%d" % i].shape[-1] for i in range(4)} == {64, 32, 16, 8}
     assert relerr(y, ref) < 5e-5
+
+
+@pytest.mark.parametrize("nsub", [2, 4])
+def test_nafnet_sampler_concurrent_subbatches(nsub):
+    """ABI 105: irsde_sample splits a chain-bearing ConditionalNAFNet batch into concurrent sub-batches (fork / join inside the captured step graph;
+    engine_api.hip: one_step_split).  Forced here at B = 4 (the heuristic starts at 32 images): the split run must reproduce the un-split one — per-image
+    lens FiLM rows, injected noise and the Philox streams are all addressed by the call-level image index — up to the tilings the smaller plans choose;
+    graph replay and eager launches of the split step are bit-identical."""
+    L = _lib.lib()
+    rs = np.random.RandomState(23)
+    kw = dict(img_channel=4, width=64, enc_blk_nums=[1, 1, 1, 2], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+    bp = O.naf_synth_params(seed=12, img_channel=4, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 2), dec_blk_nums=(1, 1, 1, 1), lens=True)
+    for k in bp:
+        if k.endswith(".beta") or k.endswith(".gamma"):
+            bp[k] = (0.3 * rs.standard_normal(bp[k].shape)).astype(np.float32)
+    m = P.latent_bokeh.ConditionalNAFNet(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in bp.items()}, strict=True)
+    m.set_compute_dtype("fp16")
+    m = m.to(DEV).eval()
+    B, T = 4, 5
+    xt = torch.from_numpy(rs.standard_normal((B, 4, 64, 64)).astype(np.float32)).to(DEV)
+    cond = torch.from_numpy(rs.standard_normal((B, 4, 64, 64)).astype(np.float32)).to(DEV)
+    li = [torch.from_numpy(rs.uniform(0.1, 1.0, B).astype(np.float32)) for _ in range(3)]
+    sde = P.IRSDE(max_sigma=50, T=T, schedule="cosine", eps=0.005, device=DEV)
+    sde.set_model(m)
+    sde.set_mu(cond)
+    sde.image_offset = 3
+    z = torch.from_numpy(O.synth_noise(9, T, (B, 4, 64, 64))).to(DEV)
+    outs = {}
+    try:
+        for n in (1, nsub):
+            L.irsde_debug_force_subbatches(n)
+            for tag, noise, seed in (("inj", z, 0), ("rng", None, 5)):
+                sde.injected_noise, sde.seed = noise, seed
+                for graph in (True, False):
+                    sde.use_graph = graph
+                    outs[n, tag, graph] = sde.reverse_sde(xt, lens_info=li).cpu().numpy()
+    finally:
+        L.irsde_debug_force_subbatches(0)
+        sde.use_graph = True
+    for tag in ("inj", "rng"):
+        assert np.isfinite(outs[nsub, tag, True]).all()
+        assert np.array_equal(outs[nsub, tag, True], outs[nsub, tag, False]), tag        # captured fork / join == eager cross-stream dependencies
+        e = relerr(outs[nsub, tag, True], outs[1, tag, True])
+        print("NAFNet sampler, %d concurrent sub-batches vs one batch (%s): %.3g" % (nsub, tag, e))
+        assert e < 2e-4, (tag, e)   # fp16-operand plans of B / nsub and B images: same roundings, different f32 summation orders through T steps
+    # the images really differ from each other (a wrong sub-batch offset into the lens / noise tables would go unnoticed otherwise)
+    assert relerr(outs[1, "rng", True][0], outs[1, "rng", True][B - 1]) > 1e-2
 
 
 def test_latent_bokeh_nafnet_vs_reference_golden(golden):
