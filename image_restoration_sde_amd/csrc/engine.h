@@ -217,6 +217,8 @@ struct PoolBlock {
 struct Plan {
     int B = 0, H = 0, W = 0, Hp = 0, Wp = 0;
     bool per_sample_film = false;
+    StepState* own_step = nullptr;   // sub-batch plans (slot >= 1) carry their own step counter / coefficient row and FiLM row: their step graphs replay
+    float* own_film = nullptr;       // on their own stream with no per-step dependency on the other parts (both live in the plan's arena)
     int slot = 0, b0 = 0;     // r05 sub-batch plans: slot >= 1 = part `slot - 1` of a split batch, holding images [b0, b0 + B) of the call (own arena, own state buffers;
                               // per-image tables — lens FiLM rows, per-sample time rows, noise / Philox index — are addressed from b0)
     std::vector<PoolBlock> pool;

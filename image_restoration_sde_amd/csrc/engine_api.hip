@@ -36,7 +36,7 @@ UpdateParams make_update(irsde_engine* e, Plan* pl) {
     u.x = pl->xin; u.mu = pl->cin; u.pred = pl->pred;
     const int64_t ps = pl->pred_stride;
     u.sb = (int64_t)pl->Hp * pl->Wp * ps; u.sc = 1; u.sy = (int64_t)pl->Wp * ps; u.sx = ps;
-    u.st = e->step; u.ctl = e->ctl;
+    u.st = pl->own_step ? pl->own_step : e->step; u.ctl = e->ctl;
     u.B = pl->B; u.C = e->cfg.in_nc; u.H = pl->H; u.W = pl->W;
     u.batch0 = pl->b0;
     return u;
@@ -48,11 +48,13 @@ void one_step(irsde_engine* e, Plan* pl, hipStream_t s) {
     launch_sde_update(make_update(e, pl), s);
 }
 
-// r05: one sampler step of a batch split into concurrent sub-batches (plans sp[0 .. n), images [b0, b0 + B / n) each): the per-step state (step index,
-// FiLM row, coefficient row) is popped once, then part 0 runs on the engine stream and part i > 0 on sub_stream[i - 1] between ev_fork and ev_join[i - 1].
-// Captured, the event record / wait pairs become the fork and join edges of ONE graph; eager, they are real cross-stream dependencies.  Nothing in a
-// part depends on another part (no cross-batch op in the score network), so the result is the un-split one up to the tilings the smaller
-// plans choose.
+// r05: a batch split into concurrent sub-batches (plans sp[0 .. n), images [b0, b0 + B / n) each).  Every part is a complete, independent sampler: its
+// own step counter / coefficient row / FiLM row (Plan::own_step, own_film), its own captured step graph, its own stream (part 0: the engine stream,
+// part i > 0: sub_stream[i - 1]) — the parts fork once behind the call's inputs (ev_fork) and join once in front of its outputs (ev_join); there is
+// no per-step dependency between them, so the hardware queues overlap one part's per-image latency-bound kernels (naf_chain_kernel: one CU per image)
+// with the other parts' bandwidth-bound ones.  (First version: fork / join INSIDE one captured step graph — the branches of a hipGraph replay did not
+// overlap on ROCm 7.2: 156.9 -> 161.6 images/s on BASELINE configs[4], gpurun_out r05c.)  Nothing in a part depends on another part (no cross-batch op
+// in the score network): the result is the un-split one up to the tilings the smaller plans choose.
 void ensure_sub_streams(irsde_engine* e, int n) {
     if (!e->ev_fork) IRSDE_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     for (int i = 0; i + 1 < n; ++i) {
@@ -60,19 +62,10 @@ void ensure_sub_streams(irsde_engine* e, int n) {
         if (!e->ev_join[i]) IRSDE_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
     }
 }
-void one_step_split(irsde_engine* e, const std::vector<Plan*>& sp, hipStream_t s) {
-    launch_step_begin(e->step, e->film_table, e->film_row, e->film_cur, e->coef_table, s);
-    IRSDE_HIP_CHECK(hipEventRecord(e->ev_fork, s));
-    for (size_t i = 1; i < sp.size(); ++i) {
-        hipStream_t t = e->sub_stream[i - 1];
-        IRSDE_HIP_CHECK(hipStreamWaitEvent(t, e->ev_fork, 0));
-        run_net(sp[i], t);
-        launch_sde_update(make_update(e, sp[i]), t);
-        IRSDE_HIP_CHECK(hipEventRecord(e->ev_join[i - 1], t));
-    }
-    run_net(sp[0], s);
-    launch_sde_update(make_update(e, sp[0]), s);
-    for (size_t i = 1; i < sp.size(); ++i) IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_join[i - 1], 0));
+void one_step_part(irsde_engine* e, Plan* pl, hipStream_t s) {
+    launch_step_begin(pl->own_step, e->film_table, e->film_row, pl->own_film, e->coef_table, s);
+    run_net(pl, s);
+    launch_sde_update(make_update(e, pl), s);
 }
 
 // irsde_debug_conv / irsde_bench_conv only: selects a kernel variant for the launches of ONE call and always returns to
@@ -343,32 +336,44 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
             ensure_sub_streams(e, nsub);
             IRSDE_HIP_CHECK(hipEventRecord(e->ev_in, user));
             IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_in, 0));
+            launch_set_ctl(e->ctl, mode, noise, (long long)img, seed, image_offset, s);   // call-level arguments, shared by the parts (read-only during the call)
+            IRSDE_HIP_CHECK(hipEventRecord(e->ev_fork, s));
             for (int i = 0; i < nsub; ++i) {
-                IRSDE_HIP_CHECK(hipMemcpyAsync(sp[i]->xin, xT + i * simg, simg * 4, hipMemcpyDeviceToDevice, s));
-                if (mu) IRSDE_HIP_CHECK(hipMemcpyAsync(sp[i]->cin, mu + i * simg, simg * 4, hipMemcpyDeviceToDevice, s));
-            }
-            launch_set_ctl(e->ctl, mode, noise, (long long)img, seed, image_offset, s);
-            launch_set_step(e->step, T, s);
-            if (graph) {
-                Plan* holder = sp[0];   // the step graph of the split batch lives (and dies) with part 0
-                if (!holder->graph_exec) {
-                    IRSDE_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                hipStream_t t = i == 0 ? s : e->sub_stream[i - 1];
+                Plan* pl = sp[i];
+                if (i > 0) IRSDE_HIP_CHECK(hipStreamWaitEvent(t, e->ev_fork, 0));
+                IRSDE_HIP_CHECK(hipMemcpyAsync(pl->xin, xT + i * simg, simg * 4, hipMemcpyDeviceToDevice, t));
+                if (mu) IRSDE_HIP_CHECK(hipMemcpyAsync(pl->cin, mu + i * simg, simg * 4, hipMemcpyDeviceToDevice, t));
+                launch_set_step(pl->own_step, T, t);
+                if (graph && !pl->graph_exec) {
+                    IRSDE_HIP_CHECK(hipStreamBeginCapture(t, hipStreamCaptureModeThreadLocal));
                     try {
-                        one_step_split(e, sp, s);
+                        one_step_part(e, pl, t);
                     } catch (...) {
                         hipGraph_t g = nullptr;
-                        (void)hipStreamEndCapture(s, &g);
+                        (void)hipStreamEndCapture(t, &g);
                         if (g) (void)hipGraphDestroy(g);
                         throw;
                     }
-                    IRSDE_HIP_CHECK(hipStreamEndCapture(s, &holder->graph));
-                    IRSDE_HIP_CHECK(hipGraphInstantiate(&holder->graph_exec, holder->graph, nullptr, nullptr, 0));
+                    IRSDE_HIP_CHECK(hipStreamEndCapture(t, &pl->graph));
+                    IRSDE_HIP_CHECK(hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0));
                 }
-                for (int i = 0; i < nsteps; ++i) IRSDE_HIP_CHECK(hipGraphLaunch(holder->graph_exec, s));
-            } else {
-                for (int i = 0; i < nsteps; ++i) one_step_split(e, sp, s);
             }
-            for (int i = 0; i < nsub; ++i) IRSDE_HIP_CHECK(hipMemcpyAsync(out + i * simg, sp[i]->xin, simg * 4, hipMemcpyDeviceToDevice, s));
+            // step-major launch order: the host feeds every part's queue in turn (a part-major order would enqueue T steps of part 0 before part 1 starts)
+            for (int k = 0; k < nsteps; ++k)
+                for (int i = 0; i < nsub; ++i) {
+                    hipStream_t t = i == 0 ? s : e->sub_stream[i - 1];
+                    if (graph) IRSDE_HIP_CHECK(hipGraphLaunch(sp[i]->graph_exec, t));
+                    else one_step_part(e, sp[i], t);
+                }
+            for (int i = 0; i < nsub; ++i) {
+                hipStream_t t = i == 0 ? s : e->sub_stream[i - 1];
+                IRSDE_HIP_CHECK(hipMemcpyAsync(out + i * simg, sp[i]->xin, simg * 4, hipMemcpyDeviceToDevice, t));
+                if (i > 0) {
+                    IRSDE_HIP_CHECK(hipEventRecord(e->ev_join[i - 1], t));
+                    IRSDE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_join[i - 1], 0));
+                }
+            }
             IRSDE_HIP_CHECK(hipEventRecord(e->ev_out, s));
             IRSDE_HIP_CHECK(hipStreamWaitEvent(user, e->ev_out, 0));
             return;

@@ -16,7 +16,7 @@ struct Builder {
     bool naive;
     int film_bstride;
     int b0 = 0;   // first image of this plan within the call's batch (sub-batch plans): base of the per-image tables
-    const float* film_base() const { return e->film_cur + (size_t)b0 * film_bstride; }
+    const float* film_base() const { return pl->own_film ? pl->own_film : e->film_cur + (size_t)b0 * film_bstride; }
     const float* cam_base() const { return e->cam_cur + (size_t)b0 * e->cam_row; }
     const float* fused_ln_g = nullptr;  // set around a conv() call: LayerNorm gain applied in that conv's epilogue
 
@@ -598,12 +598,13 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
 static int g_force_subbatches = 0;   // irsde_debug_force_subbatches (test / measurement hook): 0 = the heuristic below
 void set_force_subbatches(int n) { g_force_subbatches = n; }
 int naf_subbatches(const irsde_engine* e, int B, int H, int W) {
-    if (e->arch != 1 || (e->cfg.flags & (IRSDE_FLAG_NAIVE_CONV | IRSDE_FLAG_KEEP_ACTIVATIONS))) return 1;
+    if (e->arch == 2 || (e->cfg.flags & (IRSDE_FLAG_NAIVE_CONV | IRSDE_FLAG_KEEP_ACTIVATIONS))) return 1;
     int n = g_force_subbatches;
     if (n <= 0) {
-        static const int env = tuning_env_int("IRSDE_NAF_SUBBATCHES", 0);
+        static const int env = tuning_env_int("IRSDE_SUBBATCHES", 0);
         n = env;
     }
+    if (n <= 0 && e->arch != 1) n = 1;   // (the UNets split only when forced: measurement hook for the small strong-scaling shards)
     if (n <= 0) {
         bool chain = false;
         const int nlev = (int)e->naf_enc.size(), ps = 1 << nlev;
@@ -629,7 +630,7 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film, int s
         for (size_t i = 1; i < e->plans.size(); ++i)
             if (e->plans[i]->last_use < e->plans[lru]->last_use) lru = i;
         IRSDE_HIP_CHECK(hipDeviceSynchronize());
-        // the parts of a split batch share ONE captured graph (held by part 0): they leave together
+        // the parts of a split batch are used together: they leave together
         const int vb = e->plans[lru]->B, vh = e->plans[lru]->H, vw = e->plans[lru]->W;
         const bool split = e->plans[lru]->slot > 0;
         for (size_t i = e->plans.size(); i-- > 0;)
@@ -656,6 +657,12 @@ Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film, int s
     // F.pad 'reflect' needs pad < dim (DenoisingUNet_arch.py:82)
     if (e->arch != 1 && (pl->Hp - H >= H || pl->Wp - W >= W)) throw HipError("image too small for reflect padding");
 
+    if (slot > 0) {
+        if (per_sample_film) throw HipError("internal: sub-batch plans are sampler plans (one time step for the whole part)");
+        pl->own_film = pl->alloc((size_t)e->film_row + 64, false);
+        pl->own_step = reinterpret_cast<StepState*>(pl->alloc(sizeof(StepState) / 4 + 4, false));
+        IRSDE_HIP_CHECK(hipMemset(pl->own_step, 0, sizeof(StepState)));
+    }
     const size_t img = (size_t)B * in_nc * H * W;
     pl->xin = pl->alloc(img, false);
     pl->cin = pl->alloc(img, false);

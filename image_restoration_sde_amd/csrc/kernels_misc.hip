@@ -485,14 +485,19 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
         }
         // accumulator register r of row tile rt: pixel t0 + 32 rt + (r&3) + 8 (r>>2) + 4h, column d (k) / e (v) = l31
         float mit = -INFINITY;
+        if (t0 + kKvTile > n1) {   // (uniform) only the last tile of a chunk has pixels to mask: 128 compares + 256 selects per lane otherwise
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = t0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (n >= n1) { ak[rt][r] = -INFINITY; av[rt][r] = 0.f; }
+                }
+        }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = t0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (n >= n1) { ak[rt][r] = -INFINITY; av[rt][r] = 0.f; }
-                mit = fmaxf(mit, ak[rt][r]);
-            }
+            for (int r = 0; r < 16; ++r) mit = fmaxf(mit, ak[rt][r]);
         mit = half_max(mit);
         if (__any(mit > mrun)) {  // wave-uniform; the tile's first pixel exists, so mnew is finite
             const float mnew = fmaxf(mrun, mit);

@@ -64,6 +64,26 @@ struct NafChainArgs {
     unsigned long long* dbg;   // STAMP twin only
 };
 
+// Cross-lane sums on the vector pipe (r05; kernels_misc.hip has the same helpers and the story of why the swaps are inline assembly): the LayerNorm
+// partials are summed over the four lane quarters q = lane >> 4 (xor 16, xor 32), the SCA pool over the 16 pixel lanes n = lane & 15 of a quarter
+// (DPP quad permutes + row mirrors) — instead of __shfl_xor's ds_bpermute round trips through the LDS the GEMM passes need.
+struct NcSwap { float a, b; };
+__device__ __forceinline__ float nc_sum_quarters(float v) {
+    NcSwap r{v, v};
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r.a), "+v"(r.b));
+    v = r.a + r.b;
+    NcSwap t{v, v};
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t.a), "+v"(t.b));
+    return t.a + t.b;
+}
+__device__ __forceinline__ float nc_sum_row16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
 __device__ __forceinline__ nc_h4 cvt4(const nc_f4 v) {
     nc_h4 h;
     h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
@@ -224,9 +244,7 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             float t = 0.f;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) { const nc_f4 v = X(ct, pt); t += (v[0] + v[1]) + (v[2] + v[3]); }
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);
-            s[pt] = t;
+            s[pt] = nc_sum_quarters(t);
         }
         if (q == 0) {
 #pragma unroll
@@ -244,9 +262,7 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 const nc_f4 d = X(ct, pt) - mean[pt];
                 t += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);
-            s[pt] = t;
+            s[pt] = nc_sum_quarters(t);
         }
         if (q == 0) {
 #pragma unroll
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
         for (int pt = 0; pt < 4; ++pt) {
             const nc_f4 r0 = *reinterpret_cast<const nc_f4*>(red2 + (16 * pt + n) * 8), r1 = *reinterpret_cast<const nc_f4*>(red2 + (16 * pt + n) * 8 + 4);
             const float var = (((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3]))) * (1.0f / NC_C);
-            rstd[pt] = 1.0f / sqrtf(var + 1e-5f);
+            rstd[pt] = __builtin_amdgcn_rsqf(var + 1e-5f);   // v_rsq_f32 (1 ulp)
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
@@ -347,11 +363,7 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 }
             }
             // SCA pool (AdaptiveAvgPool2d(1)): the lane's 4 pixels are in cs; sum the 16 pixel lanes of the channel group
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-                cs[0] += __shfl_xor(cs[0], m, 64); cs[1] += __shfl_xor(cs[1], m, 64);
-                cs[2] += __shfl_xor(cs[2], m, 64); cs[3] += __shfl_xor(cs[3], m, 64);
-            }
+            cs[0] = nc_sum_row16(cs[0]); cs[1] = nc_sum_row16(cs[1]); cs[2] = nc_sum_row16(cs[2]); cs[3] = nc_sum_row16(cs[3]);
             if (n == 0) *reinterpret_cast<nc_h4*>(lds + NC_OFF_MEAN + (64 * wave + 16 * ps + 4 * q) * 2) = cvt4(cs * (1.0f / NC_PX));
             NC_STAMP(2)
         }

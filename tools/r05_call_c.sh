@@ -15,8 +15,8 @@ for L in base new; do
 done
 IRSDE_LIB_PATH=$REPO/image_restoration_sde_amd/libirsde_hip_base.so timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-profile --steps 3 --warmup 1 --model latent --dtype fp16 --batch 64 > "$OUT/lat64_base.json" 2> "$OUT/lat64_base.err"
 for N in 1 2 4; do
-  IRSDE_TUNING=1 IRSDE_NAF_SUBBATCHES=$N timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-profile --steps 3 --warmup 1 --model latent --dtype fp16 --batch 64 > "$OUT/lat64_sub$N.json" 2> "$OUT/lat64_sub$N.err"
-  IRSDE_TUNING=1 IRSDE_NAF_SUBBATCHES=$N timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-profile --steps 3 --warmup 1 --model latent --dtype fp16 --batch 32 > "$OUT/lat32_sub$N.json" 2> "$OUT/lat32_sub$N.err"
+  IRSDE_TUNING=1 IRSDE_SUBBATCHES=$N timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-profile --steps 3 --warmup 1 --model latent --dtype fp16 --batch 64 > "$OUT/lat64_sub$N.json" 2> "$OUT/lat64_sub$N.err"
+  IRSDE_TUNING=1 IRSDE_SUBBATCHES=$N timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-profile --steps 3 --warmup 1 --model latent --dtype fp16 --batch 32 > "$OUT/lat32_sub$N.json" 2> "$OUT/lat32_sub$N.err"
 done
-IRSDE_TUNING=1 IRSDE_NAF_SUBBATCHES=2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-profile --steps 3 --warmup 1 --model latent --dtype fp16 --batch 8 > "$OUT/lat8_sub2.json" 2> "$OUT/lat8_sub2.err"
+IRSDE_TUNING=1 IRSDE_SUBBATCHES=2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-profile --steps 3 --warmup 1 --model latent --dtype fp16 --batch 8 > "$OUT/lat8_sub2.json" 2> "$OUT/lat8_sub2.err"
 grep -o '"value": *[0-9.]*' "$OUT"/*.json
