@@ -594,7 +594,7 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
 // Sub-batches of a NAFNet sampler step (engine_api.hip: sample_split).  Why: on small latents most of a NAFNet evaluation is per-image latency, not
 // throughput — naf_chain_kernel keeps ONE CU per image busy for ~45 % of the step (64 of 256 CUs at BASELINE configs[4]'s batch of 64) while the other
 // levels' kernels are bandwidth-bound on all CUs: independent sub-batches on concurrent streams let one part's chain run under the other parts' levels.
-// Only where a level actually runs as a chain, and never below 16 images per part (smaller parts are launch-latency-bound themselves).
+// Only where a level actually runs as a chain, and only as two parts of >= 32 images (measured: smaller or more parts lose what the overlap wins).
 static int g_force_subbatches = 0;   // irsde_debug_force_subbatches (test / measurement hook): 0 = the heuristic below
 void set_force_subbatches(int n) { g_force_subbatches = n; }
 int naf_subbatches(const irsde_engine* e, int B, int H, int W) {
@@ -612,7 +612,7 @@ int naf_subbatches(const irsde_engine* e, int B, int H, int W) {
         if ((e->cfg.flags & IRSDE_FLAG_FP16) && !(e->cfg.flags & IRSDE_FLAG_NO_NAF_CHAIN))
             for (int i = 0; i < nlev; ++i)
                 if (e->naf_chain_enc[i].nblocks > 0 && naf_chain_shape_ok(Hp >> i, Wp >> i, e->naf_intro.Cout << i)) chain = true;
-        n = !chain ? 1 : B >= 64 ? 4 : B >= 32 ? 2 : 1;
+        n = chain && B >= 64 ? 2 : 1;   // measured (profiles/r05_notes.md section 4): 64 images as 2 x 32: +3 %; 4 parts, or parts of < 32 images: a loss
     }
     n = std::min(n, (int)irsde_engine::kMaxSub);
     while (n > 1 && B % n) --n;

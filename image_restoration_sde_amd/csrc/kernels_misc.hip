@@ -684,25 +684,30 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
     // ---- A: stage the xn tile (rows past N repeat the last pixel; their results are never stored)
     constexpr int C4 = C / 4;
     const bool full_tile = t0 + TP <= N;   // uniform; a full tile is one contiguous run of 128 * C floats (r05: no per-piece index arithmetic)
+    // r05: wave w stages ITS OWN 32-row slab of the tile (pieces i = lane + 64 j of the slab: the same pieces it adds back and stores in phase G), so when
+    // the residual IS the staged tensor (xres == xn: the PreNorm-fused plan) the raw pieces stay in registers across the block (C <= 128: 32 / 64
+    // registers of the 256 a wave has) and phase G neither re-reads the tile nor waits for it
+    constexpr int NQ = 32 * C4 / 64;
+    constexpr bool KEEP = !PAIR && C <= 128;
+    floatx4 xkeep[KEEP ? NQ : 1];
+    const bool keep_res = KEEP && full_tile && xres == xn;
     auto stage_tile = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const float* tile = xn + (img + t0) * C;
+        const float* slab_in = xn + (img + t0 + wave * 32) * C;
         // 8 loads in flight before the first LDS write of a pass (a rolled loop waits for every load in turn)
-        constexpr int NP = TP * C4 / 256;
 #pragma unroll
-        for (int j0 = 0; j0 < NP; j0 += 8) {
+        for (int j0 = 0; j0 < NQ; j0 += 8) {
             floatx4 st[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = tid + 256 * (j0 + j), row = tid / C4 + (256 / C4) * (j0 + j), c4 = tid % C4;   // (C4 divides 256; tid < 256)
-                (void)i;
-                if constexpr (FULL) st[j] = *reinterpret_cast<const floatx4*>(tile + 4 * i);
+                const int i = lane + 64 * (j0 + j), row = wave * 32 + lane / C4 + (64 / C4) * (j0 + j), c4 = lane % C4;   // (C4 divides 64)
+                if constexpr (FULL) st[j] = *reinterpret_cast<const floatx4*>(slab_in + 4 * i);
                 else st[j] = *reinterpret_cast<const floatx4*>(xn + (img + min(t0 + row, N - 1)) * C + 4 * c4);
+                if constexpr (FULL && KEEP) xkeep[j0 + j] = st[j];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = tid + 256 * (j0 + j), row = tid / C4 + (256 / C4) * (j0 + j), c4 = tid % C4;   // (C4 divides 256; tid < 256)
-                (void)i;
+                const int row = wave * 32 + lane / C4 + (64 / C4) * (j0 + j), c4 = lane % C4;
                 // ln_g != nullptr: xn == the block's x and PreNorm's LayerNorm runs here on the staged pieces
                 if (ln_g) st[j] = ln_piece<C4>(st[j], *reinterpret_cast<const floatx4*>(ln_g + 4 * c4), eps);
                 if constexpr (PAIR) {
@@ -936,14 +941,18 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     auto residual_store = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        constexpr int NQ = 32 * C4 / 64;
         const size_t slab = (img + t0 + wave * 32) * C;   // the wave's 32 rows are contiguous: element 4 i of the slab is piece i
         floatx4 xr[NQ];
+        if (FULL && KEEP && keep_res) {
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) {  // residual loads first, all in flight
-            const int i = lane + 64 * j, row = lane / C4 + (64 / C4) * j, c4 = lane % C4;   // (C4 divides 64)
-            if constexpr (FULL) xr[j] = *reinterpret_cast<const floatx4*>(xres + slab + 4 * i);
-            else xr[j] = *reinterpret_cast<const floatx4*>(xres + (img + min(t0 + wave * 32 + row, N - 1)) * C + 4 * c4);
+            for (int j = 0; j < NQ; ++j) xr[j] = xkeep[KEEP ? j : 0];   // the pieces staged in phase A
+        } else {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {  // residual loads first, all in flight
+                const int i = lane + 64 * j, row = lane / C4 + (64 / C4) * j, c4 = lane % C4;   // (C4 divides 64)
+                if constexpr (FULL) xr[j] = *reinterpret_cast<const floatx4*>(xres + slab + 4 * i);
+                else xr[j] = *reinterpret_cast<const floatx4*>(xres + (img + min(t0 + wave * 32 + row, N - 1)) * C + 4 * c4);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {

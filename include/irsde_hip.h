@@ -22,8 +22,8 @@
  *   103  IRSDE_FLAG_NO_NAF_CHAIN (the fused NAFBlock chain of the fp16 ConditionalNAFNet on 8 x 8 feature maps is on by default).
  *   104  irsde_latent_encode / irsde_latent_decode accept hidden == NULL (the skips stay resident in the engine between the two calls: no
  *        NCHW round trip of 4.8 GB per 64 images); irsde_latent_hidden exports one resident skip.
- *   105  irsde_sample on a ConditionalNAFNet whose plan contains the per-image NAFBlock chain (fp16 mode, 8 x 8 level) runs batches of >= 32 images as
- *        2 (>= 64: 4) concurrent sub-batches, each with its own step graph on its own stream (same results up to the tilings the smaller plans choose; noise / Philox
+ *   105  irsde_sample on a ConditionalNAFNet whose plan contains the per-image NAFBlock chain (fp16 mode, 8 x 8 level) runs batches of >= 64 images as
+ *        2 concurrent sub-batches, each with its own step graph on its own stream (same results up to the tilings the smaller plans choose; noise / Philox
  *        streams stay keyed by the call-level image index).  Debug header: irsde_debug_force_subbatches.  The measurement kernels (stamp / ablation /
  *        superseded twins) moved to the PROBES build (libirsde_hip_probes.so): the product library refuses their selectors.
  */
