@@ -18,6 +18,9 @@ with a hipEvent pair around every kernel on the engine's stream) to fill `roofli
 `mfma_kernel_frac` is the same over the MFMA kernels alone; the direct-convolution-equivalent rate (which exceeds the
 fp32 peak because Winograd skips multiplies) is reported as `algorithmic_equiv_TFLOPs`, never as a fraction.
 `roofline.dominant_kernel` names the kernel class with the largest share of that pass and its own fraction of the roof.
+`roofline.traffic` (r05): HBM bytes per conv launch MEASURED in the default 1-GPU run — after the timed region the script spawns two bounded rocprofv3
+counter passes of itself (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, T = 3; `live_traffic()`); without rocprofv3 (or with `--no-live-pmc` / `--no-secondary`)
+it falls back to the committed summary of the builder's passes; `traffic_source` says which.
 `cpu_baseline`: the torch-CPU port of the reference timed on this box's host cores on a bounded sample.
 
 `--scaling strong` splits ONE global batch of --batch images over the ranks (north_star: "image batches shard across the 8
@@ -228,6 +231,53 @@ def roofline_object(prof, op_text, w):
     return {k: _r(v) for k, v in r.items()}
 
 
+def live_traffic(timeout_s=150):
+    """HBM bytes per conv launch of the headline workload, MEASURED in this run: two rocprofv3 counter passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`:
+    separate runs, as guides/MI355X_MICROARCH.md prescribes; `--kernel-trace` only, no other trace domain) of THIS file on the production plan
+    (`--steps 1 --warmup 0 --T 3`), summarised like tools/pmc_summary.py: raw unit KiB, read bytes = 2 x FETCH_SIZE on gfx950, conv + Winograd-transform
+    kernels / conv launches.  Each pass is a bounded subprocess; any failure (no rocprofv3, timeout, unexpected CSV) returns None and the caller
+    falls back to the committed summary."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or os.environ.get("IRSDE_BENCH_NO_LIVE_PMC") == "1":
+        return None
+    tmp = tempfile.mkdtemp(prefix="irsde_pmc_", dir="/tmp")
+    conv_names = ("conv_igemm", "gemm_zloop", "conv3x3_halo", "wino4_fused", "conv3x3_narrow", "gemm_split")
+    try:
+        kib, launches = {}, 0
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--T", "3", "--no-profile", "--no-cpu-baseline",
+                   "--no-secondary", "--no-live-pmc"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout_s, check=True)
+            files = glob.glob(os.path.join(tmp, ctr, "**", "*counter_collection.csv"), recursive=True)
+            conv, wino, n = 0.0, 0.0, 0
+            for r in csv.DictReader(open(files[0])):
+                if r.get("Counter_Name", ctr) != ctr:
+                    continue
+                name = r["Kernel_Name"]
+                if any(k in name for k in conv_names):
+                    conv += float(r["Counter_Value"])
+                    n += 1
+                elif "wino_" in name:
+                    wino += float(r["Counter_Value"])
+            kib[ctr] = (conv, wino)
+            launches = n
+        if launches <= 0:
+            return None
+        conv_b = (2 * kib["FETCH_SIZE"][0] + kib["WRITE_SIZE"][0]) * 1024
+        wino_b = (2 * kib["FETCH_SIZE"][1] + kib["WRITE_SIZE"][1]) * 1024
+        return {"traffic": (conv_b + wino_b) / launches, "conv_only": conv_b / launches, "launches": launches}
+    except Exception:  # noqa: BLE001 - measurement extra: never lose the headline over it
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 DTYPE_LABEL = {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate+state",
                "bf16_act": "bf16 operands + bf16 activation storage / f32 accumulate+state",
                "fp16": "f16 operands / f32 accumulate+state",
@@ -429,6 +479,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the untimed event-instrumented pass (no `roofline` object)")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the two rocprofv3 counter passes that measure `roofline.traffic` (default N=1 run only)")
     a = ap.parse_args()
 
     if a.gpus < 1:
@@ -530,8 +581,13 @@ def main():
             # HBM bytes per conv launch: rocprofv3 PMC passes cannot run inside this process; the figure comes from the
             # builder's PMC run of this same command, committed under profiles/ (source named next to it)
             traffic, traffic_src = None, None
+            live = live_traffic() if (is_default and world == 1 and not a.no_live_pmc and not a.no_secondary) else None   # (the full default run only: tools/ run this file UNDER rocprofv3 with --no-secondary)
+            if live:
+                traffic = live["traffic"]
+                traffic_src = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate subprocess passes of "
+                               "bench.py --steps 1 --warmup 0 --T 3), %d conv launches, conv kernels alone %.0f bytes per launch" % (live["launches"], live["conv_only"]))
             try:
-                if is_default:
+                if is_default and traffic is None:
                     import re as _re   # the headline workload's file only: r<NN>_final_bench_pmc_hbm.json (not the latent / NAFNet / split-mode ones)
                     pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if _re.fullmatch(r"r\d+_final_bench_pmc_hbm\.json", f))
                     traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_bytes_per_launch"]

@@ -811,6 +811,11 @@ int irsde_debug_force_subbatches(int n) {
 int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out) {
     return guard([&] {
         if (!ms_out || nblocks < 1 || nblocks > 64 || B < 1 || iters < 1) throw HipError("bench_naf_chain: bad argument");
+#ifdef IRSDE_PROBES
+        if (variant != 0 && variant != 1 && variant != 2 && variant != 11) throw HipError("bench_naf_chain: bad variant");
+#else
+        if (variant != 0 && variant != 1) throw HipError("bench_naf_chain: variants 2 / 11 are measurement twins (make PROBES=1)");   // (before anything is allocated)
+#endif
         conv_global_init();
         hipStream_t s;
         IRSDE_HIP_CHECK(hipStreamCreate(&s));

@@ -107,8 +107,11 @@ enum {
     IRSDE_FLAG_NO_NAF_CHAIN = 8192,  /* r04: keep every NAFBlock on the per-layer path.  Default with IRSDE_FLAG_FP16: a run of consecutive 512-channel
                                         NAFBlocks on an 8 x 8 feature map (the 28-block level of BASELINE configs[4]'s 64 x 64 latents) runs as ONE
                                         launch, one work-group per image, activations in registers + LDS, fp16 weights streamed from L2
-                                        (csrc/naf_chain.hip).  Same operand mode; the conv1 output additionally passes through fp16 before the
-                                        depthwise conv and the SCA 1x1 conv runs with fp16 operands */
+                                        (csrc/naf_chain.hip).  Same operand mode, and these additional roundings to fp16 (all at operand level;
+                                        chain vs per-layer path 2e-4, chain vs oracle.naf_block per block <= 1e-3, tests/test_gpu_parity.py): the conv1
+                                        output before the depthwise conv, the depthwise taps, the pooled SCA mean, the SCA 1x1 conv's operands and
+                                        its output (the scale vector), and the product x * sca(x) — formed in fp16 from the fp16 gated tensor on its
+                                        way into conv3, i.e. that operand is rounded twice */
     IRSDE_FLAG_NO_WINOGRAD_F43 = 8   /* Winograd F(2x2,3x3) only (>= 256 channels); default also uses F(4x4,3x3) from 128
                                         channels up where H, W are multiples of 4 */
 };
