@@ -30,13 +30,33 @@ def family(name):
     return next((f for f in FAMILIES if f in name), None)
 
 
+OUTSIDE = {}   # counter -> [launches, KiB] of the irsde kernels OUTSIDE the sampler steps (latent encode / decode, layout kernels): reported apart
+
+
 def load(path):
-    """-> ({group: [launches, KiB]}, [(family, grid size, KiB) of every irsde kernel launch, in dispatch order])"""
+    """-> ({group: [launches, KiB]}, [(family, grid size, KiB) of every irsde kernel launch, in dispatch order]).
+    r05: only launches INSIDE a sampler step count (from a step_begin_kernel through the sde_update_kernel that ends the step) — the latent pipeline's
+    encode / decode run once per call and used to be amortised over the evaluations; they are summed into OUTSIDE instead.
+    The number of evaluations is the number of step_begin launches found (EVALS_FOUND)."""
+    global EVALS_FOUND
     agg, seq = OrderedDict(), []
     rows = list(csv.DictReader(open(path)))
     if rows and "Dispatch_Id" in rows[0]:
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    has_steps = any("step_begin_kernel" in r["Kernel_Name"] for r in rows)
+    in_step, nsteps, out = False, 0, [0, 0.0]
     for r in rows:
+        name = r["Kernel_Name"]
+        if has_steps:
+            if "step_begin_kernel" in name:
+                in_step, nsteps = True, nsteps + 1
+            if not in_step:
+                if "irsde" in name:
+                    out[0] += 1
+                    out[1] += float(r["Counter_Value"])
+                continue
+            if "sde_update_kernel" in name:
+                in_step = False   # (this row still belongs to the step)
         g = group(r["Kernel_Name"])
         a = agg.setdefault(g, [0, 0.0])
         a[0] += 1
@@ -44,14 +64,22 @@ def load(path):
         f = family(r["Kernel_Name"])
         if f:
             seq.append((f, r.get("Grid_Size", "?"), float(r["Counter_Value"])))
+    OUTSIDE[path] = out
+    if has_steps:
+        EVALS_FOUND = nsteps
     return agg, seq
 
 
+EVALS_FOUND = 0
+
+
 (fetch, fseq), (write, wseq) = load(sys.argv[1]), load(sys.argv[2])
-evals = int(sys.argv[3])
+evals = EVALS_FOUND or int(sys.argv[3])
 out = sys.argv[4]
+workload = sys.argv[5] if len(sys.argv) > 5 else "B=16 256x256 nf=64 depth=4, production plan"
 lines = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv), production plan:",
-         "#   python bench.py --steps 1 --warmup 0 --T %d --no-cpu-baseline --no-profile   (%d network evaluations, B=16 256x256)" % (evals, evals),
+         "#   bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-profile [workload arguments]   (%d network evaluations counted; workload: %s)" % (evals, workload),
+         "# only launches inside sampler steps (step_begin .. sde_update) are counted per evaluation; kernels outside them: see the last lines",
          "# (the first evaluation of a fresh engine also uploads / packs nothing in the timed kernels; graph replay launches the same kernels)",
          "# raw counter unit = KiB; gfx950 correction (guides/MI355X_MICROARCH.md, HBM section): read bytes = 2 x FETCH_SIZE.", ""]
 for title, agg in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
@@ -87,10 +115,14 @@ if len(fseq) == len(wseq) and all(a[0] == b[0] for a, b in zip(fseq, wseq)):
         lines.append("%4d %-22s %12s %12.1f %12.1f" % (i, f, grid, 2 * fk * 1024 / 1e6, wk_ * 1024 / 1e6))
 else:
     lines += ["", "(per-launch table skipped: the two passes did not record the same launch sequence)"]
+fo, wo = OUTSIDE.get(sys.argv[1], [0, 0.0]), OUTSIDE.get(sys.argv[2], [0, 0.0])
+if fo[0]:
+    lines += ["", "outside the sampler steps (once per call: latent encode / decode, layout and harness kernels): %d launches, %.2f GB corrected (2 x FETCH + WRITE)"
+              % (fo[0], (2 * fo[1] + wo[1]) * 1024 / 1e9)]
 open(out + ".txt", "w").write("\n".join(lines) + "\n")
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_summary.py, see %s.txt" % out.split("/")[-1],
            "kernel": "convolution kernels (conv_igemm + gemm_zloop + wino4_fused) + wino transforms",
-           "workload": "B=16 256x256 nf=64 depth=4, production plan",
+           "workload": workload,
            "traffic_bytes_per_launch": (conv_bytes + wino_bytes) / conv_launches,
            "conv_traffic_bytes_per_launch": conv_bytes / conv_launches,
            "bytes_per_evaluation": total / evals}, open(out + ".json", "w"), indent=1)

@@ -19,7 +19,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 F=$(find "$OUT/pmc_FETCH_SIZE" -name "*counter_collection.csv" | head -1)
 W=$(find "$OUT/pmc_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
-[ -n "$F" ] && [ -n "$W" ] && python "$REPO/tools/pmc_summary.py" "$F" "$W" 5 "$OUT/bench_pmc_hbm" > /dev/null 2> "$OUT/pmc_summary.err"
+[ -n "$F" ] && [ -n "$W" ] && python "$REPO/tools/pmc_summary.py" "$F" "$W" 5 "$OUT/bench_pmc_hbm" "bench.py default workload + ($*)" > /dev/null 2> "$OUT/pmc_summary.err"
 # 3. MFMA-pipe busy fraction per kernel
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o pmc -- $BENCH --steps 1 --warmup 0 --T 3 --no-profile > /dev/null 2> "$OUT/pmc_mfma.err"
 M=$(find "$OUT/pmc_mfma" -name "*counter_collection.csv" | head -1)
