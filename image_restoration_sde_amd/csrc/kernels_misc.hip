@@ -361,14 +361,15 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
             // r05: a full tile is one contiguous run of 128 * C floats (NHWC): element 4 i of it is piece i — no per-piece row / column / clamp arithmetic
             constexpr bool FULL = decltype(full_tag)::value;
             const float* tile = xn + ((size_t)b * N + t0) * C;
-            // 4 loads in flight before the first LDS write of a pass (a rolled loop waits for every load in turn; more than 4
-            // do not fit next to the 144 accumulator registers)
+            // r05: 8 loads in flight before the first LDS write of a pass, passes unrolled (r02: a rolled loop of 4 — four exposed HBM round trips per
+            // tile; the 144 accumulator registers it was fitted next to are not live while the tile is staged: they are zeroed behind the barrier)
             constexpr int NP = kKvTile * c4n / 256;
-#pragma unroll 1
-            for (int j0 = 0; j0 < NP; j0 += 4) {
-                floatx4 st[4];
+            constexpr int NB = NP % 8 == 0 ? 8 : 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+            for (int j0 = 0; j0 < NP; j0 += NB) {
+                floatx4 st[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
                     int i = tid + 256 * (j0 + j), row, c4;
                     if constexpr (256 % c4n == 0) { row = tid / c4n + (256 / c4n) * (j0 + j); c4 = tid % c4n; }   // (no carry: tid < 256 — constants the compiler can fold into offsets)
                     else { row = i / c4n; c4 = i - row * c4n; }
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
                     else st[j] = *reinterpret_cast<const floatx4*>(xn + ((size_t)b * N + min(t0 + row, n1 - 1)) * C + 4 * c4);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NB; ++j) {
                     int i = tid + 256 * (j0 + j), row, c4;
                     if constexpr (256 % c4n == 0) { row = tid / c4n + (256 / c4n) * (j0 + j); c4 = tid % c4n; }   // (no carry: tid < 256 — constants the compiler can fold into offsets)
                     else { row = i / c4n; c4 = i - row * c4n; }
