@@ -399,6 +399,29 @@ def test_unet_forward_512_vs_reference_golden_and_batch_plan(golden, prec):
     assert float(np.abs(sub3(yb[2:3]) - g["unet_1x512x512/t23_sub3"]).max() / np.abs(g["unet_1x512x512/t23_sub3"]).max()) < 1e-4
 
 
+def test_unet_batch16_512_sliced_fused_layers_vs_reference_golden(golden):
+    """r05: at 16 x 512 x 512 the 128-channel level-0 tensors pass 2 GiB — beyond the 32-bit buffer offsets of the fused Winograd kernels.  The plan
+    now launches those layers on 2 slices of the batch (engine_plan.hip: push_wino_fused) instead of falling back to the three-launch path: the plan
+    says so, image 11 of the batch equals the single-image evaluation, and image 3 (the golden's inputs) the REAL reference."""
+    g = golden.fullres2
+    m = unet64()
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 16, 512, 512, buf, len(buf)))
+    assert b"batch slices)" in buf.value, buf.value[-800:]
+    lq, xT = O.synth_inputs(79, 16, 512, 512)
+    lq1, xT1 = O.synth_inputs(1234, 1, 512, 512)
+    lq[3], xT[3] = lq1[0], xT1[0]
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    yb = m(x, c, 23).cpu().numpy()
+    assert np.isfinite(yb).all()
+    y1 = m(x[11:12], c[11:12], 23).cpu().numpy()
+    e = float(np.abs(y1 - yb[11:12]).max() / np.abs(yb).max())
+    ref = g["unet_1x512x512/t23_sub3"]
+    eg = float(np.abs(sub3(yb[3:4]) - ref).max() / np.abs(ref).max())
+    print("16 x 512 x 512 (sliced fused layers): image 11 vs single %.3g, image 3 vs reference %.3g" % (e, eg))
+    assert e < 5e-5 and eg < 1e-4
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_nafnet_batch8_512_equals_single_images(golden, prec):
     """BASELINE configs[3] plan: Refusion NAFNet at 8 x 512 x 512 vs eight single-image evaluations (deterministic pooled
