@@ -240,7 +240,9 @@ void launch_linear_attention(const float* qkv, float* out, int B, int N, const A
 // planes [2][256][C] of wkv * 2^k, w_inv_scale = 2^-k
 void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s,
                                  const float* ln_g = nullptr, float ln_eps = 1e-5f, const unsigned short* wkv_pair = nullptr,
-                                 float w_inv_scale = 1.f);
+                                 float w_inv_scale = 1.f, int op16 = 0, bool act_bf16 = false);
+// op16 (r05): 0 = f32 (or, with *_pair planes, the fp16 hi + lo pairs); 2 / 3 = ONE bf16 / fp16 operand plane in *_pair (IRSDE_FLAG_BF16 / _FP16:
+// [256][C] k | v rows, [128][C] q rows, [C][128] to_out rows, unscaled); act_bf16 (op16 == 2 only): xn / x / y are bf16 tensors (IRSDE_FLAG_BF16_ACT)
 void launch_attention_q_out(const float* q, float* out, int B, int N, const AttnWorkspace& ws, hipStream_t s);
 // C = 64 / 128 / 256: q projection, softmax over d, context product, to_out (+ bias), LayerNorm (* g2) and the residual in one
 // kernel: y = LayerNorm(Wout . (ctx^T softmax(Wq . xn)) + bias) * g2 + x.  wq = rows 0..127 of to_qkv.weight ([128][C]),
@@ -248,7 +250,7 @@ void launch_attention_q_out(const float* q, float* out, int B, int N, const Attn
 void launch_attention_q_out_fused(const float* xn, const float* x, const float* wq, const float* wout, const float* bias,
                                   const float* g2, float* y, int B, int N, int C, float eps, const AttnWorkspace& ws, hipStream_t s,
                                   const float* ln_g = nullptr, const unsigned short* wq_pair = nullptr, const unsigned short* wout_pair = nullptr,
-                                  float wq_inv = 1.f, float wout_inv = 1.f);   // *_pair: fp16 hi / lo planes (IRSDE_FLAG_SPLIT_F16X2), see kernels_misc.hip
+                                  float wq_inv = 1.f, float wout_inv = 1.f, int op16 = 0, bool act_bf16 = false);   // *_pair: fp16 hi / lo planes (IRSDE_FLAG_SPLIT_F16X2), see kernels_misc.hip
 
 // Full softmax attention over N tokens (denoising-sde bottleneck): qkv [B][N][384] -> out [B][N][128].
 void launch_full_attention(const float* qkv, float* out, int B, int N, hipStream_t s);

@@ -110,7 +110,7 @@ int guard(const std::function<void()>& f) {
 extern "C" {
 
 const char* irsde_last_error(void) { return g_last_error.c_str(); }
-int irsde_version(void) { return 105; }  // changelog: include/irsde_hip.h
+int irsde_version(void) { return 106; }  // changelog: include/irsde_hip.h
 
 int irsde_create(const irsde_config* cfg, irsde_engine** out) {
     return guard([&] {

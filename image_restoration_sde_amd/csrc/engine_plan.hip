@@ -391,6 +391,40 @@ struct Builder {
         const bool fused_kv = w.g2 && !naive && !x.bf16 && !(e->cfg.flags & (IRSDE_FLAG_BF16 | IRSDE_FLAG_NO_FUSED_ATTN)) &&
                               x.C % 32 == 0 && x.C <= 256;
         const bool fused_all = fused_kv && (x.C == 64 || x.C == 128 || x.C == 256) && !(e->cfg.flags & IRSDE_FLAG_NO_FUSED_LN);
+        // r05: the 16-bit operand modes (IRSDE_FLAG_BF16 [+ _ACT] / IRSDE_FLAG_FP16) take the same two fused kernels with ONE bf16 / fp16 plane per
+        // projection operand (fp32 LayerNorm, softmax, context, accumulation); with IRSDE_FLAG_BF16_ACT they read and write the bf16 tensors directly
+        const bool fused_16 = w.g2 && !naive && (e->cfg.flags & IRSDE_FLAG_BF16) && !(e->cfg.flags & (IRSDE_FLAG_NO_FUSED_ATTN | IRSDE_FLAG_NO_FUSED_LN)) &&
+                              (x.C == 64 || x.C == 128 || x.C == 256) && x.bf16 == act_bf16();
+        if (fused_16) {
+            AttnWorkspace ws;
+            ws.nch = attn_num_chunks(N, x.B);
+            ws.pmax = pl->alloc((size_t)x.B * ws.nch * 128, false);
+            ws.pctx = pl->alloc((size_t)x.B * 4 * ws.nch * 1024, false);
+            ws.psum = pl->alloc((size_t)x.B * 4 * ws.nch * 32, false);
+            ws.ctx = pl->alloc((size_t)x.B * 4 * 1024, false);
+            Tensor y = talloc(x.B, x.H, x.W, x.C);
+            if (y.bf16 != x.bf16) throw HipError("attention: mixed activation storage types");
+            const float *xp = x.p, *wqkv = w.qkv.w, *wo = w.out.w, *bo = w.out.bias, *g1 = w.g1, *g2 = w.g2;
+            float* yp = y.p;
+            const int B = x.B, C = x.C;
+            if (!bo) throw HipError("attention: to_out.0.bias missing");
+            const unsigned short* wqkv16 = e->bf16_copy(wqkv, (size_t)384 * C);   // bf16, or IEEE fp16 under IRSDE_FLAG_FP16 (rows: q | k | v)
+            const unsigned short* wo16 = e->bf16_copy(wo, (size_t)C * 128);
+            const unsigned short* wkv16 = wqkv16 + (size_t)128 * C;
+            const int op16 = (e->cfg.flags & IRSDE_FLAG_FP16) ? 3 : 2;
+            const bool abf = x.bf16;
+            const char* tag = op16 == 3 ? " (fp16 operands)" : abf ? " (bf16 operands + storage)" : " (bf16 operands)";
+            push_other(OP_ATTN, [=](hipStream_t s) {
+                launch_attention_kv_context(xp, wqkv + (size_t)128 * C, B, N, C, ws, s, g1, 1e-5f, wkv16, 1.f, op16, abf);
+            });
+            pl->net_ops.back().desc = std::string("linear_attention LayerNorm + k,v projection") + tag + " + context (fused) C=" + std::to_string(C);
+            push_other(OP_ATTN, [=](hipStream_t s) {
+                launch_attention_q_out_fused(xp, xp, wqkv, wo, bo, g2, yp, B, N, C, 1e-5f, ws, s, g1, wqkv16, wo16, 1.f, 1.f, op16, abf);
+            });
+            pl->net_ops.back().desc = std::string("linear_attention LayerNorm + q projection") + tag +
+                                      " + softmax + context + to_out + LayerNorm + residual (fused) C=" + std::to_string(C);
+            return y;
+        }
         if (fused_all) {
             // whole Residual(PreNorm(LinearAttention)) block in two kernels + the context merge: PreNorm's LayerNorm runs on
             // the tiles both kernels stage, so no normalised copy of x, no q / k / v, no attention output reach HBM

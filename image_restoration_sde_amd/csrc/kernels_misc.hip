@@ -16,8 +16,25 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx8 __attribute__((ext_vector_type(8)));
 
 namespace {
+
+// 16-bit operand type of the fused attention kernels' projections: IEEE fp16 (the hi + lo pairs of IRSDE_FLAG_SPLIT_F16X2, IRSDE_FLAG_FP16) or
+// bf16 (IRSDE_FLAG_BF16): the same 32x32x16 MFMA shape and fragment layout, fp32 accumulation
+template <bool F16OP>
+struct Mf16 {
+    using x8 = bf16x8;
+    using x4 = bf16x4;
+    static __device__ __forceinline__ floatx16 mfma(x8 a, x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Mf16<true> {
+    using x8 = f16x8;
+    using x4 = f16x4;
+    static __device__ __forceinline__ floatx16 mfma(x8 a, x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 // Activation storage type T (fp32, or bf16 under IRSDE_FLAG_BF16_ACT): arithmetic is fp32 either way.
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
@@ -320,6 +337,19 @@ __device__ __forceinline__ floatx4 ln_piece(floatx4 v, const floatx4 g, const fl
     return v * rstd * g;
 }
 
+// the same for rows stored as bf16 (IRSDE_FLAG_BF16_ACT): a 16-byte piece holds 8 channels, a row = C8 = C/8 consecutive lanes (a power of two <= 32)
+template <int C8>
+__device__ __forceinline__ floatx8 ln_piece8(floatx8 v, const float* __restrict__ g8, const float eps) {
+    const float s = group_sum<C8>(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+    const float mean = s * (1.0f / (float)(8 * C8));
+    v -= mean;
+    const float q = group_sum<C8>(((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7])));
+    const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / (float)(8 * C8)) + eps);
+    const floatx4 ga = *reinterpret_cast<const floatx4*>(g8), gb = *reinterpret_cast<const floatx4*>(g8 + 4);
+    const floatx8 g = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+    return v * rstd * g;
+}
+
 // k, v projection + context in one kernel (fp32): the k and v thirds of to_qkv never reach HBM.
 //   per 128-pixel tile of one image:  [k | v](128 px x 64) = xn(128 x C) . W_{k,v}^T   for each head (wave = head)
 //   then straight from the accumulator registers: online softmax of k over the pixels and ctx[d][e] += exp(k - m)[px][d] v[px][e].
@@ -334,14 +364,20 @@ constexpr int kKvTile = 128;
 // cross products per f32 product: fp32-equivalent, 3/16 of the f32-MFMA cycles): the staged tile is split while it is written to LDS
 // (two planes of [128][C] fp16, rows of 2 C + 16 bytes), the weights come as two pre-split planes (wkv_pair: [2][256][C], scaled by
 // the power of two that w_inv_scale undoes on the accumulators).  Everything after the projection (softmax, context) is unchanged f32.
-template <int C, bool PAIR = false>
+// MODE (r05): 0 = f32, 1 = PAIR, 2 / 3 = the 16-bit operand modes (IRSDE_FLAG_BF16 / IRSDE_FLAG_FP16; the reference is fp32 only): ONE bf16 / fp16 plane
+// of the staged tile and of the weights (wkv_pair: [256][C], unscaled), one product per f32 product — with the projection at 1/16 of its f32
+// cycles the kernel is bound by the tile it streams.  ABF (IRSDE_FLAG_BF16_ACT, MODE 2): xn is a bf16 tensor, pieces of 8 channels.
+template <int C, int MODE = 0, bool ABF = false>
 __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __restrict__ xn, const float* __restrict__ wkv,
                                                              float* __restrict__ pmax, float* __restrict__ pctx,
                                                              float* __restrict__ psum, const int N, const int chunk_len,
                                                              const int nch, const float* __restrict__ ln_g, const float ln_eps,
                                                              const unsigned short* __restrict__ wkv_pair = nullptr, const float w_inv_scale = 1.f) {
     extern __shared__ __attribute__((aligned(16))) float kv_smem[];
-    constexpr int RB = 2 * C + 16;   // PAIR: bytes per fp16 LDS row (an odd number of 16-byte slots)
+    constexpr bool PAIR = MODE == 1, P16 = MODE != 0;
+    using M16 = Mf16<MODE == 1 || MODE == 3>;
+    static_assert(!ABF || MODE == 2, "bf16 activation storage goes with the bf16 operand mode");
+    constexpr int RB = 2 * C + 16;   // 16-bit modes: bytes per LDS row (an odd number of 16-byte slots)
     const int ch = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -391,13 +427,45 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
                         char* dst = reinterpret_cast<char*>(kv_smem) + row * RB + 8 * c4;
                         *reinterpret_cast<f16x4*>(dst) = hi;
                         *reinterpret_cast<f16x4*>(dst + kKvTile * RB) = lo;
+                    } else if constexpr (P16) {   // one plane, RNE
+                        *reinterpret_cast<typename M16::x4*>(reinterpret_cast<char*>(kv_smem) + row * RB + 8 * c4) = __builtin_convertvector(st[j], typename M16::x4);
                     } else {
                         *reinterpret_cast<floatx4*>(kv_smem + row * LDA + 4 * c4) = st[j];
                     }
                 }
             }
         };
-        if (t0 + kKvTile <= n1) stage_tile(std::true_type{}); else stage_tile(std::false_type{});
+        // ABF: the tile is 128 * C bf16 (one contiguous run), 16-byte pieces of 8 channels, a row = C / 8 consecutive lanes
+        auto stage_tile_bf = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            constexpr int c8n = C >> 3;
+            const char* xb = reinterpret_cast<const char*>(xn);
+            const char* tile = xb + ((size_t)b * N + t0) * C * 2;
+            constexpr int NP = kKvTile * c8n / 256;
+            constexpr int NB = NP % 8 == 0 ? 8 : 4;
+            static_assert(256 % c8n == 0 && NP % NB == 0, "piece / thread mapping");
+#pragma unroll
+            for (int j0 = 0; j0 < NP; j0 += NB) {
+                bf16x8 st[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int i = tid + 256 * (j0 + j), row = tid / c8n + (256 / c8n) * (j0 + j), c8 = tid % c8n;
+                    if constexpr (FULL) st[j] = *reinterpret_cast<const bf16x8*>(tile + 16 * (size_t)i);
+                    else st[j] = *reinterpret_cast<const bf16x8*>(xb + (((size_t)b * N + min(t0 + row, n1 - 1)) * C + 8 * c8) * 2);
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int row = tid / c8n + (256 / c8n) * (j0 + j), c8 = tid % c8n;
+                    if (ln_g) st[j] = __builtin_convertvector(ln_piece8<c8n>(__builtin_convertvector(st[j], floatx8), ln_g + 8 * c8, ln_eps), bf16x8);
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(kv_smem) + row * RB + 16 * c8) = st[j];
+                }
+            }
+        };
+        if constexpr (ABF) {
+            if (t0 + kKvTile <= n1) stage_tile_bf(std::true_type{}); else stage_tile_bf(std::false_type{});
+        } else {
+            if (t0 + kKvTile <= n1) stage_tile(std::true_type{}); else stage_tile(std::false_type{});
+        }
         __syncthreads();
         floatx16 ak[4], av[4];
 #pragma unroll
@@ -448,6 +516,29 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { ak[rt][r] *= w_inv_scale; av[rt][r] *= w_inv_scale; }
+        } else if constexpr (P16) {
+            // one 16-bit plane: K steps of 16, lane (row l31, half h) holds k = 16 ks + 8 h .. + 7 of its pixel rows and of its weight rows
+            using x8 = typename M16::x8;
+            const char* arow = reinterpret_cast<const char*>(kv_smem) + l31 * RB + 16 * h;
+            const char* wkp = reinterpret_cast<const char*>(wkv_pair) + ((size_t)(head * kDh + l31) * C + 8 * h) * 2;
+            const char* wvp = reinterpret_cast<const char*>(wkv_pair) + ((size_t)(kHid + head * kDh + l31) * C + 8 * h) * 2;
+            constexpr int NK16 = C / 16;
+            x8 wk1[2], wv1[2];   // one K step ahead
+            wk1[0] = *reinterpret_cast<const x8*>(wkp);
+            wv1[0] = *reinterpret_cast<const x8*>(wvp);
+#pragma unroll
+            for (int ks = 0; ks < NK16; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                const int kp = (ks + 1 < NK16 ? ks + 1 : ks) * 32;
+                wk1[nxt] = *reinterpret_cast<const x8*>(wkp + kp);
+                wv1[nxt] = *reinterpret_cast<const x8*>(wvp + kp);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const x8 a = *reinterpret_cast<const x8*>(arow + rt * 32 * RB + 32 * ks);
+                    ak[rt] = M16::mfma(a, wk1[cur], ak[rt]);
+                    av[rt] = M16::mfma(a, wv1[cur], av[rt]);
+                }
+            }
         } else {
             const float* arow = kv_smem + l31 * LDA + 4 * h;
             // weight fragments (from L2) one K step = 32 MFMAs (2048 cycles) ahead of their use: two register slots, K loop
@@ -660,7 +751,9 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const T* __restrict__ qkv
 // pairs (three cross products per f32 product): the xn tile and the attention-output tile are written to LDS as two fp16 planes
 // (rows of 2 C + 16 resp. 272 bytes), the weights come as pre-split planes (wq_pair [2][128][C], wout_pair [2][C][128], scaled by powers
 // of two that wq_inv / wout_inv undo on the accumulators).  Softmax, the context product, LayerNorm and the residual stay f32.
-template <int C, bool PAIR = false>
+// MODE 2 / 3 (r05; IRSDE_FLAG_BF16 / IRSDE_FLAG_FP16): one bf16 / fp16 plane per operand (wq_pair [128][C], wout_pair [C][128], unscaled), one product.
+// ABF (IRSDE_FLAG_BF16_ACT, MODE 2): xn / xres / y are bf16 tensors (pieces of 8 channels); the arithmetic between them is the same fp32.
+template <int C, int MODE = 0, bool ABF = false>
 __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* __restrict__ xn, const float* __restrict__ xres,
                                                                const float* __restrict__ wq, const float* __restrict__ ctx,
                                                                const float* __restrict__ wout, const float* __restrict__ bias,
@@ -670,7 +763,10 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
                                                                const unsigned short* __restrict__ wout_pair = nullptr, const float wq_inv = 1.f,
                                                                const float wout_inv = 1.f) {
     constexpr int TP = 128, LDA = C + 4, LDO = kHid + 4, RT = C / 32;
-    constexpr int RBX = 2 * C + 16, RBO = 2 * kHid + 16;   // PAIR: bytes per fp16 row of the xn / attention-output planes
+    constexpr bool PAIR = MODE == 1, P16 = MODE != 0;
+    using M16 = Mf16<MODE == 1 || MODE == 3>;
+    static_assert(!ABF || MODE == 2, "bf16 activation storage goes with the bf16 operand mode");
+    constexpr int RBX = 2 * C + 16, RBO = 2 * kHid + 16;   // 16-bit modes: bytes per row of the xn / attention-output planes
     constexpr int LDY = C > kHid ? C + 4 : LDO;  // row stride of the normalised rows (phase G): they must not overlap the next wave's rows
     extern __shared__ __attribute__((aligned(16))) float qo_smem[];
     // one LDS region (67.6 KB -> two blocks per CU, whose phases overlap): the xn tile (phases A, B), then — behind a barrier —
@@ -689,9 +785,13 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
     // the residual IS the staged tensor (xres == xn: the PreNorm-fused plan) the raw pieces stay in registers across the block (C <= 128: 32 / 64
     // registers of the 256 a wave has) and phase G neither re-reads the tile nor waits for it
     constexpr int NQ = 32 * C4 / 64;
-    constexpr bool KEEP = !PAIR && C <= 128;
+    constexpr bool KEEP = !PAIR && !ABF && C <= 128;
     floatx4 xkeep[KEEP ? NQ : 1];
-    const bool keep_res = KEEP && full_tile && xres == xn;
+    // ABF: the wave's slab is 32 * C bf16; pieces of 8 channels, a row = C8 consecutive lanes; the raw pieces stay in registers (C / 4 of them) for C <= 128
+    constexpr int C8 = C / 8, NQ8 = 32 * C8 / 64;
+    constexpr bool KEEP8 = ABF && C <= 128;
+    const bool keep_res = (KEEP || KEEP8) && full_tile && xres == xn;
+    bf16x8 xkeep8[KEEP8 ? NQ8 : 1];
     auto stage_tile = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const float* slab_in = xn + (img + t0 + wave * 32) * C;
@@ -717,13 +817,42 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
                     char* dst = reinterpret_cast<char*>(qo_smem) + row * RBX + 8 * c4;
                     *reinterpret_cast<f16x4*>(dst) = hi;
                     *reinterpret_cast<f16x4*>(dst + TP * RBX) = lo;
+                } else if constexpr (P16) {   // one plane, RNE
+                    *reinterpret_cast<typename M16::x4*>(reinterpret_cast<char*>(qo_smem) + row * RBX + 8 * c4) = __builtin_convertvector(st[j], typename M16::x4);
                 } else {
                     *reinterpret_cast<floatx4*>(Xs + row * LDA + 4 * c4) = st[j];
                 }
             }
         }
     };
-    if (full_tile) stage_tile(std::true_type{}); else stage_tile(std::false_type{});
+    auto stage_tile_bf = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const char* xb = reinterpret_cast<const char*>(xn);
+        const char* slab_in = xb + (img + t0 + wave * 32) * C * 2;
+        constexpr int NB = NQ8 < 8 ? NQ8 : 8;
+#pragma unroll
+        for (int j0 = 0; j0 < NQ8; j0 += NB) {
+            bf16x8 st[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int i = lane + 64 * (j0 + j), row = wave * 32 + lane / C8 + (64 / C8) * (j0 + j), c8 = lane % C8;   // (C8 divides 64)
+                if constexpr (FULL) st[j] = *reinterpret_cast<const bf16x8*>(slab_in + 16 * (size_t)i);
+                else st[j] = *reinterpret_cast<const bf16x8*>(xb + ((img + min(t0 + row, N - 1)) * C + 8 * c8) * 2);
+                if constexpr (FULL && KEEP8) xkeep8[j0 + j] = st[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int row = wave * 32 + lane / C8 + (64 / C8) * (j0 + j), c8 = lane % C8;
+                if (ln_g) st[j] = __builtin_convertvector(ln_piece8<C8>(__builtin_convertvector(st[j], floatx8), ln_g + 8 * c8, eps), bf16x8);
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(qo_smem) + row * RBX + 16 * c8) = st[j];
+            }
+        }
+    };
+    if constexpr (ABF) {
+        if (full_tile) stage_tile_bf(std::true_type{}); else stage_tile_bf(std::false_type{});
+    } else {
+        if (full_tile) stage_tile(std::true_type{}); else stage_tile(std::false_type{});
+    }
     // context operand of phase D: ctx[d = (s&3) + 8(s>>2) + 4h][e = l31] of head = wave
     float cb[16];
     {
@@ -766,6 +895,21 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) q[ct][r] *= wq_inv;
+    } else if constexpr (P16) {
+        using x8 = typename M16::x8;
+        const char* wrow = reinterpret_cast<const char*>(wq_pair) + ((size_t)(wave * kDh + l31) * C + 8 * h) * 2;
+        const char* brow = reinterpret_cast<const char*>(qo_smem) + l31 * RBX + 16 * h;
+        constexpr int NK16 = C / 16;
+        x8 wa1[2];
+        wa1[0] = *reinterpret_cast<const x8*>(wrow);
+#pragma unroll
+        for (int ks = 0; ks < NK16; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            wa1[nxt] = *reinterpret_cast<const x8*>(wrow + (ks + 1 < NK16 ? ks + 1 : ks) * 32);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                q[ct] = M16::mfma(wa1[cur], *reinterpret_cast<const x8*>(brow + ct * 32 * RBX + 32 * ks), q[ct]);
+        }
     } else
     {
         const float* wrow = wq + (size_t)(wave * kDh + l31) * C + 4 * h;
@@ -823,6 +967,12 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
                 *reinterpret_cast<f16x4*>(orow + 16 * gq) = hi;
                 *reinterpret_cast<f16x4*>(orow + TP * RBO + 16 * gq) = lo;
             }
+        } else if constexpr (P16) {
+            char* orow = reinterpret_cast<char*>(qo_smem) + (ct * 32 + l31) * RBO + (wave * kDh + 4 * h) * 2;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<typename M16::x4*>(orow + 16 * gq) =
+                    __builtin_convertvector(floatx4{o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]}, typename M16::x4);
         } else {
             float* orow = Os + (ct * 32 + l31) * LDO + wave * kDh + 4 * h;
 #pragma unroll
@@ -871,6 +1021,24 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) yv[rt][r] *= wout_inv;
+    } else if constexpr (P16) {
+        using x8 = typename M16::x8;
+        const char* wrow = reinterpret_cast<const char*>(wout_pair) + ((size_t)l31 * kHid + 8 * h) * 2;
+        const char* brow = reinterpret_cast<const char*>(qo_smem) + (wave * 32 + l31) * RBO + 16 * h;
+        constexpr int NK16 = kHid / 16;
+        x8 wa1[2][RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) wa1[0][rt] = *reinterpret_cast<const x8*>(wrow + (size_t)rt * 32 * kHid * 2);
+#pragma unroll
+        for (int ks = 0; ks < NK16; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            const int kp = (ks + 1 < NK16 ? ks + 1 : ks) * 32;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) wa1[nxt][rt] = *reinterpret_cast<const x8*>(wrow + (size_t)rt * 32 * kHid * 2 + kp);
+            const x8 bb = *reinterpret_cast<const x8*>(brow + 32 * ks);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) yv[rt] = M16::mfma(wa1[cur][rt], bb, yv[rt]);
+        }
     } else
     {
         const float* wrow = wout + (size_t)l31 * kHid + 4 * h;
@@ -927,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
     // Ys = this wave's own 32 rows of the region.  C <= 128: row stride LDO, exactly the Os rows only this wave read in phase F.
     // C = 256: the rows are wider than an Os row, so they overlap other waves' Os rows -> wait until every wave has left phase F.
     // PAIR: the fp16 planes put other waves' Os rows inside this wave's Ys rows for every C -> always wait.
-    if constexpr (C > kHid || PAIR) __syncthreads();
+    if constexpr (C > kHid || P16) __syncthreads();
     float* yrow = Os + (wave * 32 + l31) * LDY + 4 * h;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -964,7 +1132,41 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
             else if (n < N) *reinterpret_cast<floatx4*>(y + (img + n) * C + 4 * c4) = v + xr[j];
         }
     };
-    if (full_tile) residual_store(std::true_type{}); else residual_store(std::false_type{});
+    // ABF: residual and output are bf16 rows; the sum is formed in fp32 and rounded once (RNE)
+    auto residual_store_bf = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const char* rb = reinterpret_cast<const char*>(xres);
+        char* yb = reinterpret_cast<char*>(y);
+        const size_t slab = (img + t0 + wave * 32) * C * 2;   // byte offset of the wave's 32 contiguous rows
+        bf16x8 xr[NQ8];
+        if (FULL && KEEP8 && keep_res) {
+#pragma unroll
+            for (int j = 0; j < NQ8; ++j) xr[j] = xkeep8[KEEP8 ? j : 0];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NQ8; ++j) {
+                const int i = lane + 64 * j, row = lane / C8 + (64 / C8) * j, c8 = lane % C8;
+                if constexpr (FULL) xr[j] = *reinterpret_cast<const bf16x8*>(rb + slab + 16 * (size_t)i);
+                else xr[j] = *reinterpret_cast<const bf16x8*>(rb + ((img + min(t0 + wave * 32 + row, N - 1)) * C + 8 * c8) * 2);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NQ8; ++j) {
+            const int i = lane + 64 * j, row = lane / C8 + (64 / C8) * j, c8 = lane % C8;
+            const int n = t0 + wave * 32 + row;
+            const float* yr = Os + (wave * 32 + row) * LDY + 8 * c8;
+            const floatx4 va = *reinterpret_cast<const floatx4*>(yr), vb = *reinterpret_cast<const floatx4*>(yr + 4);
+            const floatx8 v = floatx8{va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w} + __builtin_convertvector(xr[j], floatx8);
+            const bf16x8 o = __builtin_convertvector(v, bf16x8);
+            if constexpr (FULL) *reinterpret_cast<bf16x8*>(yb + slab + 16 * (size_t)i) = o;
+            else if (n < N) *reinterpret_cast<bf16x8*>(yb + ((img + n) * C + 8 * c8) * 2) = o;
+        }
+    };
+    if constexpr (ABF) {
+        if (full_tile) residual_store_bf(std::true_type{}); else residual_store_bf(std::false_type{});
+    } else {
+        if (full_tile) residual_store(std::true_type{}); else residual_store(std::false_type{});
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1561,6 +1763,13 @@ void attention_global_init() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define IRSDE_A16_ATTR(CC, MM, AA)                                                                                                                  \
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kv_ctx_kernel<CC, MM, AA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<CC, MM, AA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    IRSDE_A16_ATTR(64, 2, false); IRSDE_A16_ATTR(128, 2, false); IRSDE_A16_ATTR(256, 2, false);
+    IRSDE_A16_ATTR(64, 2, true); IRSDE_A16_ATTR(128, 2, true); IRSDE_A16_ATTR(256, 2, true);
+    IRSDE_A16_ATTR(64, 3, false); IRSDE_A16_ATTR(128, 3, false); IRSDE_A16_ATTR(256, 3, false);
+#undef IRSDE_A16_ATTR
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<64>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q_out_fused_kernel<128>),
@@ -1570,12 +1779,26 @@ void attention_global_init() {
 }
 // fp32 fused form: context from xn and the k / v weight rows (attn_kv_ctx_kernel), then q (its own [B][N][128] tensor) -> out
 void launch_attention_kv_context(const float* xn, const float* wkv, int B, int N, int C, const AttnWorkspace& ws, hipStream_t s,
-                                 const float* ln_g, float ln_eps, const unsigned short* wkv_pair, float w_inv_scale) {
+                                 const float* ln_g, float ln_eps, const unsigned short* wkv_pair, float w_inv_scale, int op16, bool act_bf16) {
     if (ln_g && (C & (C - 1))) throw HipError("attention_kv_context: the fused LayerNorm needs a power-of-two channel count");
     if (C % 32 || C > 256 || C < 32) throw HipError("attention_kv_context: C must be a multiple of 32, <= 256");
     const int len = attn_chunk_len(N, B);
     const int nch = attn_num_chunks(N, B);
     if (nch != ws.nch) throw HipError("attention workspace chunk mismatch");
+    if (op16) {   // one bf16 / fp16 operand plane (IRSDE_FLAG_BF16 / IRSDE_FLAG_FP16): C = 64 / 128 / 256
+        if (!wkv_pair || (op16 != 2 && op16 != 3) || (act_bf16 && op16 != 2) || (C != 64 && C != 128 && C != 256))
+            throw HipError("attention_kv_context: the 16-bit operand modes need their weight plane, C = 64 / 128 / 256; bf16 storage goes with bf16 operands");
+        const size_t lds1 = (size_t)kKvTile * (2 * C + 16);
+#define IRSDE_KV16_LAUNCH(CC, MM, AA) hipLaunchKernelGGL((attn_kv_ctx_kernel<CC, MM, AA>), dim3(nch, B), dim3(256), lds1, s, xn, wkv, ws.pmax, ws.pctx, ws.psum, N, len, nch, ln_g, ln_eps, wkv_pair, 1.f)
+#define IRSDE_KV16_C(CC) { if (act_bf16) IRSDE_KV16_LAUNCH(CC, 2, true); else if (op16 == 2) IRSDE_KV16_LAUNCH(CC, 2, false); else IRSDE_KV16_LAUNCH(CC, 3, false); }
+        if (C == 64) IRSDE_KV16_C(64) else if (C == 128) IRSDE_KV16_C(128) else IRSDE_KV16_C(256)
+#undef IRSDE_KV16_C
+#undef IRSDE_KV16_LAUNCH
+        hipLaunchKernelGGL(attn_ctx_finalize_kernel, dim3(B * kHeads, 4), dim3(1024), 0, s, ws.pctx, ws.psum, ws.pmax, ws.ctx, nch,
+                           1.0f / (float)N, 1.0f / sqrtf((float)kDh));
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (wkv_pair) {   // fp16-pair projection (IRSDE_FLAG_SPLIT_F16X2): C = 64 / 128 / 256
         const size_t ldsp = (size_t)2 * kKvTile * (2 * C + 16);
 #define IRSDE_KVP_LAUNCH(CC) hipLaunchKernelGGL((attn_kv_ctx_kernel<CC, true>), dim3(nch, B), dim3(256), ldsp, s, xn, wkv, ws.pmax, ws.pctx, ws.psum, N, len, nch, ln_g, ln_eps, wkv_pair, w_inv_scale)
@@ -1620,8 +1843,23 @@ void launch_attention_q_out(const float* q, float* out, int B, int N, const Attn
 void launch_attention_q_out_fused(const float* xn, const float* x, const float* wq, const float* wout, const float* bias,
                                   const float* g2, float* y, int B, int N, int C, float eps, const AttnWorkspace& ws, hipStream_t s,
                                   const float* ln_g, const unsigned short* wq_pair, const unsigned short* wout_pair, float wq_inv,
-                                  float wout_inv) {
+                                  float wout_inv, int op16, bool act_bf16) {
     if (C != 64 && C != 128 && C != 256) throw HipError("attention_q_out_fused: C must be 64, 128 or 256");
+    if (op16) {   // one bf16 / fp16 operand plane per projection
+        if (!wq_pair || !wout_pair || (op16 != 2 && op16 != 3) || (act_bf16 && op16 != 2))
+            throw HipError("attention_q_out_fused: the 16-bit operand modes need their weight planes; bf16 storage goes with bf16 operands");
+        const size_t plane_x = (size_t)128 * (2 * C + 16), plane_o = (size_t)128 * (2 * kHid + 16);
+        const size_t ys = (size_t)128 * ((C > kHid ? C : kHid) + 4) * sizeof(float);
+        const size_t lds1 = std::max(std::max(plane_x, plane_o), ys);
+        const dim3 grid1((N + 127) / 128, B);
+#define IRSDE_QO16_LAUNCH(CC, MM, AA) hipLaunchKernelGGL((attn_q_out_fused_kernel<CC, MM, AA>), grid1, dim3(256), lds1, s, xn, x, wq, ws.ctx, wout, bias, g2, y, N, eps, ln_g, wq_pair, wout_pair, 1.f, 1.f)
+#define IRSDE_QO16_C(CC) { if (act_bf16) IRSDE_QO16_LAUNCH(CC, 2, true); else if (op16 == 2) IRSDE_QO16_LAUNCH(CC, 2, false); else IRSDE_QO16_LAUNCH(CC, 3, false); }
+        if (C == 64) IRSDE_QO16_C(64) else if (C == 128) IRSDE_QO16_C(128) else IRSDE_QO16_C(256)
+#undef IRSDE_QO16_C
+#undef IRSDE_QO16_LAUNCH
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (wq_pair && wout_pair) {   // fp16-pair projections (IRSDE_FLAG_SPLIT_F16X2)
         const size_t planes_x = (size_t)2 * 128 * (2 * C + 16), planes_o = (size_t)2 * 128 * (2 * kHid + 16);
         const size_t ys = (size_t)128 * ((C > kHid ? C : kHid) + 4) * sizeof(float);

@@ -26,6 +26,8 @@
  *        2 concurrent sub-batches, each with its own step graph on its own stream (same results up to the tilings the smaller plans choose; noise / Philox
  *        streams stay keyed by the call-level image index).  Debug header: irsde_debug_force_subbatches.  The measurement kernels (stamp / ablation /
  *        superseded twins) moved to the PROBES build (libirsde_hip_probes.so): the product library refuses their selectors.
+ *   106  IRSDE_FLAG_BF16 / _BF16_ACT / _FP16: the LinearAttention blocks (C = 64 / 128 / 256) run on the fused attention kernels with 16-bit
+ *        projection operands (results differ from ABI 105 by the roundings of the q | k | v / attention-output tensors that no longer exist).
  */
 #ifndef IRSDE_HIP_H
 #define IRSDE_HIP_H
@@ -61,7 +63,11 @@ enum {
     IRSDE_FLAG_BF16 = 32,            /* reduced-precision mode (BASELINE configs[2]; the reference is fp32 only): every convolution
                                         runs on v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 (RNE) and fp32
                                         accumulation; no Winograd; everything else (state, LayerNorm, attention, FiLM,
-                                        update step) stays fp32 */
+                                        update step) stays fp32.  ABI 106: the LinearAttention blocks with 64 / 128 / 256 channels run as the
+                                        two fused kernels of the fp32 path with their three projections (to_qkv rows, to_out) on the 16-bit MFMA
+                                        (operands rounded once, RNE; LayerNorm, both softmaxes, the context and every accumulation in fp32):
+                                        q | k | v and the attention output are no longer rounded to a stored tensor.
+                                        IRSDE_FLAG_NO_FUSED_ATTN restores the to_qkv convolution + q | k | v tensor */
     IRSDE_FLAG_BF16_ACT = 128,       /* IRSDE_FLAG_BF16 plus bf16 storage of every activation tensor between the prepped input
                                         and eps_hat (conditional ConditionalUNet only): halves the HBM/L2 traffic of the
                                         bandwidth-bound layers; LayerNorm / attention / epilogue arithmetic stays fp32 */

@@ -310,6 +310,34 @@ def test_fused_attention_plan_vs_qkv_tensor_plan():
     assert 0 < e < 5e-5
 
 
+# measured (r05, one evaluation at 2 x 136 x 200, relative to the fp32 engine): see profiles/r05_notes.md section 6
+_ATTN16_TOL = {"bf16_act": 3e-2, "bf16": 3e-2, "fp16": 4e-3}
+
+
+@pytest.mark.parametrize("dtype", ["bf16_act", "bf16", "fp16"])
+def test_fused_attention_16bit_plan_vs_qkv_tensor_plan(dtype):
+    """r05 (ABI 106): the reduced-precision modes run LinearAttention (C = 64 / 128 / 256) on the two fused kernels with bf16 / fp16 projection
+    operands (bf16_act: bf16 tensors in and out) instead of to_qkv conv -> q|k|v tensor -> attention -> to_out conv.  Both plans round the same
+    operands to 16 bits; the fused one no longer rounds q | k | v / the attention output to a stored tensor, so it must be at least as close
+    to the fp32 engine as the tensor plan is (odd size: ragged tiles and chunk tails at every level)."""
+    lq, xT = O.synth_inputs(32, 2, 136, 200)
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    y32 = unet64()(x, c, 17).cpu().numpy()
+    buf = ctypes.create_string_buffer(1 << 16)
+    mf = _fresh_unet64(dtype)
+    _lib.check(_lib.lib().irsde_plan_describe(mf.engine().h, 2, 136, 200, buf, len(buf)))
+    tag = {"bf16_act": b"(bf16 operands + storage)", "bf16": b"(bf16 operands)", "fp16": b"(fp16 operands)"}[dtype]
+    assert buf.value.count(b"k,v projection " + tag) == 5 and buf.value.count(b"q projection " + tag) == 5   # C = 64, 128, 256 down; 256, 128 up
+    mu = _fresh_unet64(dtype)
+    mu.engine_flags |= _lib.FLAG_NO_FUSED_ATTN
+    _lib.check(_lib.lib().irsde_plan_describe(mu.engine().h, 2, 136, 200, buf, len(buf)))
+    assert b"(fused)" not in buf.value
+    yf, yu = mf(x, c, 17).cpu().numpy(), mu(x, c, 17).cpu().numpy()
+    ef, eu, d = relerr(yf, y32), relerr(yu, y32), relerr(yf, yu)
+    print("%s: fused attention plan vs fp32 %.3g, qkv-tensor plan vs fp32 %.3g, fused vs tensor plan %.3g" % (dtype, ef, eu, d))
+    assert np.isfinite(yf).all() and 0 < ef < _ATTN16_TOL[dtype] and ef < 1.5 * eu and d > 0
+
+
 def _fresh_unet64(dtype):
     params = O.synth_params(seed=0, nf=64, depth=4)
     mm = P.ConditionalUNet(3, 3, 64, depth=4)

@@ -50,7 +50,7 @@ def test_native_library_is_loaded():
     """The HIP extension (in-tree .so) is what runs; there is no eager/PyTorch fallback."""
     assert torch.cuda.is_available()
     L = _lib.lib()
-    assert L.irsde_version() == 105
+    assert L.irsde_version() == 106
     maps = open("/proc/self/maps").read()
     assert "libirsde_hip.so" in maps
 
