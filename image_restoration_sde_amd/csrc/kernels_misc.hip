@@ -616,10 +616,27 @@ __global__ __launch_bounds__(256, 2) void attn_kv_ctx_kernel(const float* __rest
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE >= 2) {
+            // 16-bit operand modes: the context product on the 16-bit MFMA too — exp(k - m) in [0, 1] and v rounded once (RNE), fp32 accumulation.  A K step
+            // of 16 pixels takes the lane's registers 8 s .. 8 s + 7 of a row tile for A (its column d) and B (its column e) alike: the same pixel
+            // order in both operands, 8 MFMAs of 8 passes instead of 64 of 16.  (ssum stays the fp32 sum of the unrounded exponentials.)
+            using x8 = typename M16::x8;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rt][r], av[rt][r], ctx, 0, 0, 0);
+                for (int sh = 0; sh < 2; ++sh) {
+                    const floatx8 ka = {ak[rt][8 * sh], ak[rt][8 * sh + 1], ak[rt][8 * sh + 2], ak[rt][8 * sh + 3],
+                                        ak[rt][8 * sh + 4], ak[rt][8 * sh + 5], ak[rt][8 * sh + 6], ak[rt][8 * sh + 7]};
+                    const floatx8 va = {av[rt][8 * sh], av[rt][8 * sh + 1], av[rt][8 * sh + 2], av[rt][8 * sh + 3],
+                                        av[rt][8 * sh + 4], av[rt][8 * sh + 5], av[rt][8 * sh + 6], av[rt][8 * sh + 7]};
+                    ctx = M16::mfma(__builtin_convertvector(ka, x8), __builtin_convertvector(va, x8), ctx);
+                }
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rt][r], av[rt][r], ctx, 0, 0, 0);
+        }
         __syncthreads();  // every wave is done with the tile in LDS
     }
     ssum = half_sum(ssum);
@@ -860,6 +877,14 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) cb[s2] = cp[((s2 & 3) + 8 * (s2 >> 2) + 4 * h) * 32];
     }
+    // fp16 operands (MODE 3): the context carries v / N (module_util.py:168) — O(1e-6) on a 256 x 256 map, in fp16's subnormal range — so it and with it the
+    // attention output go through the 16-bit MFMAs scaled by ctx_up = 2^ceil(log2 N) (exact), undone on the to_out accumulators in front of the bias
+    float ctx_up = 1.f;
+    if constexpr (MODE == 3) {
+        ctx_up = exp2f(ceilf(log2f((float)N)));
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) cb[s2] *= ctx_up;
+    }
     __syncthreads();
 
     // ---- B: Q^T of head = wave
@@ -954,8 +979,22 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
         floatx16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        if constexpr (MODE >= 2) {
+            // 16-bit operand modes: the context operand (rounded once per block) and the softmax probabilities (in [0, 1]) on the 16-bit MFMA, fp32
+            // accumulation.  K step sh = the d values of the lane's registers 8 sh .. 8 sh + 7, the same order in cb[] and q[]: 2 MFMAs instead of 16.
+            using x8 = typename M16::x8;
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) o = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[s2], q[ct][s2] * iz, o, 0, 0, 0);
+            for (int sh = 0; sh < 2; ++sh) {
+                // (MODE 3: cb carries the power of two `ctx_up`, see below)
+                const floatx8 ca = {cb[8 * sh], cb[8 * sh + 1], cb[8 * sh + 2], cb[8 * sh + 3], cb[8 * sh + 4], cb[8 * sh + 5], cb[8 * sh + 6], cb[8 * sh + 7]};
+                const floatx8 qa = {q[ct][8 * sh], q[ct][8 * sh + 1], q[ct][8 * sh + 2], q[ct][8 * sh + 3],
+                                    q[ct][8 * sh + 4], q[ct][8 * sh + 5], q[ct][8 * sh + 6], q[ct][8 * sh + 7]};
+                o = M16::mfma(__builtin_convertvector(ca, x8), __builtin_convertvector(qa * iz, x8), o);
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) o = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[s2], q[ct][s2] * iz, o, 0, 0, 0);
+        }
         // o[r] = out[pixel 32 ct + l31][e = (r&3) + 8(r>>2) + 4h]: four 16-byte groups per lane
         if constexpr (PAIR) {
             char* orow = reinterpret_cast<char*>(qo_smem) + (ct * 32 + l31) * RBO + (wave * kDh + 4 * h) * 2;
@@ -1038,6 +1077,13 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
             const x8 bb = *reinterpret_cast<const x8*>(brow + 32 * ks);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) yv[rt] = M16::mfma(wa1[cur][rt], bb, yv[rt]);
+        }
+        if constexpr (MODE == 3) {
+            const float dn = 1.0f / ctx_up;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[rt][r] *= dn;
         }
     } else
     {
