@@ -1450,7 +1450,7 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
             else launch_cfg<128, 32, 4, 1, 2, false, true>(p, M, nk_total, s);
         }
     } else if (p.w_bf && g_variant != 60 && g_variant != 61 && conv_halo_eligible(p)) {
-        launch_conv_halo(p, s);  // 3x3 s1 p1: LDS-resident halo tile (conv_halo.hip)
+        launch_conv_halo(p, s, g_variant == 64 ? 1 : g_variant == 65 ? -1 : 0);  // 3x3 s1 p1: LDS-resident halo tile (conv_halo.hip)
         return;
     } else if (p.w_bf && p.in_bf16) {  // bf16 operands AND bf16 activation storage
         if (p.Cout >= 128) {

@@ -713,13 +713,13 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             launch_conv_naive(p, s);
         } else {
             unsigned short *dbf = nullptr, *a0 = nullptr, *a1 = nullptr, *ar = nullptr, *ao = nullptr;
-            const bool act = naive == 204 || naive == 260 || naive == 261;  // + bf16 activation storage (IRSDE_FLAG_BF16_ACT)
-            if (naive == 4 || naive == 160 || naive == 161 || act) {  // bf16-MFMA mode (variants 60 / 61: force the 256 / 128 tile)
+            const bool act = naive == 204 || (naive >= 260 && naive <= 263);  // + bf16 activation storage (IRSDE_FLAG_BF16_ACT)
+            if (naive == 4 || (naive >= 160 && naive <= 163) || act) {  // bf16-MFMA mode (variants 60 / 61: force the 256 / 128 tile; 64 / 65: the 512- / 256-pixel halo kernel)
                 IRSDE_HIP_CHECK(hipMalloc(&dbf, pk.size() * 2));
                 launch_f32_to_bf16(dw, dbf, pk.size(), s);
                 p.w_bf = dbf;
             }
-            const bool f16 = naive == 5 || naive == 165;  // fp16-MFMA mode: production dispatch / generic 128-row tile
+            const bool f16 = naive == 5 || (naive >= 165 && naive <= 167);  // fp16-MFMA mode: production dispatch / generic 128-row tile / 512- / 256-pixel halo kernel
             if (f16) {
                 IRSDE_HIP_CHECK(hipMalloc(&dbf, pk.size() * 2));
                 launch_f32_to_f16(dw, dbf, pk.size(), s);
@@ -743,7 +743,8 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
                 p.in_bf16 = p.out_bf16 = 1;
             }
             {
-                VariantScope vs(f16 ? (naive == 165 ? 61 : 0) : act ? (naive == 204 ? 0 : naive - 200) : (naive >= 100 ? naive - 100 : 0));  // tile variants
+                const int halo_v = (naive == 162 || naive == 262 || naive == 166) ? 64 : (naive == 163 || naive == 263 || naive == 167) ? 65 : 0;   // 64 / 65: force the 512- / 256-pixel halo kernel
+                VariantScope vs(halo_v ? halo_v : f16 ? (naive == 165 ? 61 : 0) : act ? (naive == 204 ? 0 : naive - 200) : (naive >= 100 ? naive - 100 : 0));  // tile variants
                 launch_conv(p, s);
             }
             if (act) launch_bf16_to_f32(ao, out, nout, s);
@@ -904,6 +905,8 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         launch_fill_random(dfilm, (size_t)2 * Cout, 4, 0.3f, s);
         p.in0 = din; p.w = dw; p.out = dout; p.out_stride = Cout;
         unsigned short* dbf = nullptr;
+        const int halo_force = (variant == 64 || variant == 66) ? 64 : (variant == 65 || variant == 67) ? 65 : 0;   // r05: 64 / 65 = variant 62 with the 512- / 256-pixel halo kernel forced, 66 / 67 = the same on variant 63
+        if (halo_force) variant = variant <= 65 ? 62 : 63;
         if (variant >= 60 && variant <= 63) {  // bf16-MFMA mode: 60 = 256x256 tile, 61 = 128x128, 62 = automatic, 63 = automatic + bf16 activations
             IRSDE_HIP_CHECK(hipMalloc(&dbf, nw * 2));
             launch_f32_to_bf16(dw, dbf, nw, s);
@@ -1154,7 +1157,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
                 launch_conv(p, s);
             }
         };
-        VariantScope vs(variant >= 80 || variant == 63 ? 0 : variant);
+        VariantScope vs(halo_force ? halo_force : variant >= 80 || variant == 63 || variant == 62 ? 0 : variant);
         hipEvent_t e0, e1;
         IRSDE_HIP_CHECK(hipEventCreate(&e0));
         IRSDE_HIP_CHECK(hipEventCreate(&e1));

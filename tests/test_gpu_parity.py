@@ -129,7 +129,12 @@ CONV_CASES = {
     "3x3_deep_k_1536": (1, 1024, 512, 4, 4, 256, 3, 1, 1, 0, False, True, True, False),
     "3x3_wino_res_bias": (2, 256, 0, 12, 20, 256, 3, 1, 1, 0, True, False, True, True),
     "3x3_wino_upsample": (1, 256, 0, 6, 10, 256, 3, 1, 1, 1, True, False, False, False),
+    # r05: shapes for the 512-pixel x 128-channel halo kernel (conv3x3_halo2_kernel): several 16 x 32 tiles with ragged right / bottom edges, a channel
+    # count that is not a multiple of the 128-wide block (masked columns), both concat sources, the fused upsample
+    "3x3_halo2_ragged_160": (2, 64, 32, 20, 70, 160, 3, 1, 1, 0, True, True, True, True),
+    "3x3_halo2_upsample_128": (1, 64, 0, 17, 33, 128, 3, 1, 1, 1, True, False, False, False),
 }
+HALO2_CASES = ["3x3_concat_192_128", "3x3_deep_k_1536", "3x3_wino_res_bias", "3x3_wino_upsample", "3x3_halo2_ragged_160", "3x3_halo2_upsample_128"]
 
 
 @pytest.mark.parametrize("name", list(CONV_CASES))
@@ -421,6 +426,39 @@ def test_conv_kernel_bf16_storage(name):
         err = np.abs(got - ref_st)
         assert (err <= np.abs(ref_st) * 2.0 ** -7 + 1e-6).all(), (name, code, float(err.max()))
         assert (err > 0).mean() < 0.02, (name, code)                         # and almost every element is identical
+
+
+@pytest.mark.parametrize("name", HALO2_CASES)
+def test_conv_halo2_kernel(name):
+    """r05: conv3x3_halo2_kernel (16 x 32 pixels x 128 channels per block, 4 x 2 MFMA tiles per wave, three taps per barrier) forced on small shapes
+    (irsde_debug_conv 162 / 262 / 166) in its three instances — bf16 operands on fp32 tensors, bf16 tensors, fp16 operands — against the oracle with the
+    same operand roundings, and against the 256-pixel kernel it replaces on the big feature maps (163 / 263 / 167)."""
+    B, C0, C1, H, W, Cout, K, stride, pad, in_shift, has_bias, has_film, silu, has_res = CONV_CASES[name]
+    rs = np.random.RandomState(hash(name) % 2 ** 31)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, K, K)) / np.sqrt((C0 + C1) * K * K)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32) if has_bias else None
+    film = (0.3 * rs.standard_normal((1, 2 * Cout))).astype(np.float32) if has_film else None
+    Ho, Wo = H << in_shift, W << in_shift
+    res = rs.standard_normal((B, Cout, Ho, Wo)).astype(np.float32) if has_res else None
+    args = (x0, x1, w, bias, stride, pad, in_shift, film, silu)
+    with O.bf16_convs():
+        ref = oracle_conv(*args, res)
+        ref_act = O.round_bf16(oracle_conv(*args, None if res is None else O.round_bf16(res)))
+    with O.f16_convs():
+        ref16 = oracle_conv(*args, res)
+    got = run_conv(*args, res, naive=162)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    e_new, e_old = relerr(got, ref), relerr(run_conv(*args, res, naive=163), ref)
+    assert e_new < 2e-5 and e_old < 2e-5, (name, e_new, e_old)
+    e16 = relerr(run_conv(*args, res, naive=166), ref16)
+    assert e16 < 2e-5, (name, e16)
+    ga = run_conv(*args, res, naive=262)
+    assert np.array_equal(ga, O.round_bf16(ga))
+    err = np.abs(ga - ref_act)
+    assert (err <= np.abs(ref_act) * 2.0 ** -7 + 1e-6).all() and (err > 0).mean() < 0.02, (name, float(err.max()))
+    print("%s: halo2 bf16 %.3g (256-pixel kernel %.3g), fp16 %.3g, bf16 storage max %.3g" % (name, e_new, e_old, e16, float(err.max())))
 
 
 # ---------------------------------------------------------------------------------------------

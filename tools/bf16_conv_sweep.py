@@ -28,13 +28,14 @@ cases = [
     ("L1 4x4s2 64->128", 256, 256, 64, 128, 4, 2, 0, 0),
 ]
 cases = [c for c in cases if flt in c[0]]
-print("B=%d  %-26s %10s %8s %10s %8s" % (B, "layer", "62 ms", "TF/s", "63 ms", "TF/s"))
+VARS = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "62,63").split(",")]
+print("B=%d  %-26s " % (B, "layer") + " ".join("%7d ms %7s" % (v, "TF/s") for v in VARS))
 for name, H, W, Cin, Cout, K, st, up, epi in cases:
     Ho, Wo = (H << up) // st, (W << up) // st
     flops = 2.0 * B * Ho * Wo * Cin * Cout * K * K
     res = []
-    for v in (62, 63):
+    for v in VARS:
         ms = ctypes.c_double()
         rc = L.irsde_bench_conv(v, B, H, W, Cin, Cout, K, st, up, epi, 10, ctypes.byref(ms))
         res.append(ms.value if rc == 0 else float("nan"))
-    print("      %-26s %10.4f %8.1f %10.4f %8.1f" % (name, res[0], flops / res[0] / 1e9, res[1], flops / res[1] / 1e9), flush=True)
+    print("      %-26s " % name + " ".join("%10.4f %7.1f" % (r, flops / r / 1e9) for r in res), flush=True)
