@@ -460,6 +460,8 @@ def timed(wl, steps, warmup, world, dev):
 
 
 def main():
+    # RCCL / device-tensor sharing across the ranks of one node needs dmabuf IPC on this driver; the GPU box exports this already — set it for any other launcher too
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
