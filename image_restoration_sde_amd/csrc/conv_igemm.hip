@@ -1251,7 +1251,18 @@ int zloop_1x1_rows(const ConvParams& p) {
 
 // few rows (single image, deep levels): 64 x 128 tiles — a 128-row tile would be half empty or the grid under-filled
 bool zloop_small_m(const ConvParams& p) {
-    return p.Wo <= 64 || (long long)((p.Wo + 127) / 128) * ((p.Cout + 127) / 128) * p.nz < 512;
+    const long long b128 = (long long)((p.Wo + 127) / 128) * ((p.Cout + 127) / 128) * p.nz;
+    if (p.Wo <= 64 || b128 < 512) return true;
+    // r05: a ragged last round of 128-row tiles (the small-batch shards: 512 tiles x 512 channels x 36 components = 576 blocks on 512 block slots — one full round
+    // and 64 blocks alone) against 64-row tiles (1152 blocks: three rounds of half the work, ~7 % less efficient per tile); only where rounds are few
+    // (measured, one box: B = 2 / 4 / 8 x 256^2 3.11 / 3.68 / 4.03 -> 3.16 / 3.77 / 4.07 img/s; the T = 512 layers 98 -> 111 TFLOP/s.)  IRSDE_ZLOOP_RAGGED64 = the block
+    // count below which the rule applies (0 = off)
+    static const int cutoff = tuning_env_int("IRSDE_ZLOOP_RAGGED64", 2048);
+    if (cutoff <= 0 || b128 >= cutoff) return false;
+    const long long b64 = (long long)((p.Wo + 63) / 64) * ((p.Cout + 127) / 128) * p.nz;
+    const double e128 = (double)b128 / (512.0 * (double)((b128 + 511) / 512));
+    const double e64 = 0.93 * (double)b64 / (512.0 * (double)((b64 + 511) / 512));
+    return e64 > e128;
 }
 
 // components per block for gemm_zloop_kernel, or 0 = use one block per (component, tile)

@@ -30,6 +30,8 @@ extern "C" {
  *   4 bf16-MFMA mode (halo kernel for eligible 3x3 layers); 160 / 161 its generic 256 / 128 tile
  *   5 fp16-MFMA mode (IRSDE_FLAG_FP16; halo kernel for eligible 3x3 layers); 165 its generic 128 tile
  *   204 / 260 / 261 the same three with bf16 activation storage (inputs / residual are rounded, the result widened back)
+ *   162 / 262 / 166 (r05) modes 4 / 204 / 5 with the 512-pixel x 128-channel halo kernel forced (conv3x3_halo2_kernel; layers with >= 128 output channels),
+ *   163 / 263 / 167 with the 256-pixel halo kernel forced
  *   100 + v: tile variant v of the fp32 kernel (3 = 256x128, 50 = 256x256, 73 = tile-loop kernel for 1x1 layers)
  * splits > 1 forces split-K.  Synchronises `stream`. */
 int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int in_shift,
@@ -45,7 +47,7 @@ int irsde_debug_split_gemm(const float* A, const float* B, float* C, int M, int 
 /* Kernel tuning hook: average ms of one KxK convolution (pad K/2, or 4x4 s2 p1) on random NHWC data.
  * variant: 0 production dispatch, 3 / 50 fp32 256x128 / 256x256 tiles, 5 one block per CU, 6 generic pointer staging instead of
  * buffer descriptors, 7 LDS-transposed instead of direct epilogue, 60 / 61 / 62 bf16 mode (256 tile / 128 tile / automatic
- * incl. the halo kernel), 63 = 62 with bf16 activation storage, 80 / 81 Winograd F(4x4,3x3) fused kernel / three-launch path (3x3 s1 only), 82 the fused kernel once with its
+ * incl. the halo kernel), 63 = 62 with bf16 activation storage, 64 / 65 = 62 and 66 / 67 = 63 with the 512- / 256-pixel halo kernel forced (r05), 80 / 81 Winograd F(4x4,3x3) fused kernel / three-launch path (3x3 s1 only), 82 the fused kernel once with its
  * phase timeline printed to stdout, 400 the 64-cout fused Winograd kernel (r03; 401 / 402: its weight fragments / patch loads read zeros
  * without memory traffic, 403: 12 instead of 18 weight units in flight, 404 / 405: its fp16-pair twin with 12 / 18 units in flight, 406 / 407 / 408: 18 weight units in flight with the non-temporal hint on the epilogue traffic / also on the patch loads / nowhere, 410: 12 units + the epilogue hint (= 400, production)), 412 / 413 the three-launch Winograd layer with split-operand GEMMs (2 / 3
  * bf16 planes on the 128 x 128 plane-major prototype kernel), 421 / 422 / 423 the component GEMMs alone: native f32 / 2 planes / 3 planes, 480 / 481 / 482 a direct layer on the PAIR kernels (fp16 / bf16 pieces / without the 256 x 256 tile), 472 the
