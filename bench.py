@@ -343,6 +343,7 @@ class Workload:
         model.load_state_dict(synth_state_dict(model, 0))
         model = model.to(dev).eval()
         model.set_compute_dtype(w["dtype"])
+        model.engine_flags |= int(w.get("extra_flags") or 0)   # --engine-flags: measurement only (e.g. 8192 = IRSDE_FLAG_NO_NAF_CHAIN, 4096 = IRSDE_FLAG_NO_FUSED_ATTN)
         self.model = model
         max_sigma = w.get("max_sigma")
         max_sigma = max_sigma if max_sigma is not None else {"nafnet": 50, "dsde": 75, "latent": 50}.get(model_kind, 10)
@@ -478,6 +479,7 @@ def main():
                          "the headline metric is fp32")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch images per GPU; strong: one global batch of --batch images split over the GPUs")
+    ap.add_argument("--engine-flags", type=int, default=0, help="measurement only: extra IRSDE_FLAG_* bits for the score network (A/B of plan choices); never part of a reported line's default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the untimed event-instrumented pass (no `roofline` object)")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only")
@@ -543,8 +545,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
-    head = dict(model=a.model, dtype=a.dtype, mode=a.mode, batch=a.batch, size=a.size, T=a.T, max_sigma=a.max_sigma)
-    is_default = (a.model, a.dtype, a.mode, a.batch, a.size, a.T, a.max_sigma, a.scaling) == ("unet", "fp32", "sde", 16, 256, 100, None, "weak")
+    head = dict(model=a.model, dtype=a.dtype, mode=a.mode, batch=a.batch, size=a.size, T=a.T, max_sigma=a.max_sigma, extra_flags=a.engine_flags)
+    is_default = (a.model, a.dtype, a.mode, a.batch, a.size, a.T, a.max_sigma, a.scaling, a.engine_flags) == ("unet", "fp32", "sde", 16, 256, 100, None, "weak", 0)
     t_setup = time.perf_counter()
     wl = Workload(P, head, dev, rank, world, a.scaling)
     wl.short_call(2)          # untimed: weight upload + repack, plan build, graph capture (what 8 simultaneous ranks would contend on)
@@ -578,6 +580,8 @@ def main():
             # per rank: model build + weight upload / repack + plan + graph capture + a 2-step sampler call, before the timed region
             "rank_setup_s": {"min": _r(min(setup_s), 3), "max": _r(max(setup_s), 3)},
         }
+        if a.engine_flags:
+            res["config"]["engine_flags_measurement_only"] = a.engine_flags
         if prof is not None and prof["conv_ms"] > 0:
             r = roofline_object(prof, op_text, head)
             # HBM bytes per conv launch: rocprofv3 PMC passes cannot run inside this process; the figure comes from the
