@@ -271,8 +271,57 @@ def linear_attention(p, prefix, x, heads=4, dim_head=32):
     return layer_norm_c(out, p[prefix + "to_out.1.g"])
 
 
+ATTN_FUSED_16 = False   # restate the engine's fused attention kernels of the 16-bit operand modes (r05, ABI 106) instead of the q | k | v tensor plan
+
+
+class fused_attn_16:
+    """Context manager (inside bf16_convs / f16_convs): Residual(PreNorm(LinearAttention)) blocks with 64 / 128 / 256 channels are restated the way the engine's
+    fused kernels compute them in the 16-bit operand modes (attn_block_fused16): no stored q | k | v / attention-output tensor, the roundings at the MFMA operands."""
+
+    def __enter__(self):
+        global ATTN_FUSED_16
+        self.prev = ATTN_FUSED_16
+        ATTN_FUSED_16 = True
+
+    def __exit__(self, *a):
+        global ATTN_FUSED_16
+        ATTN_FUSED_16 = self.prev
+
+
+def attn_block_fused16(p, prefix, x, f16=False, store_bf16=False, heads=4, dim_head=32):
+    """Residual(PreNorm(LinearAttention)) — module_util.py:20-26,82-90,150-178 — with the roundings of the engine's fused attention kernels in the 16-bit operand modes
+    (image_restoration_sde_amd/csrc/kernels_misc.hip: attn_kv_ctx_kernel / attn_q_out_fused_kernel, MODE 2 = bf16, MODE 3 = fp16; r05).  Rounded once, to nearest even:
+    the LayerNorm output (operand of the three projections), the to_qkv / to_out weights, exp(k - max) and v (operands of the context sum), the merged context and the
+    softmax(q) probabilities (operands of the output product), the attention output (operand of to_out).  Everything else — LayerNorms, both softmaxes, the softmax
+    denominator of k (the UNROUNDED exponentials), every accumulation, bias, residual — in the working precision.  fp16: context and attention output pass the
+    MFMAs scaled by 2^ceil(log2 N) (exact; undone in front of the bias).  store_bf16: x comes from and the result goes to a bf16 tensor (IRSDE_FLAG_BF16_ACT).
+    The kernels take the maximum of k per 128-pixel tile as it runs and merge chunk partials; this restatement uses the global maximum (the difference is rounding
+    noise of individual exponentials, far below the bars of the tests)."""
+    r = round_f16 if f16 else round_bf16
+    B, C, H, W = x.shape
+    N = H * W
+    hid = heads * dim_head
+    xa = r(layer_norm_c(x, p[prefix + "fn.norm.g"])).reshape(B, C, N)
+    wqkv = r(p[prefix + "fn.fn.to_qkv.weight"].reshape(3 * hid, C))
+    qkv = np.einsum("oc,bcn->bon", wqkv, xa)
+    q, k, v = (qkv[:, i * hid:(i + 1) * hid].reshape(B, heads, dim_head, N) for i in range(3))
+    ek = np.exp(k - k.max(axis=3, keepdims=True))
+    z = ek.sum(axis=3)                                                      # [B, heads, d]: unrounded exponentials
+    ctx = np.einsum("bhdn,bhen->bhde", r(ek), r(v)) / z[..., None] / x.dtype.type(N) * x.dtype.type(dim_head ** -0.5)
+    pq = np.exp(q - q.max(axis=2, keepdims=True))
+    pq = pq / pq.sum(axis=2, keepdims=True)
+    up = x.dtype.type(2.0 ** math.ceil(math.log2(N))) if f16 else x.dtype.type(1.0)
+    out = np.einsum("bhde,bhdn->bhen", r(ctx * up), r(pq)).reshape(B, hid, N)
+    wo = r(p[prefix + "fn.fn.to_out.0.weight"].reshape(C, hid))
+    y = np.einsum("co,bon->bcn", wo, r(out)) / up + p[prefix + "fn.fn.to_out.0.bias"].reshape(1, C, 1)
+    y = layer_norm_c(y.reshape(B, C, H, W), p[prefix + "fn.fn.to_out.1.g"]) + x
+    return round_bf16(y) if store_bf16 else y
+
+
 def attn_block(p, prefix, x):
     """Residual(PreNorm(dim, LinearAttention(dim))) — module_util.py:20-26,82-90."""
+    if ATTN_FUSED_16 and (CONV_OPERANDS_BF16 or CONV_OPERANDS_F16) and x.shape[1] in (64, 128, 256) and (prefix + "fn.fn.to_out.1.g") in p:
+        return attn_block_fused16(p, prefix, x, f16=CONV_OPERANDS_F16 and not CONV_OPERANDS_BF16, store_bf16=ACT_STORAGE_BF16)
     return _st(linear_attention(p, prefix + "fn.fn.", _ln_st(x, p[prefix + "fn.norm.g"])) + x)
 
 

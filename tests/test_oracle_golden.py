@@ -333,3 +333,26 @@ def test_latent_bokeh_nafnet_vs_reference(golden):
     net = lambda x, mu, t: O.nafnet_forward(bp, x, mu, t, lens_info=li1, **kw)  # noqa: E731
     x0 = O.sample(bp, sch, g["bokeh/xt"][:1], g["bokeh/cond"][:1], "sde", noise=O.synth_noise(9, T, (1, 4, 12, 10)), net=net)
     assert relerr(x0, g["bokeh/sde"]) < 2e-3
+
+
+def test_fused_attention_16bit_restatement():
+    """O.attn_block_fused16 (the checker of the engine's fused attention kernels in the 16-bit operand modes, r05): stays within the operand-rounding noise of
+    the unrounded block, fp16 closer than bf16, and — with to_out scaled so that the attention core dominates the block — fixes the fp16 tensor plan's
+    loss of the v / N context in fp16's subnormal range (scaled by 2^ceil(log2 N) through the 16-bit products)."""
+    params = O.synth_params(seed=0, nf=64, depth=4)
+    p = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
+    pref, n = "downs.0.2.", 64 * 64
+    p[pref + "fn.fn.to_out.0.weight"] = p[pref + "fn.fn.to_out.0.weight"] * n
+    x = np.random.RandomState(0).standard_normal((1, 64, 64, 64))
+    full = O.attn_block(p, pref, x) - x
+    scale = np.abs(full).max()
+    assert scale > 0.5
+    e_bf = np.abs(O.attn_block_fused16(p, pref, x) - x - full).max() / scale
+    e_f16 = np.abs(O.attn_block_fused16(p, pref, x, f16=True) - x - full).max() / scale
+    with O.f16_convs():
+        e_tensor_f16 = np.abs(O.attn_block(p, pref, x) - x - full).max() / scale
+        with O.fused_attn_16():
+            assert np.array_equal(O.attn_block(p, pref, x), O.attn_block_fused16(p, pref, x, f16=True))
+    assert 1e-5 < e_bf < 2e-3 and e_f16 < e_bf / 4 and e_f16 < e_tensor_f16 / 10, (e_bf, e_f16, e_tensor_f16)
+    st = O.attn_block_fused16(p, pref, O.round_bf16(x), store_bf16=True)
+    assert np.array_equal(st, O.round_bf16(st))
