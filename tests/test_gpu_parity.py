@@ -461,33 +461,35 @@ def test_conv_halo2_kernel(name):
     print("%s: halo2 bf16 %.3g (256-pixel kernel %.3g), fp16 %.3g, bf16 storage max %.3g" % (name, e_new, e_old, e16, float(err.max())))
 
 
-_ATTN16_BLOCKS = {"downs.0.2.": 4096, "downs.1.2.": 1024, "downs.2.2.": 256, "ups.2.2.": 1024, "ups.3.2.": 4096}   # fused levels at 64 x 64: pixels per level
+_ATTN_BLOCK_LEVEL = {"downs.0.2.": 0, "downs.1.2.": 1, "downs.2.2.": 2, "ups.2.2.": 1, "ups.3.2.": 0}   # the fused blocks (C = 64 / 128 / 256) and their resolution level
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16_act", "bf16", "fp16"])
-def test_fused_attention_block_vs_oracle(dtype):
+@pytest.mark.parametrize("dtype,size", [("fp32", (64, 64)), ("fp32", (72, 88)), ("bf16_act", (64, 64)), ("bf16", (64, 64)), ("fp16", (64, 64)), ("fp16", (72, 88))])
+def test_fused_attention_block_vs_oracle(dtype, size):
     """r05: every fused LinearAttention block against the oracle, block by block — fp32 (the headline's kernels) against the float64 block at 5e-5 of the branch, the
     16-bit operand modes (ABI 106) against the oracle's restatement of their roundings (O.attn_block_fused16).  The block's input is read back from the engine (debug
     taps), the oracle computes the block from it in float64.  With the default synthetic weights
     the block's output is dominated by to_out's bias (the context carries v / N: O(1e-4) at 64 x 64), so a wrong attention core would move the result by 1e-6 —
-    here to_out.0.weight is scaled by the level's pixel count, which makes the branch O(1) and every stage of the core visible in it."""
+    here to_out.0.weight is scaled by the level's pixel count, which makes the branch O(1) and every stage of the core visible in it.  72 x 88 (padded to 80 x 96):
+    480 pixels at level 2 = 3.75 tiles of 128, chunk tails that are no multiple of a tile at every level (the masked paths of both kernels)."""
     nf, depth = 64, 4
+    Hp, Wp = -(-size[0] // 16) * 16, -(-size[1] // 16) * 16
     params = dict(O.synth_params(seed=0, nf=nf, depth=depth))
-    for pref, n in _ATTN16_BLOCKS.items():
-        params[pref + "fn.fn.to_out.0.weight"] = params[pref + "fn.fn.to_out.0.weight"] * np.float32(n)
+    for pref, lvl in _ATTN_BLOCK_LEVEL.items():
+        params[pref + "fn.fn.to_out.0.weight"] = params[pref + "fn.fn.to_out.0.weight"] * np.float32((Hp >> lvl) * (Wp >> lvl))
     m = P.ConditionalUNet(3, 3, nf, depth=depth)
     m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()}, strict=True)
     if dtype != "fp32":
         m.set_compute_dtype(dtype)
     m.engine_flags |= _lib.FLAG_KEEP_ACTIVATIONS
     m = m.to(DEV).eval()
-    lq, xT = O.synth_inputs(1234, 1, 64, 64)
+    lq, xT = O.synth_inputs(1234, 1, size[0], size[1])
     m(torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV), 50)
     buf = ctypes.create_string_buffer(1 << 16)
-    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 1, 64, 64, buf, len(buf)))
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 1, size[0], size[1], buf, len(buf)))
     assert buf.value.count(b"+ context (fused)") == 5 and buf.value.count(b"+ residual (fused)") == 5
     p64 = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
-    for pref in _ATTN16_BLOCKS:
+    for pref in _ATTN_BLOCK_LEVEL:
         xin = m.debug_tap(pref[:-3] + ".1").numpy().astype(np.float64)
         got = m.debug_tap(pref[:-1]).numpy().astype(np.float64)
         full = O.attn_block(p64, pref, xin)
