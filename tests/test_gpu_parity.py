@@ -462,6 +462,7 @@ def test_conv_halo2_kernel(name):
 
 
 _ATTN_BLOCK_LEVEL = {"downs.0.2.": 0, "downs.1.2.": 1, "downs.2.2.": 2, "ups.2.2.": 1, "ups.3.2.": 0}   # the fused blocks (C = 64 / 128 / 256) and their resolution level
+_ATTN_BLOCK_LEVEL_DEEP = {"downs.3.2.": 3, "mid_attn.": 3, "ups.0.2.": 3, "ups.1.2.": 2}                # C = 512 / 1024: to_qkv conv + attention kernels + to_out conv (+ LayerNorm)
 
 
 @pytest.mark.parametrize("dtype,size", [("fp32", (64, 64)), ("fp32", (72, 88)), ("bf16_act", (64, 64)), ("bf16", (64, 64)), ("fp16", (64, 64)), ("fp16", (72, 88))])
@@ -475,7 +476,10 @@ def test_fused_attention_block_vs_oracle(dtype, size):
     nf, depth = 64, 4
     Hp, Wp = -(-size[0] // 16) * 16, -(-size[1] // 16) * 16
     params = dict(O.synth_params(seed=0, nf=nf, depth=depth))
-    for pref, lvl in _ATTN_BLOCK_LEVEL.items():
+    blocks = dict(_ATTN_BLOCK_LEVEL)
+    if dtype == "fp32":
+        blocks.update(_ATTN_BLOCK_LEVEL_DEEP)   # the q | k | v tensor path of the deep levels against the same oracle
+    for pref, lvl in blocks.items():
         params[pref + "fn.fn.to_out.0.weight"] = params[pref + "fn.fn.to_out.0.weight"] * np.float32((Hp >> lvl) * (Wp >> lvl))
     m = P.ConditionalUNet(3, 3, nf, depth=depth)
     m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()}, strict=True)
@@ -489,8 +493,8 @@ def test_fused_attention_block_vs_oracle(dtype, size):
     _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 1, size[0], size[1], buf, len(buf)))
     assert buf.value.count(b"+ context (fused)") == 5 and buf.value.count(b"+ residual (fused)") == 5
     p64 = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
-    for pref in _ATTN_BLOCK_LEVEL:
-        xin = m.debug_tap(pref[:-3] + ".1").numpy().astype(np.float64)
+    for pref in blocks:
+        xin = m.debug_tap("mid_block1" if pref == "mid_attn." else pref[:-3] + ".1").numpy().astype(np.float64)
         got = m.debug_tap(pref[:-1]).numpy().astype(np.float64)
         full = O.attn_block(p64, pref, xin)
         ref = full if dtype == "fp32" else O.attn_block_fused16(p64, pref, xin, f16=dtype == "fp16", store_bf16=dtype == "bf16_act")
