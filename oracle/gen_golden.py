@@ -154,6 +154,40 @@ def gen_forward(sde_utils, ConditionalUNet):
     print("forward.npz")
 
 
+def gen_forward_attn(sde_utils, ConditionalUNet):
+    """r05: forwards of the REAL reference with attention-sensitive weights (O.attn_sensitive_params: to_out.0.weight of every LinearAttention block scaled by the
+    pixel count of its level, so that softmax / context / output product carry the block instead of to_out's bias), plus the input and output of two
+    Residual(PreNorm(LinearAttention)) modules captured by forward hooks: pins the oracle's attention restatement and the engine's attention kernels to the reference."""
+    out = {}
+    cases = {"nf64d4_1x64x64": (64, 4, 1, 64, 64, 50), "nf64d4_2x40x56": (64, 4, 2, 40, 56, 37), "nf64d4_1x32x32": (64, 4, 1, 32, 32, 77)}
+    for tag, (nf, depth, B, H, W, t) in cases.items():
+        params = O.attn_sensitive_params(O.synth_params(seed=0, nf=nf, depth=depth), H, W, depth)
+        net = build_ref_net(ConditionalUNet, params, nf, depth)
+        lq, xT = O.synth_inputs(1234, B, H, W)
+        caught = {}
+
+        def hook(name):
+            def f(mod, inp, outp):
+                caught[name + "/in"] = inp[0].detach().numpy().copy()
+                caught[name + "/out"] = outp.detach().numpy().copy()
+            return f
+        hs = []
+        if tag == "nf64d4_1x32x32":   # (the small case only: the fixtures stay small)
+            hs = [net.downs[0][2].register_forward_hook(hook("downs.0.2")), net.downs[2][2].register_forward_hook(hook("downs.2.2")),
+                  net.mid_attn.register_forward_hook(hook("mid_attn"))]
+        with torch.no_grad():
+            y = net(torch.from_numpy(xT), torch.from_numpy(lq), t).numpy()
+        for h in hs:
+            h.remove()
+        out[tag + "/cfg"] = np.array([nf, depth, B, H, W, t], dtype=np.int64)
+        out[tag + "/y"] = y
+        for k, v in caught.items():
+            out[tag + "/" + k] = v
+        print(tag, float(np.abs(y).max()), {k: v.shape for k, v in caught.items()})
+    np.savez_compressed(os.path.join(GOLD, "forward_attn.npz"), **out)
+    print("forward_attn.npz")
+
+
 def gen_steps(sde_utils):
     """Teacher-forced single reverse steps (elementwise part only) for the 3 samplers."""
     Inj = InjectedIRSDE.make(sde_utils)
@@ -645,6 +679,8 @@ def main():
         gen_schedule(sde_utils)
     if a.only in ("", "forward"):
         gen_forward(sde_utils, ConditionalUNet)
+    if a.only in ("", "forward_attn"):
+        gen_forward_attn(sde_utils, ConditionalUNet)
     if a.only in ("", "steps"):
         gen_steps(sde_utils)
     if a.only in ("", "sampler"):

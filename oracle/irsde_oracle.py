@@ -325,6 +325,23 @@ def attn_block(p, prefix, x):
     return _st(linear_attention(p, prefix + "fn.fn.", _ln_st(x, p[prefix + "fn.norm.g"])) + x)
 
 
+def attn_sensitive_params(params, H, W, depth=4):
+    """Test weights under which the LinearAttention blocks matter (r05).  With default-initialised weights a block's output is dominated by to_out's bias: the
+    context carries v / (h w) (module_util.py:168), so to_out(out) is ~1e-6 of the bias in front of the LayerNorm and a wrong attention core moves a network output
+    by ~1e-6.  Scaling every block's to_out.0.weight by the pixel count of its level makes the attention branch O(1).  H, W: the input size (padded up to a
+    multiple of 2^depth as ConditionalUNet.check_image_size does).  Returns a new dict."""
+    s = 2 ** depth
+    Hp, Wp = -(-H // s) * s, -(-W // s) * s
+    out = dict(params)
+    levels = {"downs.%d.2." % i: i for i in range(depth)}
+    levels.update({"ups.%d.2." % j: depth - 1 - j for j in range(depth)})
+    levels["mid_attn."] = depth - 1
+    for pref, lvl in levels.items():
+        k = pref + "fn.fn.to_out.0.weight"
+        out[k] = (np.asarray(params[k]) * np.asarray(params[k]).dtype.type((Hp >> lvl) * (Wp >> lvl)))
+    return out
+
+
 def res_block(p, prefix, x, temb):
     """ResBlock.forward — module_util.py:136-146 (Block :108-122)."""
     ss = linear(silu(temb), p[prefix + "mlp.1.weight"], p[prefix + "mlp.1.bias"])  # [b, 2C]

@@ -461,6 +461,24 @@ def test_conv_halo2_kernel(name):
     print("%s: halo2 bf16 %.3g (256-pixel kernel %.3g), fp16 %.3g, bf16 storage max %.3g" % (name, e_new, e_old, e16, float(err.max())))
 
 
+@pytest.mark.parametrize("tag", ["nf64d4_1x32x32", "nf64d4_1x64x64", "nf64d4_2x40x56"])
+def test_unet_forward_attention_sensitive_vs_reference(golden, tag):
+    """r05: ConditionalUNet.forward against the REAL reference with attention-sensitive weights (tests/golden/forward_attn.npz; O.attn_sensitive_params: the network
+    output moves by 0.4 of its maximum when the LinearAttention branches change — with the default synthetic weights it moves by 1e-6).  fp32 engine, all nine
+    attention blocks (fused kernels at 64 / 128 / 256 channels, the q | k | v tensor path below), incl. the reflect-padded 40 x 56 case."""
+    g = golden.forward_attn
+    nf, depth, B, H, W, t = (int(v) for v in g[tag + "/cfg"])
+    params = O.attn_sensitive_params(O.synth_params(seed=0, nf=nf, depth=depth), H, W, depth)
+    m = P.ConditionalUNet(3, 3, nf, depth=depth)
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()}, strict=True)
+    m = m.to(DEV).eval()
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    y = m(torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV), t).cpu().numpy()
+    e = relerr(y, g[tag + "/y"])
+    print("attention-sensitive forward %s vs the reference: %.3g" % (tag, e))
+    assert e < 1e-4
+
+
 _ATTN_BLOCK_LEVEL = {"downs.0.2.": 0, "downs.1.2.": 1, "downs.2.2.": 2, "ups.2.2.": 1, "ups.3.2.": 0}   # the fused blocks (C = 64 / 128 / 256) and their resolution level
 _ATTN_BLOCK_LEVEL_DEEP = {"downs.3.2.": 3, "mid_attn.": 3, "ups.0.2.": 3, "ups.1.2.": 2}                # C = 512 / 1024: to_qkv conv + attention kernels + to_out conv (+ LayerNorm)
 

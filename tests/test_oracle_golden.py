@@ -356,3 +356,27 @@ def test_fused_attention_16bit_restatement():
     assert 1e-5 < e_bf < 2e-3 and e_f16 < e_bf / 4 and e_f16 < e_tensor_f16 / 10, (e_bf, e_f16, e_tensor_f16)
     st = O.attn_block_fused16(p, pref, O.round_bf16(x), store_bf16=True)
     assert np.array_equal(st, O.round_bf16(st))
+
+
+@pytest.mark.parametrize("tag", ["nf64d4_1x32x32", "nf64d4_1x64x64", "nf64d4_2x40x56"])
+def test_unet_forward_attention_sensitive(golden, tag):
+    """r05: the REAL reference with attention-sensitive weights (O.attn_sensitive_params; oracle/gen_golden.py::gen_forward_attn).  With the default synthetic
+    weights to_out's bias dominates every LinearAttention block and the other forward goldens would not notice a wrong softmax / context / output product; here
+    the network output moves by 0.4 - 0.46 of its maximum when the attention branches change, and the oracle follows the reference to 1e-6 — whole network and, for
+    the small case, block by block on the reference's own block inputs (forward hooks)."""
+    g = golden.forward_attn
+    nf, depth, B, H, W, t = (int(v) for v in g[tag + "/cfg"])
+    base = O.synth_params(seed=0, nf=nf, depth=depth)
+    params = O.attn_sensitive_params(base, H, W, depth)
+    lq, xT = O.synth_inputs(1234, B, H, W)
+    ref = g[tag + "/y"]
+    y = O.unet_forward(params, xT, lq, t, depth=depth, dtype=np.float64)
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-5
+    if tag == "nf64d4_1x32x32":
+        y0 = O.unet_forward(base, xT, lq, t, depth=depth, dtype=np.float64)
+        assert np.abs(y0 - ref).max() / np.abs(ref).max() > 0.1          # the fixture is attention-sensitive
+        p = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
+        for name in ("downs.0.2", "downs.2.2", "mid_attn"):
+            x, out = g[tag + "/" + name + "/in"].astype(np.float64), g[tag + "/" + name + "/out"].astype(np.float64)
+            branch = np.abs(out - x).max()
+            assert branch > 0.5 and np.abs(O.attn_block(p, name + ".", x) - out).max() / branch < 1e-5, name
