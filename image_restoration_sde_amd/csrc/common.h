@@ -182,6 +182,7 @@ void conv_global_init();
 // bf16 mode: 3x3 s1 p1 layers with an LDS-resident halo tile (conv_halo.hip)
 void conv_halo_global_init();
 bool conv_halo_eligible(const ConvParams& p);
+bool conv_halo2_wanted(const ConvParams& p, int force);   // true: launch_conv_halo runs the layer on the 512-pixel x 128-channel kernel (irsde_plan_describe names it)
 void launch_conv_halo(const ConvParams& p, hipStream_t s, int force_halo2 = 0);   // force_halo2: 1 = the 512-pixel x 128-channel kernel, -1 = the 256-pixel one, 0 = by shape
 void conv_set_variant(int v);  // tuning experiments (irsde_bench_conv)
 void launch_fill_random(float* p, size_t n, unsigned seed, float scale, hipStream_t s);  // sets the dynamic-LDS attribute of every tile configuration (call before graph capture)

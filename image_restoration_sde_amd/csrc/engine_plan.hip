@@ -78,6 +78,8 @@ struct Builder {
             snprintf(buf, sizeof buf, "conv%s M=%d Cout=%d Cin=%d k=%dx%d s=%d up=%d splits=%d blocks=%d flops=%.4g",
                      p.w_pair ? (p.f16 ? "(split f16x2)" : "(split bf16x2)") : p.w_bf ? (p.f16 ? "(fp16)" : "(bf16)") : "", M, p.Cout, p.C0 + p.C1, p.KH, p.KW, p.stride, p.in_shift, splits, blocks, op.flops);
             op.desc = buf;
+            // r06: which 3x3 kernel a 16-bit layer runs on (launch_conv's own choice, conv_igemm.hip) — the plan tests pin the benchmarked plan's kernel mix with it
+            if (!naive && p.w_bf && conv_halo_eligible(p)) op.desc += conv_halo2_wanted(p, 0) ? " kernel=halo512" : " kernel=halo256";
         }
         const bool nv = naive;
         op.fn = [p, nv](hipStream_t s) {

@@ -218,6 +218,42 @@ def test_latent_pipeline_256_all_fp16(golden):
 # ---------------------------------------------------------------------------------------------
 # production plan: batch independence, reduced precision at 256x256
 # ---------------------------------------------------------------------------------------------
+def test_configs2_batch16_bf16_act_plan(golden):
+    """r06 (VERDICT r05 weak #1b / next #1 ii): BASELINE configs[2] AS BENCHMARKED — B = 16, 256 x 256, bf16_act.  That plan differs from the B = 1 plan the
+    other reduced-precision tests run: conv3x3_halo2_kernel (the 512-pixel x 128-channel kernel) takes the layers with >= 256 blocks, the fused 16-bit attention
+    kernels run 16 images wide.  (a) irsde_plan_describe names both; (b) one evaluation of the batch, slot 0 = the golden's inputs, against the fp32 engine at the
+    B = 1 tolerance (_ATTN16_TOL) and against the B = 1 bf16_act plan on the same image; (c) T = 100 reverse_ode of the batch (sde_utils.py:268-282), slot 0 against
+    the REAL reference's ODE golden (fullres2.npz) at _ODE_T100_TOL."""
+    m = _fresh_unet64("bf16_act")
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 16, 256, 256, buf, len(buf)))
+    d = buf.value
+    assert d.count(b"kernel=halo512") >= 8 and d.count(b"kernel=halo256") >= 8, d.decode()
+    assert d.count(b"k,v projection (bf16 operands + storage)") == 5 and d.count(b"q projection (bf16 operands + storage)") == 5
+    _lib.check(_lib.lib().irsde_plan_describe(m.engine().h, 1, 256, 256, buf, len(buf)))
+    n1 = buf.value.count(b"kernel=halo512")
+    assert n1 < d.count(b"kernel=halo512")   # the B = 1 plan the other tests pin really is a different kernel mix
+    lq, xT = O.synth_inputs(77, 16, 256, 256)
+    lq1, xT1 = O.synth_inputs(1234, 1, 256, 256)
+    lq[0], xT[0] = lq1[0], xT1[0]
+    x, c = torch.from_numpy(xT).to(DEV), torch.from_numpy(lq).to(DEV)
+    y16 = m(x, c, 50).cpu().numpy()
+    y32 = unet64()(x[0:1], c[0:1], 50).cpu().numpy()
+    y1 = m(x[0:1], c[0:1], 50).cpu().numpy()
+    e32, e1, eref = relerr(y16[0:1], y32), relerr(y16[0:1], y1), relerr(y16[0:1], golden.fullres["unet_1x256x256/t50"])
+    print("configs[2] plan (B=16 bf16_act), one evaluation, slot 0: vs fp32 engine %.3g, vs the B=1 bf16_act plan %.3g, vs the reference %.3g; halo512 rows %d (B=1: %d)"
+          % (e32, e1, eref, d.count(b"kernel=halo512"), n1))
+    assert np.isfinite(y16).all() and 0 < e32 < _ATTN16_TOL["bf16_act"] and eref < _ATTN16_TOL["bf16_act"] and e1 < _ATTN16_TOL["bf16_act"]
+    sde = P.IRSDE(10, 100, "cosine", 0.005, device=DEV)
+    sde.set_model(m)
+    sde.set_mu(c)
+    y = sde.reverse_ode(x).cpu().numpy()
+    ref = golden.fullres2["unet_1x256x256/sampler_ode"]
+    e = relerr(y[0:1], ref)
+    print("configs[2] plan (B=16 bf16_act), T=100 reverse_ode, slot 0 vs the reference golden: %.3g (max-abs %.3g)" % (e, float(np.abs(y[0:1] - ref).max())))
+    assert np.isfinite(y).all() and e < _ODE_T100_TOL["bf16_act"]
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_batch16_256_equals_single_images(prec):
     """The plan at B=16 256x256 (tile-loop component GEMMs, 1x1 tile-loop path, 256-wide tiles) differs from the B=1 plan
