@@ -166,6 +166,13 @@ void launch_wino_fused64_split_weights(const float* Uf, unsigned short* out, siz
 int wino_fused64_num_blocks(const ConvParams& p);
 bool wino_fused64_xcd_nb(const ConvParams& p);   // the launch maps cout blocks to XCDs (layers whose input is small next to U x rounds)
 void wino_fused_global_init();
+// r06: 32 tiles x 64 couts per work item, every weight fragment feeds two tile groups (wino_fused_t.hip); weights = wino_fused64_pack_weights order
+bool wino_fused64t_eligible(const ConvParams& p);
+long long wino_fused64t_num_items(const ConvParams& p);
+void launch_wino_fused64t(const ConvParams& p, const float* Uf, hipStream_t s, int variant = 0);
+void wino_fused64t_set_debug(unsigned long long* buf);   // stamp buffer of launch variant 5
+void wino_fused64t_set_skew(int cycles);                 // tuning: start skew per phase class
+void wino_fused_t_global_init();
 // fused NAFBlock chain (naf_chain.hip): consecutive 512-channel NAFBlocks on an 8 x 8 feature map, one work-group per image
 void naf_chain_global_init();
 void naf_chain_set_debug(unsigned long long* buf);   // stamp buffer of launch variant 11: [B][8 waves][16]

@@ -1300,6 +1300,7 @@ void conv_set_variant(int v) { g_variant = v; }
 void conv_global_init() {
     conv_halo_global_init();
     wino_fused_global_init();
+    wino_fused_t_global_init();
     naf_chain_global_init();
     attention_global_init();
     gemm_split_global_init();

@@ -658,7 +658,7 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             launch_wino_fused64(p, reinterpret_cast<const float*>(dUp), s, naive == 61 ? 52 : naive == 58 ? 44 : naive == 56 ? 24 : naive == 39 ? 9 : naive == 37 ? 4 + 64 : 4);   // 37: + cout block by XCD where legal; 39: r03's one-block-per-tile-group kernel
             IRSDE_HIP_CHECK(hipStreamSynchronize(s));
             (void)hipFree(dUf); (void)hipFree(dUp);
-        } else if (naive == 33 || naive == 34 || naive == 36 || naive == 38 || (naive >= 50 && naive <= 55) || naive == 57 || naive == 60) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
+        } else if (naive == 33 || naive == 34 || naive == 36 || naive == 38 || (naive >= 50 && naive <= 55) || naive == 57 || naive == 60 || naive == 62 || naive == 63) {  // fused Winograd F(4x4,3x3) kernels (wino_fused.hip): 33 = 32 couts per block, 34 = 64
             if (naive == 33 ? !wino_fused_eligible(p) : !wino_fused64_eligible(p)) throw HipError("debug_conv: shape not eligible for the fused Winograd kernel");
             std::vector<float> U((size_t)36 * Cout * Cin), Uf((size_t)36 * Cout * Cin);
             wino_transform_weights(pk.data(), Cout, Cin, U.data(), 4);
@@ -667,6 +667,10 @@ int irsde_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, 
             float* dUf = nullptr;
             IRSDE_HIP_CHECK(hipMalloc(&dUf, Uf.size() * 4));
             IRSDE_HIP_CHECK(hipMemcpy(dUf, Uf.data(), Uf.size() * 4, hipMemcpyHostToDevice));
+            if (naive == 62 || naive == 63) {   // r06: the two-tile-group kernel (wino_fused_t.hip; 63: + cout block by XCD where legal)
+                if (!wino_fused64t_eligible(p)) throw HipError("debug_conv: shape not eligible for the two-tile-group fused Winograd kernel");
+                launch_wino_fused64t(p, dUf, s, naive == 63 ? 64 : 0);
+            } else
             if (naive == 33) launch_wino_fused(p, dUf, s);
             else if (naive == 60) launch_wino_fused64(p, dUf, s, 48);   // r04's single-stream kernel (61: its fp16-pair twin)
             else if (naive == 55 || naive == 57) launch_wino_fused64(p, dUf, s, naive == 55 ? 20 : 40);   // the register-patch persistent kernel at fixed grid sizes (it IS production: launch_wino_fused64 defaults to persist = 1)
@@ -971,7 +975,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
         const bool split_v = variant == 412 || variant == 413 || variant == 422 || variant == 423;  // split-operand GEMMs: 41x whole three-launch layer, 42x the GEMM alone; x = planes
         unsigned short *dUs = nullptr, *dVs = nullptr;
         WinoSplitPlan sp{};
-        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410) || (variant >= 430 && variant <= 435) || (variant >= 440 && variant <= 454) || (variant >= 1000 && variant < 1064) || (variant >= 2000 && variant <= 2004) || (variant >= 2010 && variant <= 2012) || variant == 2020) {
+        if (variant == 80 || variant == 81 || variant == 421 || split_v || (variant >= 83 && variant <= 82 + 255) || (variant >= 400 && variant <= 410) || (variant >= 430 && variant <= 435) || (variant >= 440 && variant <= 454) || (variant >= 460 && variant <= 469) || (variant >= 4610 && variant <= 4613) || (variant >= 4650 && variant <= 4653) || (variant >= 4700 && variant < 4800) || (variant >= 1000 && variant < 1064) || (variant >= 2000 && variant <= 2004) || (variant >= 2010 && variant <= 2012) || variant == 2020) {
             if (K != 3 || stride != 1) throw HipError("bench_conv: Winograd variants need a 3x3 stride-1 layer");
             IRSDE_HIP_CHECK(hipMalloc(&dU, (size_t)36 * nw / 9 * 4));
             launch_fill_random(dU, (size_t)36 * nw / 9, 5, 1.0f / sqrtf((float)(9 * Cin)), s);
@@ -1035,6 +1039,45 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
                    ph[0][1], ph[0][2], ph[0][3]);
             printf("  producer waves (shader cycles): start->chunk 0 done %.0f | K loop rest %.0f | wait MFMA+acc %.0f | epilogue %.0f\n",
                    ph[1][0], ph[1][1], ph[1][2], ph[1][3]);
+            fflush(stdout);
+            (void)hipFree(dd);
+            (void)hipFree(dU);
+            dU = nullptr;
+            *ms_out = 0.0;
+            (void)hipFree(din); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dfilm);
+            (void)hipStreamDestroy(s);
+            return;
+        }
+        if (variant == 465 || (variant >= 4650 && variant <= 4653)) {   // r06: the two-tile-group kernel once with per-wave cycle stamps (4650 / 4651 / 4652: no patch traffic / output stores dropped / residual loads dropped)
+            if (!wino_fused64t_eligible(p)) throw HipError("bench_conv: shape not eligible for the two-tile-group fused Winograd kernel");
+            const int nbp = 256;
+            unsigned long long* dd = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dd, (size_t)nbp * 64 * 8));
+            launch_wino_fused64t(p, dU, s, 0);  // warm
+            IRSDE_HIP_CHECK(hipMemsetAsync(dd, 0, (size_t)nbp * 64 * 8, s));
+            wino_fused64t_set_debug(dd);
+            launch_wino_fused64t(p, dU, s, variant == 465 ? 5 : 12 + (variant - 4650));
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            wino_fused64t_set_debug(nullptr);
+            std::vector<unsigned long long> hd((size_t)nbp * 64);
+            IRSDE_HIP_CHECK(hipMemcpy(hd.data(), dd, hd.size() * 8, hipMemcpyDeviceToHost));
+            double a5[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int nwv = 0;
+            for (int bi = 0; bi < nbp; ++bi)
+                for (int w = 0; w < 8; ++w) {
+                    const unsigned long long* t = &hd[((size_t)bi * 8 + w) * 8];
+                    if (!t[3]) continue;
+                    for (int k = 0; k < 8; ++k) a5[k] += (double)t[k];
+                    nwv++;
+                }
+            const int nst = Cin / 16;
+            const double items = a5[4] / std::max(nwv, 1), chunks = items * nst;
+            printf("wino4_fused64t stamps B=%d %dx%d Cin=%d Cout=%d: %.1f items x %d chunks of 16 channels per block; shader cycles per wave (mean over %d waves)\n", B, p.Ho, p.Wo, Cin,
+                   Cout, items, nst, nwv);
+            printf("  kernel %.0f = K loops incl. transform slices %.0f (%.0f per chunk; MFMA floor per SIMD 9216) + chunk barrier waits %.0f (%.0f per chunk) + epilogue, exchange, first-chunk transform %.0f (%.0f per item)\n",
+                   a5[3] / nwv, a5[0] / nwv, a5[0] / nwv / chunks, a5[1] / nwv, a5[1] / nwv / chunks, (a5[2] + a5[5] + a5[6] + a5[7]) / nwv, (a5[2] + a5[5] + a5[6] + a5[7]) / nwv / items);
+            printf("  per item: first stage + exchange writes + ring %.0f | exchange barriers + reads %.0f | second stage, stores, gathers %.0f | zero, first-chunk transform, barrier %.0f\n",
+                   a5[5] / nwv / items, a5[6] / nwv / items, a5[7] / nwv / items, a5[2] / nwv / items);
             fflush(stdout);
             (void)hipFree(dd);
             (void)hipFree(dU);
@@ -1130,6 +1173,18 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
             } else if (variant >= 400 && variant <= 410) {  // 406 / 407 / 408: non-temporal epilogue traffic / + patch loads / no hint at all
                  // 64-cout fused Winograd kernel: 400 production, 401 no weight traffic, 402 no patch traffic, 403 short U ring, 404 / 405 fp16 pairs (ring 12 / 18)
                 launch_wino_fused64(p, dU, s, variant - 400);
+            } else if (variant >= 4700 && variant < 4800) {  // r06 tuning: the two-tile-group kernel with a start skew of (variant - 4700) x 1000 cycles per phase class
+                wino_fused64t_set_skew((variant - 4700) * 1000);
+                launch_wino_fused64t(p, dU, s, 0);
+                wino_fused64t_set_skew(0);
+            } else if (variant == 4613) {   // the residual tile gathered into registers instead of through LDS (residual layers)
+                launch_wino_fused64t(p, dU, s, 16);
+            } else if (variant >= 4610 && variant <= 4612) {  // 8-byte twins of the two-tile-group kernel: 4610 residual loads, 4611 output stores, 4612 weight units
+                launch_wino_fused64t(p, dU, s, variant - 4601);
+            } else if (variant >= 466 && variant <= 469) {  // 466 no non-temporal hint; 467 / 468 / 469 measurement twins: no transform arithmetic / + no gathers / no gathers only
+                launch_wino_fused64t(p, dU, s, variant == 466 ? 4 : variant - 461);
+            } else if (variant >= 460 && variant <= 463) {  // r06 two-tile-group kernel: 460 production, 461 / 462 weight fragments / patch gathers read zeros, 463 three weight units in flight
+                launch_wino_fused64t(p, dU, s, variant - 460);
             } else if (variant >= 448 && variant <= 454) {  // r04 single-stream kernel: 448 f32, 450 patch loads read zeros, 452 fp16 pairs; 449 / 451 / 454 measurement twins
                 launch_wino_fused64(p, dU, s, variant - 400);
             } else if (variant >= 440 && variant <= 444) {  // r04 halo kernel: 440 production, 441 / 442 weight fragments / halo fetches read zeros, 444 fp16 pairs

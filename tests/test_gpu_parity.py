@@ -281,6 +281,42 @@ def test_conv_wino_fused64_kernel_generations(shape):
         run_conv(*args, naive=38, film_bstride=fb)
 
 
+FUSED64T_SHAPES = [(3, 64, 0, 36, 44, 64, 0), (2, 32, 32, 8, 12, 128, 1), (1, 128, 64, 20, 28, 128, 0), (5, 96, 32, 4, 4, 192, 0), (1, 256, 0, 16, 16, 64, 1),
+                   (2, 64, 0, 64, 64, 64, 0), (3, 64, 0, 96, 128, 128, 0), (6, 32, 32, 32, 32, 192, 1), (6, 64, 64, 96, 128, 64, 0), (4, 64, 0, 16, 32, 512, 0)]
+
+
+@pytest.mark.parametrize("shape", FUSED64T_SHAPES)
+def test_conv_wino_fused64t(shape):
+    """r06: wino4_fused64t_kernel (csrc/wino_fused_t.hip; module_util.py:108-122) — 32 tiles x 64 couts per work item, every weight fragment feeds two tile groups,
+    the input transform inside the matrix waves (half patches + v_permlane32_swap), the second stage of the output transform across two waves through LDS.
+    Ragged 4 x 8 tile groups (tile columns 11 / 3 / 7 / 1 of 8), concat sources on a 32-channel boundary, the fused upsample, per-sample FiLM rows, bias + SiLU +
+    residual, 4 .. 16 chunks, more work items than CUs (persistent rounds) and fewer.  Against the float64 oracle at the F(4x4) bar, and — same operations in the
+    same order — BIT-IDENTICAL to the production kernel wino4_fused64p_kernel (34); the cout-block-by-XCD item map (63) bit-identical to the default one."""
+    B, C0, C1, H, W, Cout, up = shape
+    rs = np.random.RandomState(B * 131 + Cout + H)
+    x0 = rs.standard_normal((B, C0, H, W)).astype(np.float32)
+    x1 = rs.standard_normal((B, C1, H, W)).astype(np.float32) if C1 else None
+    w = (rs.standard_normal((Cout, C0 + C1, 3, 3)) / np.sqrt((C0 + C1) * 9)).astype(np.float32)
+    bias = rs.standard_normal(Cout).astype(np.float32)
+    film = (0.3 * rs.standard_normal((B, 2 * Cout))).astype(np.float32)
+    res = rs.standard_normal((B, Cout, H << up, W << up)).astype(np.float32)
+    fb = 2 * Cout
+    for args in ((x0, x1, w, bias, 1, 1, up, film, 1, res), (x0, x1, w, None, 1, 1, up, None, 0, None), (x0, x1, w, bias, 1, 1, up, None, 0, res),
+                 (x0, x1, w, None, 1, 1, up, film, 1, None)):
+        kw = {"film_bstride": fb} if args[7] is not None else {}
+        ref = oracle_conv(*args, **kw)
+        got = run_conv(*args, naive=62, **kw)
+        assert got.shape == ref.shape and np.isfinite(got).all()
+        e = relerr(got, ref)
+        prod = run_conv(*args, naive=34, **kw)
+        same = np.array_equal(got, prod)
+        print("fused64t %s silu=%d res=%d: vs oracle %.3g, bit-identical to wino4_fused64p_kernel: %s (max diff %.3g)"
+              % (shape, args[8], args[9] is not None, e, same, float(np.abs(got - prod).max())))
+        assert e < 5e-5, shape
+        assert same, shape
+        assert np.array_equal(got, run_conv(*args, naive=63, **kw)), shape
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 0, 32, 32, 128, 0), (1, 64, 64, 16, 16, 256, 1), (4, 64, 0, 16, 32, 512, 0), (3, 64, 0, 16, 16, 128, 0)])
 def test_conv_wino_fused64_xcd_mapping(shape):
     """wino4_fused64_kernel with cout block = XCD % NB (NB = 2 / 4 / 8; the last shape has 3 x 16 tile groups... an odd count the mapping

@@ -8,7 +8,7 @@ acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values
 dur = defaultdict(list)
 for path in sys.argv[2:]:
     for r in csv.DictReader(open(path)):
-        m = re.search(r"(wino4_fused(?:64[phs]?)?_kernel)<([^>]*)>", r["Kernel_Name"])
+        m = re.search(r"(wino4_fused(?:64[phst]?)?_kernel)<([^>]*)>", r["Kernel_Name"])
         if not m:
             continue
         k = m.group(1) + "<" + m.group(2).replace(" ", "") + "> grid " + r.get("Grid_Size", "?")
