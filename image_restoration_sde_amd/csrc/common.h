@@ -166,6 +166,7 @@ void launch_wino_fused64_split_weights(const float* Uf, unsigned short* out, siz
 int wino_fused64_num_blocks(const ConvParams& p);
 bool wino_fused64_xcd_nb(const ConvParams& p);   // the launch maps cout blocks to XCDs (layers whose input is small next to U x rounds)
 void wino_fused_global_init();
+int device_cu_count();   // compute units of the CURRENT device, cached per device ordinal (conv_igemm.hip)
 // r06: 32 tiles x 64 couts per work item, every weight fragment feeds two tile groups (wino_fused_t.hip); weights = wino_fused64_pack_weights order
 bool wino_fused64t_eligible(const ConvParams& p);
 long long wino_fused64t_num_items(const ConvParams& p);

@@ -29,6 +29,8 @@
 // 16-byte accesses, 512 contiguous bytes per output pixel row of a 128-wide tile.
 #include "common.h"
 #include <type_traits>
+#include <mutex>
+#include <vector>
 
 namespace irsde {
 
@@ -1260,8 +1262,9 @@ bool zloop_small_m(const ConvParams& p) {
     static const int cutoff = tuning_env_int("IRSDE_ZLOOP_RAGGED64", 2048);
     if (cutoff <= 0 || b128 >= cutoff) return false;
     const long long b64 = (long long)((p.Wo + 63) / 64) * ((p.Cout + 127) / 128) * p.nz;
-    const double e128 = (double)b128 / (512.0 * (double)((b128 + 511) / 512));
-    const double e64 = 0.93 * (double)b64 / (512.0 * (double)((b64 + 511) / 512));
+    const long long slots = 2ll * device_cu_count();   // resident block slots: two 256-thread blocks per CU
+    const double e128 = (double)b128 / ((double)slots * (double)((b128 + slots - 1) / slots));
+    const double e64 = 0.93 * (double)b64 / ((double)slots * (double)((b64 + slots - 1) / slots));
     return e64 > e128;
 }
 
@@ -1296,6 +1299,22 @@ int zloop_batch(const ConvParams& p) {
 }  // namespace
 
 void conv_set_variant(int v) { g_variant = v; }
+
+// CU count of the CURRENT device, cached per device ordinal (a process may hold parts with different CU counts)
+int device_cu_count() {
+    static std::mutex mu;
+    static std::vector<int> cache;
+    int dev = 0;
+    IRSDE_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)cache.size() <= dev) cache.resize(dev + 1, 0);
+    if (cache[dev] == 0) {
+        int n = 0;
+        IRSDE_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        cache[dev] = n > 0 ? n : 256;
+    }
+    return cache[dev];
+}
 
 void conv_global_init() {
     conv_halo_global_init();

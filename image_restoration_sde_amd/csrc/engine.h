@@ -38,6 +38,8 @@ inline bool wino_fused64_pair_enabled() { return tuning_env_int("IRSDE_WINO_FUSE
 inline int wino_fused64_max_cin() { return tuning_env_int("IRSDE_WINO_FUSED64_MAXCIN", 512); }
 inline int wino_fused64_max_cout() { return tuning_env_int("IRSDE_WINO_FUSED64_MAXCOUT", 512); }
 inline long long wino_fused64_min_tiles() { return tuning_env_int("IRSDE_WINO_FUSED64_MINT", 1024); }
+// r06: the two-tile-group kernel (wino_fused_t.hip) on the layers it measured faster on: 0 never, 1 by the rule of Plan::push_wino_fused, 2 wherever eligible
+inline int wino_fused64t_mode() { return tuning_env_int("IRSDE_WINO_FUSED64T", 1); }
 
 inline int wino_min_c(int tile) {
     return tuning_env_int(tile == 4 ? "IRSDE_WINO4_MINC" : "IRSDE_WINO2_MINC", tile == 4 ? 64 : 256);

@@ -154,6 +154,16 @@ struct Builder {
         const long long T = (long long)dd.B * (d.Ho / 4) * (d.Wo / 4);   // per launch
         const long long blocks = k64 ? wino_fused64_num_blocks(dd) : (long long)dd.B * ((d.Ho / 4 + 3) / 4) * ((d.Wo / 4 + 7) / 8) * (d.Cout / 32);
         if (T < (k64 ? wino_fused64_min_tiles() : wino_fused_min_tiles()) || blocks < 256) return false;
+        // r06: wino4_fused64t_kernel (32 tiles x 64 couts per work item, every weight fragment feeds two tile groups; bit-identical results) where it measured
+        // faster than the 16-tile kernel on the B = 16 256^2 plan (profiles/r06_o_wino_t_sweep.txt): enough K-loop work per resident block to amortise its
+        // longer prologue / epilogue (work items per block x 16-channel chunks >= 64; >= 32 for a layer without residual whose blocks walk >= 8 items), not the
+        // fused-upsample layers (their gathers are the cheaper ones: 4 tiles share a source pixel).
+        bool use_t = false;
+        if (k64 && pair_uscale == 0.f && wino_fused64t_mode() && wino_fused64t_eligible(dd)) {
+            const double per_block = (double)wino_fused64t_num_items(dd) / std::max(1, device_cu_count());
+            const double work = per_block * (Ctot / 16);
+            use_t = wino_fused64t_mode() >= 2 || (!d.in_shift && (work >= 64.0 || (work >= 32.0 && per_block >= 8.0 && !d.res)));
+        }
         Op op;
         op.kind = OP_CONV;
         op.flops = conv_flops(d);
@@ -165,7 +175,7 @@ struct Builder {
         char buf[256];
         const bool pair = pair_uscale != 0.f;
         snprintf(buf, sizeof buf, "conv(%swinograd F4 fused) %s T=%lld Cout=%d Cin=%d up=%d blocks=%lld flops=%.4g exec=%.4g%s", pair ? "split f16x2 " : "",
-                 k64 ? "16x64" : "32x32", T * parts, d.Cout, Ctot, d.in_shift, blocks * parts, op.flops, op.exec_flops,
+                 use_t ? "32x64" : k64 ? "16x64" : "32x32", T * parts, d.Cout, Ctot, d.in_shift, blocks * parts, op.flops, op.exec_flops,
                  parts > 1 ? (parts == 2 ? " (2 batch slices)" : " (4 batch slices)") : "");
         op.desc = buf;
         std::vector<ConvParams> slices;
@@ -179,7 +189,9 @@ struct Builder {
             if (dd.film && dd.film_bstride) q.film = dd.film + b0 * dd.film_bstride;
             slices.push_back(q);
         }
-        if (k64)
+        if (use_t)
+            op.fn = [slices, Uf](hipStream_t s) { for (const auto& q : slices) launch_wino_fused64t(q, Uf, s, 0); };
+        else if (k64)
             op.fn = [slices, Uf, pair](hipStream_t s) { for (const auto& q : slices) launch_wino_fused64(q, Uf, s, pair ? 4 : 0); };
         else
             op.fn = [slices, Uf](hipStream_t s) { for (const auto& q : slices) launch_wino_fused(q, Uf, s); };

@@ -1726,22 +1726,6 @@ void launch_wino_fused64_split_weights(const float* Uf, unsigned short* out, siz
 // any hint; 10: 12 units in flight + the epilogue hint = production since late r03 (0 .. -4 % against 6 on every layer class,
 // profiles/r03_wino_fused64_nt.txt).  Production (0, 4) carries the epilogue hint (IRSDE_WINO_FUSED64_NT=0 under IRSDE_TUNING=1 switches it off): the streamed
 // epilogue traffic no longer evicts the weight fragments from the XCD's 4 MB L2 - 128 -> 128 @ 256^2 1.14 -> 1.01 ms, profiles/r03_wino_fused64_nt.txt
-// CU count of the CURRENT device, cached per device ordinal (not one static for whichever device launched first)
-static int device_cu_count() {
-    static std::mutex mu;
-    static std::vector<int> cache;
-    int dev = 0;
-    IRSDE_HIP_CHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    if ((int)cache.size() <= dev) cache.resize(dev + 1, 0);
-    if (cache[dev] == 0) {
-        int n = 0;
-        IRSDE_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        cache[dev] = n > 0 ? n : 256;
-    }
-    return cache[dev];
-}
-
 void launch_wino_fused64(const ConvParams& p, const float* Uf, hipStream_t s, int variant) {
     if (!wino_fused64_eligible(p)) throw HipError("launch_wino_fused64: layer not eligible");
     if (!Uf) throw HipError("launch_wino_fused64: fused weights missing");

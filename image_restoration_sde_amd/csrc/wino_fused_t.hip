@@ -530,21 +530,6 @@ static int g_wt_skew = 0;   // tuning: start skew in cycles per phase class (irs
 void wino_fused64t_set_skew(int cycles) { g_wt_skew = cycles; }
 void wino_fused64t_set_debug(unsigned long long* buf) { g_wt_dbg = buf; }
 
-static int wt_device_cu_count() {
-    static std::mutex mu;
-    static std::vector<int> cache;
-    int dev = 0;
-    IRSDE_HIP_CHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    if ((int)cache.size() <= dev) cache.resize(dev + 1, 0);
-    if (cache[dev] == 0) {
-        int n = 0;
-        IRSDE_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        cache[dev] = n > 0 ? n : 256;
-    }
-    return cache[dev];
-}
-
 // variant: 0 production; (PROBES build) 1 weight fragments read zeros, 2 patch gathers read zeros, 3 three instead of six weight units in flight, 5 cycle stamps
 // into the buffer of wino_fused64t_set_debug(); + 64: the cout-block-by-XCD item map wherever it is legal (test hook)
 void launch_wino_fused64t(const ConvParams& p, const float* Uf, hipStream_t s, int variant) {
@@ -567,7 +552,7 @@ void launch_wino_fused64t(const ConvParams& p, const float* Uf, hipStream_t s, i
     if (ob >= 0x7fff0000ull || rb >= 0x7fff0000ull) throw HipError("launch_wino_fused64t: output / residual tensor too large for 32-bit buffer offsets");
     // (measurement twins 13 / 14: output stores / residual loads out of range — dropped by the address unit, no traffic; 12: stamps of the NOPATCH twin)
     const unsigned out_bytes = variant == 13 ? 0u : (unsigned)ob, res_bytes = variant == 14 ? 0u : (unsigned)rb;
-    const int ncu = wt_device_cu_count();
+    const int ncu = device_cu_count();
     // one block per CU; a multiple of 8 so that virtual item id % 8 stays the XCD of the block that runs it
     const dim3 pgrid((unsigned)std::min(total, std::max(8, ncu & ~7)));
     const int epi = (p.silu ? 1 : 0) | (p.res ? 2 : 0);
