@@ -601,7 +601,10 @@ def main():
             except (OSError, IndexError, KeyError, ValueError):
                 traffic, traffic_src = None, None
             r.update({"traffic": traffic, "traffic_source": traffic_src,
-                      "traffic_unit": "bytes per conv launch (2 x FETCH_SIZE + WRITE_SIZE)"})
+                      "traffic_unit": "bytes per conv launch (2 x FETCH_SIZE + WRITE_SIZE)",
+                      # the same figure per network evaluation (x the conv launches of one evaluation) next to the algorithmic bytes
+                      "traffic_per_evaluation": (traffic * r["conv_launches_per_evaluation"]) if traffic else None,
+                      "algorithmic_bytes_per_evaluation": r["algorithmic_bytes_per_launch"] * r["conv_launches_per_evaluation"]})
             res["roofline"] = r
 
     # ---- secondary workloads: the other BASELINE configs, after the headline has been timed.  Every phase that ends in a collective

@@ -13,6 +13,9 @@ namespace irsde {
 struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+struct HipOutOfMemory : HipError {   // a device allocation failed: the plan cache evicts and retries (engine_plan.hip, get_plan)
+    using HipError::HipError;
+};
 
 // Tuning knobs (A/B experiments logged under profiles/) are honoured only when IRSDE_TUNING=1 is set: a stray
 // environment variable must not change the launch plan the parity tests validated.  Returns the integer value of

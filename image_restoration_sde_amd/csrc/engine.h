@@ -252,7 +252,12 @@ struct Plan {
             }
         }
         float* p = nullptr;
-        IRSDE_HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 64) * sizeof(float)));
+        const hipError_t err = hipMalloc(&p, std::max<size_t>(n, 64) * sizeof(float));
+        if (err == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            throw HipOutOfMemory("plan arena: hipMalloc of " + std::to_string(std::max<size_t>(n, 64) * sizeof(float)) + " bytes failed (out of memory)");
+        }
+        IRSDE_HIP_CHECK(err);
         pool.push_back({p, n, false});
         return p;
     }
@@ -353,6 +358,7 @@ struct irsde_engine {
     std::vector<double> op_ms;          // per launch group of the last profiled plan (summed over steps)
     std::vector<std::string> op_desc;
     int op_steps = 0;
+    int op_split = 1;   // concurrent sub-batches the sampler would run the profiled batch as (the event-instrumented pass times the un-split plan)
     std::vector<hipEvent_t> ev_pool;
     std::mutex mu;
 

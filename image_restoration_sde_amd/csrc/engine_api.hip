@@ -429,6 +429,7 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
             e->op_desc.clear();
             for (auto& op : pl->net_ops) e->op_desc.push_back(op.desc);
             e->op_steps = nsteps;
+            e->op_split = naf_subbatches(e, B, H, W);
             for (size_t k = 0; k < kinds.size(); ++k) {
                 float t;
                 IRSDE_HIP_CHECK(hipEventElapsedTime(&t, e->ev_pool[k], e->ev_pool[k + 1]));
@@ -525,6 +526,10 @@ int irsde_op_profile(irsde_engine* e, char* buf, int buflen) {
             snprintf(line, sizeof line, "%9.4f ms  %s\n", e->op_ms[i] / std::max(e->op_steps, 1), e->op_desc[i].c_str());
             out += line;
         }
+        if (e->op_split > 1) {   // (label what was timed — parsers skip lines without the "ms" column)
+            snprintf(line, sizeof line, "note: the un-split plan; irsde_sample runs this batch as %d concurrent sub-batches (own plans, streams, step graphs)\n", e->op_split);
+            out += line;
+        }
         strncpy(buf, out.c_str(), buflen - 1);
         buf[buflen - 1] = 0;
     });
@@ -539,6 +544,8 @@ int irsde_plan_describe(irsde_engine* e, int B, int H, int W, char* buf, int buf
         Plan* pl = get_plan(e, B, H, W, false);
         std::string out;
         for (auto& op : pl->net_ops) out += op.desc + "\n";
+        const int nsub = naf_subbatches(e, B, H, W);
+        if (nsub > 1) out += "note: the un-split plan; irsde_sample runs this batch as " + std::to_string(nsub) + " concurrent sub-batches of " + std::to_string(B / nsub) + " images (own plans)\n";
         strncpy(buf, out.c_str(), buflen - 1);
         buf[buflen - 1] = 0;
     });

@@ -1,6 +1,7 @@
 // Plan construction: one network evaluation as a static launch list over a static activation arena
 // (ConditionalUNet / ConditionalNAFNet forward, latent UNet encode / decode).
 #include "engine.h"
+#include <atomic>
 
 using namespace irsde;
 
@@ -669,11 +670,13 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
 // throughput — naf_chain_kernel keeps ONE CU per image busy for ~45 % of the step (64 of 256 CUs at BASELINE configs[4]'s batch of 64) while the other
 // levels' kernels are bandwidth-bound on all CUs: independent sub-batches on concurrent streams let one part's chain run under the other parts' levels.
 // Only where a level actually runs as a chain, and only as two parts of >= 32 images (measured: smaller or more parts lose what the overlap wins).
-static int g_force_subbatches = 0;   // irsde_debug_force_subbatches (test / measurement hook): 0 = the heuristic below
-void set_force_subbatches(int n) { g_force_subbatches = n; }
+// irsde_debug_force_subbatches (test / measurement hook): 0 = the heuristic below.  Process-wide (every engine sees it) and read under each engine's own
+// mutex: atomic, and not to be toggled while another thread is sampling — the split decides which plans a call builds.
+static std::atomic<int> g_force_subbatches{0};
+void set_force_subbatches(int n) { g_force_subbatches.store(n, std::memory_order_relaxed); }
 int naf_subbatches(const irsde_engine* e, int B, int H, int W) {
     if (e->arch == 2 || (e->cfg.flags & (IRSDE_FLAG_NAIVE_CONV | IRSDE_FLAG_KEEP_ACTIVATIONS))) return 1;
-    int n = g_force_subbatches;
+    int n = g_force_subbatches.load(std::memory_order_relaxed);
     if (n <= 0) {
         static const int env = tuning_env_int("IRSDE_SUBBATCHES", 0);
         n = env;
@@ -693,24 +696,44 @@ int naf_subbatches(const irsde_engine* e, int B, int H, int W) {
     return std::max(n, 1);
 }
 
+// The least recently used plan leaves the cache (with the other parts of its split batch: they are used together).  Returns false when the cache is empty.
+static bool evict_lru_plan(irsde_engine* e) {
+    if (e->plans.empty()) return false;
+    size_t lru = 0;
+    for (size_t i = 1; i < e->plans.size(); ++i)
+        if (e->plans[i]->last_use < e->plans[lru]->last_use) lru = i;
+    IRSDE_HIP_CHECK(hipDeviceSynchronize());
+    const int vb = e->plans[lru]->B, vh = e->plans[lru]->H, vw = e->plans[lru]->W;
+    const bool split = e->plans[lru]->slot > 0;
+    for (size_t i = e->plans.size(); i-- > 0;)
+        if (i == lru || (split && e->plans[i]->slot > 0 && e->plans[i]->B == vb && e->plans[i]->H == vh && e->plans[i]->W == vw))
+            e->plans.erase(e->plans.begin() + i);
+    return true;
+}
+
+static Plan* build_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film, int slot, int b0);
+
+// Cached plans are bounded by count (8: a split batch holds up to four sub-batch plans) AND by device memory: every plan owns its activation arena
+// (16 x 512^2: several GiB), so a build that runs out of memory drops the least recently used plans and tries again instead of failing the sampler call
+// (ADVICE r05).
 Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film, int slot, int b0) {
     for (auto& p : e->plans)
         if (p->B == B && p->H == H && p->W == W && p->per_sample_film == per_sample_film && p->slot == slot && p->b0 == b0) {
             p->last_use = ++e->use_counter;
             return p.get();
         }
-    if (e->plans.size() >= 8) {  // LRU eviction (8: a split batch holds up to four sub-batch plans)
-        size_t lru = 0;
-        for (size_t i = 1; i < e->plans.size(); ++i)
-            if (e->plans[i]->last_use < e->plans[lru]->last_use) lru = i;
-        IRSDE_HIP_CHECK(hipDeviceSynchronize());
-        // the parts of a split batch are used together: they leave together
-        const int vb = e->plans[lru]->B, vh = e->plans[lru]->H, vw = e->plans[lru]->W;
-        const bool split = e->plans[lru]->slot > 0;
-        for (size_t i = e->plans.size(); i-- > 0;)
-            if (i == lru || (split && e->plans[i]->slot > 0 && e->plans[i]->B == vb && e->plans[i]->H == vh && e->plans[i]->W == vw))
-                e->plans.erase(e->plans.begin() + i);
+    if (e->plans.size() >= 8) evict_lru_plan(e);
+    for (;;) {
+        try {
+            return build_plan(e, B, H, W, per_sample_film, slot, b0);
+        } catch (const HipOutOfMemory&) {
+            // (the parts of the split batch being built are the most recently used entries: they go last)
+            if (!evict_lru_plan(e)) throw;
+        }
     }
+}
+
+static Plan* build_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film, int slot, int b0) {
     ensure_film_cur(e, per_sample_film ? b0 + B : 1);
     if (naf_lens(e)) {
         if (e->cam_set < b0 + B) throw HipError("latent-bokeh ConditionalNAFNet: irsde_set_lens_info must cover the batch first");

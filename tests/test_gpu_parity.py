@@ -11,6 +11,7 @@ Tolerances (floating point path, fp32 arithmetic on both sides):
       perturbations ~200x; the reference's own fp32-vs-fp64 gap is of the same size)
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -1492,3 +1493,19 @@ def test_latent_bokeh_nafnet_vs_reference_golden(golden):
     sde.image_offset = 1
     one = sde.reverse_ode(xt[1:2], lens_info=[t[1:2] for t in li]).cpu().numpy()
     assert relerr(one, both[1:2]) < 1e-4
+
+
+def test_group_sum_probe_toolchain_guard(tmp_path):
+    """the cross-lane sums of the fp32 LayerNorm / attention / chain kernels (DPP + v_permlane16/32_swap inline assembly with a hand-placed
+    s_nop) are opaque to LLVM's hazard recognizer.  tools/probe/group_sum_probe.hip holds the same helpers next to the __shfl_xor butterflies they replace:
+    built with THIS toolchain and run on THIS GPU, every width must agree — a hipcc bump that breaks the wait-state assumption fails here by name
+    (module_util.py:20-26 LayerNorm is the first caller)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probe", "group_sum_probe.hip")
+    exe = str(tmp_path / "group_sum_probe")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", src, "-o", exe], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
