@@ -40,7 +40,7 @@ SYMBOLS = [
     "irsde_last_error", "irsde_version", "irsde_create", "irsde_create_nafnet", "irsde_destroy", "irsde_num_weights",
     "irsde_weight_name", "irsde_weight_shape", "irsde_load_weight", "irsde_finalize_weights",
     "irsde_set_schedule", "irsde_unet_forward", "irsde_sample", "irsde_sde_step", "irsde_philox_normal",
-    "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv", "irsde_plan_describe", "irsde_bench_conv", "irsde_op_profile", "irsde_debug_split_gemm", "irsde_bench_naf_chain", "irsde_debug_force_subbatches",
+    "irsde_get_profile", "irsde_debug_tap", "irsde_work_model", "irsde_debug_conv", "irsde_plan_describe", "irsde_bench_conv", "irsde_op_profile", "irsde_debug_split_gemm", "irsde_bench_naf_chain", "irsde_debug_force_subbatches", "irsde_debug_force_chain_groups",
     "irsde_eval_metrics", "irsde_tensor2img",
     "irsde_set_lens_info", "irsde_create_latent_unet", "irsde_latent_shapes", "irsde_latent_encode", "irsde_latent_decode", "irsde_latent_hidden",
 ]
@@ -126,6 +126,7 @@ def _declare(lib):
     lib.irsde_bench_conv.argtypes = [c.c_int] * 11 + [c.POINTER(c.c_double)]
     lib.irsde_bench_naf_chain.argtypes = [c.c_int] * 4 + [c.POINTER(c.c_double)]
     lib.irsde_debug_force_subbatches.argtypes = [c.c_int]
+    lib.irsde_debug_force_chain_groups.argtypes = [c.c_int]
     lib.irsde_debug_split_gemm.argtypes = [P, P, P, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, P]
     lib.irsde_eval_metrics.argtypes = [P, P, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double), P]
     lib.irsde_tensor2img.argtypes = [P, P, c.c_int, c.c_int, c.c_int, c.c_int, P]

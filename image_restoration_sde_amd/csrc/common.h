@@ -185,6 +185,15 @@ size_t naf_chain_weight_halves(int nblocks);   // fp16 fragment streams [8 waves
 size_t naf_chain_vec_floats(int nblocks);      // fp32 per-channel vectors [nblocks][NV_TOTAL = 14848]
 void launch_naf_chain(const float* x, float* out, const unsigned short* w, const float* vecs, int nblocks, int B, const float* film, int film_bstride,
                       int film_off, const float* cam, int cam_bstride, int cam_off, hipStream_t s, int variant = 0);
+// r06: G = 2 / 4 work-groups per image (the groups trade operand slices through L2; see naf_chain.hip)
+std::vector<int> naf_chain_split_order(int nblocks, int G);   // fragment permutation: split stream position -> one-group stream position
+void naf_chain_build_split_weights(const unsigned short* w1, unsigned short* dst, int nblocks, int G, hipStream_t s);
+size_t naf_chain_split_scratch_bytes(int B);
+int naf_chain_split_groups(int B, int G);                     // work-groups that must be co-resident
+void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG, const float* vecs, int nblocks, int B, const float* film, int film_bstride,
+                            int film_off, const float* cam, int cam_bstride, int cam_off, int G, void* scratch, hipStream_t s);
+const unsigned* naf_chain_split_error_flag(const void* scratch, int B);
+void naf_chain_split_reset(void* scratch, int B);
 void attention_global_init();
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)

@@ -40,6 +40,8 @@ inline int wino_fused64_max_cout() { return tuning_env_int("IRSDE_WINO_FUSED64_M
 inline long long wino_fused64_min_tiles() { return tuning_env_int("IRSDE_WINO_FUSED64_MINT", 1024); }
 // r06: the two-tile-group kernel (wino_fused_t.hip) on the layers it measured faster on: 0 never, 1 by the rule of Plan::push_wino_fused, 2 wherever eligible
 inline int wino_fused64t_mode() { return tuning_env_int("IRSDE_WINO_FUSED64T", 1); }
+// r06: work-groups per image of the NAFBlock chain kernel: 0 = as many (4, 2) as fit the compute units next to the call's other sub-batches, 1 = the one-group kernel, 2 / 4 forced (if they fit)
+inline int naf_chain_split_mode() { return tuning_env_int("IRSDE_NAF_CHAIN_SPLIT", 0); }
 
 inline int wino_min_c(int tile) {
     return tuning_env_int(tile == 4 ? "IRSDE_WINO4_MINC" : "IRSDE_WINO2_MINC", tile == 4 ? 64 : 256);
@@ -114,6 +116,7 @@ struct NafChainW {
     unsigned short* w = nullptr;
     float* vecs = nullptr;
     int nblocks = 0, film_off = 0, cam_off = 0;
+    unsigned short* wsplit[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [G]: the fragment streams of the G-groups-per-image kernel, built on first use
 };
 
 enum OpKind { OP_CONV = 0, OP_LN = 1, OP_ATTN = 2, OP_OTHER = 3, OP_WINO = 4, OP_NKINDS = 5 };
@@ -235,6 +238,8 @@ struct Plan {
     hipGraph_t graph = nullptr;
     double conv_flops = 0, conv_bytes = 0, conv_exec_flops = 0;
     uint64_t last_use = 0;
+    std::vector<std::pair<void*, int>> chain_scratch;   // (scratch, images) of the split chain launches, for the reset after an error
+    std::vector<const unsigned*> chain_err;   // error flags of the split chain launches (naf_chain.hip): non-zero = the groups of an image were not co-resident
 
     ~Plan() {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -358,6 +363,7 @@ struct irsde_engine {
     std::vector<double> op_ms;          // per launch group of the last profiled plan (summed over steps)
     std::vector<std::string> op_desc;
     int op_steps = 0;
+    int plan_parts = 1;   // concurrent sub-batch plans the sampler call being prepared runs (set by irsde_sample around get_plan: the split chain's CU budget)
     int op_split = 1;   // concurrent sub-batches the sampler would run the profiled batch as (the event-instrumented pass times the un-split plan)
     std::vector<hipEvent_t> ev_pool;
     std::mutex mu;
@@ -455,6 +461,8 @@ void ensure_film_cur(irsde_engine* e, int rows);
 // engine_plan.hip: one network evaluation as a static launch list over a static arena
 Plan* get_plan(irsde_engine* e, int B, int H, int W, bool per_sample_film, int slot = 0, int b0 = 0);
 int naf_subbatches(const irsde_engine* e, int B, int H, int W);
+void set_force_chain_groups(int g);   // irsde_debug_force_chain_groups
+int forced_chain_groups();
 void set_force_subbatches(int n);                                 // irsde_debug_force_subbatches   // how many concurrent sub-batches the sampler splits a NAFNet batch into (1 = none)
 LatentPlan* get_latent_plan(irsde_engine* e, int B, int H, int W, bool decode);
 

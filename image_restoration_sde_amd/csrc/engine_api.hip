@@ -110,7 +110,7 @@ int guard(const std::function<void()>& f) {
 extern "C" {
 
 const char* irsde_last_error(void) { return g_last_error.c_str(); }
-int irsde_version(void) { return 106; }  // changelog: include/irsde_hip.h
+int irsde_version(void) { return 107; }  // changelog: include/irsde_hip.h
 
 int irsde_create(const irsde_config* cfg, irsde_engine** out) {
     return guard([&] {
@@ -326,11 +326,26 @@ int irsde_sample(irsde_engine* e, int mode, const float* xT, const float* mu, co
         const bool profile = (flags & IRSDE_SAMPLE_PROFILE) != 0;
         const bool graph = (flags & IRSDE_SAMPLE_GRAPH) != 0 && !profile;
         const size_t img = (size_t)B * e->cfg.in_nc * H * W;
+        // r06: a split NAFBlock-chain launch (naf_chain.hip, G work-groups per image) whose groups were not co-resident raised its error flag instead of
+        // hanging the GPU: the results of that call were garbage — fail loudly at the next one (the call itself is asynchronous)
+        for (auto& p : e->plans)
+            for (const unsigned* f : p->chain_err) {
+                unsigned v = 0;
+                IRSDE_HIP_CHECK(hipMemcpy(&v, f, 4, hipMemcpyDeviceToHost));
+                if (v) {
+                    for (auto& sc : p->chain_scratch) naf_chain_split_reset(sc.first, sc.second);
+                    char code[32];
+                    snprintf(code, sizeof code, " [flag 0x%x]", v);
+                    throw HipError(std::string("sample: the previous call's split NAFBlock-chain kernel timed out waiting for a work-group that was not resident (its results were invalid); "
+                                               "set IRSDE_TUNING=1 IRSDE_NAF_CHAIN_SPLIT=1 if other work shares this GPU") + code);
+                }
+            }
         const int nsub = profile ? 1 : naf_subbatches(e, B, H, W);   // (the event-instrumented pass times the un-split plan: its kernels are the same)
         if (nsub > 1) {
             const int Bs = B / nsub;
             const size_t simg = img / nsub;
             std::vector<Plan*> sp(nsub);
+            struct PartsScope { irsde_engine* e; PartsScope(irsde_engine* e_, int n) : e(e_) { e->plan_parts = n; } ~PartsScope() { e->plan_parts = 1; } } parts_scope(e, nsub);
             for (int i = 0; i < nsub; ++i) sp[i] = get_plan(e, Bs, H, W, false, i + 1, i * Bs);
             for (int i = 0; i < nsub; ++i) (void)get_plan(e, Bs, H, W, false, i + 1, i * Bs);   // (all parts most recently used: none of them is the next eviction victim)
             ensure_sub_streams(e, nsub);
@@ -815,6 +830,11 @@ int irsde_debug_split_gemm(const float* A, const float* Bm, float* C, int M, int
     });
 }
 
+int irsde_debug_force_chain_groups(int g) {
+    set_force_chain_groups(g == 1 || g == 2 || g == 4 ? g : 0);
+    return IRSDE_OK;
+}
+
 int irsde_debug_force_subbatches(int n) {
     set_force_subbatches(n < 0 ? 0 : n);
     return IRSDE_OK;
@@ -823,10 +843,11 @@ int irsde_debug_force_subbatches(int n) {
 int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out) {
     return guard([&] {
         if (!ms_out || nblocks < 1 || nblocks > 64 || B < 1 || iters < 1) throw HipError("bench_naf_chain: bad argument");
+        const int G = variant == 22 ? 2 : variant == 24 ? 4 : 1;   // r06: 22 / 24 = the kernel with 2 / 4 work-groups per image
 #ifdef IRSDE_PROBES
-        if (variant != 0 && variant != 1 && variant != 2 && variant != 11) throw HipError("bench_naf_chain: bad variant");
+        if (variant != 0 && variant != 1 && variant != 2 && variant != 11 && G == 1) throw HipError("bench_naf_chain: bad variant");
 #else
-        if (variant != 0 && variant != 1) throw HipError("bench_naf_chain: variants 2 / 11 are measurement twins (make PROBES=1)");   // (before anything is allocated)
+        if (variant != 0 && variant != 1 && G == 1) throw HipError("bench_naf_chain: variants 2 / 11 are measurement twins (make PROBES=1)");   // (before anything is allocated)
 #endif
         conv_global_init();
         hipStream_t s;
@@ -849,7 +870,20 @@ int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms
             launch_fill_random(dwf, n, 4 + (unsigned)(o / chunk), 0.04f, s);
             launch_f32_to_f16(dwf, dw + o, n, s);
         }
-        launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant == 11 ? 1 : variant);   // warm
+        unsigned short* dwg = nullptr;
+        void* dscratch = nullptr;
+        if (G > 1) {
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            IRSDE_HIP_CHECK(hipMalloc(&dwg, nw * 2));
+            naf_chain_build_split_weights(dw, dwg, nblocks, G, s);
+            IRSDE_HIP_CHECK(hipMalloc(&dscratch, naf_chain_split_scratch_bytes(B)));
+            IRSDE_HIP_CHECK(hipMemset(dscratch, 0, naf_chain_split_scratch_bytes(B)));
+        }
+        auto run = [&]() {
+            if (G > 1) launch_naf_chain_split(dx, dout, dwg, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, G, dscratch, s);
+            else launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant == 11 ? 1 : variant);
+        };
+        run();   // warm
         if (variant == 11) {   // the stamp twin once: per-phase cycle budget per block, averaged over all waves
             unsigned long long* dd = nullptr;
             IRSDE_HIP_CHECK(hipMalloc(&dd, (size_t)B * 8 * 16 * 8));
@@ -874,12 +908,18 @@ int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms
         IRSDE_HIP_CHECK(hipEventCreate(&e0));
         IRSDE_HIP_CHECK(hipEventCreate(&e1));
         IRSDE_HIP_CHECK(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant == 11 ? 1 : variant);
+        for (int i = 0; i < iters; ++i) run();
         IRSDE_HIP_CHECK(hipEventRecord(e1, s));
         IRSDE_HIP_CHECK(hipStreamSynchronize(s));
         float ms = 0.f;
         IRSDE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
         *ms_out = ms / iters;
+        if (G > 1) {
+            unsigned flag = 0;
+            IRSDE_HIP_CHECK(hipMemcpy(&flag, naf_chain_split_error_flag(dscratch, B), 4, hipMemcpyDeviceToHost));
+            (void)hipFree(dwg); (void)hipFree(dscratch);
+            if (flag) throw HipError("bench_naf_chain: the split kernel's groups were not co-resident (spin timeout)");
+        }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         (void)hipFree(dx); (void)hipFree(dout); (void)hipFree(dwf); (void)hipFree(dvec); (void)hipFree(dfilm); (void)hipFree(dw);
         (void)hipStreamDestroy(s);

@@ -361,11 +361,26 @@ struct Builder {
     bool naf_chain_ok(const NafChainW& cw, const Tensor& x) const {
         return cw.nblocks > 0 && !naive && !x.bf16 && naf_chain_shape_ok(x.H, x.W, x.C);
     }
-    Tensor nafchain(const NafChainW& cw, const Tensor& x) {
+    // r06: G work-groups per image where they all fit the compute units at the same time (a spinning group holds its CU): the batch's groups next to
+    // those of the call's other concurrent sub-batches
+    int chain_groups(int B) const {
+        const int mode = forced_chain_groups() ? forced_chain_groups() : naf_chain_split_mode();
+        if (mode == 1) return 1;
+        const int budget = device_cu_count() / std::max(1, pl->slot > 0 ? e->plan_parts : 1);
+        for (int G = 4; G >= 2; G >>= 1)
+            if ((mode == 0 || mode == G) && naf_chain_split_groups(B, G) <= budget) return G;
+        return 1;
+    }
+    Tensor nafchain(NafChainW& cw, const Tensor& x) {
         Tensor out = talloc(x.B, x.H, x.W, x.C);
         const float *xp = x.p, *film = film_base(), *cam = naf_lens(e) ? cam_base() : nullptr;
         float* op = out.p;
         const int B = x.B, fb = film_bstride, cb = e->cam_row;
+        const int G = chain_groups(B);
+        if (G > 1 && !cw.wsplit[G]) {
+            cw.wsplit[G] = reinterpret_cast<unsigned short*>(e->dmalloc((naf_chain_weight_halves(cw.nblocks) + 1) / 2));
+            naf_chain_build_split_weights(cw.w, cw.wsplit[G], cw.nblocks, G, e->stream);
+        }
         const NafChainW c = cw;
         Op o;
         o.kind = OP_CONV;
@@ -376,10 +391,18 @@ struct Builder {
         pl->conv_flops += o.flops;
         pl->conv_exec_flops += o.exec_flops;
         pl->conv_bytes += o.bytes;
-        char buf[160];
-        snprintf(buf, sizeof buf, "naf_chain(fp16) blocks=%d B=%d c=%d hw=%dx%d flops=%.4g", c.nblocks, B, x.C, x.H, x.W, o.flops);
+        char buf[200];
+        snprintf(buf, sizeof buf, "naf_chain(fp16) blocks=%d B=%d c=%d hw=%dx%d groups=%d flops=%.4g", c.nblocks, B, x.C, x.H, x.W, G, o.flops);
         o.desc = buf;
-        o.fn = [=](hipStream_t s) { launch_naf_chain(xp, op, c.w, c.vecs, c.nblocks, B, film, fb, c.film_off, cam, cb, c.cam_off, s); };
+        if (G > 1) {
+            void* scratch = pl->alloc((naf_chain_split_scratch_bytes(B) + 3) / 4, false);
+            IRSDE_HIP_CHECK(hipMemset(scratch, 0, naf_chain_split_scratch_bytes(B)));   // (the error flag is read by irsde_sample even if this plan never ran)
+            pl->chain_err.push_back(naf_chain_split_error_flag(scratch, B));
+            pl->chain_scratch.push_back({scratch, B});
+            o.fn = [=](hipStream_t s) { launch_naf_chain_split(xp, op, c.wsplit[G], c.vecs, c.nblocks, B, film, fb, c.film_off, cam, cb, c.cam_off, G, scratch, s); };
+        } else {
+            o.fn = [=](hipStream_t s) { launch_naf_chain(xp, op, c.w, c.vecs, c.nblocks, B, film, fb, c.film_off, cam, cb, c.cam_off, s); };
+        }
         pl->net_ops.push_back(std::move(o));
         return out;
     }
@@ -672,6 +695,9 @@ void build_naf_plan(irsde_engine* e, Plan* pl, Builder& b, int P) {
 // Only where a level actually runs as a chain, and only as two parts of >= 32 images (measured: smaller or more parts lose what the overlap wins).
 // irsde_debug_force_subbatches (test / measurement hook): 0 = the heuristic below.  Process-wide (every engine sees it) and read under each engine's own
 // mutex: atomic, and not to be toggled while another thread is sampling — the split decides which plans a call builds.
+static std::atomic<int> g_force_chain_groups{0};   // irsde_debug_force_chain_groups: 0 = the rule (Builder::chain_groups)
+void set_force_chain_groups(int g) { g_force_chain_groups.store(g, std::memory_order_relaxed); }
+int forced_chain_groups() { return g_force_chain_groups.load(std::memory_order_relaxed); }
 static std::atomic<int> g_force_subbatches{0};
 void set_force_subbatches(int n) { g_force_subbatches.store(n, std::memory_order_relaxed); }
 int naf_subbatches(const irsde_engine* e, int B, int H, int W) {

@@ -20,6 +20,17 @@
 // Arithmetic: the 16-bit operand mode's (IRSDE_FLAG_FP16): fp16 operands, fp32 accumulation, fp32 residual stream / LayerNorm / depthwise conv / gates.
 // Differences to the per-layer path, all at operand-rounding level: the conv1 output passes through fp16 before the depthwise conv (staging grid),
 // and the SCA 1x1 conv runs on the MFMA pipe with fp16 operands.
+//
+// r06 — G work-groups per image (G = 2 / 4; VERDICT r05 "a chain kernel that uses more than one CU per image").  What bounds the one-group kernel is ONE CU
+// streaming the block's 3.67 MB of fp16 weights through its ~30 B/clk vector-memory return path (49 us per block whatever the batch): at the per-GPU
+// shard of BASELINE configs[4] (8 images) 8 of 256 CUs work for 57 % of the step.  Group g of an image owns the output channels [512 g / G, 512 (g + 1) / G)
+// of every 512-wide tensor (gate pairs (j, j + 512) of the 1024-wide ones) and streams 1 / G of the weights; every GEMM still needs the FULL operand image,
+// so per block the groups of an image trade slices through L2 five times — the fp32 residual stream in front of both LayerNorms (each group normalises
+// the whole image itself: the LayerNorm code and its summation order are the one-group kernel's), the gated tensor (+ pooled means) behind conv1 and
+// conv4, the SCA scale vector — each closed by an arrive / spin barrier on a per-image counter (agent-scope release / acquire fences).  The groups of an
+// image get block ids of one residue mod 8 = one XCD (the exchange stays in that XCD's L2).  Co-residency: a spinning group holds its CU, so every group of
+// an image must be resident at the same time: the launch keeps the grid <= the CUs the caller says are free (launch_naf_chain_split), and a spin that
+// exceeds ~1 s sets an error flag instead of hanging the GPU (irsde_sample checks it and fails the call).
 #include "common.h"
 
 namespace irsde {
@@ -62,7 +73,55 @@ struct NafChainArgs {
     int nblocks;
     unsigned w_bytes;
     unsigned long long* dbg;   // STAMP twin only
+    // G > 1 (naf_chain_kernel<.., G>): exchange buffers of the image's groups
+    unsigned short* xgate;     // [B][64 px][512] fp16: the gated tensors
+    unsigned short* xvec;      // [B][2][512] fp16: pooled means | SCA scale vector
+    unsigned* ctr;             // [B][4] barrier counters (zero between launches: the kernel restores them) | [4 B]: error word
+    int B;
 };
+
+// Barrier of the G groups of one image (all 512 threads of each call it).  The exchanged tensors are written with 16-byte sc1 (write-through) stores and read
+// with sc1 loads (guides/cdna_hip_programming.md 6, Guideline 16: valid under ANY placement of the groups; a release / acquire fence pair per barrier —
+// buffer_wbl2 + buffer_inv — measured 4 - 7x slower here, profiles/r06_notes.md): every wave drains its stores, one lane arrives on a counter of the image
+// and polls it relaxed.
+// Counters: three per image, barrier i on c[i % 3] (target G); behind barrier i group 0 zeroes c[(i + 2) % 3] — last used by barrier i - 1, which every group
+// has left (it arrived at i), next used by barrier i + 2, which nobody reaches before group 0 (its store drained) arrives at i + 1.  At the end every group
+// counts itself out on a fourth word and the last one zeroes all four: the launch leaves the state it found, with no memset node in the step graph (a captured
+// hipMemsetAsync in front of the kernel replayed 0x01 bytes on this stack: counters and error flag came up as 0x01010101).
+// A spin past NC_SPIN_LIMIT polls (~1 s: a group that is not resident) raises the launch's error word (0x10000 | barrier index); once it is up nobody waits
+// any more — the results are garbage and the next irsde_sample call on the engine fails and re-zeroes the state.
+constexpr int NC_SPIN_LIMIT = 1 << 20;
+constexpr int NC_SC1 = 16;   // cache-policy bit of the raw buffer builtins on gfx950: sc1
+__device__ __forceinline__ void nc_group_barrier(unsigned* cnt, unsigned* err, const unsigned index, const unsigned G, const bool zeroer, const int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* c = cnt + index % 3u;
+        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 255) == 0) {
+                if (spins >= NC_SPIN_LIMIT) {
+                    __hip_atomic_store(err, 0x10000u | (index & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // another group gave up: nobody waits any more
+            }
+        }
+        if (zeroer) __hip_atomic_store(cnt + (index + 2u) % 3u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}
+// the end of the launch: the last group of the image to leave restores the counters
+__device__ __forceinline__ void nc_group_exit(unsigned* cnt, const unsigned G, const int tid) {
+    if (tid == 0) {
+        if (__hip_atomic_fetch_add(cnt + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) __hip_atomic_store(cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 // Cross-lane sums on the vector pipe (r05; kernels_misc.hip has the same helpers and the story of why the swaps are inline assembly): the LayerNorm
 // partials are summed over the four lane quarters q = lane >> 4 (xor 16, xor 32), the SCA pool over the 16 pixel lanes n = lane & 15 of a quarter
@@ -97,13 +156,14 @@ struct WStream {
     int pos;        // fragment index of ring slot 0 (bytes / 1024), multiple of 16
 };
 
-// One GEMM pass: acc[t][pt] += sum_k W_t[., k] B[k, pixel tile pt] over K = 512 for the 2 weight tiles t the stream delivers per k step (32 fragments: 16 / (NC_RING / 2)
-// rounds of the fragment ring).  NPT: pixel tiles (4: the image; 1: the SCA matvec, every column carries the same vector).  SCALE: B fragments are
-// multiplied by the fp16 vector at sv (the SCA scale per input channel, DenoisingNAFNet_arch.py:68) on their way into the MFMA.
+// One GEMM pass: acc[t][pt] += sum_k W_t[., k] B[k, pixel tile pt] over K = 512 for the NT weight tiles t the stream delivers per k step (16 NT fragments:
+// 16 NT / NC_RING rounds of the fragment ring).  NPT: pixel tiles (4: the image; 1: the SCA matvec, every column carries the same vector).  SCALE: B fragments
+// are multiplied by the fp16 vector at sv (the SCA scale per input channel, DenoisingNAFNet_arch.py:68) on their way into the MFMA.
 // bsrc[c]: LDS address of this lane's B fragment of k steps ks with (ks & 3) == c (see the swizzle); + (ks >> 2) * 256, pixel tile stride 16 rows.
-template <int NPT, bool SCALE, int NC_RING>
-__device__ __forceinline__ void gemm_pass(nc_f4 (&acc)[2][NPT], const char* const* bsrc, const char* sv, nc_f4 (&ring)[NC_RING], WStream& ws) {
-    constexpr int KSU = NC_RING / 2;   // k steps per round of the ring (a multiple of 4)
+template <int NT, int NPT, bool SCALE, int NC_RING>
+__device__ __forceinline__ void gemm_pass(nc_f4 (&acc)[NT][NPT], const char* const* bsrc, const char* sv, nc_f4 (&ring)[NC_RING], WStream& ws) {
+    constexpr int KSU = NC_RING / NT;   // k steps per round of the ring (a multiple of 4)
+    static_assert(KSU % 4 == 0 && 16 % KSU == 0, "ring rounds");
 #pragma unroll 1
     for (int ko = 0; ko < 16 / KSU; ++ko) {
 #pragma unroll
@@ -117,13 +177,13 @@ __device__ __forceinline__ void gemm_pass(nc_f4 (&acc)[2][NPT], const char* cons
                 for (int pt = 0; pt < NPT; ++pt) bq[pt] = bq[pt] * s8;
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int pt = 0; pt < NPT; ++pt)
-                    acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nc_h8, ring[kk * 2 + t]), bq[pt], acc[t][pt], 0, 0, 0);
+                    acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nc_h8, ring[kk * NT + t]), bq[pt], acc[t][pt], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                ring[kk * 2 + t] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, ws.lane_off, (ws.pos + NC_RING + kk * 2 + t) * 1024, 0));
+            for (int t = 0; t < NT; ++t)
+                ring[kk * NT + t] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, ws.lane_off, (ws.pos + NC_RING + kk * NT + t) * 1024, 0));
             __builtin_amdgcn_sched_barrier(0);
         }
         ws.pos += NC_RING;
@@ -137,8 +197,14 @@ __device__ __forceinline__ void gemm_pass(nc_f4 (&acc)[2][NPT], const char* cons
 // STAMP (irsde_bench_naf_chain variant 11): per-wave cycle totals per phase into a.dbg[(block * 8 + wave) * 16 ..]: 0 norm1, 1 conv1 GEMM passes,
 // 2 depthwise conv + gate, 3 SCA pool barrier, 4 sca.1 GEMM, 5 conv3 GEMM + residual, 6 norm2, 7 conv4 GEMM + gate, 8 conv5 GEMM + residual, 9 barriers
 // behind sca / conv4, 15 whole kernel
-template <int NC_RING, bool XG, bool STAMP = false>
+// G: work-groups per image (1: the r04 kernel, unchanged; 2 / 4: see the file header).  NTW = 4 / G 16-channel tiles per wave.
+template <int NC_RING, bool XG, bool STAMP = false, int G = 1>
 __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a) {
+    static_assert(G == 1 || G == 2 || G == 4, "groups per image");
+    static_assert(G == 1 || (!XG && !STAMP), "the split kernel has no measurement twins");
+    constexpr int NTW = 4 / G;                 // 16-channel tiles per wave of a 512-wide tensor (gate pairs of a 1024-wide one)
+    constexpr int NT3 = NTW >= 2 ? 2 : 1;      // weight tiles per k step of the 512 -> 512 passes (sca.1, conv3, conv5)
+    constexpr int NP3 = NTW / NT3;             // ... and passes
     unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_t0 = 0;
     if constexpr (STAMP) st_t0 = st_t = __builtin_amdgcn_s_memtime();
 #define NC_STAMP(K)                                                       \
@@ -152,7 +218,24 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
-    const int b = blockIdx.x;
+    // image and group of this work-group.  G > 1: block id v runs on XCD v & 7 — the G groups of an image share a residue (one L2): image = 8 slot + xcd
+    int b = blockIdx.x, grp = 0;
+    if constexpr (G > 1) {
+        const int v = blockIdx.x, idx = v >> 3;
+        grp = idx % G;
+        b = (idx / G) * 8 + (v & 7);
+        if (b >= a.B) return;
+    }
+    const int cown = grp * (NC_C / G) + wave * (16 * NTW);   // first of this wave's 16 NTW channels
+    unsigned* const ctr = G > 1 ? a.ctr + 4 * b : nullptr;
+    unsigned* const err = G > 1 ? a.ctr + 4 * a.B : nullptr;
+    unsigned nbar = 0;
+    auto group_barrier = [&]() {
+        if constexpr (G > 1) {
+            nc_group_barrier(ctr, err, nbar, G, grp == 0, tid);
+            nbar += 1;
+        }
+    };
 
     // ---- LDS addressing ----
     // operand image element (px, k): byte px * 1024 + (((k >> 3) ^ (px & 15)) << 4) + (k & 7) * 2   (the XOR touches the low 4 bits of the chunk index only)
@@ -189,19 +272,19 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
     const bool dw_row_active = (n >> 3) == (q & 1);
     const int dw_widx = (n & 7) >> 1, dw_wsh = (n & 1) * 16;
 
-    // ---- weight stream ----
+    // ---- weight stream: [G groups][8 waves][nblocks][448 / G fragments] ----
     WStream ws;
     ws.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, a.w_bytes, 0x00020000);
-    ws.lane_off = wave * (a.nblocks * NC_FRAGS_PER_BLOCK * 1024) + lane * 16;
+    ws.lane_off = (grp * 8 + wave) * (a.nblocks * (NC_FRAGS_PER_BLOCK / G) * 1024) + lane * 16;
     ws.pos = 0;
     nc_f4 ring[NC_RING];
 #pragma unroll
     for (int i = 0; i < NC_RING; ++i) ring[i] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, ws.lane_off, i * 1024, 0));
 
-    // ---- residual stream: x[ct][pt] = channels 64 w + 16 ct + 4 q .. + 3 of pixel 16 pt + n ----
-    nc_f4 x[XG ? 1 : 4][XG ? 1 : 4];
+    // ---- residual stream: x[ct][pt] = channels cown + 16 ct + 4 q .. + 3 of pixel 16 pt + n ----
+    nc_f4 x[XG ? 1 : NTW][XG ? 1 : 4];
     const float* xin = a.x + (size_t)b * NC_PX * NC_C;
-    float* const xg = a.out + (size_t)b * NC_PX * NC_C + 64 * wave + 4 * q + n * NC_C;   // + 16 ct + pt * 16 * NC_C
+    float* const xg = a.out + (size_t)b * NC_PX * NC_C + cown + 4 * q + n * NC_C;   // + 16 ct + pt * 16 * NC_C
     if constexpr (XG) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
@@ -210,32 +293,59 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 *reinterpret_cast<nc_f4*>(xg + 16 * ct + pt * 16 * NC_C) = *reinterpret_cast<const nc_f4*>(xin + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q);
     } else {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < NTW; ++ct)
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) x[ct][pt] = *reinterpret_cast<const nc_f4*>(xin + (16 * pt + n) * NC_C + 64 * wave + 16 * ct + 4 * q);
+            for (int pt = 0; pt < 4; ++pt) x[ct][pt] = *reinterpret_cast<const nc_f4*>(xin + (16 * pt + n) * NC_C + cown + 16 * ct + 4 * q);
     }
-    const int chl = 64 * wave + 4 * q;   // + 16 ct: this lane's channels of a 512-wide tensor
+    // G > 1: the exchange tensors of the image through buffer descriptors (sc1 stores / loads)
+    typedef unsigned nc_u4x __attribute__((ext_vector_type(4)));
+    typedef unsigned nc_u2x __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * NC_PX * NC_C, 0, G > 1 ? NC_PX * NC_C * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gate =
+        __builtin_amdgcn_make_buffer_rsrc(G > 1 ? a.xgate + (size_t)b * NC_PX * NC_C : const_cast<unsigned short*>(a.w), 0, G > 1 ? NC_PX * NC_C * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_vec =
+        __builtin_amdgcn_make_buffer_rsrc(G > 1 ? a.xvec + (size_t)b * 2 * NC_C : const_cast<unsigned short*>(a.w), 0, G > 1 ? 2 * NC_C * 2 : 0, 0x00020000);
+    const int chl = cown + 4 * q;        // + 16 ct: this lane's channels of a 512-wide tensor
+    const int chl1 = 64 * wave + 4 * q;  // + 16 ct: the lane's channels in the LayerNorm over the WHOLE image (every group normalises all 512 channels)
 
     // LayerNorm over the channels (module_util.py:20-26: biased variance, eps 1e-5) * g, then the block's FiLM x * (scale + 1) + shift
     // (DenoisingNAFNet_arch.py:63-64,74-75), result as the fp16 operand image in bufA.  Two passes like layernorm_kernel.
     // (the epilogue vectors of the GEMM passes are requested BEFORE the pass and return under it: a load issued where it is used waits for its own L2
     // latency behind the weight ring's loads — ~45 such waits per block were most of the kernel's time, profiles/r04_naf_chain_bench_a.txt.  The LayerNorm's
     // own vectors are not: 48 more live registers across a GEMM pass spill the residual stream)
+    // G > 1: the whole image's residual stream is read from `src` (the input tensor before the first block, the output tensor — where every group
+    // stores its slice in front of the barrier — afterwards): the same lane layout, operations and summation order as the one-group kernel.
     struct LnVec { nc_f4 g[4], fs[4], fh[4]; };
     auto ln_prefetch = [&](LnVec& v, const float* g, const float* fscale, const float* fshift) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            v.g[ct] = *reinterpret_cast<const nc_f4*>(g + chl + 16 * ct);
-            v.fs[ct] = *reinterpret_cast<const nc_f4*>(fscale + chl + 16 * ct);
-            v.fh[ct] = *reinterpret_cast<const nc_f4*>(fshift + chl + 16 * ct);
+            v.g[ct] = *reinterpret_cast<const nc_f4*>(g + chl1 + 16 * ct);
+            v.fs[ct] = *reinterpret_cast<const nc_f4*>(fscale + chl1 + 16 * ct);
+            v.fh[ct] = *reinterpret_cast<const nc_f4*>(fshift + chl1 + 16 * ct);
         }
     };
-    auto layernorm_to_A = [&](const float* g, const float* fscale, const float* fshift) {
+    auto layernorm_to_A = [&](const float* g, const float* fscale, const float* fshift, const bool from_input) {
         LnVec lv;
         ln_prefetch(lv, g, fscale, fshift);
+        nc_f4 xf[G > 1 ? 4 : 1][G > 1 ? 4 : 1];
+        if constexpr (G > 1) {
+            if (from_input) {   // (the first block: the launch's input tensor, plain loads)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) xf[ct][pt] = *reinterpret_cast<const nc_f4*>(xin + (16 * pt + n) * NC_C + chl1 + 16 * ct);
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt)
+                        xf[ct][pt] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((16 * pt + n) * NC_C + chl1 + 16 * ct) * 4, 0, NC_SC1));
+            }
+        }
         // XG: every pass re-reads the lane's 16 vectors from L2 instead of holding them (the ring of 32 fragments owns the registers)
         auto X = [&](const int ct, const int pt) -> nc_f4 {
-            if constexpr (XG) return *reinterpret_cast<const nc_f4*>(xg + 16 * ct + pt * 16 * NC_C);
+            if constexpr (G > 1) return xf[ct][pt];
+            else if constexpr (XG) return *reinterpret_cast<const nc_f4*>(xg + 16 * ct + pt * 16 * NC_C);
             else return x[ct][pt];
         };
         float s[4];
@@ -286,18 +396,63 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
         }
         __syncthreads();
     };
+    // G > 1: the gated tensor.  Every group writes its channel slice into its own bufB (like the one-group kernel), publishes it — 16-byte chunks, LDS ->
+    // exchange buffer, plain [px][512] fp16 — and behind the group barrier fetches the other groups' slices into bufB (+ the pooled means into the LDS mean vector)
+    constexpr int CH8 = 64 / G;   // 16-byte chunks (8 channels) per pixel of a group's slice
+    auto publish_gated = [&]() {
+        if constexpr (G > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < (NC_PX * CH8) / 512; ++i) {
+                const int idx = tid + 512 * i, px = idx / CH8, c8 = grp * CH8 + idx % CH8;
+                const nc_u4x v = *reinterpret_cast<const nc_u4x*>(lds + NC_OFF_B + px * NC_ROW + ((c8 ^ (px & 15)) << 4));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_gate, px * NC_ROW + c8 * 16, 0, NC_SC1);
+            }
+        }
+    };
+    auto fetch_gated = [&](const bool with_mean) {
+        if constexpr (G > 1) {
+            constexpr int NO = 64 - CH8, NI = (NC_PX * NO) / 512;   // chunks per pixel of the other groups; per thread
+            nc_u4x c[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int idx = tid + 512 * i, px = idx / NO, r = idx % NO, c8 = r < grp * CH8 ? r : r + CH8;
+                c[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gate, px * NC_ROW + c8 * 16, 0, NC_SC1);
+            }
+            nc_u4x mv = {0u, 0u, 0u, 0u};
+            if (with_mean && tid < 64) mv = __builtin_amdgcn_raw_buffer_load_b128(rs_vec, tid * 16, 0, NC_SC1);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int idx = tid + 512 * i, px = idx / NO, r = idx % NO, c8 = r < grp * CH8 ? r : r + CH8;
+                *reinterpret_cast<nc_u4x*>(lds + NC_OFF_B + px * NC_ROW + ((c8 ^ (px & 15)) << 4)) = c[i];
+            }
+            if (with_mean && tid < 64) *reinterpret_cast<nc_u4x*>(lds + NC_OFF_MEAN + tid * 16) = mv;
+            __syncthreads();
+        }
+    };
+    auto put_gated = [&](const int cb, const int pt, const nc_h4 hv) { *reinterpret_cast<nc_h4*>(lds + NC_OFF_B + wr_off(cb, pt)) = hv; };
+    // G > 1: this lane's slice of the residual stream into the output tensor (the exchange buffer of the LayerNorms, and the result)
+    auto put_x = [&]() {
+        if constexpr (G > 1) {
+#pragma unroll
+            for (int ct = 0; ct < NTW; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nc_u4x, x[ct][pt]), rs_x, ((16 * pt + n) * NC_C + chl + 16 * ct) * 4, 0, NC_SC1);
+        }
+    };
 
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const float* vec = a.vecs + (size_t)blk * NV_TOTAL;
         const float* film = a.film + (size_t)b * a.film_bstride + a.film_off + blk * (4 * NC_C);
         // ===== norm1 + time FiLM -> bufA =====
-        layernorm_to_A(vec + NV_G1, film + NC_C, film);
+        layernorm_to_A(vec + NV_G1, film + NC_C, film, blk == 0);
         NC_STAMP(0)
 
         // ===== conv1 (1x1, 512 -> 1024) + conv2 (depthwise 3x3) + SimpleGate -> bufB; channel means for the SCA pool =====
-        // four passes of one gate pair of 16-channel tiles: lo = channels j = 64 w + 16 ps (+ 4 q + i), hi = j + 512
+        // NTW passes of one gate pair of 16-channel tiles: lo = channels j = cown + 16 ps (+ 4 q + i), hi = j + 512
 #pragma unroll 1
-        for (int ps = 0; ps < 4; ++ps) {
+        for (int ps = 0; ps < NTW; ++ps) {
             nc_f4 acc[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -310,14 +465,14 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             nc_f4 b1v[2], dbv[2];
             nc_u4 tapa[2], tapb[2];
             auto dw_prefetch = [&](const int hi) {
-                const int cb = (hi ? NC_C : 0) + 64 * wave + 16 * ps;
+                const int cb = (hi ? NC_C : 0) + cown + 16 * ps;
                 b1v[hi] = *reinterpret_cast<const nc_f4*>(vec + NV_B1 + cb + 4 * q);
                 dbv[hi] = *reinterpret_cast<const nc_f4*>(vec + NV_DWB + cb + 4 * q);
                 tapa[hi] = *reinterpret_cast<const nc_u4*>(vec + NV_TAP + (cb + n) * 8);
                 tapb[hi] = *reinterpret_cast<const nc_u4*>(vec + NV_TAP + (cb + n) * 8 + 4);
             };
             dw_prefetch(0);
-            gemm_pass<4, false, NC_RING>(acc, bsrcA, nullptr, ring, ws);
+            gemm_pass<2, 4, false, NC_RING>(acc, bsrcA, nullptr, ring, ws);
             NC_STAMP(1)
             dw_prefetch(1);
             __builtin_amdgcn_sched_barrier(0);
@@ -358,56 +513,77 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                     } else {
                         const nc_f4 gv = dwlo[pt] * o[pt];
                         cs += gv;
-                        *reinterpret_cast<nc_h4*>(lds + NC_OFF_B + wr_off(64 * wave + 16 * ps, pt)) = cvt4(gv);
+                        put_gated(cown + 16 * ps, pt, cvt4(gv));
                     }
                 }
             }
             // SCA pool (AdaptiveAvgPool2d(1)): the lane's 4 pixels are in cs; sum the 16 pixel lanes of the channel group
             cs[0] = nc_sum_row16(cs[0]); cs[1] = nc_sum_row16(cs[1]); cs[2] = nc_sum_row16(cs[2]); cs[3] = nc_sum_row16(cs[3]);
-            if (n == 0) *reinterpret_cast<nc_h4*>(lds + NC_OFF_MEAN + (64 * wave + 16 * ps + 4 * q) * 2) = cvt4(cs * (1.0f / NC_PX));
+            if (n == 0) {
+                const nc_h4 mh = cvt4(cs * (1.0f / NC_PX));
+                if constexpr (G > 1) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(nc_u2x, mh), rs_vec, (cown + 16 * ps + 4 * q) * 2, 0, NC_SC1);
+                else *reinterpret_cast<nc_h4*>(lds + NC_OFF_MEAN + (cown + 16 * ps + 4 * q) * 2) = mh;
+            }
             NC_STAMP(2)
         }
-        __syncthreads();
+        if constexpr (G > 1) {
+            publish_gated();
+            group_barrier();        // every group's gated slice and pooled means are out
+            fetch_gated(true);
+        } else {
+            __syncthreads();
+        }
         NC_STAMP(3)
-        // ===== sca.1 (1x1 conv on the pooled vector): s = W mean + b for this wave's 64 channels -> the fp16 scale vector =====
+        // ===== sca.1 (1x1 conv on the pooled vector): s = W mean + b for this wave's channels -> the fp16 scale vector =====
         {
             const char* msrc[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) msrc[c] = lds + NC_OFF_MEAN + (c * 32 + 8 * q) * 2;   // every column reads the same 8 k values of its k step
 #pragma unroll 1
-            for (int ps = 0; ps < 2; ++ps) {
-                nc_f4 as[2][1];
-                as[0][0] = nc_f4{0.f, 0.f, 0.f, 0.f};
-                as[1][0] = nc_f4{0.f, 0.f, 0.f, 0.f};
-                const nc_f4 sb0 = *reinterpret_cast<const nc_f4*>(vec + NV_SCAB + chl + 16 * (2 * ps)), sb1 = *reinterpret_cast<const nc_f4*>(vec + NV_SCAB + chl + 16 * (2 * ps + 1));
-                gemm_pass<1, false, NC_RING>(as, msrc, nullptr, ring, ws);
+            for (int ps = 0; ps < NP3; ++ps) {
+                nc_f4 as[NT3][1];
+                nc_f4 sbv[NT3];
+#pragma unroll
+                for (int t = 0; t < NT3; ++t) {
+                    as[t][0] = nc_f4{0.f, 0.f, 0.f, 0.f};
+                    sbv[t] = *reinterpret_cast<const nc_f4*>(vec + NV_SCAB + chl + 16 * (NT3 * ps + t));
+                }
+                gemm_pass<NT3, 1, false, NC_RING>(as, msrc, nullptr, ring, ws);
                 if (n == 0) {
-                    *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + (chl + 16 * (2 * ps)) * 2) = cvt4(as[0][0] + sb0);
-                    *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + (chl + 16 * (2 * ps + 1)) * 2) = cvt4(as[1][0] + sb1);
+#pragma unroll
+                    for (int t = 0; t < NT3; ++t) {
+                        const nc_h4 sh = cvt4(as[t][0] + sbv[t]);
+                        if constexpr (G > 1) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(nc_u2x, sh), rs_vec, (NC_C + chl + 16 * (NT3 * ps + t)) * 2, 0, NC_SC1);
+                        else *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + (chl + 16 * (NT3 * ps + t)) * 2) = sh;
+                    }
                 }
             }
         }
         NC_STAMP(4)
+        if constexpr (G > 1) {
+            group_barrier();        // the whole scale vector is out
+            if (tid < 64) *reinterpret_cast<nc_u4x*>(lds + NC_OFF_S + tid * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_vec, NC_C * 2 + tid * 16, 0, NC_SC1);
+        }
         __syncthreads();
         NC_STAMP(9)
         // ===== conv3 (1x1, 512 -> 512) on x * sca(x); y = inp + conv3 * beta =====
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            nc_f4 acc[2][4];
+        for (int ps = 0; ps < NP3; ++ps) {
+            nc_f4 acc[NT3][4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT3; ++t)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
-            nc_f4 b3v[2], bev[2];
+            nc_f4 b3v[NT3], bev[NT3];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                b3v[t] = *reinterpret_cast<const nc_f4*>(vec + NV_B3 + chl + 16 * (2 * ps + t));
-                bev[t] = *reinterpret_cast<const nc_f4*>(vec + NV_BETA + chl + 16 * (2 * ps + t));
+            for (int t = 0; t < NT3; ++t) {
+                b3v[t] = *reinterpret_cast<const nc_f4*>(vec + NV_B3 + chl + 16 * (NT3 * ps + t));
+                bev[t] = *reinterpret_cast<const nc_f4*>(vec + NV_BETA + chl + 16 * (NT3 * ps + t));
             }
-            gemm_pass<4, true, NC_RING>(acc, bsrcB, lds + NC_OFF_S + 8 * q * 2, ring, ws);
+            gemm_pass<NT3, 4, true, NC_RING>(acc, bsrcB, lds + NC_OFF_S + 8 * q * 2, ring, ws);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ct = 2 * ps + t;
+            for (int t = 0; t < NT3; ++t) {
+                const int ct = NT3 * ps + t;
                 const nc_f4 b3 = b3v[t], be = bev[t];
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) {
@@ -421,18 +597,22 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             }
         }
         NC_STAMP(5)
+        if constexpr (G > 1) {
+            put_x();
+            group_barrier();        // the whole residual stream is in the output tensor
+        }
         // ===== norm2 + time FiLM -> bufA (its barriers also fence conv3's reads of bufB) =====
-        layernorm_to_A(vec + NV_G2, film + 3 * NC_C, film + 2 * NC_C);
+        layernorm_to_A(vec + NV_G2, film + 3 * NC_C, film + 2 * NC_C, false);
         NC_STAMP(6)
         // ===== conv4 (1x1, 512 -> 1024) + SimpleGate (+ lens FiLM) -> bufB =====
 #pragma unroll 1
-        for (int ps = 0; ps < 4; ++ps) {
+        for (int ps = 0; ps < NTW; ++ps) {
             nc_f4 acc[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
-            const int ch = 64 * wave + 16 * ps + 4 * q;
+            const int ch = cown + 16 * ps + 4 * q;
             const nc_f4 blo = *reinterpret_cast<const nc_f4*>(vec + NV_B4 + ch), bhi = *reinterpret_cast<const nc_f4*>(vec + NV_B4 + NC_C + ch);
             nc_f4 cs = {0.f, 0.f, 0.f, 0.f}, cf = {0.f, 0.f, 0.f, 0.f};
             if (a.cam) {
@@ -440,35 +620,41 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 cs = *reinterpret_cast<const nc_f4*>(cam + ch);
                 cf = *reinterpret_cast<const nc_f4*>(cam + NC_C + ch);
             }
-            gemm_pass<4, false, NC_RING>(acc, bsrcA, nullptr, ring, ws);
+            gemm_pass<2, 4, false, NC_RING>(acc, bsrcA, nullptr, ring, ws);
             cs = cs + 1.0f;
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 const nc_f4 v = ((acc[0][pt] + blo) * (acc[1][pt] + bhi)) * cs + cf;
-                *reinterpret_cast<nc_h4*>(lds + NC_OFF_B + wr_off(64 * wave + 16 * ps, pt)) = cvt4(v);
+                put_gated(cown + 16 * ps, pt, cvt4(v));
             }
         }
         NC_STAMP(7)
-        __syncthreads();
+        if constexpr (G > 1) {
+            publish_gated();
+            group_barrier();        // every group's gated slice is out
+            fetch_gated(false);
+        } else {
+            __syncthreads();
+        }
         NC_STAMP(9)
         // ===== conv5 (1x1, 512 -> 512); out = y + conv5 * gamma =====
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            nc_f4 acc[2][4];
+        for (int ps = 0; ps < NP3; ++ps) {
+            nc_f4 acc[NT3][4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT3; ++t)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[t][pt] = nc_f4{0.f, 0.f, 0.f, 0.f};
-            nc_f4 b5v[2], gav[2];
+            nc_f4 b5v[NT3], gav[NT3];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                b5v[t] = *reinterpret_cast<const nc_f4*>(vec + NV_B5 + chl + 16 * (2 * ps + t));
-                gav[t] = *reinterpret_cast<const nc_f4*>(vec + NV_GAMMA + chl + 16 * (2 * ps + t));
+            for (int t = 0; t < NT3; ++t) {
+                b5v[t] = *reinterpret_cast<const nc_f4*>(vec + NV_B5 + chl + 16 * (NT3 * ps + t));
+                gav[t] = *reinterpret_cast<const nc_f4*>(vec + NV_GAMMA + chl + 16 * (NT3 * ps + t));
             }
-            gemm_pass<4, false, NC_RING>(acc, bsrcB, nullptr, ring, ws);
+            gemm_pass<NT3, 4, false, NC_RING>(acc, bsrcB, nullptr, ring, ws);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ct = 2 * ps + t;
+            for (int t = 0; t < NT3; ++t) {
+                const int ct = NT3 * ps + t;
                 const nc_f4 b5 = b5v[t], ga = gav[t];
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) {
@@ -483,8 +669,13 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
         }
         NC_STAMP(8)
         // (the next block's norm1 writes bufA: every wave has passed the barrier behind conv4; its barriers fence conv5's reads of bufB)
+        if constexpr (G > 1) {
+            put_x();                                        // (behind the last block: the result)
+            if (blk + 1 < a.nblocks) group_barrier();       // the whole residual stream is in the output tensor: the next block's norm1 reads it
+        }
     }
-    if constexpr (!XG) {
+    if constexpr (G > 1) nc_group_exit(ctr, G, tid);
+    if constexpr (!XG && G == 1) {
         float* xout = a.out + (size_t)b * NC_PX * NC_C;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
@@ -512,6 +703,8 @@ void naf_chain_set_debug(unsigned long long* buf) { g_nc_dbg = buf; }
 
 void naf_chain_global_init() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef IRSDE_PROBES
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -527,6 +720,7 @@ void launch_naf_chain(const float* x, float* out, const unsigned short* w, const
     a.film_bstride = film_bstride; a.film_off = film_off; a.cam_bstride = cam_bstride; a.cam_off = cam_off;
     a.nblocks = nblocks;
     a.dbg = g_nc_dbg;
+    a.xgate = nullptr; a.xvec = nullptr; a.ctr = nullptr; a.B = B;
     const size_t wb = naf_chain_weight_halves(nblocks) * 2;
     if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain: weight stream too large for 32-bit buffer offsets");
     a.w_bytes = (unsigned)wb;
@@ -542,6 +736,111 @@ void launch_naf_chain(const float* x, float* out, const unsigned short* w, const
         default: throw HipError("launch_naf_chain: bad variant (11 / 2 are measurement variants: make PROBES=1)");
     }
     IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+// ---- G groups per image (r06) ----
+// The split kernel's weight streams are a permutation of the one-group streams' 1 KB fragments: order[i] = index (in fragments) into the G = 1 buffer of the
+// i-th fragment of the [G][8 waves][nblocks][448 / G] buffer.  Same enumeration as pack_naf_chain (engine_weights.hip) and the kernel's passes.
+std::vector<int> naf_chain_split_order(int nblocks, int G) {
+    if (G != 2 && G != 4) throw HipError("naf_chain_split_order: G must be 2 or 4");
+    const int NTW = 4 / G, NT3 = NTW >= 2 ? 2 : 1, NP3 = NTW / NT3;
+    // fragment id = (conv 0..4, 16-channel tile 0..63, k step): position in the one-group buffer
+    auto pos1 = [&](int conv, int tile, int ks, int blk) -> int {
+        // one-group stream of wave w1, block blk: [conv1: 4 ps x 16 ks x (lo, hi)] [sca: 2 ps x 16 x 2] [conv3] [conv4 as conv1] [conv5]
+        const bool gated = conv == 0 || conv == 3;
+        const int base = conv == 0 ? 0 : conv == 1 ? 128 : conv == 2 ? 192 : conv == 3 ? 256 : 384;
+        int w1, f;
+        if (gated) {
+            const int hi = tile >= 32 ? 1 : 0, t = tile & 31;   // 32 lo tiles, then 32 hi tiles
+            w1 = t >> 2;
+            f = base + ((t & 3) * 16 + ks) * 2 + hi;
+        } else {
+            w1 = tile >> 2;
+            const int tt = tile & 3;
+            f = base + ((tt >> 1) * 16 + ks) * 2 + (tt & 1);
+        }
+        return (w1 * nblocks + blk) * NC_FRAGS_PER_BLOCK + f;
+    };
+    std::vector<int> order;
+    order.reserve((size_t)8 * nblocks * NC_FRAGS_PER_BLOCK);
+    for (int g = 0; g < G; ++g)
+        for (int w = 0; w < 8; ++w)
+            for (int blk = 0; blk < nblocks; ++blk) {
+                const int tile0 = (g * (NC_C / G) + w * 16 * NTW) / 16;
+                auto gated = [&](int conv) {
+                    for (int ps = 0; ps < NTW; ++ps)
+                        for (int ks = 0; ks < 16; ++ks) { order.push_back(pos1(conv, tile0 + ps, ks, blk)); order.push_back(pos1(conv, 32 + tile0 + ps, ks, blk)); }
+                };
+                auto plain = [&](int conv) {
+                    for (int ps = 0; ps < NP3; ++ps)
+                        for (int ks = 0; ks < 16; ++ks)
+                            for (int t = 0; t < NT3; ++t) order.push_back(pos1(conv, tile0 + NT3 * ps + t, ks, blk));
+                };
+                gated(0); plain(1); plain(2); gated(3); plain(4);
+            }
+    if (order.size() != (size_t)8 * nblocks * NC_FRAGS_PER_BLOCK) throw HipError("naf_chain_split_order: stream length mismatch");
+    return order;
+}
+
+namespace {
+__global__ void naf_chain_permute_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int* __restrict__ order, const int nfrag) {
+    const int f = blockIdx.x;
+    if (f >= nfrag) return;
+    dst[(size_t)f * 64 + threadIdx.x] = src[(size_t)order[f] * 64 + threadIdx.x];
+}
+}  // namespace
+
+// dst = the [G][8][nblocks][448 / G] fragment streams built from the one-group buffer w1 (both naf_chain_weight_halves(nblocks) halves)
+void naf_chain_build_split_weights(const unsigned short* w1, unsigned short* dst, int nblocks, int G, hipStream_t s) {
+    const std::vector<int> order = naf_chain_split_order(nblocks, G);
+    int* dorder = nullptr;
+    IRSDE_HIP_CHECK(hipMalloc(&dorder, order.size() * sizeof(int)));
+    IRSDE_HIP_CHECK(hipMemcpy(dorder, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(naf_chain_permute_kernel, dim3((unsigned)order.size()), dim3(64), 0, s, reinterpret_cast<const uint4*>(w1), reinterpret_cast<uint4*>(dst),
+                       dorder, (int)order.size());
+    IRSDE_HIP_CHECK(hipGetLastError());
+    IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(dorder);
+}
+
+size_t naf_chain_split_scratch_bytes(int B) { return (size_t)B * (NC_PX * NC_C * 2 + 2 * NC_C * 2) + (4 * (size_t)B + 1) * 4 + 64; }
+
+// Work-groups the split launch needs resident at the same time: 8 ceil(B / 8) G (an image's groups share a block-id residue mod 8 = an XCD)
+int naf_chain_split_groups(int B, int G) { return 8 * ((B + 7) / 8) * G; }
+
+// G = 2 / 4 groups per image.  wG: the split weight streams (naf_chain_build_split_weights); scratch: naf_chain_split_scratch_bytes(B) bytes, 16-byte aligned —
+// [gated tensors][vectors][4 B counters + error word], ZERO before the first launch (the kernel leaves the counters zero; naf_chain_split_reset after an error).
+// The caller guarantees naf_chain_split_groups(B, G) <= the CUs no other resident kernel holds for long (see the file header).
+void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG, const float* vecs, int nblocks, int B, const float* film, int film_bstride,
+                            int film_off, const float* cam, int cam_bstride, int cam_off, int G, void* scratch, hipStream_t s) {
+    if (G != 2 && G != 4) throw HipError("launch_naf_chain_split: G must be 2 or 4");
+    if (naf_chain_split_groups(B, G) > device_cu_count()) throw HipError("launch_naf_chain_split: more work-groups than compute units (they must be co-resident)");
+    NafChainArgs a;
+    a.x = x; a.out = out; a.w = wG; a.vecs = vecs; a.film = film; a.cam = cam;
+    a.film_bstride = film_bstride; a.film_off = film_off; a.cam_bstride = cam_bstride; a.cam_off = cam_off;
+    a.nblocks = nblocks;
+    a.dbg = nullptr;
+    char* sc = reinterpret_cast<char*>(scratch);
+    a.xgate = reinterpret_cast<unsigned short*>(sc);
+    a.xvec = reinterpret_cast<unsigned short*>(sc + (size_t)B * NC_PX * NC_C * 2);
+    a.ctr = reinterpret_cast<unsigned*>(sc + (size_t)B * (NC_PX * NC_C * 2 + 2 * NC_C * 2));
+    a.B = B;
+    const size_t wb = naf_chain_weight_halves(nblocks) * 2;
+    if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain_split: weight stream too large for 32-bit buffer offsets");
+    a.w_bytes = (unsigned)wb;
+    const dim3 grid((unsigned)naf_chain_split_groups(B, G));
+    if (G == 2) hipLaunchKernelGGL((naf_chain_kernel<8, false, false, 2>), grid, dim3(512), NC_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((naf_chain_kernel<8, false, false, 4>), grid, dim3(512), NC_LDS_BYTES, s, a);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+// the error word of a split launch's scratch buffer (device pointer): non-zero after a run whose groups were not co-resident
+const unsigned* naf_chain_split_error_flag(const void* scratch, int B) {
+    return reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(scratch) + (size_t)B * (NC_PX * NC_C * 2 + 2 * NC_C * 2)) + 4 * B;
+}
+// counters + error word back to zero (synchronous; after an error was reported)
+void naf_chain_split_reset(void* scratch, int B) {
+    IRSDE_HIP_CHECK(hipMemset(reinterpret_cast<char*>(scratch) + (size_t)B * (NC_PX * NC_C * 2 + 2 * NC_C * 2), 0, (4 * (size_t)B + 1) * 4));
 }
 
 }  // namespace irsde

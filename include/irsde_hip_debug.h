@@ -55,13 +55,18 @@ int irsde_debug_split_gemm(const float* A, const float* B, float* C, int M, int 
 int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K, int stride, int up, int epi, int iters,
                      double* ms_out);
 /* Times naf_chain_kernel (csrc/naf_chain.hip) alone on synthetic data: `nblocks` consecutive 512-channel NAFBlocks on B images of 8 x 8 pixels,
- * `iters` launches; variant 1 residual stream in registers + ring of 8 weight fragments (= 0, production), 2 residual stream in L2 + ring of 16.
+ * `iters` launches; variant 1 residual stream in registers + ring of 8 weight fragments (= 0, production), 2 residual stream in L2 + ring of 16,
+ * 22 / 24 the kernel on 2 / 4 work-groups per image (r06).
  * *ms_out = milliseconds per launch.  (tools/naf_chain_bench.py) */
 int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out);
 /* Test / measurement hook (process-wide): the number of concurrent sub-batches irsde_sample splits a ConditionalNAFNet batch into — n >= 1 forces it
  * (1 = never split; clipped to 4 and to a divisor of the batch), 0 returns to the heuristic (2 parts from 64 images on, and only where a level
  * runs as a NAFBlock chain).  Plans are cached per split, so changing it never invalidates anything. */
 int irsde_debug_force_subbatches(int n);
+/* Test / measurement hook (process-wide): work-groups per image of the NAFBlock chain kernel in plans built from now on — 1 the one-group kernel, 2 / 4
+ * forced (where 8 ceil(B / 8) g groups fit the compute units next to the call's other sub-batches, else fewer), 0 returns to the rule (as many as fit).
+ * Plans already built keep their choice: use a fresh engine (or another batch shape) per setting. */
+int irsde_debug_force_chain_groups(int g);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ int main(void) {
     int nd = 0, n, i;
     size_t total = 0;
 
-    if (irsde_version() != 106) return fail("version");
+    if (irsde_version() != 107) return fail("version");
 
     memset(&cfg, 0, sizeof cfg);
     cfg.in_nc = 3; cfg.out_nc = 3; cfg.nf = 64; cfg.depth = 4;

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_string():
     L = _lib.lib()
-    assert L.irsde_version() == 106
+    assert L.irsde_version() == 107
     assert isinstance(L.irsde_last_error(), bytes)
 
 

@@ -51,7 +51,7 @@ def test_native_library_is_loaded():
     """The HIP extension (in-tree .so) is what runs; there is no eager/PyTorch fallback."""
     assert torch.cuda.is_available()
     L = _lib.lib()
-    assert L.irsde_version() == 106
+    assert L.irsde_version() == 107
     maps = open("/proc/self/maps").read()
     assert "libirsde_hip.so" in maps
 
@@ -1509,3 +1509,84 @@ def test_group_sum_probe_toolchain_guard(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(r.stdout)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("B", [2, 8, 11])
+def test_naf_chain_groups_per_image_equal_one_group(B):
+    """r06 (ABI 107, csrc/naf_chain.hip): the NAFBlock chain (DenoisingNAFNet_arch.py:56-83) on 2 / 4 work-groups per image — each group owns a slice of the
+    output channels, streams 1 / G of the weights and trades operand slices with the image's other groups through L2 (five barriers per block) — must give
+    the ONE-group kernel's result bit for bit: same operations in the same order (the LayerNorms run on the whole gathered image in the one-group lane
+    layout).  B = 2 / 8 / 11: one partly filled group of eight block-id residues, one full, two with a ragged second one; three-block and one-block runs;
+    lens FiLM on.  The plan must say which kernel it launches."""
+    rs = np.random.RandomState(40 + B)
+    encs = (1, 1, 1, 3)
+    kw = dict(img_channel=4, width=64, enc_blk_nums=list(encs), middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+    bp = O.naf_synth_params(seed=12, img_channel=4, width=64, middle_blk_num=1, enc_blk_nums=encs, dec_blk_nums=(1, 1, 1, 1), lens=True)
+    for k in bp:
+        if k.endswith(".beta") or k.endswith(".gamma"):
+            bp[k] = (0.5 * rs.standard_normal(bp[k].shape)).astype(np.float32)
+    xt = torch.from_numpy(rs.standard_normal((B, 4, 64, 64)).astype(np.float32)).to(DEV)
+    cond = torch.from_numpy(rs.standard_normal((B, 4, 64, 64)).astype(np.float32)).to(DEV)
+    li = [torch.from_numpy(rs.uniform(0.1, 1.0, B).astype(np.float32)) for _ in range(3)]
+    t = torch.from_numpy(rs.randint(1, 90, B))
+    L = _lib.lib()
+    outs = {}
+    try:
+        for g in (1, 2, 4):
+            L.irsde_debug_force_chain_groups(g)
+            m = P.latent_bokeh.ConditionalNAFNet(**kw)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in bp.items()}, strict=True)
+            m.engine_flags = _lib.FLAG_FP16
+            m = m.to(DEV).eval()
+            outs[g] = m(xt, cond, t, lens_info=li).cpu().numpy()
+            buf = ctypes.create_string_buffer(1 << 16)
+            _lib.check(L.irsde_plan_describe(m.engine(torch.device(DEV)).h, B, 64, 64, buf, len(buf)))
+            assert buf.value.count(b"naf_chain(fp16)") == 2 and buf.value.count(b"groups=%d " % g) == 2, buf.value[-800:]   # encoder level 3 (three blocks), decoder level 0 (one)
+    finally:
+        L.irsde_debug_force_chain_groups(0)
+    assert np.isfinite(outs[1]).all()
+    for g in (2, 4):
+        d = float(np.abs(outs[g] - outs[1]).max())
+        print("naf chain B=%d: %d groups per image vs one: max diff %.3g (bit-identical: %s)" % (B, g, d, np.array_equal(outs[g], outs[1])))
+        assert np.array_equal(outs[g], outs[1]), (B, g, d)
+
+
+@pytest.mark.parametrize("B", [8, 5])
+def test_naf_chain_groups_sampler_graph_replay(B):
+    """r06: the split chain inside irsde_sample — ONE captured step graph replayed T times (the kernel restores its barrier counters itself: no memset node),
+    two calls in a row (second call = pure replay), eager as well: 4 groups per image must reproduce the one-group sampler bit for bit, and no call may
+    leave the co-residency error word set (sde_utils.py:252-266 is the loop)."""
+    rs = np.random.RandomState(70 + B)
+    kw = dict(img_channel=4, width=64, enc_blk_nums=[1, 1, 1, 2], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+    bp = O.naf_synth_params(seed=13, img_channel=4, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 2), dec_blk_nums=(1, 1, 1, 1), lens=True)
+    for k in bp:
+        if k.endswith(".beta") or k.endswith(".gamma"):
+            bp[k] = (0.5 * rs.standard_normal(bp[k].shape)).astype(np.float32)
+    mu = torch.from_numpy(rs.rand(B, 4, 64, 64).astype(np.float32)).to(DEV)
+    li = [torch.from_numpy(rs.uniform(0.1, 1.0, B).astype(np.float32)) for _ in range(3)]
+    xT = mu + torch.from_numpy((0.5 * rs.standard_normal((B, 4, 64, 64))).astype(np.float32)).to(DEV)   # (one terminal state for both engines)
+    L = _lib.lib()
+    res = {}
+    try:
+        for g in (1, 4):
+            L.irsde_debug_force_chain_groups(g)
+            m = P.latent_bokeh.ConditionalNAFNet(**kw)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in bp.items()}, strict=True)
+            m.engine_flags = _lib.FLAG_FP16
+            m = m.to(DEV).eval()
+            sde = P.IRSDE(max_sigma=50, T=100, schedule="cosine", eps=0.005, device=torch.device(DEV))
+            sde.set_model(m)
+            sde.seed = 11
+            sde.set_mu(mu)
+            outs = []
+            for graph in (True, True, False):
+                sde.use_graph = graph
+                outs.append(sde.reverse_sde(xT.clone(), T=6, lens_info=li).cpu().numpy())
+            sde.reverse_sde(xT.clone(), T=1, lens_info=li)   # (a call after the last one: this is where a co-residency error of the previous call would be raised)
+            torch.cuda.synchronize()
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), g   # replay = first launch = eager
+            res[g] = outs[0]
+    finally:
+        L.irsde_debug_force_chain_groups(0)
+    assert np.isfinite(res[1]).all()
+    assert np.array_equal(res[4], res[1]), float(np.abs(res[4] - res[1]).max())
