@@ -843,7 +843,7 @@ int irsde_debug_force_subbatches(int n) {
 int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out) {
     return guard([&] {
         if (!ms_out || nblocks < 1 || nblocks > 64 || B < 1 || iters < 1) throw HipError("bench_naf_chain: bad argument");
-        const int G = variant == 22 ? 2 : variant == 24 ? 4 : 1;   // r06: 22 / 24 = the kernel with 2 / 4 work-groups per image
+        const int G = variant == 22 ? 2 : (variant == 24 || variant == 25) ? 4 : 1;   // (25, PROBES build: 24 + its cycle stamps)   // r06: 22 / 24 = the kernel with 2 / 4 work-groups per image
 #ifdef IRSDE_PROBES
         if (variant != 0 && variant != 1 && variant != 2 && variant != 11 && G == 1) throw HipError("bench_naf_chain: bad variant");
 #else
@@ -884,6 +884,35 @@ int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms
             else launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant == 11 ? 1 : variant);
         };
         run();   // warm
+        if (variant == 25) {
+#ifdef IRSDE_PROBES
+            const int ng = naf_chain_split_groups(B, 4);
+            unsigned long long* dd = nullptr;
+            IRSDE_HIP_CHECK(hipMalloc(&dd, (size_t)ng * 8 * 16 * 8));
+            IRSDE_HIP_CHECK(hipMemsetAsync(dd, 0, (size_t)ng * 8 * 16 * 8, s));
+            naf_chain_set_debug(dd);
+            run();
+            IRSDE_HIP_CHECK(hipStreamSynchronize(s));
+            naf_chain_set_debug(nullptr);
+            std::vector<unsigned long long> hd((size_t)ng * 8 * 16);
+            IRSDE_HIP_CHECK(hipMemcpy(hd.data(), dd, hd.size() * 8, hipMemcpyDeviceToHost));
+            double acc[16] = {0};
+            double nwv = 0;
+            for (size_t w = 0; w < (size_t)ng * 8; ++w) {
+                if (!hd[w * 16 + 15]) continue;   // (a group of an image slot past the batch)
+                for (int k = 0; k < 16; ++k) acc[k] += (double)hd[w * 16 + k];
+                nwv += 1;
+            }
+            static const char* names[12] = {"norm1 (incl. residual-stream fetch)", "conv1 GEMM passes", "depthwise 3x3 + gate + pool", "gated fetch behind barrier (pool)", "sca.1 GEMM", "conv3 GEMM + residual", "norm2 (incl. residual-stream fetch)", "conv4 GEMM + gate", "conv5 GEMM + residual", "scale-vector / gated fetch (sca, conv4)", "group barriers (5 per block)", "publishing (gated slice, residual slice)"};
+            printf("naf_chain stamps, 4 groups per image: %d blocks, B=%d; shader cycles per wave and block (mean over %.0f waves)\n", nblocks, B, nwv);
+            for (int k = 0; k < 12; ++k) printf("  %-42s %9.0f\n", names[k], acc[k] / nwv / nblocks);
+            printf("  %-42s %9.0f\n", "whole kernel / blocks", acc[15] / nwv / nblocks);
+            fflush(stdout);
+            (void)hipFree(dd);
+#else
+            throw HipError("bench_naf_chain: variant 25 is a measurement twin (make PROBES=1)");
+#endif
+        }
         if (variant == 11) {   // the stamp twin once: per-phase cycle budget per block, averaged over all waves
             unsigned long long* dd = nullptr;
             IRSDE_HIP_CHECK(hipMalloc(&dd, (size_t)B * 8 * 16 * 8));

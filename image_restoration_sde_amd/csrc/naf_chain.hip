@@ -201,11 +201,11 @@ __device__ __forceinline__ void gemm_pass(nc_f4 (&acc)[NT][NPT], const char* con
 template <int NC_RING, bool XG, bool STAMP = false, int G = 1>
 __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a) {
     static_assert(G == 1 || G == 2 || G == 4, "groups per image");
-    static_assert(G == 1 || (!XG && !STAMP), "the split kernel has no measurement twins");
+    static_assert(G == 1 || !XG, "the split kernel keeps the residual stream in registers");
     constexpr int NTW = 4 / G;                 // 16-channel tiles per wave of a 512-wide tensor (gate pairs of a 1024-wide one)
     constexpr int NT3 = NTW >= 2 ? 2 : 1;      // weight tiles per k step of the 512 -> 512 passes (sca.1, conv3, conv5)
     constexpr int NP3 = NTW / NT3;             // ... and passes
-    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_t0 = 0;
+    unsigned long long st[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_t0 = 0;   // (10 .. 12, G > 1: group barriers, gated fetch + publish, residual-stream publish)
     if constexpr (STAMP) st_t0 = st_t = __builtin_amdgcn_s_memtime();
 #define NC_STAMP(K)                                                       \
     if constexpr (STAMP) {                                                \
@@ -232,8 +232,10 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
     unsigned nbar = 0;
     auto group_barrier = [&]() {
         if constexpr (G > 1) {
+            NC_STAMP(11)
             nc_group_barrier(ctr, err, nbar, G, grp == 0, tid);
             nbar += 1;
+            NC_STAMP(10)
         }
     };
 
@@ -684,8 +686,8 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
     }
     if constexpr (STAMP) {
         if (lane == 0 && a.dbg) {
-            unsigned long long* d = a.dbg + ((size_t)b * 8 + wave) * 16;
-            for (int i = 0; i < 10; ++i) d[i] = st[i];
+            unsigned long long* d = a.dbg + ((size_t)(G > 1 ? (int)blockIdx.x : b) * 8 + wave) * 16;
+            for (int i = 0; i < 12; ++i) d[i] = st[i];
             d[15] = __builtin_amdgcn_s_memtime() - st_t0;
         }
     }
@@ -706,6 +708,7 @@ void naf_chain_global_init() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef IRSDE_PROBES
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
@@ -819,7 +822,7 @@ void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG
     a.x = x; a.out = out; a.w = wG; a.vecs = vecs; a.film = film; a.cam = cam;
     a.film_bstride = film_bstride; a.film_off = film_off; a.cam_bstride = cam_bstride; a.cam_off = cam_off;
     a.nblocks = nblocks;
-    a.dbg = nullptr;
+    a.dbg = g_nc_dbg;   // (PROBES build, G = 4: the cycle-stamp twin when a stamp buffer is set)
     char* sc = reinterpret_cast<char*>(scratch);
     a.xgate = reinterpret_cast<unsigned short*>(sc);
     a.xvec = reinterpret_cast<unsigned short*>(sc + (size_t)B * NC_PX * NC_C * 2);
@@ -829,6 +832,13 @@ void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG
     if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain_split: weight stream too large for 32-bit buffer offsets");
     a.w_bytes = (unsigned)wb;
     const dim3 grid((unsigned)naf_chain_split_groups(B, G));
+#ifdef IRSDE_PROBES
+    if (G == 4 && a.dbg) {
+        hipLaunchKernelGGL((naf_chain_kernel<8, false, true, 4>), grid, dim3(512), NC_LDS_BYTES, s, a);
+        IRSDE_HIP_CHECK(hipGetLastError());
+        return;
+    }
+#endif
     if (G == 2) hipLaunchKernelGGL((naf_chain_kernel<8, false, false, 2>), grid, dim3(512), NC_LDS_BYTES, s, a);
     else hipLaunchKernelGGL((naf_chain_kernel<8, false, false, 4>), grid, dim3(512), NC_LDS_BYTES, s, a);
     IRSDE_HIP_CHECK(hipGetLastError());

@@ -12,6 +12,37 @@
 #include <vector>
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// part 2 (r06): the same question for the 16-bit matrix instruction of the bf16 / fp16 modes (v_mfma_f32_32x32x16_bf16: 16 passes = 64 cycles? measured):
+// 4 independent MFMAs + NV vector instructions per loop, every wave both streams
+template <int KIND, int NV>
+__global__ __launch_bounds__(512, 2) void kb(const float* __restrict__ src, float* __restrict__ out, const int iters) {
+    const floatx4 u0 = reinterpret_cast<const floatx4*>(src)[threadIdx.x * 2], u1 = reinterpret_cast<const floatx4*>(src)[threadIdx.x * 2 + 1];
+    const bf16x8 a = __builtin_bit_cast(bf16x8, u0), b = __builtin_bit_cast(bf16x8, u1);
+    floatx16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    floatx2 r[8];
+    for (int i = 0; i < 8; ++i) r[i] = floatx2{u0[i & 3] * 1e-3f, u1[i & 3] * 1e-3f};
+    for (int it = 0; it < iters; ++it) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, acc[3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if constexpr (KIND == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(r[i & 7]) : "v"(r[(i + 3) & 7]), "v"(r[(i + 5) & 7]));
+            else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r[i & 7].x) : "v"(r[(i + 3) & 7].y), "v"(r[(i + 5) & 7].x));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int q = 0; q < 16; ++q) s += acc[i][q];
+    for (int i = 0; i < 8; ++i) s += r[i].x + r[i].y;
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
 
 template <int KIND, int NV>
 __device__ __forceinline__ void vec_ops(floatx2 (&r)[8], float* lds) {
@@ -87,6 +118,28 @@ double run() {
     return tf;
 }
 
+template <int KIND, int NV>
+void runb() {
+    const int nb = 256;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    int iters = 20000;
+    hipLaunchKernelGGL((kb<KIND, NV>), dim3(nb), dim3(512), 0, 0, g_src, g_out, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((kb<KIND, NV>), dim3(nb), dim3(512), 0, 0, g_src, g_out, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    iters = (int)(iters * 120.0 / ms);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((kb<KIND, NV>), dim3(nb), dim3(512), 0, 0, g_src, g_out, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)nb * 8.0 * iters * 4 * 32768.0;
+    const double tf = flop / ms / 1e9;
+    printf("v_mfma_f32_32x32x16_bf16 x 4 + %3d x %s per wave and loop : %8.1f TFLOP/s (%.3f of 2516.6)   %.0f nominal cycles per loop and SIMD\n", NV,
+           KIND == 0 ? "v_pk_fma_f32" : "v_fma_f32", tf, tf / 2516.6, ms * 1e-3 * 2.4e9 / iters);
+}
+
 template <int MODE, int KIND>
 void sweep(const char* name) {
     printf("---- %s, %s\n", name, MODE == 0 ? "every wave: 8 MFMAs + NV vector ops per loop (2 waves per SIMD)" : "matrix waves (1 per SIMD) beside vector waves (1 per SIMD, 2 NV ops per loop)");
@@ -116,5 +169,8 @@ int main() {
     sweep<1, 0>("v_pk_fma_f32");
     sweep<1, 1>("v_fma_f32");
     sweep<1, 4>("v_mov_b32");
+    printf("---- 16-bit matrix instruction (random operands: the chip clocks down under it, profiles/r05_mfma_sustained.txt), every wave 4 MFMAs + NV vector ops per loop\n");
+    runb<0, 0>(); runb<0, 4>(); runb<0, 8>(); runb<0, 16>(); runb<0, 32>(); runb<0, 64>();
+    runb<1, 0>(); runb<1, 8>(); runb<1, 16>(); runb<1, 32>(); runb<1, 64>();
     return 0;
 }
