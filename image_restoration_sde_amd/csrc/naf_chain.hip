@@ -75,6 +75,7 @@ struct NafChainArgs {
     unsigned long long* dbg;   // STAMP twin only
     // G > 1 (naf_chain_kernel<.., G>): exchange buffers of the image's groups
     unsigned short* xgate;     // [B][64 px][512] fp16: the gated tensors
+    unsigned short* xnorm;     // [B][64 px][512] fp16: the LayerNorm outputs (operand image of conv1 / conv4)
     unsigned short* xvec;      // [B][2][512] fp16: pooled means | SCA scale vector
     unsigned* ctr;             // [B][4] barrier counters (zero between launches: the kernel restores them) | [4 B]: error word
     int B;
@@ -305,6 +306,8 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * NC_PX * NC_C, 0, G > 1 ? NC_PX * NC_C * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_gate =
         __builtin_amdgcn_make_buffer_rsrc(G > 1 ? a.xgate + (size_t)b * NC_PX * NC_C : const_cast<unsigned short*>(a.w), 0, G > 1 ? NC_PX * NC_C * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_norm =
+        __builtin_amdgcn_make_buffer_rsrc(G > 1 ? a.xnorm + (size_t)b * NC_PX * NC_C : const_cast<unsigned short*>(a.w), 0, G > 1 ? NC_PX * NC_C * 2 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_vec =
         __builtin_amdgcn_make_buffer_rsrc(G > 1 ? a.xvec + (size_t)b * 2 * NC_C : const_cast<unsigned short*>(a.w), 0, G > 1 ? 2 * NC_C * 2 : 0, 0x00020000);
     const int chl = cown + 4 * q;        // + 16 ct: this lane's channels of a 512-wide tensor
@@ -326,77 +329,109 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             v.fh[ct] = *reinterpret_cast<const nc_f4*>(fshift + chl1 + 16 * ct);
         }
     };
+    // G > 1: group grp normalises the NPO = 4 / G pixel tiles pt0 .. pt0 + NPO - 1 of the image (all 512 channels — the one-group lane layout, operations and summation
+    // order per pixel: bit-identical rows), publishes its rows of the fp16 operand image and fetches the other groups' rows behind a group barrier: a quarter of the
+    // LayerNorm work and 80 instead of 128 KB of exchange reads per group for one more barrier (every group normalising the whole image: 15-16k cycles per
+    // LayerNorm of the block's 82k, profiles/r06_zz_chain_stamps.txt).
+    constexpr int NPO = G > 1 ? 4 / G : 4;
+    const int pt0 = G > 1 ? grp * NPO : 0;
     auto layernorm_to_A = [&](const float* g, const float* fscale, const float* fshift, const bool from_input) {
         LnVec lv;
         ln_prefetch(lv, g, fscale, fshift);
-        nc_f4 xf[G > 1 ? 4 : 1][G > 1 ? 4 : 1];
+        nc_f4 xf[G > 1 ? 4 : 1][G > 1 ? NPO : 1];
         if constexpr (G > 1) {
             if (from_input) {   // (the first block: the launch's input tensor, plain loads)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) xf[ct][pt] = *reinterpret_cast<const nc_f4*>(xin + (16 * pt + n) * NC_C + chl1 + 16 * ct);
+                    for (int pp = 0; pp < NPO; ++pp) xf[ct][pp] = *reinterpret_cast<const nc_f4*>(xin + (16 * (pt0 + pp) + n) * NC_C + chl1 + 16 * ct);
             } else {
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                    for (int pt = 0; pt < 4; ++pt)
-                        xf[ct][pt] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((16 * pt + n) * NC_C + chl1 + 16 * ct) * 4, 0, NC_SC1));
+                    for (int pp = 0; pp < NPO; ++pp)
+                        xf[ct][pp] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((16 * (pt0 + pp) + n) * NC_C + chl1 + 16 * ct) * 4, 0, NC_SC1));
             }
         }
+        // (pp = index into the group's own pixel tiles; G = 1: pp = pt)
         // XG: every pass re-reads the lane's 16 vectors from L2 instead of holding them (the ring of 32 fragments owns the registers)
-        auto X = [&](const int ct, const int pt) -> nc_f4 {
-            if constexpr (G > 1) return xf[ct][pt];
-            else if constexpr (XG) return *reinterpret_cast<const nc_f4*>(xg + 16 * ct + pt * 16 * NC_C);
-            else return x[ct][pt];
+        auto X = [&](const int ct, const int pp) -> nc_f4 {
+            if constexpr (G > 1) return xf[ct][pp];
+            else if constexpr (XG) return *reinterpret_cast<const nc_f4*>(xg + 16 * ct + pp * 16 * NC_C);
+            else return x[ct][pp];
         };
-        float s[4];
+        float s[NPO];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
+        for (int pp = 0; pp < NPO; ++pp) {
             float t = 0.f;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) { const nc_f4 v = X(ct, pt); t += (v[0] + v[1]) + (v[2] + v[3]); }
-            s[pt] = nc_sum_quarters(t);
+            for (int ct = 0; ct < 4; ++ct) { const nc_f4 v = X(ct, pp); t += (v[0] + v[1]) + (v[2] + v[3]); }
+            s[pp] = nc_sum_quarters(t);
         }
         if (q == 0) {
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) red1[(16 * pt + n) * 8 + wave] = s[pt];
+            for (int pp = 0; pp < NPO; ++pp) red1[(16 * (pt0 + pp) + n) * 8 + wave] = s[pp];
         }
         __syncthreads();
-        float mean[4], rstd[4];
+        float mean[NPO], rstd[NPO];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            const nc_f4 r0 = *reinterpret_cast<const nc_f4*>(red1 + (16 * pt + n) * 8), r1 = *reinterpret_cast<const nc_f4*>(red1 + (16 * pt + n) * 8 + 4);
-            mean[pt] = (((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3]))) * (1.0f / NC_C);
+        for (int pp = 0; pp < NPO; ++pp) {
+            const int px = 16 * (pt0 + pp) + n;
+            const nc_f4 r0 = *reinterpret_cast<const nc_f4*>(red1 + px * 8), r1 = *reinterpret_cast<const nc_f4*>(red1 + px * 8 + 4);
+            mean[pp] = (((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3]))) * (1.0f / NC_C);
             float t = 0.f;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                const nc_f4 d = X(ct, pt) - mean[pt];
+                const nc_f4 d = X(ct, pp) - mean[pp];
                 t += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
-            s[pt] = nc_sum_quarters(t);
+            s[pp] = nc_sum_quarters(t);
         }
         if (q == 0) {
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) red2[(16 * pt + n) * 8 + wave] = s[pt];
+            for (int pp = 0; pp < NPO; ++pp) red2[(16 * (pt0 + pp) + n) * 8 + wave] = s[pp];
         }
         __syncthreads();
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            const nc_f4 r0 = *reinterpret_cast<const nc_f4*>(red2 + (16 * pt + n) * 8), r1 = *reinterpret_cast<const nc_f4*>(red2 + (16 * pt + n) * 8 + 4);
+        for (int pp = 0; pp < NPO; ++pp) {
+            const int px = 16 * (pt0 + pp) + n;
+            const nc_f4 r0 = *reinterpret_cast<const nc_f4*>(red2 + px * 8), r1 = *reinterpret_cast<const nc_f4*>(red2 + px * 8 + 4);
             const float var = (((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3]))) * (1.0f / NC_C);
-            rstd[pt] = __builtin_amdgcn_rsqf(var + 1e-5f);   // v_rsq_f32 (1 ulp)
+            rstd[pp] = __builtin_amdgcn_rsqf(var + 1e-5f);   // v_rsq_f32 (1 ulp)
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             const nc_f4 gg = lv.g[ct], fs = lv.fs[ct] + 1.0f, fh = lv.fh[ct];
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-                const nc_f4 v = ((X(ct, pt) - mean[pt]) * rstd[pt] * gg) * fs + fh;
-                *reinterpret_cast<nc_h4*>(lds + wr_off(64 * wave + 16 * ct, pt)) = cvt4(v);
+            for (int pp = 0; pp < NPO; ++pp) {
+                const nc_f4 v = ((X(ct, pp) - mean[pp]) * rstd[pp] * gg) * fs + fh;
+                *reinterpret_cast<nc_h4*>(lds + wr_off(64 * wave + 16 * ct, pt0 + pp)) = cvt4(v);
             }
         }
         __syncthreads();
+        if constexpr (G > 1) {
+            // the group's rows (16 NPO pixels x 64 chunks of 16 bytes) out, barrier, the other groups' rows in
+            constexpr int NOWN = (16 * NPO * 64) / 512, NOTH = ((NC_PX - 16 * NPO) * 64) / 512;
+#pragma unroll
+            for (int i = 0; i < NOWN; ++i) {
+                const int idx = tid + 512 * i, px = 16 * pt0 + (idx >> 6), c8 = idx & 63;
+                const nc_u4x v = *reinterpret_cast<const nc_u4x*>(lds + px * NC_ROW + ((c8 ^ (px & 15)) << 4));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_norm, px * NC_ROW + c8 * 16, 0, NC_SC1);
+            }
+            group_barrier();
+            nc_u4x c[NOTH];
+#pragma unroll
+            for (int i = 0; i < NOTH; ++i) {
+                const int idx = tid + 512 * i, r = idx >> 6, px = r < 16 * pt0 ? r : r + 16 * NPO, c8 = idx & 63;
+                c[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_norm, px * NC_ROW + c8 * 16, 0, NC_SC1);
+            }
+#pragma unroll
+            for (int i = 0; i < NOTH; ++i) {
+                const int idx = tid + 512 * i, r = idx >> 6, px = r < 16 * pt0 ? r : r + 16 * NPO, c8 = idx & 63;
+                *reinterpret_cast<nc_u4x*>(lds + px * NC_ROW + ((c8 ^ (px & 15)) << 4)) = c[i];
+            }
+            __syncthreads();
+        }
     };
     // G > 1: the gated tensor.  Every group writes its channel slice into its own bufB (like the one-group kernel), publishes it — 16-byte chunks, LDS ->
     // exchange buffer, plain [px][512] fp16 — and behind the group barrier fetches the other groups' slices into bufB (+ the pooled means into the LDS mean vector)
@@ -723,7 +758,7 @@ void launch_naf_chain(const float* x, float* out, const unsigned short* w, const
     a.film_bstride = film_bstride; a.film_off = film_off; a.cam_bstride = cam_bstride; a.cam_off = cam_off;
     a.nblocks = nblocks;
     a.dbg = g_nc_dbg;
-    a.xgate = nullptr; a.xvec = nullptr; a.ctr = nullptr; a.B = B;
+    a.xgate = nullptr; a.xnorm = nullptr; a.xvec = nullptr; a.ctr = nullptr; a.B = B;
     const size_t wb = naf_chain_weight_halves(nblocks) * 2;
     if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain: weight stream too large for 32-bit buffer offsets");
     a.w_bytes = (unsigned)wb;
@@ -806,13 +841,13 @@ void naf_chain_build_split_weights(const unsigned short* w1, unsigned short* dst
     (void)hipFree(dorder);
 }
 
-size_t naf_chain_split_scratch_bytes(int B) { return (size_t)B * (NC_PX * NC_C * 2 + 2 * NC_C * 2) + (4 * (size_t)B + 1) * 4 + 64; }
+size_t naf_chain_split_scratch_bytes(int B) { return (size_t)B * (2 * NC_PX * NC_C * 2 + 2 * NC_C * 2) + (4 * (size_t)B + 1) * 4 + 64; }
 
 // Work-groups the split launch needs resident at the same time: 8 ceil(B / 8) G (an image's groups share a block-id residue mod 8 = an XCD)
 int naf_chain_split_groups(int B, int G) { return 8 * ((B + 7) / 8) * G; }
 
 // G = 2 / 4 groups per image.  wG: the split weight streams (naf_chain_build_split_weights); scratch: naf_chain_split_scratch_bytes(B) bytes, 16-byte aligned —
-// [gated tensors][vectors][4 B counters + error word], ZERO before the first launch (the kernel leaves the counters zero; naf_chain_split_reset after an error).
+// [gated tensors][LayerNorm outputs][vectors][4 B counters + error word], ZERO before the first launch (the kernel leaves the counters zero; naf_chain_split_reset after an error).
 // The caller guarantees naf_chain_split_groups(B, G) <= the CUs no other resident kernel holds for long (see the file header).
 void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG, const float* vecs, int nblocks, int B, const float* film, int film_bstride,
                             int film_off, const float* cam, int cam_bstride, int cam_off, int G, void* scratch, hipStream_t s) {
@@ -825,8 +860,9 @@ void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG
     a.dbg = g_nc_dbg;   // (PROBES build, G = 4: the cycle-stamp twin when a stamp buffer is set)
     char* sc = reinterpret_cast<char*>(scratch);
     a.xgate = reinterpret_cast<unsigned short*>(sc);
-    a.xvec = reinterpret_cast<unsigned short*>(sc + (size_t)B * NC_PX * NC_C * 2);
-    a.ctr = reinterpret_cast<unsigned*>(sc + (size_t)B * (NC_PX * NC_C * 2 + 2 * NC_C * 2));
+    a.xnorm = reinterpret_cast<unsigned short*>(sc + (size_t)B * NC_PX * NC_C * 2);
+    a.xvec = reinterpret_cast<unsigned short*>(sc + (size_t)B * 2 * NC_PX * NC_C * 2);
+    a.ctr = reinterpret_cast<unsigned*>(sc + (size_t)B * (2 * NC_PX * NC_C * 2 + 2 * NC_C * 2));
     a.B = B;
     const size_t wb = naf_chain_weight_halves(nblocks) * 2;
     if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain_split: weight stream too large for 32-bit buffer offsets");
@@ -846,11 +882,11 @@ void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG
 
 // the error word of a split launch's scratch buffer (device pointer): non-zero after a run whose groups were not co-resident
 const unsigned* naf_chain_split_error_flag(const void* scratch, int B) {
-    return reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(scratch) + (size_t)B * (NC_PX * NC_C * 2 + 2 * NC_C * 2)) + 4 * B;
+    return reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(scratch) + (size_t)B * (2 * NC_PX * NC_C * 2 + 2 * NC_C * 2)) + 4 * B;
 }
 // counters + error word back to zero (synchronous; after an error was reported)
 void naf_chain_split_reset(void* scratch, int B) {
-    IRSDE_HIP_CHECK(hipMemset(reinterpret_cast<char*>(scratch) + (size_t)B * (NC_PX * NC_C * 2 + 2 * NC_C * 2), 0, (4 * (size_t)B + 1) * 4));
+    IRSDE_HIP_CHECK(hipMemset(reinterpret_cast<char*>(scratch) + (size_t)B * (2 * NC_PX * NC_C * 2 + 2 * NC_C * 2), 0, (4 * (size_t)B + 1) * 4));
 }
 
 }  // namespace irsde
