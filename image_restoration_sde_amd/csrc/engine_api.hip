@@ -903,7 +903,7 @@ int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms
                 for (int k = 0; k < 16; ++k) acc[k] += (double)hd[w * 16 + k];
                 nwv += 1;
             }
-            static const char* names[12] = {"norm1 (incl. residual-stream fetch)", "conv1 GEMM passes", "depthwise 3x3 + gate + pool", "gated fetch behind barrier (pool)", "sca.1 GEMM", "conv3 GEMM + residual", "norm2 (incl. residual-stream fetch)", "conv4 GEMM + gate", "conv5 GEMM + residual", "scale-vector / gated fetch (sca, conv4)", "group barriers (7 per block)", "publishing (gated slice, residual slice)"};
+            static const char* names[12] = {"norm1 (incl. residual-stream fetch)", "conv1 GEMM passes", "depthwise 3x3 + gate + pool", "gated fetch behind barrier (pool)", "sca.1 GEMM", "conv3 GEMM + residual", "norm2 (incl. residual-stream fetch)", "conv4 GEMM + gate", "conv5 GEMM + residual", "scale-vector / gated fetch (sca, conv4)", "group barriers (6 per block)", "publishing (gated slice, residual slice)"};
             printf("naf_chain stamps, 4 groups per image: %d blocks, B=%d; shader cycles per wave and block (mean over %.0f waves)\n", nblocks, B, nwv);
             for (int k = 0; k < 12; ++k) printf("  %-42s %9.0f\n", names[k], acc[k] / nwv / nblocks);
             printf("  %-42s %9.0f\n", "whole kernel / blocks", acc[15] / nwv / nblocks);

@@ -315,7 +315,7 @@ NafBlockW pack_nafblock(irsde_engine* e, const std::string& p, int c) {
 
 
 // The fp16 weight streams + fp32 vectors of naf_chain_kernel (csrc/naf_chain.hip) for the blocks `prefixes` (consecutive 512-channel NAFBlocks).
-// Stream of wave w, block i: [conv1: 4 passes x 16 k steps x (lo tile, hi tile)] [sca.1: 2 passes x 16 x 2 tiles] [conv3: same] [conv4: as conv1]
+// Stream of wave w, block i: [conv1: 4 passes x 16 k steps x (lo tile, hi tile)] [sca.1: 16 k steps x 4 tiles] [conv3: 2 passes x 16 x 2 tiles] [conv4: as conv1]
 // [conv5: as conv3]; a fragment = 64 lanes x 8 halves: lane l holds W[tile channel base + (l & 15)][32 ks + 8 (l >> 4) + 0 .. 7].
 NafChainW pack_naf_chain(irsde_engine* e, const std::vector<std::string>& prefixes, const NafBlockW& first) {
     constexpr int C = 512, FR = 448;
@@ -357,7 +357,11 @@ NafChainW pack_naf_chain(irsde_engine* e, const std::vector<std::string>& prefix
                         frag(W, 64 * wave + 32 * ps + 16, ks);
                     }
             };
-            gated(w1); plain(ws); plain(w3); gated(w4); plain(w5);
+            auto sca = [&](const float* W) {   // r06: [k step][tile of the wave]: four quarters of 4 k steps, each accumulated on its own (naf_chain.hip)
+                for (int ks = 0; ks < 16; ++ks)
+                    for (int t = 0; t < 4; ++t) frag(W, 64 * wave + 16 * t, ks);
+            };
+            gated(w1); sca(ws); plain(w3); gated(w4); plain(w5);
             if (dst != w.data() + ((size_t)wave * nb + i + 1) * FR * 512) throw HipError("pack_naf_chain: stream length mismatch");
         }
         float* v = vecs.data() + (size_t)i * NV;

@@ -76,7 +76,7 @@ struct NafChainArgs {
     // G > 1 (naf_chain_kernel<.., G>): exchange buffers of the image's groups
     unsigned short* xgate;     // [B][64 px][512] fp16: the gated tensors
     unsigned short* xnorm;     // [B][64 px][512] fp16: the LayerNorm outputs (operand image of conv1 / conv4)
-    unsigned short* xvec;      // [B][2][512] fp16: pooled means | SCA scale vector
+    float* xvec;               // [B][4 quarters][512] fp32: the sca.1 partial sums
     unsigned* ctr;             // [B][4] barrier counters (zero between launches: the kernel restores them) | [4 B]: error word
     int B;
 };
@@ -302,14 +302,13 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
     }
     // G > 1: the exchange tensors of the image through buffer descriptors (sc1 stores / loads)
     typedef unsigned nc_u4x __attribute__((ext_vector_type(4)));
-    typedef unsigned nc_u2x __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * NC_PX * NC_C, 0, G > 1 ? NC_PX * NC_C * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_gate =
         __builtin_amdgcn_make_buffer_rsrc(G > 1 ? a.xgate + (size_t)b * NC_PX * NC_C : const_cast<unsigned short*>(a.w), 0, G > 1 ? NC_PX * NC_C * 2 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_norm =
         __builtin_amdgcn_make_buffer_rsrc(G > 1 ? a.xnorm + (size_t)b * NC_PX * NC_C : const_cast<unsigned short*>(a.w), 0, G > 1 ? NC_PX * NC_C * 2 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_vec =
-        __builtin_amdgcn_make_buffer_rsrc(G > 1 ? a.xvec + (size_t)b * 2 * NC_C : const_cast<unsigned short*>(a.w), 0, G > 1 ? 2 * NC_C * 2 : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(G > 1 ? a.xvec + (size_t)b * 4 * NC_C : const_cast<float*>(a.vecs), 0, G > 1 ? 4 * NC_C * 4 : 0, 0x00020000);
     const int chl = cown + 4 * q;        // + 16 ct: this lane's channels of a 512-wide tensor
     const int chl1 = 64 * wave + 4 * q;  // + 16 ct: the lane's channels in the LayerNorm over the WHOLE image (every group normalises all 512 channels)
 
@@ -447,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             }
         }
     };
-    auto fetch_gated = [&](const bool with_mean) {
+    auto fetch_gated = [&](const float* sca_bias) {   // sca_bias != nullptr: + the scale vector from the groups' sca.1 partials
         if constexpr (G > 1) {
             constexpr int NO = 64 - CH8, NI = (NC_PX * NO) / 512;   // chunks per pixel of the other groups; per thread
             nc_u4x c[NI];
@@ -456,14 +455,18 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
                 const int idx = tid + 512 * i, px = idx / NO, r = idx % NO, c8 = r < grp * CH8 ? r : r + CH8;
                 c[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gate, px * NC_ROW + c8 * 16, 0, NC_SC1);
             }
-            nc_u4x mv = {0u, 0u, 0u, 0u};
-            if (with_mean && tid < 64) mv = __builtin_amdgcn_raw_buffer_load_b128(rs_vec, tid * 16, 0, NC_SC1);
+            nc_f4 pq[4], sb = {0.f, 0.f, 0.f, 0.f};
+            if (sca_bias && tid < 128) {   // thread t: channels 4 t .. 4 t + 3
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pq[k] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(rs_vec, (k * NC_C + 4 * tid) * 4, 0, NC_SC1));
+                sb = *reinterpret_cast<const nc_f4*>(sca_bias + 4 * tid);
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int idx = tid + 512 * i, px = idx / NO, r = idx % NO, c8 = r < grp * CH8 ? r : r + CH8;
                 *reinterpret_cast<nc_u4x*>(lds + NC_OFF_B + px * NC_ROW + ((c8 ^ (px & 15)) << 4)) = c[i];
             }
-            if (with_mean && tid < 64) *reinterpret_cast<nc_u4x*>(lds + NC_OFF_MEAN + tid * 16) = mv;
+            if (sca_bias && tid < 128) *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + 4 * tid * 2) = cvt4((((pq[0] + pq[1]) + pq[2]) + pq[3]) + sb);
             __syncthreads();
         }
     };
@@ -558,50 +561,70 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             cs[0] = nc_sum_row16(cs[0]); cs[1] = nc_sum_row16(cs[1]); cs[2] = nc_sum_row16(cs[2]); cs[3] = nc_sum_row16(cs[3]);
             if (n == 0) {
                 const nc_h4 mh = cvt4(cs * (1.0f / NC_PX));
-                if constexpr (G > 1) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(nc_u2x, mh), rs_vec, (cown + 16 * ps + 4 * q) * 2, 0, NC_SC1);
-                else *reinterpret_cast<nc_h4*>(lds + NC_OFF_MEAN + (cown + 16 * ps + 4 * q) * 2) = mh;
+                *reinterpret_cast<nc_h4*>(lds + NC_OFF_MEAN + (cown + 16 * ps + 4 * q) * 2) = mh;   // (G > 1: the group's own 512 / G channels — the K range of its sca.1 partial)
             }
             NC_STAMP(2)
         }
-        if constexpr (G > 1) {
-            publish_gated();
-            group_barrier();        // every group's gated slice and pooled means are out
-            fetch_gated(true);
-        } else {
-            __syncthreads();
-        }
+        if constexpr (G > 1) publish_gated();   // (starts with a barrier of the work-group: the pooled means are in LDS)
+        else __syncthreads();
         NC_STAMP(3)
-        // ===== sca.1 (1x1 conv on the pooled vector): s = W mean + b for this wave's channels -> the fp16 scale vector =====
+        // ===== sca.1 (1x1 conv on the pooled vector): s = W mean + b -> the fp16 scale vector =====
+        // r06: the K = 512 sum in four quarters of 128 input channels (4 k steps), each accumulated from zero, s = ((p0 + p1) + p2) + p3 + b; wave w owns the output
+        // channels 64 w .. 64 w + 63 (four 16-channel tiles).  One group: all four quarters in turn.  G groups: group g computes the quarters of ITS gated channels —
+        // their pooled means never leave the group — and publishes the fp32 partials with the gated slice: one exchange (and barrier) less per block, the same bits.
         {
             const char* msrc[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) msrc[c] = lds + NC_OFF_MEAN + (c * 32 + 8 * q) * 2;   // every column reads the same 8 k values of its k step
-#pragma unroll 1
-            for (int ps = 0; ps < NP3; ++ps) {
-                nc_f4 as[NT3][1];
-                nc_f4 sbv[NT3];
+            constexpr int NQ = 4 / G;   // quarters per group
+            nc_f4 tot[4];
 #pragma unroll
-                for (int t = 0; t < NT3; ++t) {
-                    as[t][0] = nc_f4{0.f, 0.f, 0.f, 0.f};
-                    sbv[t] = *reinterpret_cast<const nc_f4*>(vec + NV_SCAB + chl + 16 * (NT3 * ps + t));
+            for (int qq = 0; qq < NQ; ++qq) {
+                const int qg = grp * NQ + qq;   // quarter = k steps 4 qg .. 4 qg + 3
+                nc_f4 cur[4] = {nc_f4{0.f, 0.f, 0.f, 0.f}, nc_f4{0.f, 0.f, 0.f, 0.f}, nc_f4{0.f, 0.f, 0.f, 0.f}, nc_f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {   // two rounds of the ring: 2 k steps x 4 tiles
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const nc_h8 bq = *reinterpret_cast<const nc_h8*>(msrc[2 * hf + k2] + qg * 256);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            cur[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nc_h8, ring[k2 * 4 + t]), bq, cur[t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            ring[k2 * 4 + t] = __builtin_bit_cast(nc_f4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, ws.lane_off, (ws.pos + NC_RING + k2 * 4 + t) * 1024, 0));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ws.pos += NC_RING;
                 }
-                gemm_pass<NT3, 1, false, NC_RING>(as, msrc, nullptr, ring, ws);
+                if constexpr (G > 1) {
+                    if (n == 0) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nc_u4x, cur[t]), rs_vec, (qg * NC_C + 64 * wave + 16 * t + 4 * q) * 4, 0, NC_SC1);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) tot[t] = qq == 0 ? cur[t] : tot[t] + cur[t];
+                }
+            }
+            if constexpr (G == 1) {
                 if (n == 0) {
 #pragma unroll
-                    for (int t = 0; t < NT3; ++t) {
-                        const nc_h4 sh = cvt4(as[t][0] + sbv[t]);
-                        if constexpr (G > 1) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(nc_u2x, sh), rs_vec, (NC_C + chl + 16 * (NT3 * ps + t)) * 2, 0, NC_SC1);
-                        else *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + (chl + 16 * (NT3 * ps + t)) * 2) = sh;
+                    for (int t = 0; t < 4; ++t) {
+                        const nc_f4 sb = *reinterpret_cast<const nc_f4*>(vec + NV_SCAB + 64 * wave + 16 * t + 4 * q);
+                        *reinterpret_cast<nc_h4*>(lds + NC_OFF_S + (64 * wave + 16 * t + 4 * q) * 2) = cvt4(tot[t] + sb);
                     }
                 }
             }
         }
         NC_STAMP(4)
         if constexpr (G > 1) {
-            group_barrier();        // the whole scale vector is out
-            if (tid < 64) *reinterpret_cast<nc_u4x*>(lds + NC_OFF_S + tid * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_vec, NC_C * 2 + tid * 16, 0, NC_SC1);
+            group_barrier();        // every group's gated slice and sca.1 partials are out
+            fetch_gated(vec + NV_SCAB);
+        } else {
+            __syncthreads();
         }
-        __syncthreads();
         NC_STAMP(9)
         // ===== conv3 (1x1, 512 -> 512) on x * sca(x); y = inp + conv3 * beta =====
 #pragma unroll
@@ -669,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
         if constexpr (G > 1) {
             publish_gated();
             group_barrier();        // every group's gated slice is out
-            fetch_gated(false);
+            fetch_gated(nullptr);
         } else {
             __syncthreads();
         }
@@ -792,6 +815,9 @@ std::vector<int> naf_chain_split_order(int nblocks, int G) {
             const int hi = tile >= 32 ? 1 : 0, t = tile & 31;   // 32 lo tiles, then 32 hi tiles
             w1 = t >> 2;
             f = base + ((t & 3) * 16 + ks) * 2 + hi;
+        } else if (conv == 1) {   // sca.1: [quarter][k step of the quarter][tile of the wave]
+            w1 = tile >> 2;
+            f = base + ks * 4 + (tile & 3);
         } else {
             w1 = tile >> 2;
             const int tt = tile & 3;
@@ -814,7 +840,12 @@ std::vector<int> naf_chain_split_order(int nblocks, int G) {
                         for (int ks = 0; ks < 16; ++ks)
                             for (int t = 0; t < NT3; ++t) order.push_back(pos1(conv, tile0 + NT3 * ps + t, ks, blk));
                 };
-                gated(0); plain(1); plain(2); gated(3); plain(4);
+                auto sca = [&]() {   // group g: the quarters of its own gated channels, every output tile of wave w
+                    for (int qq = 0; qq < 4 / G; ++qq)
+                        for (int kk = 0; kk < 4; ++kk)
+                            for (int t = 0; t < 4; ++t) order.push_back(pos1(1, 4 * w + t, 4 * (g * (4 / G) + qq) + kk, blk));
+                };
+                gated(0); sca(); plain(2); gated(3); plain(4);
             }
     if (order.size() != (size_t)8 * nblocks * NC_FRAGS_PER_BLOCK) throw HipError("naf_chain_split_order: stream length mismatch");
     return order;
@@ -841,7 +872,7 @@ void naf_chain_build_split_weights(const unsigned short* w1, unsigned short* dst
     (void)hipFree(dorder);
 }
 
-size_t naf_chain_split_scratch_bytes(int B) { return (size_t)B * (2 * NC_PX * NC_C * 2 + 2 * NC_C * 2) + (4 * (size_t)B + 1) * 4 + 64; }
+size_t naf_chain_split_scratch_bytes(int B) { return (size_t)B * (2 * NC_PX * NC_C * 2 + 4 * NC_C * 4) + (4 * (size_t)B + 1) * 4 + 64; }
 
 // Work-groups the split launch needs resident at the same time: 8 ceil(B / 8) G (an image's groups share a block-id residue mod 8 = an XCD)
 int naf_chain_split_groups(int B, int G) { return 8 * ((B + 7) / 8) * G; }
@@ -861,8 +892,8 @@ void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG
     char* sc = reinterpret_cast<char*>(scratch);
     a.xgate = reinterpret_cast<unsigned short*>(sc);
     a.xnorm = reinterpret_cast<unsigned short*>(sc + (size_t)B * NC_PX * NC_C * 2);
-    a.xvec = reinterpret_cast<unsigned short*>(sc + (size_t)B * 2 * NC_PX * NC_C * 2);
-    a.ctr = reinterpret_cast<unsigned*>(sc + (size_t)B * (2 * NC_PX * NC_C * 2 + 2 * NC_C * 2));
+    a.xvec = reinterpret_cast<float*>(sc + (size_t)B * 2 * NC_PX * NC_C * 2);
+    a.ctr = reinterpret_cast<unsigned*>(sc + (size_t)B * (2 * NC_PX * NC_C * 2 + 4 * NC_C * 4));
     a.B = B;
     const size_t wb = naf_chain_weight_halves(nblocks) * 2;
     if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain_split: weight stream too large for 32-bit buffer offsets");
@@ -882,11 +913,11 @@ void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG
 
 // the error word of a split launch's scratch buffer (device pointer): non-zero after a run whose groups were not co-resident
 const unsigned* naf_chain_split_error_flag(const void* scratch, int B) {
-    return reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(scratch) + (size_t)B * (2 * NC_PX * NC_C * 2 + 2 * NC_C * 2)) + 4 * B;
+    return reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(scratch) + (size_t)B * (2 * NC_PX * NC_C * 2 + 4 * NC_C * 4)) + 4 * B;
 }
 // counters + error word back to zero (synchronous; after an error was reported)
 void naf_chain_split_reset(void* scratch, int B) {
-    IRSDE_HIP_CHECK(hipMemset(reinterpret_cast<char*>(scratch) + (size_t)B * (2 * NC_PX * NC_C * 2 + 2 * NC_C * 2), 0, (4 * (size_t)B + 1) * 4));
+    IRSDE_HIP_CHECK(hipMemset(reinterpret_cast<char*>(scratch) + (size_t)B * (2 * NC_PX * NC_C * 2 + 4 * NC_C * 4), 0, (4 * (size_t)B + 1) * 4));
 }
 
 }  // namespace irsde
