@@ -25,9 +25,9 @@
 // streaming the block's 3.67 MB of fp16 weights through its ~30 B/clk vector-memory return path (49 us per block whatever the batch): at the per-GPU
 // shard of BASELINE configs[4] (8 images) 8 of 256 CUs work for 57 % of the step.  Group g of an image owns the output channels [512 g / G, 512 (g + 1) / G)
 // of every 512-wide tensor (gate pairs (j, j + 512) of the 1024-wide ones) and streams 1 / G of the weights; every GEMM still needs the FULL operand image,
-// so per block the groups of an image trade slices through L2 five times — the fp32 residual stream in front of both LayerNorms (each group normalises
-// the whole image itself: the LayerNorm code and its summation order are the one-group kernel's), the gated tensor (+ pooled means) behind conv1 and
-// conv4, the SCA scale vector — each closed by an arrive / spin barrier on a per-image counter (agent-scope release / acquire fences).  The groups of an
+// so per block the groups of an image trade slices through L2 six times — the fp32 residual stream in front of both LayerNorms, the LayerNorm rows (group g
+// normalises the pixel tiles g in the one-group lane layout and summation order), the gated tensor + the group's sca.1 partial sums behind conv1, the gated
+// tensor behind conv4 — each closed by an arrive / spin barrier on a per-image counter (agent-scope release / acquire fences).  The groups of an
 // image get block ids of one residue mod 8 = one XCD (the exchange stays in that XCD's L2).  Co-residency: a spinning group holds its CU, so every group of
 // an image must be resident at the same time: the launch keeps the grid <= the CUs the caller says are free (launch_naf_chain_split), and a spin that
 // exceeds ~1 s sets an error flag instead of hanging the GPU (irsde_sample checks it and fails the call).
@@ -582,11 +582,13 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
             for (int qq = 0; qq < NQ; ++qq) {
                 const int qg = grp * NQ + qq;   // quarter = k steps 4 qg .. 4 qg + 3
                 nc_f4 cur[4] = {nc_f4{0.f, 0.f, 0.f, 0.f}, nc_f4{0.f, 0.f, 0.f, 0.f}, nc_f4{0.f, 0.f, 0.f, 0.f}, nc_f4{0.f, 0.f, 0.f, 0.f}};
+                constexpr int KPR = NC_RING / 4;   // k steps (x 4 tiles) per round of the ring
+                static_assert(KPR == 2 || KPR == 4, "ring of 8 or 16 fragments");
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {   // two rounds of the ring: 2 k steps x 4 tiles
+                for (int hf = 0; hf < 4 / KPR; ++hf) {
 #pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2) {
-                        const nc_h8 bq = *reinterpret_cast<const nc_h8*>(msrc[2 * hf + k2] + qg * 256);
+                    for (int k2 = 0; k2 < KPR; ++k2) {
+                        const nc_h8 bq = *reinterpret_cast<const nc_h8*>(msrc[KPR * hf + k2] + qg * 256);
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
                             cur[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nc_h8, ring[k2 * 4 + t]), bq, cur[t], 0, 0, 0);
