@@ -3,7 +3,7 @@
 // followed by NV vector instructions on private registers (inline assembly: nothing the compiler can fold or move) —
 //   MODE 0  every wave issues both streams (the two-tile-group kernel wino4_fused64t: the transform inside the matrix waves)
 //   MODE 1  waves 0-3 (one per SIMD) issue MFMAs only, waves 4-7 the vector stream only, 2 NV per loop (wino4_fused64p: producer waves beside matrix waves)
-// KIND: 0 v_pk_fma_f32, 1 v_fma_f32, 2 v_permlane32_swap, 3 ds_write_b64 (LDS, 8 B / lane), 4 v_mov_b32.
+// KIND: 0 v_pk_fma_f32, 1 v_fma_f32, 2 v_permlane32_swap, 3 ds_write_b64 (LDS, 8 B / lane), 4 v_mov_b32, 5 v_exp_f32, 6 v_rcp_f32.
 // Prints the MFMA rate against the no-vector-work case.  If the two pipes issued independently the rate would not move until NV x (cycles per op) reached 256.
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_valu_coissue tools/probe/mfma_valu_coissue.hip && ./mfma_valu_coissue
 #include <hip/hip_runtime.h>
@@ -52,6 +52,8 @@ __device__ __forceinline__ void vec_ops(floatx2 (&r)[8], float* lds) {
         else if constexpr (KIND == 1) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r[i & 7].x) : "v"(r[(i + 3) & 7].y), "v"(r[(i + 5) & 7].x));
         else if constexpr (KIND == 2) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r[i & 7].x), "+v"(r[i & 7].y));
         else if constexpr (KIND == 3) asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(size_t)lds), "v"(r[i & 7]) : "memory");
+        else if constexpr (KIND == 5) asm volatile("v_exp_f32 %0, %1" : "=v"(r[i & 7].x) : "v"(r[(i + 3) & 7].y));
+        else if constexpr (KIND == 6) asm volatile("v_rcp_f32 %0, %1" : "=v"(r[i & 7].x) : "v"(r[(i + 3) & 7].y));
         else asm volatile("v_mov_b32 %0, %1" : "=v"(r[i & 7].x) : "v"(r[(i + 3) & 7].y));
     }
     if constexpr (KIND == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -166,6 +168,8 @@ int main() {
     sweep<0, 2>("v_permlane32_swap_b32");
     sweep<0, 3>("ds_write_b64");
     sweep<0, 4>("v_mov_b32");
+    sweep<0, 5>("v_exp_f32 (transcendental)");
+    sweep<0, 6>("v_rcp_f32 (transcendental)");
     sweep<1, 0>("v_pk_fma_f32");
     sweep<1, 1>("v_fma_f32");
     sweep<1, 4>("v_mov_b32");
