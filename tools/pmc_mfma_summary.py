@@ -14,7 +14,7 @@ for r in csv.DictReader(open(sys.argv[1])):
 
 
 def group(name):
-    m = re.search(r"(gemm_zloop_kernel|conv_igemm_kernel|conv3x3_halo2_kernel|conv3x3_halo_bf16_kernel|wino4_fused64p_kernel|wino4_fused64h_kernel|wino4_fused64_kernel|wino4_fused_kernel|naf_chain_kernel|dwconv_gate_kernel|gemm_split2i_kernel|gemm_split_kernel|wino_input_split_kernel|wino_input_kernel|wino_output_kernel|"
+    m = re.search(r"(gemm_zloop_kernel|conv_igemm_kernel|conv3x3_halo2_kernel|conv3x3_halo_bf16_kernel|wino4_fused64p_kernel|wino4_fused64t_kernel|wino4_fused64h_kernel|wino4_fused64_kernel|wino4_fused_kernel|naf_chain_kernel|dwconv_gate_kernel|gemm_split2i_kernel|gemm_split_kernel|wino_input_split_kernel|wino_input_kernel|wino_output_kernel|"
                   r"layernorm_kernel|attn_\w+_kernel|conv3x3_narrow_kernel)(<[^>]*>)?", name)
     if not m:
         return None
