@@ -121,7 +121,7 @@ def cpu_baseline(size, T, budget_s=20.0):
 # kernel classes of the event pass: description prefix (engine_plan.hip `op.desc`) -> the HIP kernel behind it (short names: the
 # whole JSON line has to fit the driver's 8 KB record; what each kernel does is in DESIGN.md section 3)
 KERNEL_CLASSES = [
-    ("conv(winograd F4 fused)", "wino4_fused64p_kernel"),
+    ("conv(winograd F4 fused)", "wino4_fused64p_kernel"),   # (r06: the class = wino4_fused64p_kernel + wino4_fused64t_kernel, whichever the plan picked per layer)
     ("conv(winograd", "gemm_zloop_kernel (Winograd component GEMMs)"),
     ("conv(split f16x2 winograd F4 fused)", "wino4_fused64p_kernel<PAIR>"),
     ("conv(split f16x2) M=", "conv_igemm_kernel<PAIR>"),
