@@ -1368,6 +1368,18 @@ bool conv_use_tile256(int M, int Cout, int splits, int nk_total) {
     return nb % 256 == 0 || nb >= 1024;
 }
 
+// r06 (measurement knob, default off): the under-filled-grid rule of the 16-bit-operand kernels for the f32 direct kernels — column-tile width 128 / 64 / 32
+static int f32_narrow(const ConvParams& p, int M) {
+    int bn = p.Cout >= 128 ? 128 : p.Cout > 32 ? 64 : 32;
+    static const int k = tuning_env_int("IRSDE_SMALL_BN_F32", 0);
+    if (k && g_variant == 0) {
+        const long long slots = (long long)k * device_cu_count();
+        auto blocks = [&](int n) { return (long long)((M + 127) / 128) * ((p.Cout + n - 1) / n) * p.splits * p.nz; };
+        while (bn > 32 && blocks(bn) < slots) bn >>= 1;
+    }
+    return bn;
+}
+
 void launch_conv(const ConvParams& p, hipStream_t s) {
     const int M = p.B * p.Ho * p.Wo;
     const int Ctot = p.C0 + p.C1;
@@ -1472,8 +1484,15 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.in_scale) {  // NAFNet SCA fused into the staging (128-row tiles only)
         if (p.C1) throw HipError("launch_conv: in_scale needs a single source");
         if (p.w_bf) {
-            if (p.Cout >= 128) launch_cfg<128, 128, 2, 2, 2, true, true>(p, M, nk_total, s);
-            else if (p.Cout > 32) launch_cfg<128, 64, 2, 2, 2, true, true>(p, M, nk_total, s);
+            int bn = p.Cout >= 128 ? 128 : p.Cout > 32 ? 64 : 32;
+            static const int small_bn = tuning_env_int("IRSDE_SMALL_BN", 2);   // block slots per CU the grid should fill (0 = rule off)
+            if (small_bn && g_variant == 0) {   // (see the rule at the plain 16-bit-operand branch below)
+                const long long slots = (long long)small_bn * device_cu_count();
+                auto blocks = [&](int n) { return (long long)((M + 127) / 128) * ((p.Cout + n - 1) / n) * p.splits * p.nz; };
+                while (bn > 32 && blocks(bn) < slots) bn >>= 1;
+            }
+            if (bn == 128) launch_cfg<128, 128, 2, 2, 2, true, true>(p, M, nk_total, s);
+            else if (bn == 64) launch_cfg<128, 64, 2, 2, 2, true, true>(p, M, nk_total, s);
             else launch_cfg<128, 32, 4, 1, 2, true, true>(p, M, nk_total, s);
         } else {
             if (p.Cout >= 128) launch_cfg<128, 128, 2, 2, 2, false, true>(p, M, nk_total, s);
@@ -1495,17 +1514,27 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
             launch_cfg<128, 32, 4, 1, 2, true, false, true>(p, M, nk_total, s);
         }
     } else if (p.w_bf) {  // bf16 operands, fp32 accumulation
-        if (p.Cout >= 128) {
+        // r06: an under-filled grid of 16-bit-operand tiles is latency-bound — one block per CU keeps ~24 KB of loads in flight against 2 us of cross-XCD
+        // latency (the small-batch NAFNet levels of configs[4]: every 1x1 layer took 17-19 us whatever its size) — narrower column tiles put 2-4 blocks on a CU
+        // (the A rows are re-read from L2).  IRSDE_SMALL_BN = block slots per CU to fill (0 switches the rule off).
+        int bn = p.Cout >= 128 ? 128 : p.Cout > 32 ? 64 : 32;
+        static const int small_bn = tuning_env_int("IRSDE_SMALL_BN", 2);   // block slots per CU the grid should fill (0 = rule off)
+        if (small_bn && g_variant == 0) {
+            const long long slots = (long long)small_bn * device_cu_count();
+            auto blocks = [&](int n) { return (long long)((M + 127) / 128) * ((p.Cout + n - 1) / n) * p.splits * p.nz; };
+            while (bn > 32 && blocks(bn) < slots) bn >>= 1;
+        }
+        if (bn == 128) {
             if (g_variant != 61 && (g_variant == 60 || conv_use_tile256(M, p.Cout, p.splits, nk_total)))
                 launch_cfg<256, 256, 2, 4, 2, true>(p, M, nk_total, s);
             else
                 launch_cfg<128, 128, 2, 2, 2, true>(p, M, nk_total, s);
-        } else if (p.Cout > 32) {
+        } else if (bn == 64) {
             launch_cfg<128, 64, 2, 2, 2, true>(p, M, nk_total, s);
         } else {
             launch_cfg<128, 32, 4, 1, 2, true>(p, M, nk_total, s);
         }
-    } else if (p.Cout >= 128) {
+    } else if (p.Cout >= 128 && f32_narrow(p, M) == 128) {
         if (g_variant == 3)
             launch_cfg<256, 128, 4, 2, 2, false>(p, M, nk_total, s);
         else if (g_variant == 50)
@@ -1516,7 +1545,7 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
             launch_cfg<256, 256, 2, 4, 2, false>(p, M, nk_total, s);
         else
             launch_cfg<128, 128, 2, 2, 2, false>(p, M, nk_total, s);
-    } else if (p.Cout > 32) {
+    } else if (p.Cout > 32 && f32_narrow(p, M) >= 64) {
         launch_cfg<128, 64, 2, 2, 2, false>(p, M, nk_total, s);
     } else {
         launch_cfg<128, 32, 4, 1, 2, false>(p, M, nk_total, s);
