@@ -1683,6 +1683,31 @@ __global__ __launch_bounds__(256) void sca_mean_kernel(const float* __restrict__
 }
 
 // s[b][o] = bias[o] + sum_k W[o][k] * mean[b][k]   (AdaptiveAvgPool2d(1) -> 1x1 conv, DenoisingNAFNet_arch.py:29-33)
+// r06: both steps in one launch for the small feature maps (the latent network's levels: every launch there costs ~5 us whatever it does, profiles/r06_notes.md 3b).
+// Every block sums the image's tile partials itself — the same four strided partial sums and the same order as sca_mean_kernel: the same bits — and
+// computes four output channels.
+__global__ __launch_bounds__(256) void sca_fused_kernel(const float* __restrict__ partial, const int ntiles, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ s_out, const int c, const float inv_hw) {
+    extern __shared__ float sca_mean_lds[];
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < c; k += 256) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q0 = 0; q0 < ntiles; q0 += 4)
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+                if (q0 + tl < ntiles) t[tl] += partial[((size_t)b * ntiles + q0 + tl) * c + k];
+        sca_mean_lds[k] = ((t[0] + t[1]) + (t[2] + t[3])) * inv_hw;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= c) return;
+    const float* wr = W + (size_t)o * c;
+    float t = 0.f;
+    for (int k = lane; k < c; k += 64) t = fmaf(wr[k], sca_mean_lds[k], t);
+    t = wave_xor_sum(t, 64);
+    if (lane == 0) s_out[(size_t)b * c + o] = t + bias[o];
+}
 __global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ mean, const float* __restrict__ W,
                                                   const float* __restrict__ bias, float* __restrict__ s_out, const int c) {
     const int b = blockIdx.y;
@@ -1759,8 +1784,12 @@ void launch_dwconv_gate(const float* u, const float* w, const float* bias, float
 
 void launch_sca(const float* partial, int ntiles, const float* W, const float* bias, float* mean, float* s_out, int B,
                 int c, int HW, hipStream_t s) {
-    hipLaunchKernelGGL(sca_mean_kernel, dim3((c + 63) / 64, B), dim3(256), 0, s, partial, ntiles, mean, c, 1.0f / (float)HW);
-    hipLaunchKernelGGL(sca_kernel, dim3((c + 3) / 4, B), dim3(256), 0, s, mean, W, bias, s_out, c);
+    if ((long long)ntiles * c <= 65536 && c <= 4096) {   // small maps: one launch (every block re-sums <= 256 KB of partials from L2)
+        hipLaunchKernelGGL(sca_fused_kernel, dim3((c + 3) / 4, B), dim3(256), (size_t)c * 4, s, partial, ntiles, W, bias, s_out, c, 1.0f / (float)HW);
+    } else {
+        hipLaunchKernelGGL(sca_mean_kernel, dim3((c + 63) / 64, B), dim3(256), 0, s, partial, ntiles, mean, c, 1.0f / (float)HW);
+        hipLaunchKernelGGL(sca_kernel, dim3((c + 3) / 4, B), dim3(256), 0, s, mean, W, bias, s_out, c);
+    }
     IRSDE_HIP_CHECK(hipGetLastError());
 }
 
