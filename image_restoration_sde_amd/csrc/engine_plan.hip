@@ -715,7 +715,10 @@ int naf_subbatches(const irsde_engine* e, int B, int H, int W) {
         if ((e->cfg.flags & IRSDE_FLAG_FP16) && !(e->cfg.flags & IRSDE_FLAG_NO_NAF_CHAIN))
             for (int i = 0; i < nlev; ++i)
                 if (e->naf_chain_enc[i].nblocks > 0 && naf_chain_shape_ok(Hp >> i, Wp >> i, e->naf_intro.Cout << i)) chain = true;
-        n = chain && B >= 64 ? 2 : 1;   // measured (profiles/r05_notes.md section 4): 64 images as 2 x 32: +3 %; 4 parts, or parts of < 32 images: a loss
+        // r05 (profiles/r05_notes.md section 4): 64 images as 2 x 32: +3 %, smaller parts a loss — with the chain on one CU per image.  r06: the chain runs on 4 groups per
+        // image and everything else at these batches is latency-bound on an under-filled GPU: two parts pay from 8 images on (8 / 16 / 24 / 32 / 48 / 64 images:
+        // +1.9 / +2.7 / +2.6 / +4.1 / +1.7 / +2 %, profiles/r06_aq_subbatch_ab.txt); 4 parts lose at every batch (two of four streams run, two wait)
+        n = chain && B >= 8 ? 2 : 1;
     }
     n = std::min(n, (int)irsde_engine::kMaxSub);
     while (n > 1 && B % n) --n;

@@ -28,6 +28,7 @@
  *        superseded twins) moved to the PROBES build (libirsde_hip_probes.so): the product library refuses their selectors.
  *   106  IRSDE_FLAG_BF16 / _BF16_ACT / _FP16: the LinearAttention blocks (C = 64 / 128 / 256) run on the fused attention kernels with 16-bit
  *        projection operands (results differ from ABI 105 by the roundings of the q | k | v / attention-output tensors that no longer exist).
+ *        (ABI 107: from 8 images on.)
  *   107  the per-image NAFBlock chain of the fp16 ConditionalNAFNet runs on 2 / 4 work-groups per image where they fit the compute units (results equal
  *        to the one-group kernel's: same operations in the same order); a split launch whose groups were not co-resident fails the NEXT irsde_sample
  *        call on the engine instead of hanging the GPU.  Debug header: irsde_debug_force_chain_groups; irsde_bench_naf_chain variants 22 / 24.

@@ -60,7 +60,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
  * *ms_out = milliseconds per launch.  (tools/naf_chain_bench.py) */
 int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out);
 /* Test / measurement hook (process-wide): the number of concurrent sub-batches irsde_sample splits a ConditionalNAFNet batch into — n >= 1 forces it
- * (1 = never split; clipped to 4 and to a divisor of the batch), 0 returns to the heuristic (2 parts from 64 images on, and only where a level
+ * (1 = never split; clipped to 4 and to a divisor of the batch), 0 returns to the heuristic (2 parts from 8 images on (r06; r05: 64), and only where a level
  * runs as a NAFBlock chain).  Plans are cached per split, so changing it never invalidates anything. */
 int irsde_debug_force_subbatches(int n);
 /* Test / measurement hook (process-wide): work-groups per image of the NAFBlock chain kernel in plans built from now on — 1 the one-group kernel, 2 / 4
