@@ -194,6 +194,7 @@ void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG
                             int film_off, const float* cam, int cam_bstride, int cam_off, int G, void* scratch, hipStream_t s);
 const unsigned* naf_chain_split_error_flag(const void* scratch, int B);
 void naf_chain_split_reset(void* scratch, int B);
+void naf_chain_set_sabotage(int on);   // PROBES build: one group per image never arrives (test of the spin limit)
 void attention_global_init();
 
 double conv_flops(const ConvParams& p);  // 2*M*Cout*K (algorithmic)

@@ -843,7 +843,7 @@ int irsde_debug_force_subbatches(int n) {
 int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out) {
     return guard([&] {
         if (!ms_out || nblocks < 1 || nblocks > 64 || B < 1 || iters < 1) throw HipError("bench_naf_chain: bad argument");
-        const int G = variant == 22 ? 2 : (variant == 24 || variant == 25) ? 4 : 1;   // (25, PROBES build: 24 + its cycle stamps)   // r06: 22 / 24 = the kernel with 2 / 4 work-groups per image
+        const int G = variant == 22 ? 2 : (variant == 24 || variant == 25 || variant == 26) ? 4 : 1;   // (26, PROBES build: 24 with one group per image missing — must report the spin timeout)   // (25, PROBES build: 24 + its cycle stamps)   // r06: 22 / 24 = the kernel with 2 / 4 work-groups per image
 #ifdef IRSDE_PROBES
         if (variant != 0 && variant != 1 && variant != 2 && variant != 11 && G == 1) throw HipError("bench_naf_chain: bad variant");
 #else
@@ -883,6 +883,14 @@ int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms
             if (G > 1) launch_naf_chain_split(dx, dout, dwg, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, G, dscratch, s);
             else launch_naf_chain(dx, dout, dw, dvec, nblocks, B, dfilm, 0, 0, nullptr, 0, 0, s, variant == 11 ? 1 : variant);
         };
+        if (variant == 26) {
+#ifdef IRSDE_PROBES
+            naf_chain_set_sabotage(1);
+#else
+            throw HipError("bench_naf_chain: variant 26 is a PROBES-build test");
+#endif
+        }
+        struct SabotageOff { ~SabotageOff() { naf_chain_set_sabotage(0); } } sabotage_off;
         run();   // warm
         if (variant == 25) {
 #ifdef IRSDE_PROBES

@@ -79,6 +79,7 @@ struct NafChainArgs {
     float* xvec;               // [B][4 quarters][512] fp32: the sca.1 partial sums
     unsigned* ctr;             // [B][4] barrier counters (zero between launches: the kernel restores them) | [4 B]: error word
     int B;
+    int sabotage;              // PROBES build, test of the spin limit: group 1 of every image leaves at once, the others must time out and end
 };
 
 // Barrier of the G groups of one image (all 512 threads of each call it).  The exchanged tensors are written with 16-byte sc1 (write-through) stores and read
@@ -226,6 +227,9 @@ __global__ __launch_bounds__(512, 2) void naf_chain_kernel(const NafChainArgs a)
         grp = idx % G;
         b = (idx / G) * 8 + (v & 7);
         if (b >= a.B) return;
+#ifdef IRSDE_PROBES
+        if (a.sabotage && grp == 1) return;
+#endif
     }
     const int cown = grp * (NC_C / G) + wave * (16 * NTW);   // first of this wave's 16 NTW channels
     unsigned* const ctr = G > 1 ? a.ctr + 4 * b : nullptr;
@@ -762,6 +766,8 @@ size_t naf_chain_vec_floats(int nblocks) { return (size_t)nblocks * NV_TOTAL; }
 
 static unsigned long long* g_nc_dbg = nullptr;
 void naf_chain_set_debug(unsigned long long* buf) { g_nc_dbg = buf; }
+static int g_nc_sabotage = 0;   // (PROBES build only reads it: irsde_bench_naf_chain variant 26)
+void naf_chain_set_sabotage(int on) { g_nc_sabotage = on; }
 
 void naf_chain_global_init() {
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_chain_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -783,7 +789,7 @@ void launch_naf_chain(const float* x, float* out, const unsigned short* w, const
     a.film_bstride = film_bstride; a.film_off = film_off; a.cam_bstride = cam_bstride; a.cam_off = cam_off;
     a.nblocks = nblocks;
     a.dbg = g_nc_dbg;
-    a.xgate = nullptr; a.xnorm = nullptr; a.xvec = nullptr; a.ctr = nullptr; a.B = B;
+    a.xgate = nullptr; a.xnorm = nullptr; a.xvec = nullptr; a.ctr = nullptr; a.B = B; a.sabotage = 0;
     const size_t wb = naf_chain_weight_halves(nblocks) * 2;
     if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain: weight stream too large for 32-bit buffer offsets");
     a.w_bytes = (unsigned)wb;
@@ -897,6 +903,7 @@ void launch_naf_chain_split(const float* x, float* out, const unsigned short* wG
     a.xvec = reinterpret_cast<float*>(sc + (size_t)B * 2 * NC_PX * NC_C * 2);
     a.ctr = reinterpret_cast<unsigned*>(sc + (size_t)B * (2 * NC_PX * NC_C * 2 + 4 * NC_C * 4));
     a.B = B;
+    a.sabotage = g_nc_sabotage;
     const size_t wb = naf_chain_weight_halves(nblocks) * 2;
     if (wb >= 0x7fff0000ull) throw HipError("launch_naf_chain_split: weight stream too large for 32-bit buffer offsets");
     a.w_bytes = (unsigned)wb;

@@ -56,7 +56,7 @@ int irsde_bench_conv(int variant, int B, int H, int W, int Cin, int Cout, int K,
                      double* ms_out);
 /* Times naf_chain_kernel (csrc/naf_chain.hip) alone on synthetic data: `nblocks` consecutive 512-channel NAFBlocks on B images of 8 x 8 pixels,
  * `iters` launches; variant 1 residual stream in registers + ring of 8 weight fragments (= 0, production), 2 residual stream in L2 + ring of 16,
- * 22 / 24 the kernel on 2 / 4 work-groups per image (r06; 25, PROBES build: 24 + its per-phase cycle stamps).
+ * 22 / 24 the kernel on 2 / 4 work-groups per image (r06; 25, PROBES build: 24 + its per-phase cycle stamps; 26, PROBES build: 24 with one group per image missing — the call must fail with the spin timeout).
  * *ms_out = milliseconds per launch.  (tools/naf_chain_bench.py) */
 int irsde_bench_naf_chain(int variant, int nblocks, int B, int iters, double* ms_out);
 /* Test / measurement hook (process-wide): the number of concurrent sub-batches irsde_sample splits a ConditionalNAFNet batch into — n >= 1 forces it

@@ -1590,3 +1590,22 @@ def test_naf_chain_groups_sampler_graph_replay(B):
         L.irsde_debug_force_chain_groups(0)
     assert np.isfinite(res[1]).all()
     assert np.array_equal(res[4], res[1]), float(np.abs(res[4] - res[1]).max())
+
+
+def test_naf_chain_spin_limit_ends_the_launch():
+    """r06: the safety net of the split NAFBlock chain.  A group that never arrives (PROBES build, irsde_bench_naf_chain variant 26: group 1 of every image
+    leaves at once — what a work-group that is not resident looks like to the others) must not hang the GPU: every waiting group gives up after its spin limit,
+    the launch ENDS (seconds, not the harness's kill), the call reports the co-residency timeout, and the next, healthy launch runs and is correct in speed
+    and result state (the counters were left dirty: the error path re-zeroes them)."""
+    import time
+    Lp = _lib.probes_lib()
+    ms = ctypes.c_double()
+    t0 = time.time()
+    rc = Lp.irsde_bench_naf_chain(26, 2, 8, 1, ctypes.byref(ms))
+    dt = time.time() - t0
+    msg = Lp.irsde_last_error().decode()
+    print("sabotaged launch: rc %d after %.1f s: %s" % (rc, dt, msg[:120]))
+    assert rc != 0 and "co-resident" in msg, (rc, msg)
+    assert dt < 60.0, dt
+    rc = Lp.irsde_bench_naf_chain(24, 2, 8, 3, ctypes.byref(ms))
+    assert rc == 0 and 0.0 < ms.value < 5.0, (rc, ms.value, Lp.irsde_last_error())
