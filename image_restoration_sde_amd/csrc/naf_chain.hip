@@ -88,8 +88,9 @@ struct NafChainArgs {
 // and polls it relaxed.
 // Counters: three per image, barrier i on c[i % 3] (target G); behind barrier i group 0 zeroes c[(i + 2) % 3] — last used by barrier i - 1, which every group
 // has left (it arrived at i), next used by barrier i + 2, which nobody reaches before group 0 (its store drained) arrives at i + 1.  At the end every group
-// counts itself out on a fourth word and the last one zeroes all four: the launch leaves the state it found, with no memset node in the step graph (a captured
-// hipMemsetAsync in front of the kernel replayed 0x01 bytes on this stack: counters and error flag came up as 0x01010101).
+// counts itself out on a fourth word and the last one zeroes all four: the launch leaves the state it found, with no memset node in the step graph (with a
+// hipMemsetAsync in front of the kernel the engine's replayed step graph showed counters and error word 0x01010101; an isolated probe replays memset nodes
+// correctly — tools/probe/graph_memset_probe.hip — so the cause was not identified).
 // A spin past NC_SPIN_LIMIT polls (~1 s: a group that is not resident) raises the launch's error word (0x10000 | barrier index); once it is up nobody waits
 // any more — the results are garbage and the next irsde_sample call on the engine fails and re-zeroes the state.
 constexpr int NC_SPIN_LIMIT = 1 << 20;
