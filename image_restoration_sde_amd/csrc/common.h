@@ -234,7 +234,15 @@ void launch_layernorm_film(const float* x, const float* g, const float* scale, c
                            int64_t pixels_per_image, float* out, int64_t M, int C, float eps, hipStream_t s);
 // NAFNet: depthwise 3x3 (pad 1, bias) over u [B][H][W][2c] fused with SimpleGate -> out [B][H][W][c], plus per-tile
 // channel sums partial[b][tile][c] (deterministic two-stage global average pool).  w: [9][2c], bias: [2c].
-int dwgate_tiles(int H, int W, int c);  // tiles of launch_dwconv_gate = rows of its `partial` buffer per image
+int dwgate_tiles(int H, int W, int c);
+// r06: NAFBlock norm + FiLM + 1x1 convolution (+ SimpleGate) in one launch, fp16 operand mode, c = 64 / 128 / 256 (kernels_misc.hip)
+bool naf_lnconv_ok(int c, int Cout, long long M);
+void launch_naf_pwconv(const float* x, const float* in_scale, int64_t pixels_per_image, const unsigned short* w16, const float* bias, const float* ch_scale,
+                       const float* res, float* out, int64_t M, int c, int Cout, hipStream_t s);
+void naf_lnconv_global_init();
+void launch_naf_lnconv(const float* x, const float* g, const float* fscale, const float* fshift, int film_bstride, int64_t pixels_per_image,
+                       const unsigned short* w16, const float* bias, float* out, int64_t M, int c, int Cout, int gate, const float* gate_film,
+                       int gate_film_bstride, hipStream_t s);  // tiles of launch_dwconv_gate = rows of its `partial` buffer per image
 void launch_dwconv_gate(const float* u, const float* w, const float* bias, float* out, float* partial, int B, int H, int W,
                         int c, hipStream_t s);
 // NAFNet SCA: s[b][o] = bias[o] + sum_k W[o][k] * mean_hw(gated)[b][k]

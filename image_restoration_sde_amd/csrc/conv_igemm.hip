@@ -1322,6 +1322,7 @@ void conv_global_init() {
     wino_fused_t_global_init();
     naf_chain_global_init();
     attention_global_init();
+    naf_lnconv_global_init();
     gemm_split_global_init();
     IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_zloop_kernel<128, 128, 2, 2, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -41,6 +41,8 @@ inline long long wino_fused64_min_tiles() { return tuning_env_int("IRSDE_WINO_FU
 // r06: the two-tile-group kernel (wino_fused_t.hip) on the layers it measured faster on: 0 never, 1 by the rule of Plan::push_wino_fused, 2 wherever eligible
 inline int wino_fused64t_mode() { return tuning_env_int("IRSDE_WINO_FUSED64T", 1); }
 // r06: work-groups per image of the NAFBlock chain kernel: 0 = as many (4, 2) as fit the compute units next to the call's other sub-batches, 1 = the one-group kernel, 2 / 4 forced (if they fit)
+// r06: NAFBlock norm + 1x1 convolution as one launch on the small-channel levels of the fp16 operand mode (1; 0 = LayerNorm kernel + convolution kernel)
+inline bool naf_lnconv_enabled() { return tuning_env_int("IRSDE_NAF_LNCONV", 1) != 0; }
 inline int naf_chain_split_mode() { return tuning_env_int("IRSDE_NAF_CHAIN_SPLIT", 0); }
 
 inline int wino_min_c(int tile) {

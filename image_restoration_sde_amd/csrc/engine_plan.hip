@@ -301,6 +301,60 @@ struct Builder {
         return out;
     }
 
+    // r06: norm + FiLM + 1x1 convolution (+ SimpleGate) as one launch (naf_lnconv_kernel, kernels_misc.hip): fp16 operand mode, c = 64 / 128 / 256
+    bool lnconv_ok(const ConvW& cw, const Tensor& x) const {
+        return !naive && (e->cfg.flags & IRSDE_FLAG_FP16) && naf_lnconv_enabled() && cw.KH == 1 && cw.KW == 1 &&
+               naf_lnconv_ok(x.C, cw.Cout, (long long)x.B * x.H * x.W);
+    }
+    Tensor lnconv(const ConvW& cw, const Tensor& x, const float* g, const float* fscale, const float* fshift, int gate, const float* gate_film) {
+        const int64_t M = (int64_t)x.B * x.H * x.W, ppi = (int64_t)x.H * x.W;
+        const int c = x.C, Cout = cw.Cout, fb = film_bstride, gfb = gate_film ? e->cam_row : 0;
+        Tensor out = talloc(x.B, x.H, x.W, gate ? Cout / 2 : Cout);
+        const unsigned short* w16 = e->bf16_copy(cw.w, (size_t)Cout * c);   // (IRSDE_FLAG_FP16: the copy holds IEEE fp16)
+        const float *xp = x.p, *bias = cw.bias;
+        float* op = out.p;
+        Op o;
+        o.kind = OP_CONV;
+        o.flops = 2.0 * (double)M * c * Cout;
+        o.exec_flops = o.flops;
+        o.bytes = 4.0 * (double)M * c + 4.0 * (double)M * (gate ? Cout / 2 : Cout) + 2.0 * (double)Cout * c;
+        pl->conv_flops += o.flops;
+        pl->conv_exec_flops += o.exec_flops;
+        pl->conv_bytes += o.bytes;
+        char buf[200];
+        snprintf(buf, sizeof buf, "conv(fp16, LayerNorm + FiLM fused%s) M=%lld Cout=%d Cin=%d k=1x1 blocks=%lld flops=%.4g", gate ? ", gate" : "", (long long)M, Cout, c,
+                 (long long)((M + 63) / 64) * (Cout / 64), o.flops);
+        o.desc = buf;
+        o.fn = [=](hipStream_t s) { launch_naf_lnconv(xp, g, fscale, fshift, fb, ppi, w16, bias, op, M, c, Cout, gate, gate_film, gfb, s); };
+        pl->net_ops.push_back(std::move(o));
+        return out;
+    }
+
+    // conv3 / conv5 on the same kernel (no LayerNorm): out = res + (W (in * in_scale) + bias) * ch_scale
+    Tensor pwconv(const ConvW& cw, const Tensor& in, const float* in_scale, const float* ch_scale, const Tensor& res) {
+        const int64_t M = (int64_t)in.B * in.H * in.W, ppi = (int64_t)in.H * in.W;
+        const int c = in.C, Cout = cw.Cout;
+        Tensor out = talloc(in.B, in.H, in.W, Cout);
+        const unsigned short* w16 = e->bf16_copy(cw.w, (size_t)Cout * c);
+        const float *xp = in.p, *bias = cw.bias, *rp = res.p;
+        float* op = out.p;
+        Op o;
+        o.kind = OP_CONV;
+        o.flops = 2.0 * (double)M * c * Cout;
+        o.exec_flops = o.flops;
+        o.bytes = 4.0 * (double)M * c + 8.0 * (double)M * Cout + 2.0 * (double)Cout * c;
+        pl->conv_flops += o.flops;
+        pl->conv_exec_flops += o.exec_flops;
+        pl->conv_bytes += o.bytes;
+        char buf[200];
+        snprintf(buf, sizeof buf, "conv(fp16, one-piece K%s) M=%lld Cout=%d Cin=%d k=1x1 blocks=%lld flops=%.4g", in_scale ? ", SCA scale" : "", (long long)M, Cout, c,
+                 (long long)((M + 63) / 64) * (Cout / 64), o.flops);
+        o.desc = buf;
+        o.fn = [=](hipStream_t s) { launch_naf_pwconv(xp, in_scale, ppi, w16, bias, ch_scale, rp, op, M, c, Cout, s); };
+        pl->net_ops.push_back(std::move(o));
+        return out;
+    }
+
     // NAFBlock.forward — DenoisingNAFNet_arch.py:56-82
     Tensor nafblock(const NafBlockW& w, const Tensor& x) {
         const int64_t M = (int64_t)x.B * x.H * x.W;
@@ -308,14 +362,19 @@ struct Builder {
         const int c = w.c;
         const float* film = film_base() + w.film_off;  // [shift_att | scale_att | shift_ffn | scale_ffn]
         const int fb = film_bstride;
-        Tensor t1 = talloc(x.B, x.H, x.W, c);
-        {
-            const float *xp = x.p, *g = w.g1;
-            float* o = t1.p;
-            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm_film(xp, g, film + c, film, fb, ppi, o, M, c, 1e-5f, s); });
+        Tensor u;
+        if (lnconv_ok(w.conv1, x)) {
+            u = lnconv(w.conv1, x, w.g1, film + c, film, 0, nullptr);
+        } else {
+            Tensor t1 = talloc(x.B, x.H, x.W, c);
+            {
+                const float *xp = x.p, *g = w.g1;
+                float* o = t1.p;
+                push_other(OP_LN, [=](hipStream_t s) { launch_layernorm_film(xp, g, film + c, film, fb, ppi, o, M, c, 1e-5f, s); });
+            }
+            u = conv_naf(w.conv1, t1, ConvOpts());
+            tfree(t1);
         }
-        Tensor u = conv_naf(w.conv1, t1, ConvOpts());
-        tfree(t1);
         Tensor gt = talloc(x.B, x.H, x.W, c);
         const int nt = dwgate_tiles(x.H, x.W, c);
         float* partial = pl->alloc((size_t)x.B * nt * c, true);
@@ -331,27 +390,42 @@ struct Builder {
             });
         }
         tfree(u);
-        ConvOpts o3;
-        o3.in_scale = sca; o3.ch_scale = w.beta; o3.res = &x;
-        Tensor y = conv_naf(w.conv3, gt, o3);
+        Tensor y;
+        if (lnconv_ok(w.conv3, gt) && x.C == w.conv3.Cout) {
+            y = pwconv(w.conv3, gt, sca, w.beta, x);
+        } else {
+            ConvOpts o3;
+            o3.in_scale = sca; o3.ch_scale = w.beta; o3.res = &x;
+            y = conv_naf(w.conv3, gt, o3);
+        }
         tfree(gt);
         pl->release(partial);
         pl->release(sca);
         pl->release(mean);
-        Tensor t2 = talloc(x.B, x.H, x.W, c);
-        {
-            const float *yp = y.p, *g = w.g2;
-            float* o = t2.p;
-            push_other(OP_LN, [=](hipStream_t s) { launch_layernorm_film(yp, g, film + 3 * c, film + 2 * c, fb, ppi, o, M, c, 1e-5f, s); });
+        Tensor v;
+        if (lnconv_ok(w.conv4, y)) {
+            v = lnconv(w.conv4, y, w.g2, film + 3 * c, film + 2 * c, 1, naf_lens(e) ? cam_base() + w.cam_off : nullptr);
+        } else {
+            Tensor t2 = talloc(x.B, x.H, x.W, c);
+            {
+                const float *yp = y.p, *g = w.g2;
+                float* o = t2.p;
+                push_other(OP_LN, [=](hipStream_t s) { launch_layernorm_film(yp, g, film + 3 * c, film + 2 * c, fb, ppi, o, M, c, 1e-5f, s); });
+            }
+            ConvOpts o4;
+            o4.gate = 1;
+            if (naf_lens(e)) o4.gate_film = cam_base() + w.cam_off;  // x * (cam_scale + 1) + cam_shift after the gate (:82-83)
+            v = conv_naf(w.conv4, t2, o4);
+            tfree(t2);
         }
-        ConvOpts o4;
-        o4.gate = 1;
-        if (naf_lens(e)) o4.gate_film = cam_base() + w.cam_off;  // x * (cam_scale + 1) + cam_shift after the gate (:82-83)
-        Tensor v = conv_naf(w.conv4, t2, o4);
-        tfree(t2);
-        ConvOpts o5;
-        o5.ch_scale = w.gamma; o5.res = &y;
-        Tensor out = conv_naf(w.conv5, v, o5);
+        Tensor out;
+        if (lnconv_ok(w.conv5, v) && y.C == w.conv5.Cout) {
+            out = pwconv(w.conv5, v, nullptr, w.gamma, y);
+        } else {
+            ConvOpts o5;
+            o5.ch_scale = w.gamma; o5.res = &y;
+            out = conv_naf(w.conv5, v, o5);
+        }
         tfree(v);
         tfree(y);
         return out;

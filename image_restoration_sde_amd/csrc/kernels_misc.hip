@@ -1722,6 +1722,161 @@ __global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ mean
     if (lane == 0) s_out[(size_t)b * c + o] = t + bias[o];
 }
 
+// ---------------------------------------------------------------------------------------------
+// r06: NAFBlock norm1 + conv1 / norm2 + conv4 as ONE launch on the small-channel levels of the fp16 operand mode (c = 64 / 128 / 256: the latent network outside
+// the chain): LayerNorm + time FiLM (DenoisingNAFNet_arch.py:63-64,74-75) of a 64-pixel tile straight into the fp16 A operand in LDS, the whole K = c in one
+// piece (no K loop, every load of the tile in flight at once), v_mfma_f32_32x32x16_f16 against a 64-column weight tile, then bias (conv1) or bias + SimpleGate
+// (+ lens FiLM) (conv4).  Why: at these sizes a launch costs ~5 us whatever it does and the two-kernel form pays three or four serialised memory latencies
+// (profiles/r06_notes.md 3b).  The LayerNorm arithmetic is layernorm_kernel's (KV = 1: L = c / 4 lanes per pixel, one float4 each, the same summation order,
+// this file is compiled without FMA contraction) and the rounding to fp16 is the consuming convolution's: the same operand bits as the two-kernel path.
+// ---------------------------------------------------------------------------------------------
+struct NafLnConvArgs {
+    const float* x;          // [M][c] fp32
+    const float* g;          // LayerNorm gain [c]
+    const float* fscale;     // FiLM rows (row of image b at + b * film_bstride)
+    const float* fshift;
+    int film_bstride;
+    long long ppi;           // pixels per image
+    const unsigned short* w; // fp16 [Cout][c]
+    const float* bias;       // [Cout]
+    float* out;              // [M][Cout] or (gate) [M][Cout / 2]
+    const float* gate_film;  // gate only: per-image [scale (Cout / 2) | shift (Cout / 2)] or nullptr
+    int gate_film_bstride;
+    int gate;
+    int M, Cout;
+    // PRO 1 / 2 (conv3 / conv5: no LayerNorm): the A operand is x itself, PRO 1 times the per-image channel scale in_scale[b][c] (SCA, :68) before the rounding;
+    // epilogue out = res + (acc + bias) * ch_scale (beta / gamma, :70,81)
+    const float* in_scale;
+    const float* ch_scale;
+    const float* res;
+};
+
+// PRO: 0 LayerNorm + FiLM, 1 per-image channel scale, 2 plain
+template <int C, int PRO = 0>
+__global__ __launch_bounds__(256, 2) void naf_lnconv_kernel(const NafLnConvArgs a) {
+    constexpr int L = C / 4;                 // lanes per pixel (16 / 32 / 64)
+    constexpr int RPP = 256 / L;             // pixels per pass of the block
+    constexpr int NPASS = 64 / RPP;          // passes (4 / 8 / 16): one float4 per lane and pass
+    constexpr int ROWB = C * 2 + 16;         // LDS row stride (bytes): K halves + 16-byte pad (conflict-free 16-byte fragment reads)
+    extern __shared__ __attribute__((aligned(16))) char lnc_lds[];
+    char* As = lnc_lds;                      // [64 pixels][ROWB]
+    char* Bs = lnc_lds + 64 * ROWB;          // [64 output channels][ROWB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk_n = a.Cout / 64;
+    // XCD-aware remap: the column tiles of a pixel tile run back to back on one XCD (they share the pixel tile in L2)
+    int wgid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int mblk = wgid / nblk_n, nblk = wgid - mblk * nblk_n;
+    const int m0 = mblk * 64, n0 = nblk * 64;
+    // ---- every load of the tile first: the pixel rows, the weight tile, the LayerNorm / FiLM vectors ----
+    const int li = tid % L, sub = tid / L;
+    float4 v[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int m = m0 + ps * RPP + sub;
+        v[ps] = *reinterpret_cast<const float4*>(a.x + (size_t)(m < a.M ? m : a.M - 1) * C + 4 * li);
+    }
+    constexpr int BCH = (64 * C * 2 / 16) / 256;   // 16-byte chunks of the weight tile per thread (2 / 4 / 8)
+    floatx4 wv[BCH];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int idx = tid + 256 * i, row = idx / (C / 8), ch = idx % (C / 8);
+        wv[i] = *reinterpret_cast<const floatx4*>(reinterpret_cast<const char*>(a.w) + ((size_t)(n0 + row) * C) * 2 + ch * 16);
+    }
+    float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (PRO == 0) gg = reinterpret_cast<const float4*>(a.g)[li];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int idx = tid + 256 * i, row = idx / (C / 8), ch = idx % (C / 8);
+        *reinterpret_cast<floatx4*>(Bs + row * ROWB + ch * 16) = wv[i];
+    }
+    // ---- LayerNorm + FiLM of the 64 pixels (layernorm_kernel, KV = 1), rounded to fp16 into the A tile ----
+    const float invC = 1.0f / (float)C;
+    if constexpr (PRO != 0) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            floatx4 f = {v[ps].x, v[ps].y, v[ps].z, v[ps].w};
+            if constexpr (PRO == 1) {   // (conv_igemm's INSCALE staging: fp32 product, then the rounding)
+                const int m = m0 + ps * RPP + sub;
+                const float4 sc = *reinterpret_cast<const float4*>(a.in_scale + (size_t)((m < a.M ? m : a.M - 1) / a.ppi) * C + 4 * li);
+                f = f * floatx4{sc.x, sc.y, sc.z, sc.w};
+            }
+            *reinterpret_cast<f16x4*>(As + (ps * RPP + sub) * ROWB + li * 8) = __builtin_convertvector(f, f16x4);
+        }
+    } else
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int m = m0 + ps * RPP + sub;
+        float s = (v[ps].x + v[ps].y) + (v[ps].z + v[ps].w);
+        for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * invC;
+        float4 d = v[ps];
+        d.x -= mean; d.y -= mean; d.z -= mean; d.w -= mean;
+        float q = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = 1.0f / sqrtf(q * invC + 1e-5f);
+        const size_t frow = (size_t)(a.film_bstride ? (m < a.M ? m : a.M - 1) / a.ppi : 0) * a.film_bstride;
+        const float4 s4 = reinterpret_cast<const float4*>(a.fscale + frow)[li];
+        const float4 h4 = reinterpret_cast<const float4*>(a.fshift + frow)[li];
+        float4 o4;
+        o4.x = d.x * rstd * gg.x; o4.y = d.y * rstd * gg.y; o4.z = d.z * rstd * gg.z; o4.w = d.w * rstd * gg.w;
+        o4.x = o4.x * (s4.x + 1.0f) + h4.x; o4.y = o4.y * (s4.y + 1.0f) + h4.y;
+        o4.z = o4.z * (s4.z + 1.0f) + h4.z; o4.w = o4.w * (s4.w + 1.0f) + h4.w;
+        const floatx4 f = {o4.x, o4.y, o4.z, o4.w};
+        *reinterpret_cast<f16x4*>(As + (ps * RPP + sub) * ROWB + li * 8) = __builtin_convertvector(f, f16x4);
+    }
+    __syncthreads();
+    // ---- 64 x 64 x C on the matrix pipe: wave (wm, wn) owns a 32 x 32 tile ----
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const char* ap = As + (wm * 32 + l31) * ROWB + h * 16;
+    const char* bp = Bs + (wn * 32 + l31) * ROWB + h * 16;
+#pragma unroll
+    for (int ks = 0; ks < C / 16; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(ap + ks * 32), *reinterpret_cast<const f16x8*>(bp + ks * 32), acc, 0, 0, 0);
+    // ---- epilogue: acc[r] = row 8 (r >> 2) + 4 h + (r & 3), column l31 of the wave's tile ----
+    const int n = n0 + wn * 32 + l31;
+    const float bn = a.bias[n];
+    if constexpr (PRO != 0) {   // out = res + (acc + bias) * ch_scale
+        const float cs = a.ch_scale[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (m < a.M) {
+                float t = (acc[r] + bn) * cs;
+                t += a.res[(size_t)m * a.Cout + n];
+                a.out[(size_t)m * a.Cout + n] = t;
+            }
+        }
+    } else if (!a.gate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (m < a.M) a.out[(size_t)m * a.Cout + n] = acc[r] + bn;
+        }
+    } else {   // SimpleGate: the packed weight rows pair columns (2 j, 2 j + 1); product j, then the per-image lens FiLM
+        const int ch = a.Cout >> 1, oc = n >> 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            const float t = acc[r] + bn;
+            const float other = __shfl_xor(t, 1, 64);
+            float gv = (lane & 1) ? other * t : t * other;   // v[2 j] * v[2 j + 1]
+            if (a.gate_film) {
+                const float* f = a.gate_film + (size_t)((m < a.M ? m : a.M - 1) / a.ppi) * a.gate_film_bstride;
+                gv = gv * (f[oc] + 1.0f) + f[ch + oc];
+            }
+            if (!(lane & 1) && m < a.M) a.out[(size_t)m * ch + oc] = gv;
+        }
+    }
+}
+
 __global__ void row_gate_kernel(const float* __restrict__ in, float* __restrict__ out, const int rows, const int h) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * h) return;
@@ -1771,6 +1926,51 @@ void launch_layernorm_film(const float* x, const float* g, const float* scale, c
 int dwgate_tiles(int H, int W, int c) {
     const DwGeom g = dw_geom(H, W, c);
     return g.tiles_x * g.tiles_y;
+}
+
+bool naf_lnconv_ok(int c, int Cout, long long M) { return (c == 64 || c == 128 || c == 256) && Cout % 64 == 0 && M > 0 && M < (1ll << 31); }
+
+void naf_lnconv_global_init() {
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_lnconv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_lnconv_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_lnconv_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_lnconv_kernel<256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IRSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(naf_lnconv_kernel<256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+
+// norm + FiLM + 1x1 convolution (fp16 operands: w16 = the layer's fp16 weight copy [Cout][c]) in one launch; gate: SimpleGate epilogue (+ gate_film)
+void launch_naf_lnconv(const float* x, const float* g, const float* fscale, const float* fshift, int film_bstride, int64_t pixels_per_image,
+                       const unsigned short* w16, const float* bias, float* out, int64_t M, int c, int Cout, int gate, const float* gate_film,
+                       int gate_film_bstride, hipStream_t s) {
+    if (!naf_lnconv_ok(c, Cout, M)) throw HipError("naf_lnconv: unsupported shape");
+    NafLnConvArgs a;
+    a.x = x; a.g = g; a.fscale = fscale; a.fshift = fshift; a.film_bstride = film_bstride; a.ppi = pixels_per_image;
+    a.w = w16; a.bias = bias; a.out = out; a.gate_film = gate_film; a.gate_film_bstride = gate_film_bstride; a.gate = gate;
+    a.M = (int)M; a.Cout = Cout;
+    a.in_scale = nullptr; a.ch_scale = nullptr; a.res = nullptr;
+    const dim3 grid((unsigned)(((M + 63) / 64) * (Cout / 64)));
+    const size_t lds = (size_t)128 * (c * 2 + 16);
+    if (c == 64) hipLaunchKernelGGL(naf_lnconv_kernel<64>, grid, dim3(256), lds, s, a);
+    else if (c == 128) hipLaunchKernelGGL(naf_lnconv_kernel<128>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(naf_lnconv_kernel<256>, grid, dim3(256), lds, s, a);
+    IRSDE_HIP_CHECK(hipGetLastError());
+}
+
+// conv3 / conv5 of a NAFBlock on the same kernel: out = res + (W (x * in_scale) + bias) * ch_scale, in_scale (per image and input channel) optional
+void launch_naf_pwconv(const float* x, const float* in_scale, int64_t pixels_per_image, const unsigned short* w16, const float* bias, const float* ch_scale,
+                       const float* res, float* out, int64_t M, int c, int Cout, hipStream_t s) {
+    if (!naf_lnconv_ok(c, Cout, M) || !ch_scale || !res) throw HipError("naf_pwconv: unsupported shape");
+    NafLnConvArgs a;
+    a.x = x; a.g = nullptr; a.fscale = nullptr; a.fshift = nullptr; a.film_bstride = 0; a.ppi = pixels_per_image;
+    a.w = w16; a.bias = bias; a.out = out; a.gate_film = nullptr; a.gate_film_bstride = 0; a.gate = 0;
+    a.M = (int)M; a.Cout = Cout;
+    a.in_scale = in_scale; a.ch_scale = ch_scale; a.res = res;
+    const dim3 grid((unsigned)(((M + 63) / 64) * (Cout / 64)));
+    const size_t lds = (size_t)128 * (c * 2 + 16);
+#define IRSDE_PW(CC) do { if (in_scale) hipLaunchKernelGGL((naf_lnconv_kernel<CC, 1>), grid, dim3(256), lds, s, a); else hipLaunchKernelGGL((naf_lnconv_kernel<CC, 2>), grid, dim3(256), lds, s, a); } while (0)
+    if (c == 64) IRSDE_PW(64); else if (c == 128) IRSDE_PW(128); else IRSDE_PW(256);
+#undef IRSDE_PW
+    IRSDE_HIP_CHECK(hipGetLastError());
 }
 
 void launch_dwconv_gate(const float* u, const float* w, const float* bias, float* out, float* partial, int B, int H, int W,
