@@ -1609,3 +1609,50 @@ def test_naf_chain_spin_limit_ends_the_launch():
     assert dt < 60.0, dt
     rc = Lp.irsde_bench_naf_chain(24, 2, 8, 3, ctypes.byref(ms))
     assert rc == 0 and 0.0 < ms.value < 5.0, (rc, ms.value, Lp.irsde_last_error())
+
+
+def test_naf_lnconv_kernel_vs_two_kernel_path(tmp_path):
+    """r06: naf_lnconv_kernel (csrc/kernels_misc.hip: NAFBlock norm + FiLM + 1x1 convolution, SCA-scaled conv3, conv5 as one-piece-K launches in the fp16 operand mode,
+    DenoisingNAFNet_arch.py:56-83) against the path it replaces (layernorm_kernel + conv_igemm_kernel: IRSDE_NAF_LNCONV=0, only reachable under IRSDE_TUNING=1, so the
+    old path runs in a child process).  Same LayerNorm arithmetic, same fp16 operand rounding, same k order on the same MFMA, but not bit-identical: the
+    epilogues are compiled differently (conv_igemm.hip with FMA contraction, kernels_misc.hip without), and a last-bit fp32 difference now and then flips the
+    fp16 rounding of a later operand.  So the bar is relative to the fp32 engine on the same input: the forward of a lens-conditioned latent NAFNet (every level
+    c = 64 / 128 / 256 outside the chain, [B] timesteps, B = 3 with ragged 64-pixel tiles at the deep levels) through the fused kernels is no further from the
+    fp32 engine than through the two-kernel path (measured 4.25e-4 / 3.95e-4 of max|out|; 1.8e-4 between the two), and the two agree within 5e-4."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import image_restoration_sde_amd as P
+from image_restoration_sde_amd import _lib
+from oracle import irsde_oracle as O
+rs = np.random.RandomState(91)
+kw = dict(img_channel=4, width=64, enc_blk_nums=[1, 1, 1, 1], middle_blk_num=1, dec_blk_nums=[1, 1, 1, 1])
+bp = O.naf_synth_params(seed=14, img_channel=4, width=64, middle_blk_num=1, enc_blk_nums=(1, 1, 1, 1), dec_blk_nums=(1, 1, 1, 1), lens=True)
+for k in bp:
+    if k.endswith(".beta") or k.endswith(".gamma"):
+        bp[k] = (0.5 * rs.standard_normal(bp[k].shape)).astype(np.float32)
+m = P.latent_bokeh.ConditionalNAFNet(**kw)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in bp.items()}, strict=True)
+m.engine_flags = _lib.FLAG_FP16 if sys.argv[2] == "fp16" else 0
+m = m.to("cuda:0").eval()
+B = 3
+xt = torch.from_numpy(rs.standard_normal((B, 4, 48, 40)).astype(np.float32)).cuda()
+cond = torch.from_numpy(rs.standard_normal((B, 4, 48, 40)).astype(np.float32)).cuda()
+li = [torch.from_numpy(rs.uniform(0.1, 1.0, B).astype(np.float32)) for _ in range(3)]
+out = m(xt, cond, torch.tensor([3, 50, 97]), lens_info=li).cpu().numpy()
+np.save(sys.argv[1], out)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, mode, env in (("fused", "fp16", {}), ("two_kernels", "fp16", {"IRSDE_TUNING": "1", "IRSDE_NAF_LNCONV": "0"}), ("fp32", "fp32", {})):
+        f = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", script, f, mode], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(f)
+    e = relerr(res["fused"], res["two_kernels"])
+    ef, eo = relerr(res["fused"], res["fp32"]), relerr(res["two_kernels"], res["fp32"])
+    print("naf_lnconv_kernel vs layernorm_kernel + conv_igemm_kernel: rel err %.3g, bit-identical: %s; against the fp32 engine: %.3g (fused) / %.3g (two kernels)"
+          % (e, np.array_equal(res["fused"], res["two_kernels"]), ef, eo))
+    assert ef < 1.25 * eo + 1e-5, (ef, eo)     # the fused path is no further from the fp32 engine than the path it replaces
+    assert np.isfinite(res["fused"]).all() and e < 5e-4, e
