@@ -1032,29 +1032,35 @@ __global__ __launch_bounds__(256, 2) void attn_q_out_fused_kernel(const float* _
         constexpr size_t WPL = (size_t)C * kHid * 2;   // bytes between the hi and the lo plane of Wout
         const char* brow = reinterpret_cast<const char*>(qo_smem) + (wave * 32 + l31) * RBO + 16 * h;
         constexpr int NK16 = kHid / 16;
-        f16x8 wa2[2][2][RT];
+        // r06: C = 256 (RT = 8 row tiles) walks its row tiles in two halves: 128 accumulators + a double-buffered fragment pair per row tile of ALL eight
+        // was 256 + registers (177 spilled to scratch); per accumulator the products arrive in the same order (bit-identical)
+        constexpr int RH = RT > 4 ? RT / 4 : RT;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            wa2[0][0][rt] = *reinterpret_cast<const f16x8*>(wrow + (size_t)rt * 32 * kHid * 2);
-            wa2[0][1][rt] = *reinterpret_cast<const f16x8*>(wrow + WPL + (size_t)rt * 32 * kHid * 2);
-        }
+        for (int r0 = 0; r0 < RT; r0 += RH) {
+            f16x8 wa2[2][2][RH];
 #pragma unroll
-        for (int ks = 0; ks < NK16; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            const int kp = (ks + 1 < NK16 ? ks + 1 : ks) * 32;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                wa2[nxt][0][rt] = *reinterpret_cast<const f16x8*>(wrow + (size_t)rt * 32 * kHid * 2 + kp);
-                wa2[nxt][1][rt] = *reinterpret_cast<const f16x8*>(wrow + WPL + (size_t)rt * 32 * kHid * 2 + kp);
+            for (int rt = 0; rt < RH; ++rt) {
+                wa2[0][0][rt] = *reinterpret_cast<const f16x8*>(wrow + (size_t)(r0 + rt) * 32 * kHid * 2);
+                wa2[0][1][rt] = *reinterpret_cast<const f16x8*>(wrow + WPL + (size_t)(r0 + rt) * 32 * kHid * 2);
             }
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(brow + 32 * ks);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(brow + TP * RBO + 32 * ks);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) yv[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][0][rt], bl, yv[rt], 0, 0, 0);
+            for (int ks = 0; ks < NK16; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                const int kp = (ks + 1 < NK16 ? ks + 1 : ks) * 32;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) yv[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][1][rt], bh, yv[rt], 0, 0, 0);
+                for (int rt = 0; rt < RH; ++rt) {
+                    wa2[nxt][0][rt] = *reinterpret_cast<const f16x8*>(wrow + (size_t)(r0 + rt) * 32 * kHid * 2 + kp);
+                    wa2[nxt][1][rt] = *reinterpret_cast<const f16x8*>(wrow + WPL + (size_t)(r0 + rt) * 32 * kHid * 2 + kp);
+                }
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(brow + 32 * ks);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(brow + TP * RBO + 32 * ks);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) yv[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][0][rt], bh, yv[rt], 0, 0, 0);
+                for (int rt = 0; rt < RH; ++rt) yv[r0 + rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][0][rt], bl, yv[r0 + rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RH; ++rt) yv[r0 + rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][1][rt], bh, yv[r0 + rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RH; ++rt) yv[r0 + rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2[cur][0][rt], bh, yv[r0 + rt], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
